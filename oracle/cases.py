@@ -1,0 +1,72 @@
+"""ORACLE tooling (test infrastructure): case tables and deterministic input/weight generators shared by
+``oracle/gen_golden.py`` (which runs the real reference on them) and the tests (which replay them through
+the oracle restatement and through the HIP path)."""
+import numpy as np
+import torch
+
+GITS_TSTEPS = [80, 10.9836, 3.8811, 1.584, 0.5666, 0.1698, 0.002]     # diff-solvers-main/launch.sh:122
+
+
+def make_inputs(kw, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, kw['img_channels'], kw['img_resolution'], kw['img_resolution'], generator=g)
+    lab = None
+    if kw['label_dim']:
+        idx = torch.randint(kw['label_dim'], (B,), generator=g)
+        lab = torch.eye(kw['label_dim'])[idx]
+    return x, lab
+
+
+SAMPLER_CASES = [
+    # tag, solver fn name, schedule kind/rho, num_steps, extra kwargs
+    ('euler', 'euler_sampler', 'polynomial', 7, 6, {}),
+    ('euler_afs_d0', 'euler_sampler', 'polynomial', 7, 6, dict(afs=True, denoise_to_zero=True)),
+    ('heun', 'heun_sampler', 'polynomial', 7, 5, {}),
+    ('heun_afs', 'heun_sampler', 'polynomial', 7, 5, dict(afs=True)),
+    ('dpm2', 'dpm_2_sampler', 'polynomial', 7, 5, {}),
+    ('dpm2_r03_afs', 'dpm_2_sampler', 'logsnr', 7, 5, dict(r=0.3, afs=True)),
+    ('ipndm4', 'ipndm_sampler', 'polynomial', 7, 8, dict(max_order=4)),
+    ('ipndm3_afs', 'ipndm_sampler', 'polynomial', 7, 6, dict(max_order=3, afs=True)),
+    ('ipndm2', 'ipndm_sampler', 'polynomial', 7, 6, dict(max_order=2)),
+    ('ipndm4_gits', 'ipndm_sampler', None, None, 7, dict(max_order=4)),
+    ('ipndmv4', 'ipndm_v_sampler', 'polynomial', 7, 8, dict(max_order=4)),
+    ('ipndmv3_afs', 'ipndm_v_sampler', 'logsnr', 7, 6, dict(max_order=3, afs=True)),
+    ('deis_tab3', 'deis_sampler', 'time_uniform', 2, 7, dict(max_order=3, deis_mode='tab')),
+    ('deis_tab4_afs', 'deis_sampler', 'time_uniform', 2, 8, dict(max_order=4, deis_mode='tab', afs=True)),
+    ('deis_rhoab4', 'deis_sampler', 'polynomial', 7, 8, dict(max_order=4, deis_mode='rhoab')),
+    ('dpmpp2m', 'dpm_pp_sampler', 'logsnr', 7, 7, dict(max_order=2, predict_x0=True, lower_order_final=True)),
+    ('dpmpp3m', 'dpm_pp_sampler', 'logsnr', 7, 8, dict(max_order=3, predict_x0=True, lower_order_final=True)),
+    ('dpmpp3m_nolof_afs', 'dpm_pp_sampler', 'logsnr', 7, 6, dict(max_order=3, predict_x0=True, lower_order_final=False, afs=True)),
+    ('dpmpp2m_eps', 'dpm_pp_sampler', 'logsnr', 7, 6, dict(max_order=2, predict_x0=False, lower_order_final=True)),
+    ('dpmpp3m_eps_d0', 'dpm_pp_sampler', 'polynomial', 7, 6, dict(max_order=3, predict_x0=False, lower_order_final=True, denoise_to_zero=True)),
+    ('unipc3_bh2', 'unipc_sampler', 'logsnr', 7, 7, dict(max_order=3, predict_x0=True, lower_order_final=True, variant='bh2')),
+    ('unipc2_bh1_eps', 'unipc_sampler', 'logsnr', 7, 6, dict(max_order=2, predict_x0=False, lower_order_final=True, variant='bh1')),
+    ('unipc3_afs', 'unipc_sampler', 'polynomial', 7, 6, dict(max_order=3, predict_x0=True, lower_order_final=False, variant='bh2', afs=True)),
+]
+
+
+AMED_CASES = [
+    # tag, student sampler, num_steps, schedule, rho, afs, predictor kwargs, sampler kwargs
+    ('amed', 'amed', 4, 'time_uniform', 1, True, dict(scale_dir=0.01, scale_time=0), {}),
+    ('amed_noafs_st', 'amed', 4, 'polynomial', 7, False, dict(scale_dir=0.01, scale_time=0.05), {}),
+    ('amed_euler', 'euler', 4, 'polynomial', 7, False, dict(scale_dir=0.01, scale_time=0), {}),
+    ('amed_ipndm', 'ipndm', 4, 'polynomial', 7, True, dict(scale_dir=0.01, scale_time=0), dict(max_order=4)),
+    ('amed_ipndm3', 'ipndm', 5, 'polynomial', 7, False, dict(scale_dir=0.05, scale_time=0.05), dict(max_order=3)),
+    ('amed_dpm2', 'dpm', 4, 'polynomial', 7, False, dict(scale_dir=0.01, scale_time=0), {}),
+    ('amed_dpmpp', 'dpmpp', 4, 'logsnr', 7, True, dict(scale_dir=0.01, scale_time=0), dict(max_order=3, predict_x0=True, lower_order_final=True)),
+    ('amed_dpmpp2_eps', 'dpmpp', 4, 'logsnr', 7, False, dict(scale_dir=0.02, scale_time=0), dict(max_order=2, predict_x0=False, lower_order_final=True)),
+]
+
+
+def amed_predictor_params(seed, scale_dir, scale_time):
+    """Deterministic AMED_predictor weights keyed like its state_dict (training/networks.py:107-117)."""
+    g = torch.Generator().manual_seed(seed)
+    shapes = [('map_layer0.weight', (8, 8)), ('map_layer0.bias', (8,)), ('enc_layer0.weight', (128, 64)), ('enc_layer0.bias', (128,)),
+              ('enc_layer1.weight', (4, 128)), ('enc_layer1.bias', (4,)), ('fc_r.weight', (1, 20)), ('fc_r.bias', (1,))]
+    if scale_dir:
+        shapes += [('fc_scale_dir.weight', (1, 20)), ('fc_scale_dir.bias', (1,))]
+    if scale_time:
+        shapes += [('fc_scale_time.weight', (1, 20)), ('fc_scale_time.bias', (1,))]
+    return {k: (torch.randn(s, generator=g) * (0.3 if k.endswith('weight') else 0.1)) for k, s in shapes}
+
+

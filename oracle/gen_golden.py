@@ -1,0 +1,186 @@
+"""ORACLE tooling: generate tests/golden/*.npz by running the REAL reference (``/root/reference``) on CPU.
+
+Run in the build container only (``/root/reference`` does not exist on the GPU box):
+
+    python oracle/gen_golden.py            # all parts, each in its own interpreter
+    python oracle/gen_golden.py --part net # one part
+
+Every fixture stores the inputs and the reference's outputs.  Network weights are NOT stored: they are
+regenerated on any machine from ``arch.init_params(spec, seed)`` (CPU generator, deterministic), and this
+script loads exactly those tensors into the reference ``EDMPrecond`` before running it.
+
+Parts
+  net       reference EDMPrecond.forward on tiny SongUNet / class-cond SongUNet / DhariwalUNet and the full
+            CIFAR-10 SongUNet                      (diff-solvers-main/models/networks_edm.py)
+  sched     get_schedule (4 kinds incl. GITS dp_list), DEIS coefficient lists, dynamic thresholding
+            (diff-solvers-main/solver_utils.py, gits-main/solver_utils.py)
+  samplers  every sampler of diff-solvers-main/solvers.py on a tiny net, with trajectories; config-1
+            (Euler, NFE=10, B=8, CIFAR-10 net) final images
+  amed      amed-solver-main/solvers_amed.py (AMED-Solver + plugins) with a random-init AMED_predictor
+"""
+import argparse
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+OUT = os.path.join(ROOT, 'tests', 'golden')
+sys.path.insert(0, ROOT)
+from oracle.cases import (GITS_TSTEPS, SAMPLER_CASES, AMED_CASES, make_inputs as _inputs,  # noqa: E402
+                          amed_predictor_params)
+
+def _ref_net(name, seed):
+    import diff_sampler_amd.arch as arch
+    from models.networks_edm import EDMPrecond
+    kw = dict(arch.NAMED_CONFIGS[name])
+    spec = arch.edm_precond_spec(**kw)
+    params = arch.init_params(spec, seed=seed)
+    net = EDMPrecond(**kw).eval()
+    missing, unexpected = net.load_state_dict(params, strict=False)
+    assert not unexpected and all('resample_filter' in m for m in missing)
+    return net, kw
+
+
+def part_net():
+    sys.path.insert(0, os.path.join(REF, 'diff-solvers-main'))
+    for name, B, seed in [('tiny_song', 3, 11), ('tiny_song_cond', 3, 12), ('tiny_adm', 3, 13), ('tiny_song_amed', 2, 14),
+                          ('cifar10', 2, 15)]:
+        net, kw = _ref_net(name, seed)
+        x, lab = _inputs(kw, B, seed + 100)
+        sig = torch.tensor([80.0, 1.7, 0.05][:B])
+        x = x * sig.reshape(-1, 1, 1, 1)
+        with torch.no_grad():
+            out_vec = net(x, sig, class_labels=lab)                 # per-sample sigma
+            out_sc = net(x, torch.tensor(0.6), class_labels=lab)    # 0-dim sigma (the samplers' usual call)
+        np.savez(os.path.join(OUT, f'net_{name}.npz'), config=name, seed=seed, x=x.numpy(), sigma=sig.numpy(),
+                 labels=(lab.numpy() if lab is not None else np.zeros(0, np.float32)),
+                 out_vec=out_vec.numpy(), out_scalar=out_sc.numpy())
+        print('net', name, float(out_vec.abs().max()))
+
+
+def part_sched():
+    sys.path.insert(0, os.path.join(REF, 'gits-main'))
+    import solver_utils as su
+    d = {}
+    for kind, rho in [('polynomial', 7), ('logsnr', 7), ('time_uniform', 2), ('time_uniform', 1)]:
+        for n in [2, 6, 7, 11, 36]:
+            d[f'{kind}_rho{rho}_n{n}'] = su.get_schedule(n, 0.002, 80., schedule_type=kind, schedule_rho=rho).numpy()
+    dp = [0, 12, 25, 37, 48, 55, 60]
+    d['gits_poly7_n61_dp'] = su.get_schedule(61, 0.002, 80., schedule_type='polynomial', schedule_rho=7, dp_list=dp).numpy()
+    d['gits_dp_list'] = np.array(dp)
+    np.savez(os.path.join(OUT, 'schedule.npz'), **d)
+
+    d = {}
+    for tag, ts in [('tu2_n7', su.get_schedule(7, 0.002, 80., schedule_type='time_uniform', schedule_rho=2)),
+                    ('poly7_n11', su.get_schedule(11, 0.002, 80., schedule_type='polynomial', schedule_rho=7)),
+                    ('gits', torch.tensor(GITS_TSTEPS))]:
+        d[f'{tag}_t'] = ts.numpy()
+        for mo in [2, 3, 4]:
+            C = su.get_deis_coeff_list(ts, mo, deis_mode='tab')
+            for i, row in enumerate(C):
+                d[f'{tag}_tab{mo}_{i}'] = np.array([float(c) for c in row], dtype=np.float32)
+        C = su.get_deis_coeff_list(ts, 4, deis_mode='rhoab')
+        for i, row in enumerate(C):
+            d[f'{tag}_rhoab4_{i}'] = np.array([float(c) for c in row], dtype=np.float32)
+    np.savez(os.path.join(OUT, 'deis.npz'), **d)
+
+    g = torch.Generator().manual_seed(5)
+    d = {}
+    for tag, shape, amp in [('c32', (4, 3, 32, 32), 1.5), ('c64', (2, 3, 64, 64), 0.7), ('sd', (2, 4, 64, 64), 3.0), ('small', (3, 3, 8, 8), 1.0)]:
+        x = torch.randn(shape, generator=g) * amp
+        d[f'{tag}_x'] = x.numpy()
+        d[f'{tag}_y'] = su.dynamic_thresholding_fn(x).numpy()
+    np.savez(os.path.join(OUT, 'threshold.npz'), **d)
+    print('sched ok')
+
+
+def part_samplers():
+    sys.path.insert(0, os.path.join(REF, 'diff-solvers-main'))
+    import solvers
+    import solver_utils as su
+    for netname, seed in [('tiny_song', 21), ('tiny_song_cond', 22)]:
+        net, kw = _ref_net(netname, seed)
+        latents, lab = _inputs(kw, 2, seed + 100)
+        d = dict(latents=latents.numpy(), labels=(lab.numpy() if lab is not None else np.zeros(0, np.float32)), seed=seed, config=netname)
+        for tag, fn, kind, rho, n, extra in SAMPLER_CASES:
+            if netname == 'tiny_song_cond' and tag not in ('euler', 'ipndm4', 'dpmpp2m', 'heun', 'unipc3_bh2'):
+                continue
+            extra = dict(extra)
+            if kind is None:
+                ts = torch.tensor(GITS_TSTEPS)
+            else:
+                ts = su.get_schedule(n, 0.002, 80., schedule_type=kind, schedule_rho=rho)
+            if fn == 'deis_sampler':
+                extra['coeff_list'] = su.get_deis_coeff_list(ts, extra['max_order'], deis_mode=extra.pop('deis_mode'))
+            want_eps = fn != 'unipc_sampler'
+            res = getattr(solvers, fn)(net, latents, class_labels=lab, num_steps=n, t_steps=ts, return_inters=True,
+                                        return_eps=want_eps, **extra)
+            if want_eps:
+                inters, eps = res
+                d[f'{tag}_eps'] = eps.numpy()
+            else:
+                inters = res
+            d[f'{tag}_t'] = ts.numpy()
+            d[f'{tag}_inters'] = inters.numpy()
+            print(netname, tag, tuple(inters.shape), float(inters[-1].abs().max()))
+        np.savez_compressed(os.path.join(OUT, f'sampler_{netname}.npz'), **d)
+
+    # BASELINE config 1: EDM CIFAR-10, Euler NFE=10, batch 8.
+    net, kw = _ref_net('cifar10', 31)
+    latents = torch.randn(8, 3, 32, 32, generator=torch.Generator().manual_seed(0))
+    ts = su.get_schedule(11, 0.002, 80., schedule_type='polynomial', schedule_rho=7)
+    out = solvers.euler_sampler(net, latents, num_steps=11, t_steps=ts)
+    out2 = solvers.dpm_pp_sampler(net, latents[:2], num_steps=6, max_order=2, schedule_type='logsnr')
+    np.savez_compressed(os.path.join(OUT, 'sampler_cifar10_config1.npz'), seed=31, latents=latents.numpy(), t=ts.numpy(),
+                        euler_nfe10=out.numpy(), dpmpp2m_nfe5_b2=out2.numpy())
+    print('config1', float(out.abs().max()))
+
+
+def part_amed():
+    sys.path.insert(0, os.path.join(REF, 'amed-solver-main'))
+    import solvers_amed
+    from training.networks import AMED_predictor
+    from models.networks_edm import EDMPrecond
+    import diff_sampler_amd.arch as arch
+    for netname, seed in [('tiny_song_amed', 41), ('tiny_song_amed_cond', 42)]:
+        kw = dict(arch.NAMED_CONFIGS[netname])
+        spec = arch.edm_precond_spec(**kw)
+        net = EDMPrecond(**kw).eval()
+        net.load_state_dict(arch.init_params(spec, seed=seed), strict=False)
+        latents, lab = _inputs(kw, 2, seed + 100)
+        d = dict(latents=latents.numpy(), labels=(lab.numpy() if lab is not None else np.zeros(0, np.float32)), seed=seed, config=netname)
+        for tag, stu, n, kind, rho, afs, pk, sk in AMED_CASES:
+            if netname.endswith('cond') and tag not in ('amed', 'amed_ipndm'):
+                continue
+            pred = AMED_predictor(num_steps=n, sampler_stu=stu, sampler_tea='heun', M=1, schedule_type=kind, schedule_rho=rho,
+                                  afs=afs, **pk, **{k: v for k, v in sk.items() if k in ('max_order', 'predict_x0', 'lower_order_final')}).eval()
+            pp = amed_predictor_params(1000 + len(tag), pk['scale_dir'], pk['scale_time'])
+            pred.load_state_dict(pp, strict=True)
+            fn = {'amed': solvers_amed.amed_sampler, 'euler': solvers_amed.euler_sampler, 'ipndm': solvers_amed.ipndm_sampler,
+                  'dpm': solvers_amed.dpm_2_sampler, 'dpmpp': solvers_amed.dpm_pp_sampler}[stu]
+            with torch.no_grad():
+                inters = fn(net, latents, class_labels=lab, num_steps=n, sigma_min=0.002, sigma_max=80., schedule_type=kind,
+                            schedule_rho=rho, afs=afs, return_inters=True, AMED_predictor=pred, **sk)
+            d[f'{tag}_inters'] = inters.numpy()
+            d[f'{tag}_pseed'] = 1000 + len(tag)
+            print(netname, tag, tuple(inters.shape), float(inters[-1].abs().max()))
+        np.savez_compressed(os.path.join(OUT, f'sampler_{netname}.npz'), **d)
+
+
+PARTS = dict(net=part_net, sched=part_sched, samplers=part_samplers, amed=part_amed)
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--part', default=None, choices=list(PARTS))
+    args = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_grad_enabled(True)
+    if args.part:
+        PARTS[args.part]()
+    else:
+        for p in PARTS:   # separate interpreters: the sub-projects reuse module names (solver_utils, models, ...)
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), '--part', p])

@@ -1,0 +1,413 @@
+"""ORACLE (test infrastructure, not product code): CPU restatement of the reference ODE samplers.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+file; the shipped path (``diff-sampler_amd/``) never does.
+
+Restated (citations relative to /root/reference/):
+  * time schedules                 diff-solvers-main/solver_utils.py:6-52, gits-main/solver_utils.py:52-53
+  * dynamic thresholding           diff-solvers-main/solver_utils.py:77-86
+  * DPM-Solver++ 1/2M/3M updates   diff-solvers-main/solver_utils.py:102-163 (+``scale`` amed-solver-main/solver_utils.py:90-160)
+  * DEIS tAB / rhoAB coefficients  diff-solvers-main/solver_utils.py:297-400
+  * euler/heun/dpm_2/ipndm/ipndm_v/deis/dpm_pp samplers   diff-solvers-main/solvers.py:19-713
+  * AMED-Solver, AMED-plugin euler/ipndm/dpm_2/dpm_pp      amed-solver-main/solvers_amed.py:69-631
+  * AMED predictor MLP             amed-solver-main/training/networks.py:121-155
+
+Shape of the restatement: ONE driver (``sample``) walks the schedule and calls a per-solver rule; the
+reference has one ~90-line function per solver.  The arithmetic inside each rule is written in the same
+operation order as the cited lines so that, given the same ``net``, the trajectory is reproduced to the
+last bit on CPU (checked against ``tests/golden/sampler_*.npz``, which were produced by the real
+reference functions -- see ``oracle/gen_golden.py``).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+
+# ------------------------------------------------------------------------------------------------
+# schedules
+
+def schedule(num_steps, sigma_min=0.002, sigma_max=80.0, kind='polynomial', rho=7, dp_list=None):
+    if kind == 'polynomial':
+        i = torch.arange(num_steps)
+        t = (sigma_max ** (1 / rho) + i / (num_steps - 1) * (sigma_min ** (1 / rho) - sigma_max ** (1 / rho))) ** rho
+    elif kind == 'logsnr':
+        hi = -1 * torch.log(torch.tensor(sigma_min))
+        lo = -1 * torch.log(torch.tensor(sigma_max))
+        t = (-torch.linspace(lo.item(), hi.item(), steps=num_steps)).exp()
+    elif kind == 'time_uniform':
+        eps_s = 1e-3
+        beta_d = 2 * (np.log(torch.tensor(sigma_min) ** 2 + 1) / eps_s - np.log(torch.tensor(sigma_max) ** 2 + 1)) / (eps_s - 1)
+        beta_min = np.log(torch.tensor(sigma_max) ** 2 + 1) - 0.5 * beta_d
+        i = torch.arange(num_steps)
+        tt = (1 + i / (num_steps - 1) * (eps_s ** (1 / rho) - 1)) ** rho
+        t = (np.e ** (0.5 * beta_d * (tt ** 2) + beta_min * tt) - 1) ** 0.5
+    else:
+        raise ValueError("Got wrong schedule type {}".format(kind))
+    if dp_list is not None:
+        t = t[dp_list]
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+# DPM-Solver++ pieces
+
+def threshold(x0, p=0.995):
+    s = torch.quantile(x0.abs().reshape(x0.shape[0], -1), p, dim=1)
+    s = torch.maximum(s, torch.ones_like(s))[:, None, None, None]
+    return torch.clamp(x0, -s, s) / s
+
+
+def _r4(t):
+    return t.reshape(-1, 1, 1, 1)
+
+
+def dpmpp_step(x, ms, ts, t, order, predict_x0=True, scale=1, scaled_form=False):
+    """One multistep DPM-Solver++ update in VE form (lambda = -log sigma).
+
+    scaled_form=False: association of diff-solvers-main/solver_utils.py:102-163;
+    scaled_form=True : association of amed-solver-main/solver_utils.py:102-160 (``- scale * ( ... )``)."""
+    t = _r4(t)
+    lam = lambda s: -1 * s.log()
+    if order == 1:
+        s = _r4(ts[-1])
+        h = lam(t) - lam(s)
+        phi1 = torch.expm1(-h) if predict_x0 else torch.expm1(h)
+        return (t / s) * x - scale * phi1 * ms[-1] if predict_x0 else x - scale * t * phi1 * ms[-1]
+    if order == 2:
+        m1, m0 = ms[-2], ms[-1]
+        t1, t0 = _r4(ts[-2]), _r4(ts[-1])
+        h0 = lam(t0) - lam(t1)
+        h = lam(t) - lam(t0)
+        r0 = h0 / h
+        d10 = (1. / r0) * (m0 - m1)
+        phi1 = torch.expm1(-h) if predict_x0 else torch.expm1(h)
+        if not scaled_form:
+            if predict_x0:
+                return (t / t0) * x - phi1 * m0 - 0.5 * phi1 * d10
+            return x - t * phi1 * m0 - 0.5 * t * phi1 * d10
+        if predict_x0:
+            return (t / t0) * x - scale * (phi1 * m0 + 0.5 * phi1 * d10)
+        return x - scale * (t * phi1 * m0 + 0.5 * t * phi1 * d10)
+    if order == 3:
+        m2, m1, m0 = ms[-3], ms[-2], ms[-1]
+        t2, t1, t0 = _r4(ts[-3]), _r4(ts[-2]), _r4(ts[-1])
+        h1 = lam(t1) - lam(t2)
+        h0 = lam(t0) - lam(t1)
+        h = lam(t) - lam(t0)
+        r0, r1 = h0 / h, h1 / h
+        d10 = (1. / r0) * (m0 - m1)
+        d11 = (1. / r1) * (m1 - m2)
+        d1 = d10 + (r0 / (r0 + r1)) * (d10 - d11)
+        d2 = (1. / (r0 + r1)) * (d10 - d11)
+        phi1 = torch.expm1(-h) if predict_x0 else torch.expm1(h)
+        phi2 = phi1 / h + 1. if predict_x0 else phi1 / h - 1.
+        phi3 = phi2 / h - 0.5
+        if not scaled_form:
+            if predict_x0:
+                return (t / t0) * x - phi1 * m0 + phi2 * d1 - phi3 * d2
+            return x - t * phi1 * m0 - t * phi2 * d1 - t * phi3 * d2
+        if predict_x0:
+            return (t / t0) * x - scale * (phi1 * m0 - phi2 * d1 + phi3 * d2)
+        return x - scale * (t * phi1 * m0 + t * phi2 * d1 + t * phi3 * d2)
+    raise ValueError("Solver order must be 1 or 2 or 3, got {}".format(order))
+
+
+# ------------------------------------------------------------------------------------------------
+# DEIS coefficients
+
+def _vp_consts(sigma_min=0.002, sigma_max=80, eps_s=1e-3):
+    beta_d = 2 * (np.log(torch.tensor(sigma_min) ** 2 + 1) / eps_s - np.log(torch.tensor(sigma_max) ** 2 + 1)) / (eps_s - 1)
+    beta_min = np.log(torch.tensor(sigma_max) ** 2 + 1) - 0.5 * beta_d
+    return beta_d, beta_min
+
+
+def deis_coeffs(t_steps, max_order, N=10000, mode='tab'):
+    t_steps = t_steps.detach().cpu()
+    out = []
+    if mode == 'tab':
+        beta_d, beta_min = _vp_consts()
+        tau = ((beta_min ** 2 + 2 * beta_d * (t_steps ** 2 + 1).log()).sqrt() - beta_min) / beta_d
+        b0, b1 = beta_min, beta_d + beta_min
+        for i in range(len(tau) - 1):
+            order = min(i + 1, max_order)
+            if order == 1:
+                out.append([])
+                continue
+            a, b = tau[i], tau[i + 1]
+            grid = torch.linspace(a, b, N)
+            dgrid = (b - a) / N
+            with torch.enable_grad():
+                grid.requires_grad_(True)
+                alpha = torch.exp(-0.5 * grid ** 2 * (b1 - b0) - grid * b0)
+                alpha.log().sum().backward()
+                dlog = grid.grad
+            integrand = -0.5 * dlog / torch.sqrt(alpha * (1 - alpha))
+            nodes = tau[[i - k for k in range(order)]]
+            row = []
+            for j in range(order):
+                poly = 1
+                for k in range(order):
+                    if k != j:
+                        poly *= (grid - nodes[k]) / (nodes[j] - nodes[k])
+                row.append(torch.sum(integrand * poly) * dgrid)
+            out.append(row)
+        return out
+    if mode == 'rhoab':
+        def int2(a, b, s, e, c):
+            v = (e ** 3 - s ** 3) / 3 - (e ** 2 - s ** 2) * (a + b) / 2 + (e - s) * a * b
+            return v / ((c - a) * (c - b))
+
+        def int3(a, b, c, s, e, d):
+            v = (e ** 4 - s ** 4) / 4 - (e ** 3 - s ** 3) * (a + b + c) / 3 \
+                + (e ** 2 - s ** 2) * (a * b + a * c + b * c) / 2 - (e - s) * a * b * c
+            return v / ((d - a) * (d - b) * (d - c))
+
+        row = None
+        for i in range(len(t_steps) - 1):
+            tc, tn = t_steps[i], t_steps[i + 1]
+            order = min(i, max_order)
+            if order == 0:
+                out.append([])
+                continue
+            pt = t_steps[[i - k for k in range(order + 1)]]
+            if order == 1:
+                row = [((tn - pt[1]) ** 2 - (tc - pt[1]) ** 2) / (2 * (tc - pt[1])), (tn - tc) ** 2 / (2 * (pt[1] - tc))]
+            elif order == 2:
+                row = [int2(pt[1], pt[2], tc, tn, tc), int2(tc, pt[2], tc, tn, pt[1]), int2(tc, pt[1], tc, tn, pt[2])]
+            elif order == 3:
+                row = [int3(pt[1], pt[2], pt[3], tc, tn, tc), int3(tc, pt[2], pt[3], tc, tn, pt[1]),
+                       int3(tc, pt[1], pt[3], tc, tn, pt[2]), int3(tc, pt[1], pt[2], tc, tn, pt[3])]
+            out.append(row)      # order >= 4 re-appends the previous row (reference quirk)
+        return out
+    raise ValueError(mode)
+
+
+# ------------------------------------------------------------------------------------------------
+# AMED predictor (functional over a state_dict)
+
+def amed_predict(p, cfg, bottleneck, t_cur, t_next):
+    """Returns (r, scale_dir, scale_time), each [B,1,1,1].  cfg: dict(scale_dir=float, scale_time=float)."""
+    def emb_of(t):
+        half = p['map_layer0.weight'].shape[1] // 2
+        f = torch.arange(0, half, dtype=torch.float32) / (half - 1)
+        f = (1 / 10000) ** f
+        e = t.reshape(1,).ger(f)
+        e = torch.cat([e.cos(), e.sin()], dim=1)
+        e = e.reshape(1, 2, -1).flip(1).reshape(1, -1)
+        e = e @ p['map_layer0.weight'].t() + p['map_layer0.bias']
+        return torch.nn.functional.silu(e).repeat(bottleneck.shape[0], 1)
+
+    emb = torch.cat((emb_of(t_cur), emb_of(t_next)), dim=1)
+    z = bottleneck.reshape(bottleneck.shape[0], -1)
+    z = torch.nn.functional.silu(z @ p['enc_layer0.weight'].t() + p['enc_layer0.bias'])
+    z = z @ p['enc_layer1.weight'].t() + p['enc_layer1.bias']
+    feat = torch.cat((z, emb), dim=1)
+    r = torch.sigmoid(feat @ p['fc_r.weight'].t() + p['fc_r.bias']).reshape(-1, 1, 1, 1)
+    sd = torch.ones_like(r)
+    st = torch.ones_like(r)
+    if cfg.get('scale_dir', 0):
+        s = cfg['scale_dir']
+        v = torch.sigmoid(feat @ p['fc_scale_dir.weight'].t() + p['fc_scale_dir.bias'])
+        sd = (v / (1 / (2 * s)) + (1 - s)).reshape(-1, 1, 1, 1)
+    if cfg.get('scale_time', 0):
+        s = cfg['scale_time']
+        v = torch.sigmoid(feat @ p['fc_scale_time.weight'].t() + p['fc_scale_time.bias'])
+        st = (v / (1 / (2 * s)) + (1 - s)).reshape(-1, 1, 1, 1)
+    return r, sd, st
+
+
+# ------------------------------------------------------------------------------------------------
+# the driver
+
+
+
+def _ab_step(order, step, d, hist):
+    """step * AB_k(d, hist), with the reference's left-to-right association ``step * (numerator) / den``
+    (solvers.py:345-352: the division is applied AFTER the multiplication by the step)."""
+    if order == 1:
+        return step * d
+    if order == 2:
+        return step * (3 * d - hist[-1]) / 2
+    if order == 3:
+        return step * (23 * d - 16 * hist[-1] + 5 * hist[-2]) / 12
+    return step * (55 * d - 59 * hist[-1] + 37 * hist[-2] - 9 * hist[-3]) / 24
+
+
+def _push(hist, d, cap):
+    if len(hist) == cap:
+        for k in range(cap - 1):
+            hist[k] = hist[k + 1]
+        hist[-1] = d          # max_order == 1 -> IndexError, like the reference (solvers.py:358-361)
+    else:
+        hist.append(d)
+
+
+def sample(solver, net, latents, t_steps, class_labels=None, afs=False, denoise_to_zero=False,
+           max_order=None, r=0.5, coeff_list=None, predict_x0=True, lower_order_final=True, num_steps=None,
+           predictor=None, want_inters=False, want_eps=False):
+    """Run one reference sampler.  ``net(x, sigma, class_labels=...)`` -> denoised.
+
+    solver: euler | heun | dpm_2 | ipndm | ipndm_v | deis | dpm_pp, or amed | amed_euler | amed_ipndm |
+            amed_dpm_2 | amed_dpm_pp with ``predictor`` = callable(bottleneck|None, t_cur, t_next) ->
+            (r, scale_dir, scale_time) and ``net.last_bottleneck`` holding the U-Net bottleneck.
+    Returns x (or (inters[, eps]) when requested) exactly like the reference functions.
+    """
+    D = lambda x, t: net(x, t, class_labels=class_labels)
+    afs_d = lambda x, t: x / ((1 + t ** 2).sqrt())
+    n = len(t_steps)
+    x = latents * t_steps[0]
+    inters, eps = [x.unsqueeze(0)], []
+    hist, hist_t = [], []
+    amed = solver.startswith('amed')
+    B = latents.shape[0]
+    if solver in ('ipndm', 'ipndm_v', 'deis', 'amed_ipndm'):
+        assert 1 <= max_order <= 4
+    if solver in ('dpm_pp', 'amed_dpm_pp'):
+        assert 1 <= max_order <= 3
+        total = (2 * num_steps - 1) if amed else num_steps
+
+    for i in range(n - 1):
+        t, tn = t_steps[i], t_steps[i + 1]
+        xc = x
+        # ---- first evaluation (or AFS) --------------------------------------------------------------
+        if solver in ('ipndm_v', 'deis', 'amed_ipndm', 'amed_dpm_pp'):
+            use_afs = afs and len(hist) == 0
+        else:
+            use_afs = afs and i == 0
+        if use_afs:
+            d = afs_d(xc, t)
+            den = xc - t * d
+        else:
+            den = D(xc, t)
+            d = (xc - den) / t
+        if amed:
+            t4, tn4 = t.reshape(-1, 1, 1, 1), tn.reshape(-1, 1, 1, 1)
+            bott = torch.zeros(B, 8, 8) if use_afs else net.last_bottleneck.mean(dim=1)
+            rr, sdir, stime = predictor(bott, t4, tn4)
+            tm = (tn4 ** rr) * (t4 ** (1 - rr))
+
+        # ---- per-solver update ------------------------------------------------------------------------
+        if solver == 'euler':
+            x = xc + (tn - t) * d
+        elif solver == 'heun':
+            x = xc + (tn - t) * d
+            dp = (x - D(x, tn)) / tn
+            x = xc + (tn - t) * (0.5 * d + 0.5 * dp)
+        elif solver == 'dpm_2':
+            tm_ = (tn ** r) * (t ** (1 - r))
+            x = xc + (tm_ - t) * d
+            dp = (x - D(x, tm_)) / tm_
+            x = xc + (tn - t) * ((1 / (2 * r)) * dp + (1 - 1 / (2 * r)) * d)
+        elif solver == 'ipndm':
+            order = min(max_order, i + 1)
+            x = xc + _ab_step(order, tn - t, d, hist)
+            _push(hist, d, max_order - 1)
+        elif solver == 'ipndm_v':
+            order = min(max_order, i + 1)
+            if order == 1:
+                x = xc + (tn - t) * d
+            else:
+                hn = tn - t
+                h1 = t - t_steps[i - 1]
+                if order == 2:
+                    c1 = (2 + (hn / h1)) / 2
+                    c2 = -(hn / h1) / 2
+                    x = xc + (tn - t) * (c1 * d + c2 * hist[-1])
+                else:
+                    h2 = t_steps[i - 1] - t_steps[i - 2]
+                    tmp1 = (1 - hn / (3 * (hn + h1)) * (hn * (hn + h1)) / (h1 * (h1 + h2))) / 2
+                    if order == 3:
+                        c1 = (2 + (hn / h1)) / 2 + tmp1
+                        c2 = -(hn / h1) / 2 - (1 + h1 / h2) * tmp1
+                        c3 = tmp1 * h1 / h2
+                        x = xc + (tn - t) * (c1 * d + c2 * hist[-1] + c3 * hist[-2])
+                    else:
+                        h3 = t_steps[i - 2] - t_steps[i - 3]
+                        tmp2 = ((1 - hn / (3 * (hn + h1))) / 2 + (1 - hn / (2 * (hn + h1))) * hn / (6 * (hn + h1 + h2))) \
+                            * (hn * (hn + h1) * (hn + h1 + h2)) / (h1 * (h1 + h2) * (h1 + h2 + h3))
+                        c1 = (2 + (hn / h1)) / 2 + tmp1 + tmp2
+                        c2 = -(hn / h1) / 2 - (1 + h1 / h2) * tmp1 - (1 + (h1 / h2) + (h1 * (h1 + h2) / (h2 * (h2 + h3)))) * tmp2
+                        c3 = tmp1 * h1 / h2 + ((h1 / h2) + (h1 * (h1 + h2) / (h2 * (h2 + h3))) * (1 + h2 / h3)) * tmp2
+                        c4 = -tmp2 * (h1 * (h1 + h2) / (h2 * (h2 + h3))) * h1 / h2
+                        x = xc + (tn - t) * (c1 * d + c2 * hist[-1] + c3 * hist[-2] + c4 * hist[-3])
+            _push(hist, d, max_order - 1)
+        elif solver == 'deis':
+            assert coeff_list is not None
+            order = min(max_order, i + 1)
+            if order == 1:
+                x = xc + (tn - t) * d
+            else:
+                cs = coeff_list[i]
+                if len(cs) != order:
+                    raise ValueError('too many values to unpack' if len(cs) > order else 'not enough values to unpack')
+                x = xc + cs[0] * d
+                for k in range(1, order):
+                    x = x + cs[k] * hist[-k]
+            _push(hist, d, max_order - 1)
+        elif solver == 'dpm_pp':
+            hist.append(threshold(den) if predict_x0 else d)
+            hist_t.append(t)
+            if lower_order_final:
+                order = i + 1 if i + 1 < max_order else min(max_order, num_steps - (i + 1))
+            else:
+                order = min(max_order, i + 1)
+            x = dpmpp_step(xc, hist, hist_t, tn, order, predict_x0=predict_x0)
+            hist, hist_t = hist[-3:], hist_t[-3:]
+        elif solver == 'amed':
+            x = xc + (tm - t4) * d
+            dm = (x - D(x, stime * tm)) / tm
+            x = xc + sdir * (tn4 - t4) * dm
+        elif solver == 'amed_euler':
+            x = xc + (tm - t4) * d
+            dm = (x - D(x, stime * tm)) / tm
+            x = x + sdir * (tn4 - tm) * dm
+        elif solver == 'amed_dpm_2':
+            x = xc + (tm - t4) * d
+            dm = (x - D(x, stime * tm)) / tm
+            x = xc + sdir * (tn4 - t4) * ((1 / (2 * rr)) * dm + (1 - 1 / (2 * rr)) * d)
+        elif solver == 'amed_ipndm':
+            order = min(max_order, len(hist) + 1)
+            x = xc + _ab_step(order, tm - t4, d, hist)
+            _push(hist, d, max_order - 1)
+            order = min(max_order, len(hist) + 1)
+            d2 = (x - D(x, stime * tm)) / tm
+            x = x + _ab_step(order, sdir * (tn4 - tm), d2, hist)
+            _push(hist, d2, max_order - 1)
+        elif solver == 'amed_dpm_pp':
+            step_cur = 2 * i + 1
+            hist.append(threshold(den) if predict_x0 else d)
+            hist_t.append(t4)
+            order = (step_cur if step_cur < max_order else min(max_order, total - step_cur)) if lower_order_final \
+                else min(max_order, step_cur)
+            x = dpmpp_step(xc, hist, hist_t, tm, order, predict_x0=predict_x0, scaled_form=True)
+            step_cur += 1
+            den2 = D(x, stime * tm)
+            hist.append(threshold(den2) if predict_x0 else ((x - den2) / tm))
+            hist_t.append(tm)
+            order = (step_cur if step_cur < max_order else min(max_order, total - step_cur)) if lower_order_final \
+                else min(step_cur, max_order)
+            x = dpmpp_step(x, hist, hist_t, tn4, order, predict_x0=predict_x0, scale=sdir, scaled_form=True)
+            hist, hist_t = hist[-3:], hist_t[-3:]
+        else:
+            raise ValueError(solver)
+        if want_inters:
+            inters.append(x.unsqueeze(0))
+        if want_eps:
+            eps.append(d.unsqueeze(0))
+
+    if denoise_to_zero:
+        x = D(x, t_steps[-1])
+        if want_inters:
+            inters.append(x.unsqueeze(0))
+    if want_inters:
+        if want_eps:
+            return torch.cat(inters, dim=0), torch.cat(eps, dim=0)
+        return torch.cat(inters, dim=0)
+    return x
+
+
+SOLVERS = ('euler', 'heun', 'dpm_2', 'ipndm', 'ipndm_v', 'deis', 'dpm_pp',
+           'amed', 'amed_euler', 'amed_ipndm', 'amed_dpm_2', 'amed_dpm_pp')
