@@ -1,0 +1,102 @@
+"""ctypes binding of csrc/libdsamd.so (the C ABI declared in include/ds_engine.h).
+
+There is no CPU fallback: if the library is missing or a call fails, an exception is raised.  PyTorch is used by
+callers only for device memory (``tensor.data_ptr()``) and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libdsamd.so')
+
+c_float_p = C.POINTER(C.c_float)
+vp = C.c_void_p
+
+DS_ACT_NONE, DS_ACT_SILU = 0, 1
+DS_RESAMPLE_NONE, DS_RESAMPLE_DOWN, DS_RESAMPLE_UP = 0, 1, 2
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [('x0', vp), ('x1', vp), ('c0', C.c_int), ('c1', C.c_int), ('ld0', C.c_int), ('ld1', C.c_int),
+                ('n', C.c_int), ('h', C.c_int), ('w', C.c_int), ('taps', C.c_int), ('wgt', vp), ('cout', C.c_int),
+                ('bias', vp), ('cbias', vp), ('cbias_ld', C.c_int), ('cbias_rows', C.c_int), ('res', vp),
+                ('res_ld', C.c_int), ('out_scale', C.c_float), ('act', C.c_int), ('out', vp), ('out_ld', C.c_int)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [('a', vp), ('lda', C.c_int), ('a_bstride', C.c_longlong), ('a_hstride', C.c_longlong),
+                ('b', vp), ('ldb', C.c_int), ('b_bstride', C.c_longlong), ('b_hstride', C.c_longlong),
+                ('c', vp), ('ldc', C.c_int), ('c_bstride', C.c_longlong), ('c_hstride', C.c_longlong),
+                ('m', C.c_int), ('n', C.c_int), ('k', C.c_int), ('batch', C.c_int), ('heads', C.c_int),
+                ('alpha', C.c_float), ('rowbias', vp), ('colbias', vp), ('act', C.c_int)]
+
+
+class NormArgs(C.Structure):
+    _fields_ = [('x0', vp), ('x1', vp), ('c0', C.c_int), ('c1', C.c_int), ('ld0', C.c_int), ('ld1', C.c_int),
+                ('n', C.c_int), ('h', C.c_int), ('w', C.c_int), ('groups', C.c_int), ('eps', C.c_float),
+                ('mean', vp), ('rstd', vp), ('gamma', vp), ('beta', vp), ('scale', vp), ('shift', vp),
+                ('ss_ld', C.c_int), ('ss_rows', C.c_int), ('act', C.c_int), ('resample', C.c_int), ('out', vp),
+                ('out_ld', C.c_int)]
+
+
+class UpdateArgs(C.Structure):
+    _fields_ = [('xe', vp), ('xb', vp), ('f', vp), ('raw', C.c_int), ('f_ld', C.c_int), ('hist', vp * 3),
+                ('coefs', vp), ('coef_rows', C.c_int), ('hcoefs', C.c_float * 8), ('afs', C.c_int),
+                ('sigma_data', C.c_float), ('m_out', vp), ('store_d', C.c_int), ('x_out', vp),
+                ('n', C.c_int), ('c', C.c_int), ('h', C.c_int), ('w', C.c_int)]
+
+
+_SIGNATURES = {
+    'ds_version': (C.c_int, []),
+    'ds_error_string': (C.c_char_p, [C.c_int]),
+    'ds_conv2d_nhwc': (C.c_int, [C.POINTER(ConvArgs), vp]),
+    'ds_gemm_nt_batched': (C.c_int, [C.POINTER(GemmArgs), vp]),
+    'ds_gn_stats': (C.c_int, [C.POINTER(NormArgs), vp]),
+    'ds_norm_act': (C.c_int, [C.POINTER(NormArgs), vp]),
+    'ds_softmax_rows': (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp]),
+    'ds_noise_embed': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp]),
+    'ds_stem_im2col': (C.c_int, [vp, vp, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
+    'ds_solver_update': (C.c_int, [C.POINTER(UpdateArgs), vp]),
+    'ds_table_select': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp]),
+    'ds_dynamic_threshold': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp]),
+    'ds_scale': (C.c_int, [vp, C.c_float, vp, C.c_longlong, vp]),
+    'ds_quantize_u8_nhwc': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'ds_copy_rows': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_longlong, C.c_int, vp]),
+    'ds_channel_mean': (C.c_int, [vp, C.c_int, C.c_int, C.c_longlong, vp, vp]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+_lib = None
+
+
+class DsError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libdsamd.so (once).  Raises if it has not been built -- there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DsError(f'{LIB_PATH} is missing: build it with `python diff-sampler_amd/build.py` '
+                      f'(or __graft_entry__.build()).  The HIP engine has no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(code, what=''):
+    if code != 0:
+        msg = load().ds_error_string(code)
+        raise DsError(f'{what or "libdsamd call"} failed with code {code}: {msg.decode() if msg else "?"}')
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

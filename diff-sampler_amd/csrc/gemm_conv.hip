@@ -1,0 +1,255 @@
+// Implicit-GEMM convolution / batched NT GEMM on the gfx950 fp32 matrix pipe.
+//
+// One kernel core serves every contraction of the denoiser (3x3 conv, 1x1 conv, Linear, QK^T, PV):
+//     C[m, n] = sum_k A(m, k) * B(n, k)          (both operands k-contiguous in memory: "NT")
+//   conv mode : A(m, k) is gathered on the fly from the NHWC activation(s): k = tap*Ctot + c addresses the
+//               zero-padded 3x3 neighbour `tap` of output pixel m, channel c of the concatenation [x0 | x1]
+//               (the decoder's torch.cat is never materialised);  B = packed weights [Cout_pad][K].
+//   gemm mode : A, B plain strided row-major matrices, batched over blockIdx.z (attention).
+//
+// Tiling (CDNA4, wave64): block tile 128(M) x 128(N) x 32(K), 256 threads = 4 waves in a 2x2 grid, each wave
+// owns a 64x64 sub-tile = 2x2 MFMA tiles of v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 64 cycles each,
+// 157 TFLOP/s chip peak).  Global -> register -> LDS staging with double-buffered LDS (one barrier per K tile):
+// the global loads of tile k+1 are issued before the 64 MFMAs of tile k and written to the other LDS buffer
+// after them.  LDS rows are padded to 36 floats so that the ds_read_b128 fragment reads (16 distinct rows per
+// lane group, stride 144 B) hit 16 distinct 16-B bank slots: conflict free.
+// Fragment trick: lane l of an MFMA holds A[row = l&31][kslot = l>>5]; one ds_read_b128 fetches 4 consecutive k
+// for that lane, and register r of the read feeds MFMA number r, i.e. MFMA r contracts k = {8*ks + r, 8*ks+4+r}.
+// A and B use the same k permutation, so the sum over k is unchanged.
+#include "ds_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, LDSK = 36;
+constexpr int SMEM_BYTES = 2 * (BM + BN) * LDSK * (int)sizeof(float);   // 73,728 B -> 2 blocks / CU
+
+struct KParams {
+    // A side (conv gather)
+    const float* a0; const float* a1; int c0, c1, lda0, lda1; int H, W, HW, taps;
+    // A side (gemm) uses a0/lda0 plus batch strides
+    long long a_bs, a_hs;
+    // B side
+    const float* b; int ldb; long long b_bs, b_hs; int nrows_b;   // rows of B that may be read
+    int M, N, K;
+    // epilogue
+    float* out; int ldo; long long o_bs, o_hs;
+    const float* colbias; const float* rowbias;
+    const float* cbias; int cbias_ld; int cbias_bcast;
+    const float* res; int res_ld;
+    float scale; int act; int heads;
+};
+
+template <int MODE>   // 0 = conv gather, 1 = batched gemm
+__global__ void __launch_bounds__(256, 2) igemm_f32_kernel(const KParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * BM * LDSK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int ld_row = tid >> 3, ld_col = (tid & 7) * 4;
+
+    const float* a_base = p.a0;
+    const float* b_base = p.b;
+    float* o_base = p.out;
+    if (MODE == 1) {
+        const int zb = blockIdx.z / p.heads, zh = blockIdx.z - zb * p.heads;
+        a_base += zb * p.a_bs + zh * p.a_hs;
+        b_base += zb * p.b_bs + zh * p.b_hs;
+        o_base += zb * p.o_bs + zh * p.o_hs;
+    }
+
+    // Per-thread row bookkeeping for the 4 A rows and 4 B rows this thread stages.
+    bool a_ok[4];
+    int a_oh[4], a_ow[4];
+    size_t a_off[4];
+    size_t b_off[4];
+    bool b_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ld_row + 32 * i;
+        a_ok[i] = m < p.M;
+        if (MODE == 0) {
+            const int img = m / p.HW;
+            const int rem = m - img * p.HW;
+            a_oh[i] = rem / p.W;
+            a_ow[i] = rem - a_oh[i] * p.W;
+            a_off[i] = (size_t)img * p.HW;
+        } else {
+            a_oh[i] = a_ow[i] = 0;
+            a_off[i] = (size_t)m * p.lda0 + ld_col;
+        }
+        const int n = n0 + ld_row + 32 * i;
+        b_ok[i] = n < p.nrows_b;
+        b_off[i] = (size_t)n * p.ldb + ld_col;
+    }
+    const int Ctot = p.c0 + p.c1;
+
+    f32x4 ra[4], rb[4];
+    auto load_tiles = [&](int kt) {
+        const int k0 = kt * BK;
+        if (MODE == 0) {
+            const int tap = k0 / Ctot;
+            const int c = k0 - tap * Ctot;
+            int dy = 0, dx = 0;
+            if (p.taps == 9) { const int ty = tap / 3; dy = ty - 1; dx = tap - ty * 3 - 1; }
+            const float* src; int ld;
+            if (c < p.c0) { src = p.a0 + c + ld_col; ld = p.lda0; } else { src = p.a1 + (c - p.c0) + ld_col; ld = p.lda1; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ih = a_oh[i] + dy, iw = a_ow[i] + dx;
+                const bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok) v = *reinterpret_cast<const f32x4*>(src + (a_off[i] + (size_t)(ih * p.W + iw)) * ld);
+                ra[i] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (a_ok[i]) v = *reinterpret_cast<const f32x4*>(a_base + a_off[i] + k0);
+                ra[i] = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b_ok[i]) v = *reinterpret_cast<const f32x4*>(b_base + b_off[i] + k0);
+            rb[i] = v;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        float* as = As + buf * BM * LDSK + ld_row * LDSK + ld_col;
+        float* bs = Bs + buf * BN * LDSK + ld_row * LDSK + ld_col;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(as + 32 * i * LDSK) = ra[i];
+            *reinterpret_cast<f32x4*>(bs + 32 * i * LDSK) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int KT = p.K / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    const int frag_off = (lane & 31) * LDSK + (lane >> 5) * 4;
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1) < KT;
+        if (more) load_tiles(kt + 1);
+
+        const float* as = As + cur * BM * LDSK + wr * 64 * LDSK + frag_off;
+        const float* bs = Bs + cur * BN * LDSK + wc * 64 * LDSK + frag_off;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(as + ks * 8);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(as + 32 * LDSK + ks * 8);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bs + ks * 8);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(bs + 32 * LDSK + ks * 8);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[r], b0[r], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[r], b1[r], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], b0[r], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], b1[r], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (more) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wc * 64 + j * 32 + (lane & 31);
+        if (col >= p.N) continue;
+        const float cb = p.colbias ? p.colbias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= p.M) continue;
+                float v = acc[i][j][r];
+                if (MODE == 1) v *= p.scale;          // gemm: alpha scales the product, biases added after
+                v += cb;
+                if (p.rowbias) v += p.rowbias[row];
+                if (p.cbias) {
+                    const int img = p.cbias_bcast ? 0 : row / p.HW;
+                    v += p.cbias[(size_t)img * p.cbias_ld + col];
+                }
+                if (p.res) v += p.res[(size_t)row * p.res_ld + col];
+                if (MODE == 0) v *= p.scale;          // conv: (acc + bias + residual) * skip_scale
+                if (p.act == DS_ACT_SILU) v = ds_silu(v);
+                o_base[(size_t)row * p.ldo + col] = v;
+            }
+        }
+    }
+}
+
+template <int MODE>
+int launch(const KParams& p, int batch, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f32_kernel<MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, batch);
+    hipLaunchKernelGGL(igemm_f32_kernel<MODE>, grid, dim3(256), SMEM_BYTES, stream, p);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+}  // namespace
+
+extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
+    if (!a || !a->x0 || !a->wgt || !a->out) return DS_E_ARG;
+    if (a->taps != 1 && a->taps != 9) return DS_E_ARG;
+    if (a->c0 <= 0 || a->c0 % 32 || a->c1 < 0 || a->c1 % 32) return DS_E_SHAPE;
+    if (a->c1 && !a->x1) return DS_E_ARG;
+    if ((a->ld0 & 3) || (a->c1 && (a->ld1 & 3))) return DS_E_ALIGN;
+    if (!ds_aligned16(a->x0) || (a->c1 && !ds_aligned16(a->x1)) || !ds_aligned16(a->wgt)) return DS_E_ALIGN;
+    if (a->n <= 0 || a->h <= 0 || a->w <= 0 || a->cout <= 0) return DS_E_ARG;
+    const long long M = (long long)a->n * a->h * a->w;
+    if (M > 0x7fffffffLL - BM) return DS_E_SHAPE;
+    KParams p{};
+    p.a0 = a->x0; p.a1 = a->x1; p.c0 = a->c0; p.c1 = a->c1; p.lda0 = a->ld0; p.lda1 = a->ld1;
+    p.H = a->h; p.W = a->w; p.HW = a->h * a->w; p.taps = a->taps;
+    p.M = (int)M; p.N = a->cout; p.K = a->taps * (a->c0 + a->c1);
+    p.b = a->wgt; p.ldb = p.K; p.nrows_b = ((a->cout + BN - 1) / BN) * BN;   // weights are row-padded
+    p.out = a->out; p.ldo = a->out_ld;
+    p.colbias = a->bias; p.rowbias = nullptr;
+    p.cbias = a->cbias; p.cbias_ld = a->cbias_ld; p.cbias_bcast = (a->cbias_rows == 1);
+    p.res = a->res; p.res_ld = a->res_ld;
+    p.scale = a->out_scale; p.act = a->act; p.heads = 1;
+    return launch<0>(p, 1, (hipStream_t)stream);
+}
+
+extern "C" int ds_gemm_nt_batched(const ds_gemm_args* a, void* stream) {
+    if (!a || !a->a || !a->b || !a->c) return DS_E_ARG;
+    if (a->m <= 0 || a->n <= 0 || a->k <= 0 || a->batch <= 0 || a->heads <= 0) return DS_E_ARG;
+    if (a->k % 32) return DS_E_SHAPE;
+    if ((a->lda & 3) || (a->ldb & 3) || (a->a_bstride & 3) || (a->a_hstride & 3) || (a->b_bstride & 3) || (a->b_hstride & 3))
+        return DS_E_ALIGN;
+    if (!ds_aligned16(a->a) || !ds_aligned16(a->b)) return DS_E_ALIGN;
+    KParams p{};
+    p.a0 = a->a; p.lda0 = a->lda; p.a_bs = a->a_bstride; p.a_hs = a->a_hstride;
+    p.b = a->b; p.ldb = a->ldb; p.b_bs = a->b_bstride; p.b_hs = a->b_hstride; p.nrows_b = a->n;
+    p.out = a->c; p.ldo = a->ldc; p.o_bs = a->c_bstride; p.o_hs = a->c_hstride;
+    p.M = a->m; p.N = a->n; p.K = a->k; p.HW = 1; p.H = p.W = 1; p.taps = 1; p.c0 = a->k; p.c1 = 0;
+    p.colbias = a->colbias; p.rowbias = a->rowbias; p.cbias = nullptr; p.res = nullptr;
+    p.scale = a->alpha; p.act = a->act; p.heads = a->heads;
+    return launch<1>(p, a->batch * a->heads, (hipStream_t)stream);
+}

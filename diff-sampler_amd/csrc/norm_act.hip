@@ -1,0 +1,285 @@
+// HBM-bound kernels of the denoiser: GroupNorm statistics, fused normalise+affine+SiLU+resample, row softmax,
+// noise embedding, stem im2col, channel mean.  NHWC fp32, float4 (16 B / lane) accesses everywhere, channels are the
+// fastest dimension so a wave reads whole 1 KiB pixel rows.
+#include "ds_common.h"
+
+namespace {
+
+// --------------------------------------------------------------------------------------------------------------
+// GroupNorm statistics.  One block per image; thread t owns channel quad (t % CQ) and walks pixels t / CQ, t / CQ + PL, ...
+// Sums are kept in fp64 (one pass, no cancellation problem in E[x^2] - E[x]^2), reduced through LDS atomics per group.
+__global__ void __launch_bounds__(1024) gn_stats_kernel(const ds_norm_args a, int CQ, int PL) {
+    __shared__ double s_sum[64];
+    __shared__ double s_sq[64];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x;
+    if (tid < 64) { s_sum[tid] = 0.0; s_sq[tid] = 0.0; }
+    __syncthreads();
+    const int C = a.c0 + a.c1;
+    const int cpg = C / a.groups;
+    const int HW = a.h * a.w;
+    const int cq = tid % CQ, pl = tid / CQ;
+    if (pl < PL) {
+        const int c = cq * 4;
+        const float* src; int ld;
+        if (c < a.c0) { src = a.x0 + c; ld = a.ld0; } else { src = a.x1 + (c - a.c0); ld = a.ld1; }
+        src += (size_t)n * HW * ld;
+        double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+        for (int p = pl; p < HW; p += PL) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)p * ld);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[j] += (double)v[j]; q[j] += (double)v[j] * (double)v[j]; }
+        }
+        // merge the channels of this quad that fall in the same group before touching LDS
+        int g_prev = c / cpg;
+        double ss = s[0], qq = q[0];
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+            const int g = (c + j) / cpg;
+            if (g != g_prev) {
+                atomicAdd(&s_sum[g_prev], ss); atomicAdd(&s_sq[g_prev], qq);
+                ss = 0.0; qq = 0.0; g_prev = g;
+            }
+            ss += s[j]; qq += q[j];
+        }
+        atomicAdd(&s_sum[g_prev], ss); atomicAdd(&s_sq[g_prev], qq);
+    }
+    __syncthreads();
+    if (tid < a.groups) {
+        const double cnt = (double)cpg * (double)HW;
+        const double mean = s_sum[tid] / cnt;
+        double var = s_sq[tid] / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        a.mean[(size_t)n * a.groups + tid] = (float)mean;
+        a.rstd[(size_t)n * a.groups + tid] = (float)(1.0 / sqrt(var + (double)a.eps));
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// y = resample(act((x - mean) * A + B)).  grid = (pixel chunks, images); thread = (channel quad, pixel lane).
+__global__ void __launch_bounds__(1024) norm_act_kernel(const ds_norm_args a, int CQ, int PL, int chunk) {
+    const int tid = threadIdx.x;
+    const int n = blockIdx.y;
+    const int cq = tid % CQ, pl = tid / CQ;
+    if (pl >= PL) return;
+    const int C = a.c0 + a.c1;
+    const int c = cq * 4;
+    const float* src; int ld;
+    if (c < a.c0) { src = a.x0 + c; ld = a.ld0; } else { src = a.x1 + (c - a.c0); ld = a.ld1; }
+    const int H = a.h, W = a.w;
+    src += (size_t)n * H * W * ld;
+
+    float mu[4], A[4], Bc[4];
+    const int cpg = a.mean ? C / a.groups : 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float m = 0.f, r = 1.f;
+        if (a.mean) { const int g = (c + j) / cpg; m = a.mean[(size_t)n * a.groups + g]; r = a.rstd[(size_t)n * a.groups + g]; }
+        const float gm = a.gamma ? a.gamma[c + j] : 1.f;
+        const float bt = a.beta ? a.beta[c + j] : 0.f;
+        float sc1 = 1.f, sh = 0.f;
+        if (a.scale) {
+            const size_t row = (a.ss_rows == 1) ? 0 : (size_t)n;
+            sc1 = a.scale[row * a.ss_ld + c + j] + 1.f;
+            sh = a.shift[row * a.ss_ld + c + j];
+        }
+        mu[j] = m; A[j] = r * gm * sc1; Bc[j] = bt * sc1 + sh;
+    }
+    const bool identity = !a.mean && !a.gamma && !a.scale;
+    auto xf = [&](const f32x4 v) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float t = identity ? v[j] : (v[j] - mu[j]) * A[j] + Bc[j];
+            o[j] = (a.act == DS_ACT_SILU) ? ds_silu(t) : t;
+        }
+        return o;
+    };
+
+    const int OH = (a.resample == DS_RESAMPLE_DOWN) ? H / 2 : (a.resample == DS_RESAMPLE_UP ? H * 2 : H);
+    const int OW = (a.resample == DS_RESAMPLE_DOWN) ? W / 2 : (a.resample == DS_RESAMPLE_UP ? W * 2 : W);
+    float* dst = a.out + (size_t)n * OH * OW * a.out_ld + c;
+    const int p_begin = blockIdx.x * chunk;
+    const int p_end = min(p_begin + chunk, OH * OW);
+    for (int p = p_begin + pl; p < p_end; p += PL) {
+        f32x4 o;
+        if (a.resample == DS_RESAMPLE_NONE) {
+            o = xf(*reinterpret_cast<const f32x4*>(src + (size_t)p * ld));
+        } else if (a.resample == DS_RESAMPLE_UP) {
+            const int oh = p / OW, ow = p - oh * OW;
+            o = xf(*reinterpret_cast<const f32x4*>(src + (size_t)((oh >> 1) * W + (ow >> 1)) * ld));
+        } else {
+            const int oh = p / OW, ow = p - oh * OW;
+            const float* s0 = src + (size_t)((2 * oh) * W + 2 * ow) * ld;
+            const f32x4 v00 = xf(*reinterpret_cast<const f32x4*>(s0));
+            const f32x4 v01 = xf(*reinterpret_cast<const f32x4*>(s0 + ld));
+            const f32x4 v10 = xf(*reinterpret_cast<const f32x4*>(s0 + (size_t)W * ld));
+            const f32x4 v11 = xf(*reinterpret_cast<const f32x4*>(s0 + (size_t)W * ld + ld));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = ((v00[j] + v01[j]) + (v10[j] + v11[j])) * 0.25f;
+        }
+        *reinterpret_cast<f32x4*>(dst + (size_t)p * a.out_ld) = o;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// Row softmax: one wave per row, 4 rows per block.
+__global__ void __launch_bounds__(256) softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y, long long rows,
+                                                           int cols, int ld) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * ld;
+    float* yr = y + row * ld;
+    float mx = -INFINITY;
+    for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, xr[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int c = lane; c < cols; c += 64) sum += __expf(xr[c] - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+    for (int c = lane; c < cols; c += 64) yr[c] = __expf(xr[c] - mx) * inv;
+}
+
+// --------------------------------------------------------------------------------------------------------------
+__global__ void noise_embed_kernel(const float* __restrict__ sigma, int bs, const float* __restrict__ freqs, int nch, int swap,
+                                   float* __restrict__ out, int out_ld) {
+    const int half = nch / 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= bs * half) return;
+    const int b = idx / half, i = idx - b * half;
+    const float cn = logf(sigma[b]) / 4.0f;       // c_noise (networks_edm.py:491)
+    const float ang = cn * freqs[i];
+    const float cs = cosf(ang), sn = sinf(ang);
+    float* o = out + (size_t)b * out_ld;
+    if (swap) { o[i] = sn; o[half + i] = cs; } else { o[i] = cs; o[half + i] = sn; }
+}
+
+// rows = pixels; k = tap*c + ch, zero-padded to kpad.
+__global__ void stem_im2col_kernel(const float* __restrict__ x, const float* __restrict__ sigma, int sigma_rows, float sd,
+                                   int n, int c, int h, int w, float* __restrict__ out, int kpad) {
+    const long long total = (long long)n * h * w * kpad;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % kpad);
+        const long long pix = idx / kpad;
+        const int ow = (int)(pix % w);
+        const int oh = (int)((pix / w) % h);
+        const int img = (int)(pix / ((long long)w * h));
+        float v = 0.f;
+        if (k < 9 * c) {
+            const int tap = k / c, ch = k - tap * c;
+            const int ih = oh + tap / 3 - 1, iw = ow + tap % 3 - 1;
+            if ((unsigned)ih < (unsigned)h && (unsigned)iw < (unsigned)w) {
+                const float s = sigma[sigma_rows == 1 ? 0 : img];
+                v = ds_c_in(s, sd) * x[(((size_t)img * c + ch) * h + ih) * w + iw];
+            }
+        }
+        out[idx] = v;
+    }
+}
+
+__global__ void channel_mean_kernel(const float* __restrict__ x, int ld, int c, long long rows, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * ld;
+    float s = 0.f;
+    for (int i = lane; i < c; i += 64) s += xr[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[row] = s / (float)c;
+}
+
+int norm_geometry(const ds_norm_args* a, int* CQ, int* PL) {
+    const int C = a->c0 + a->c1;
+    if (C <= 0 || (C & 3) || (a->c0 & 3)) return DS_E_SHAPE;
+    if (C / 4 > 1024) return DS_E_SHAPE;
+    *CQ = C / 4;
+    *PL = 1024 / *CQ;
+    if (*PL > a->h * a->w) *PL = a->h * a->w;
+    if (*PL < 1) *PL = 1;
+    return DS_OK;
+}
+
+}  // namespace
+
+extern "C" int ds_gn_stats(const ds_norm_args* a, void* stream) {
+    if (!a || !a->x0 || !a->mean || !a->rstd) return DS_E_ARG;
+    if (a->groups <= 0 || a->groups > 64 || (a->c0 + a->c1) % a->groups) return DS_E_SHAPE;
+    if ((a->ld0 & 3) || (a->c1 && (a->ld1 & 3))) return DS_E_ALIGN;
+    int CQ, PL;
+    int rc = norm_geometry(a, &CQ, &PL);
+    if (rc) return rc;
+    int threads = CQ * PL;
+    threads = ((threads + 63) / 64) * 64;
+    if (threads < 64) threads = 64;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(a->n), dim3(threads), 0, (hipStream_t)stream, *a, CQ, PL);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+extern "C" int ds_norm_act(const ds_norm_args* a, void* stream) {
+    if (!a || !a->x0 || !a->out) return DS_E_ARG;
+    if ((a->mean == nullptr) != (a->rstd == nullptr)) return DS_E_ARG;
+    if ((a->scale == nullptr) != (a->shift == nullptr)) return DS_E_ARG;
+    if ((a->ld0 & 3) || (a->c1 && (a->ld1 & 3)) || (a->out_ld & 3)) return DS_E_ALIGN;
+    if (a->resample == DS_RESAMPLE_DOWN && ((a->h | a->w) & 1)) return DS_E_SHAPE;
+    int CQ, PL;
+    int rc = norm_geometry(a, &CQ, &PL);
+    if (rc) return rc;
+    const int OH = (a->resample == DS_RESAMPLE_DOWN) ? a->h / 2 : (a->resample == DS_RESAMPLE_UP ? a->h * 2 : a->h);
+    const int OW = (a->resample == DS_RESAMPLE_DOWN) ? a->w / 2 : (a->resample == DS_RESAMPLE_UP ? a->w * 2 : a->w);
+    if (PL > OH * OW) PL = OH * OW;
+    int threads = ((CQ * PL + 63) / 64) * 64;
+    // enough blocks per image to cover the chip even at small batch: aim for >= 2048 blocks in total
+    int chunks = (2048 + a->n - 1) / a->n;
+    const int max_chunks = (OH * OW + PL - 1) / PL;
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+    int chunk = (OH * OW + chunks - 1) / chunks;
+    chunk = ((chunk + PL - 1) / PL) * PL;
+    chunks = (OH * OW + chunk - 1) / chunk;
+    hipLaunchKernelGGL(norm_act_kernel, dim3(chunks, a->n), dim3(threads), 0, (hipStream_t)stream, *a, CQ, PL, chunk);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+extern "C" int ds_softmax_rows(const float* x, float* y, long long rows, int cols, int ld, void* stream) {
+    if (!x || !y || rows <= 0 || cols <= 0 || ld < cols) return DS_E_ARG;
+    const long long blocks = (rows + 3) / 4;
+    if (blocks > 0x7fffffffLL) return DS_E_SHAPE;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, rows, cols, ld);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+extern "C" int ds_noise_embed(const float* sigma, int bs, const float* freqs, int nch, int swap, float* out, int out_ld,
+                              void* stream) {
+    if (!sigma || !freqs || !out || bs <= 0 || nch <= 0 || (nch & 1)) return DS_E_ARG;
+    const int total = bs * (nch / 2);
+    hipLaunchKernelGGL(noise_embed_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, sigma, bs, freqs, nch,
+                       swap, out, out_ld);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+extern "C" int ds_stem_im2col(const float* x, const float* sigma, int sigma_rows, float sigma_data, int n, int c, int h, int w,
+                              float* out, int kpad, void* stream) {
+    if (!x || !sigma || !out || n <= 0 || c <= 0 || kpad < 9 * c || (kpad % 32)) return DS_E_ARG;
+    const long long total = (long long)n * h * w * kpad;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(stem_im2col_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, sigma, sigma_rows,
+                       sigma_data, n, c, h, w, out, kpad);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+extern "C" int ds_channel_mean(const float* x, int ld, int c, long long rows, float* out, void* stream) {
+    if (!x || !out || rows <= 0 || c <= 0) return DS_E_ARG;
+    hipLaunchKernelGGL(channel_mean_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ld, c, rows, out);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}

@@ -1,0 +1,306 @@
+// Solver-side kernels: fused EDM-precondition + ODE update (HBM bound, one pass over every operand), dynamic
+// thresholding (exact torch.quantile semantics via LDS radix select), latent scaling, uint8 quantisation.
+#include "ds_common.h"
+
+namespace {
+
+struct Coefs { float cx, cm, ch0, ch1, ch2, t, sig, pad; };
+
+__device__ __forceinline__ Coefs load_coefs(const ds_update_args& a, int img) {
+    Coefs c;
+    if (a.coefs) {
+        const float* r = a.coefs + (size_t)(a.coef_rows == 1 ? 0 : img) * 8;
+        c.cx = r[0]; c.cm = r[1]; c.ch0 = r[2]; c.ch1 = r[3]; c.ch2 = r[4]; c.t = r[5]; c.sig = r[6]; c.pad = 0.f;
+    } else {
+        c.cx = a.hcoefs[0]; c.cm = a.hcoefs[1]; c.ch0 = a.hcoefs[2]; c.ch1 = a.hcoefs[3]; c.ch2 = a.hcoefs[4];
+        c.t = a.hcoefs[5]; c.sig = a.hcoefs[6]; c.pad = 0.f;
+    }
+    return c;
+}
+
+// One thread = 4 consecutive pixels of one image, all channels.  Every NCHW plane access is a float4 (16 B/lane,
+// 1 KiB per wave instruction); the raw NHWC network output (3 or 4 channels, row = f_ld floats) is read as whole rows.
+template <int VEC>
+__global__ void __launch_bounds__(256) solver_update_kernel(const ds_update_args a) {
+    const int HW = a.h * a.w;
+    const int groups_per_img = HW / VEC;
+    const long long total = (long long)a.n * groups_per_img;
+    for (long long gidx = (long long)blockIdx.x * blockDim.x + threadIdx.x; gidx < total; gidx += (long long)gridDim.x * blockDim.x) {
+        const int img = (int)(gidx / groups_per_img);
+        const int p0 = (int)(gidx - (long long)img * groups_per_img) * VEC;
+        const Coefs k = load_coefs(a, img);
+        float cskip = 0.f, cout_ = 0.f;
+        if (a.raw) { cskip = ds_c_skip(k.sig, a.sigma_data); cout_ = ds_c_out(k.sig, a.sigma_data); }
+        const float afs_div = sqrtf(1.0f + k.t * k.t);
+        for (int ch = 0; ch < a.c; ++ch) {
+            const size_t off = ((size_t)img * a.c + ch) * HW + p0;
+            float xe[VEC], xb[VEC], f[VEC], h0[VEC], h1[VEC], h2[VEC];
+            if (VEC == 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(a.xe + off);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) xe[j] = v[j];
+            } else {
+                xe[0] = a.xe[off];
+            }
+            if (a.xb != a.xe) {
+                if (VEC == 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(a.xb + off);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) xb[j] = v[j];
+                } else {
+                    xb[0] = a.xb[off];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) xb[j] = xe[j];
+            }
+            if (!a.afs) {
+                if (a.raw) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) f[j] = a.f[((size_t)img * HW + p0 + j) * a.f_ld + ch];
+                } else if (VEC == 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(a.f + off);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) f[j] = v[j];
+                } else {
+                    f[0] = a.f[off];
+                }
+            }
+            auto ldh = [&](const float* hp, float (&dst)[VEC]) {
+                if (!hp) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) dst[j] = 0.f;
+                } else if (VEC == 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(hp + off);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) dst[j] = v[j];
+                } else {
+                    dst[0] = hp[off];
+                }
+            };
+            ldh(a.hist[0], h0); ldh(a.hist[1], h1); ldh(a.hist[2], h2);
+
+            float m[VEC], xo[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float D, d;
+                if (a.afs) {
+                    d = xe[j] / afs_div;                          // solvers.py:77
+                    D = xe[j] - k.t * d;                          // solvers.py:680
+                } else {
+                    D = a.raw ? cskip * xe[j] + cout_ * f[j] : f[j];   // networks_edm.py:495
+                    d = (xe[j] - D) / k.t;                        // solvers.py:80
+                }
+                m[j] = a.store_d ? d : D;
+                float acc = k.cx * xb[j] + k.cm * m[j];
+                if (a.hist[0]) acc += k.ch0 * h0[j];
+                if (a.hist[1]) acc += k.ch1 * h1[j];
+                if (a.hist[2]) acc += k.ch2 * h2[j];
+                xo[j] = acc;
+            }
+            if (VEC == 4) {
+                if (a.m_out) { f32x4 v = {m[0], m[1], m[2], m[3]}; *reinterpret_cast<f32x4*>(a.m_out + off) = v; }
+                if (a.x_out) { f32x4 v = {xo[0], xo[1], xo[2], xo[3]}; *reinterpret_cast<f32x4*>(a.x_out + off) = v; }
+            } else {
+                if (a.m_out) a.m_out[off] = m[0];
+                if (a.x_out) a.x_out[off] = xo[0];
+            }
+        }
+    }
+}
+
+__global__ void table_select_kernel(const float* __restrict__ table, int row_floats, int* __restrict__ step, int advance,
+                                    float* __restrict__ dst) {
+    const int s = *step;
+    for (int i = threadIdx.x; i < row_floats; i += blockDim.x) dst[i] = table[(size_t)s * row_floats + i];
+    __syncthreads();
+    if (advance && threadIdx.x == 0) *step = s + 1;
+}
+
+__global__ void __launch_bounds__(256) scale_kernel(const float* __restrict__ x, float a, float* __restrict__ y, long long count) {
+    const long long n4 = count >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        v *= a;
+        reinterpret_cast<f32x4*>(y)[i] = v;
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) y[i] = a * x[i];
+}
+
+__global__ void __launch_bounds__(256) copy_rows_kernel(const float* __restrict__ src, int src_ld, float* __restrict__ dst, int dst_ld,
+                                                        long long rows, int cols) {
+    const long long total = rows * cols;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / cols;
+        const int c = (int)(i - r * cols);
+        dst[r * dst_ld + c] = src[r * src_ld + c];
+    }
+}
+
+__global__ void __launch_bounds__(256) quantize_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, int n, int c, int h, int w) {
+    const long long total = (long long)n * h * w;
+    const int HW = h * w;
+    for (long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (long long)gridDim.x * blockDim.x) {
+        const int img = (int)(pix / HW);
+        const int p = (int)(pix - (long long)img * HW);
+        for (int ch = 0; ch < c; ++ch) {
+            float v = x[((size_t)img * c + ch) * HW + p] * 127.5f + 128.0f;
+            v = fminf(fmaxf(v, 0.0f), 255.0f);
+            out[pix * c + ch] = (uint8_t)v;        // truncation, like .to(torch.uint8) (sample.py:311)
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// Dynamic thresholding.  One block per sample.  |x| bit patterns are staged in LDS; an 8-bit-digit radix select
+// finds the two order statistics around rank p*(n-1); torch.quantile's linear interpolation (lerp) follows.
+__device__ unsigned radix_select(const unsigned* vals, int n, unsigned rank, unsigned* hist) {
+    unsigned prefix = 0, mask = 0;
+    for (int pass = 3; pass >= 0; --pass) {
+        const int shift = pass * 8;
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const unsigned v = vals[i];
+            if ((v & mask) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        // every thread scans the 256-bin histogram (uniform result, no extra barrier data hazards)
+        unsigned cum = 0, digit = 0, before = 0;
+        for (int b = 0; b < 256; ++b) {
+            const unsigned hcount = hist[b];
+            if (cum + hcount > rank) { digit = b; before = cum; break; }
+            cum += hcount;
+        }
+        rank -= before;
+        prefix |= digit << shift;
+        mask |= 255u << shift;
+        __syncthreads();
+    }
+    return prefix;
+}
+
+__global__ void __launch_bounds__(512) dynamic_threshold_kernel(const float* __restrict__ x0, float* __restrict__ out, int per, float p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned sm[];
+    unsigned* vals = sm;
+    unsigned* hist = sm + per;
+    __shared__ unsigned s_cnt;
+    __shared__ unsigned s_min;
+    const float* x = x0 + (size_t)blockIdx.x * per;
+    float* y = out + (size_t)blockIdx.x * per;
+    for (int i = threadIdx.x; i < per; i += blockDim.x) vals[i] = __float_as_uint(fabsf(x[i]));
+    if (threadIdx.x == 0) { s_cnt = 0; s_min = 0xffffffffu; }
+    __syncthreads();
+    const float rank = p * (float)(per - 1);        // fp32, as ATen computes it
+    const float lo_f = floorf(rank);
+    const float w = rank - lo_f;
+    const unsigned lo = (unsigned)lo_f;
+    const unsigned hi = (unsigned)ceilf(rank);
+    const unsigned v_lo = radix_select(vals, per, lo, hist);
+    unsigned v_hi = v_lo;
+    if (hi != lo) {
+        unsigned cnt = 0, mn = 0xffffffffu;
+        for (int i = threadIdx.x; i < per; i += blockDim.x) {
+            const unsigned v = vals[i];
+            if (v <= v_lo) ++cnt; else mn = min(mn, v);
+        }
+        atomicAdd(&s_cnt, cnt);
+        atomicMin(&s_min, mn);
+        __syncthreads();
+        v_hi = (s_cnt >= hi + 1) ? v_lo : s_min;
+    }
+    const float a = __uint_as_float(v_lo), b = __uint_as_float(v_hi);
+    // at::lerp: weight < 0.5 ? a + w (b - a) : b - (b - a) (1 - w)
+    float s = (w < 0.5f) ? a + w * (b - a) : b - (b - a) * (1.0f - w);
+    s = fmaxf(s, 1.0f);
+    for (int i = threadIdx.x; i < per; i += blockDim.x) {
+        const float v = fminf(fmaxf(x[i], -s), s);
+        y[i] = v / s;
+    }
+}
+
+}  // namespace
+
+extern "C" int ds_solver_update(const ds_update_args* a, void* stream) {
+    if (!a || !a->xe || !a->xb) return DS_E_ARG;
+    if (!a->afs && !a->f) return DS_E_ARG;
+    if (!a->x_out && !a->m_out) return DS_E_ARG;
+    if (a->n <= 0 || a->c <= 0 || a->h <= 0 || a->w <= 0) return DS_E_ARG;
+    if (a->coefs && a->coef_rows != 1 && a->coef_rows != a->n) return DS_E_ARG;
+    const int HW = a->h * a->w;
+    bool vec4 = (HW % 4 == 0) && ds_aligned16(a->xe) && ds_aligned16(a->xb) && (a->raw || !a->f || ds_aligned16(a->f)) &&
+                (!a->x_out || ds_aligned16(a->x_out)) && (!a->m_out || ds_aligned16(a->m_out));
+    for (int i = 0; i < 3; ++i) if (a->hist[i] && !ds_aligned16(a->hist[i])) vec4 = false;
+    const long long work = (long long)a->n * (vec4 ? HW / 4 : HW);
+    long long blocks = (work + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (vec4) hipLaunchKernelGGL(solver_update_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL(solver_update_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+extern "C" int ds_table_select(const float* table, int row_floats, int* step, int advance, float* dst, void* stream) {
+    if (!table || !step || !dst || row_floats <= 0) return DS_E_ARG;
+    hipLaunchKernelGGL(table_select_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, table, row_floats, step, advance, dst);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+extern "C" int ds_dynamic_threshold(const float* x0, float* out, int n, int per, float p, void* stream) {
+    if (!x0 || !out || n <= 0 || per <= 1) return DS_E_ARG;
+    const size_t smem = ((size_t)per + 256) * sizeof(unsigned);
+    if (smem > 150 * 1024) return DS_E_SHAPE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dynamic_threshold_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(dynamic_threshold_kernel, dim3(n), dim3(512), smem, (hipStream_t)stream, x0, out, per, p);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+extern "C" int ds_scale(const float* x, float a, float* y, long long count, void* stream) {
+    if (!x || !y || count <= 0) return DS_E_ARG;
+    if (!ds_aligned16(x) || !ds_aligned16(y)) return DS_E_ALIGN;
+    long long blocks = ((count >> 2) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, a, y, count);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+extern "C" int ds_quantize_u8_nhwc(const float* x, uint8_t* out, int n, int c, int h, int w, void* stream) {
+    if (!x || !out || n <= 0 || c <= 0) return DS_E_ARG;
+    long long blocks = ((long long)n * h * w + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, out, n, c, h, w);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+extern "C" int ds_copy_rows(const float* src, int src_ld, float* dst, int dst_ld, long long rows, int cols, void* stream) {
+    if (!src || !dst || rows <= 0 || cols <= 0) return DS_E_ARG;
+    long long blocks = (rows * cols + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, src_ld, dst, dst_ld, rows, cols);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+extern "C" int ds_version(void) { return 1; }
+
+extern "C" const char* ds_error_string(int code) {
+    switch (code) {
+        case DS_OK: return "ok";
+        case DS_E_ARG: return "invalid argument";
+        case DS_E_ALIGN: return "pointer or leading dimension not 16-byte aligned";
+        case DS_E_SHAPE: return "unsupported shape";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}

@@ -1,0 +1,486 @@
+"""Denoiser engine: compiles a ``UNetSpec`` + reference-keyed weights into a flat launch plan of libdsamd kernels.
+
+What it replaces: ``EDMPrecond.forward`` -> ``SongUNet/DhariwalUNet.forward`` -> ``UNetBlock.forward``
+(diff-solvers-main/models/networks_edm.py:482-496, :312-355, :427-453, :158-179), i.e. the ~600 ATen launches per
+network evaluation of the reference, by ~10 hand-written launches per block:
+
+    GN stats -> normalise+SiLU(+resample) -> 3x3 implicit GEMM (+bias +emb) -> GN stats -> normalise+SiLU
+      -> 3x3 implicit GEMM (+bias +skip +scale)   [+ 1x1 skip projection, + attention: 1x1 qk, V^T, QK^T, softmax, PV, proj]
+
+Activations are NHWC fp32 and live in engine-owned workspaces (allocated once per batch size through torch, which
+is only the allocator here); the decoder's ``torch.cat`` is never materialised (both sources are read in place).
+The plan is a list of (C function, prebuilt argument struct): running it is a tight ctypes loop, and because no
+pointer changes between calls it can be captured in a hipGraph (see ``graph.py``).
+
+``EDMDenoiser`` is the drop-in for the reference ``net`` object: same call signature and attributes
+(``img_resolution, img_channels, label_dim, sigma_min, sigma_max``) plus the raw fast path the fused solvers use.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib, arch
+from ._lib import (ConvArgs, GemmArgs, NormArgs, DS_ACT_NONE, DS_ACT_SILU, DS_RESAMPLE_NONE, DS_RESAMPLE_DOWN,
+                   DS_RESAMPLE_UP)
+from .ops import pack_conv_weight, pack_linear_weight
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class _Op:
+    """One launch: C entry point + argument tuple (struct by reference or scalars)."""
+    __slots__ = ('fn', 'args', 'name', 'keep')
+
+    def __init__(self, fn, args, name, keep=()):
+        self.fn, self.args, self.name, self.keep = fn, args, name, keep
+
+
+class _Plan:
+    def __init__(self):
+        self.ops: List[_Op] = []
+        self.bufs: Dict[str, torch.Tensor] = {}
+
+    def run(self, stream):
+        for op in self.ops:
+            rc = op.fn(*op.args, stream)
+            if rc:
+                _lib.check(rc, op.name)
+
+
+class UNetEngine:
+    def __init__(self, spec: arch.UNetSpec, params: Dict[str, torch.Tensor], device='cuda'):
+        self.spec = spec
+        self.device = torch.device(device)
+        self.lib = _lib.load()
+        self._plans: Dict[tuple, _Plan] = {}
+        self._pack(params)
+
+    # ------------------------------------------------------------------------------------------ weights
+    def _pack(self, params):
+        spec, dev = self.spec, self.device
+        g = lambda k: params[k].detach().to(device=dev, dtype=torch.float32)
+        w: Dict[str, torch.Tensor] = {}
+        m = 'model'
+        song = spec.model_type == 'SongUNet'
+        # embedding MLP
+        half = spec.noise_channels // 2
+        freqs = torch.arange(0, half, dtype=torch.float32)
+        freqs = freqs / (half - (1 if spec.pos_endpoint else 0))
+        freqs = (1 / spec.pos_max_positions) ** freqs            # exactly networks_edm.py:193-195, on the host
+        w['freqs'] = freqs.to(dev)
+        w['map0.w'] = pack_linear_weight(g(f'{m}.map_layer0.weight')); w['map0.b'] = g(f'{m}.map_layer0.bias')
+        w['map1.w'] = pack_linear_weight(g(f'{m}.map_layer1.weight')); w['map1.b'] = g(f'{m}.map_layer1.bias')
+        if spec.label_dim:
+            wl = g(f'{m}.map_label.weight')
+            if song:
+                wl = wl * math.sqrt(spec.label_dim)              # class_labels * sqrt(in_features), networks_edm.py:320
+            w['label.w'] = pack_linear_weight(wl)
+            w['label.b'] = g(f'{m}.map_label.bias') if f'{m}.map_label.bias' in params else None
+        # per-block affine layers, concatenated into one GEMM
+        aff_w, aff_b, off = [], [], 0
+        self.aff_off: Dict[str, int] = {}
+        for b in spec.blocks:
+            if b.kind != 'block':
+                continue
+            p = f'{m}.{b.name}'
+            aff_w.append(g(f'{p}.affine.weight')); aff_b.append(g(f'{p}.affine.bias'))
+            self.aff_off[b.name] = off
+            off += aff_w[-1].shape[0]
+        self.aff_total = off
+        w['aff.w'] = pack_linear_weight(torch.cat(aff_w, 0)); w['aff.b'] = torch.cat(aff_b, 0).contiguous()
+        # blocks
+        for b in spec.blocks:
+            p = f'{m}.{b.name}'
+            if b.kind == 'conv':
+                w[f'{b.name}.w'] = pack_conv_weight(g(f'{p}.weight')); w[f'{b.name}.b'] = g(f'{p}.bias')
+                continue
+            for leaf in ('norm0', 'norm1'):
+                w[f'{b.name}.{leaf}.g'] = g(f'{p}.{leaf}.weight'); w[f'{b.name}.{leaf}.b'] = g(f'{p}.{leaf}.bias')
+            w[f'{b.name}.conv0.w'] = pack_conv_weight(g(f'{p}.conv0.weight')); w[f'{b.name}.conv0.b'] = g(f'{p}.conv0.bias')
+            w[f'{b.name}.conv1.w'] = pack_conv_weight(g(f'{p}.conv1.weight')); w[f'{b.name}.conv1.b'] = g(f'{p}.conv1.bias')
+            if b.skip_conv:
+                w[f'{b.name}.skip.w'] = pack_conv_weight(g(f'{p}.skip.weight')); w[f'{b.name}.skip.b'] = g(f'{p}.skip.bias')
+            if b.heads:
+                c, h = b.cout, b.heads
+                ch = c // h
+                w[f'{b.name}.norm2.g'] = g(f'{p}.norm2.weight'); w[f'{b.name}.norm2.b'] = g(f'{p}.norm2.bias')
+                # reference layout of the 3C output channels: index = (head*ch + c)*3 + {q,k,v}  (networks_edm.py:174)
+                wq = g(f'{p}.qkv.weight').reshape(h, ch, 3, c)
+                bq = g(f'{p}.qkv.bias').reshape(h, ch, 3)
+                w[f'{b.name}.qk.w'] = pack_linear_weight(torch.cat([wq[:, :, 0].reshape(c, c), wq[:, :, 1].reshape(c, c)], 0))
+                w[f'{b.name}.qk.b'] = torch.cat([bq[:, :, 0].reshape(c), bq[:, :, 1].reshape(c)], 0).contiguous()
+                w[f'{b.name}.v.w'] = wq[:, :, 2].reshape(c, c).contiguous()
+                w[f'{b.name}.v.b'] = bq[:, :, 2].reshape(c).contiguous()
+                w[f'{b.name}.proj.w'] = pack_conv_weight(g(f'{p}.proj.weight')); w[f'{b.name}.proj.b'] = g(f'{p}.proj.bias')
+        w['out.g'] = g(f'{m}.{spec.out_norm}.weight'); w['out.b'] = g(f'{m}.{spec.out_norm}.bias')
+        w['outc.w'] = pack_conv_weight(g(f'{m}.{spec.out_conv}.weight')); w['outc.b'] = g(f'{m}.{spec.out_conv}.bias')
+        self.w = w
+
+    # ------------------------------------------------------------------------------------------ plan
+    def plan(self, B: int, emb_rows: int) -> _Plan:
+        key = (B, emb_rows)
+        if key in self._plans:
+            return self._plans[key]
+        spec, dev, w, lib = self.spec, self.device, self.w, self.lib
+        P = _Plan()
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        R = spec.img_resolution
+        Bs = emb_rows
+        E, NC = spec.emb_channels, spec.noise_channels
+        kpad = -(-9 * spec.in_channels // 32) * 32
+        song = spec.model_type == 'SongUNet'
+
+        # ---- inputs / outputs -------------------------------------------------------------------------------
+        bufs = P.bufs
+        bufs['x'] = new(B, spec.in_channels, R, R)           # NCHW, un-scaled (c_in is applied by the stem)
+        bufs['sigma'] = new(B)                                # per-sample sigma (row 0 only when Bs == 1 and scalar)
+        bufs['sigma_rows'] = torch.zeros(1, dtype=torch.int32, device=dev)
+        bufs['out'] = new(B * R * R, 4)                       # raw network output F, NHWC rows padded to 4 floats
+        if spec.label_dim:
+            lpad = -(-spec.label_dim // 32) * 32
+            bufs['labels'] = torch.zeros(Bs, lpad, dtype=torch.float32, device=dev)
+
+        # ---- workspace sizing -------------------------------------------------------------------------------
+        max_act = kpad * R * R
+        max_h = 0
+        max_attn = 0
+        max_sc = 0
+        for b in spec.blocks:
+            if b.kind != 'block':
+                max_h = max(max_h, b.cout * b.res_out ** 2)
+                continue
+            hw = b.res_out ** 2
+            max_act = max(max_act, b.cin * hw, b.cout * hw)
+            max_h = max(max_h, b.cout * hw, b.cin * hw)
+            if b.heads:
+                max_attn = max(max_attn, 2 * b.cout * hw)
+                max_sc = max(max_sc, b.heads * hw * hw)
+        act = new(B * max_act)
+        hbuf = new(B * max_h)
+        sres = new(B * max_h)            # resampled skip-path input
+        sproj = new(B * max_h)           # projected skip
+        mean = new(B * 64); rstd = new(B * 64)
+        if max_attn:
+            n2 = new(B * max_attn // 2); qk = new(B * max_attn); vt = new(B * max_attn // 2)
+            ao = new(B * max_attn // 2); sc = new(B * max_sc)
+        bufs.update(act=act, hbuf=hbuf, sres=sres, sproj=sproj)
+
+        def add(fn, args, name, keep=()):
+            P.ops.append(_Op(fn, args, name, keep))
+
+        def conv(x0, c0, ld0, n, h, wd, wgt, cout, out, out_ld, taps, name, x1=None, c1=0, ld1=0, bias=None, cbias=None,
+                 cbias_ld=0, cbias_rows=1, res=None, res_ld=0, scale=1.0, act_=DS_ACT_NONE):
+            a = ConvArgs(_ptr(x0), _ptr(x1), c0, c1, ld0, ld1, n, h, wd, taps, _ptr(wgt), cout, _ptr(bias), _ptr(cbias),
+                         cbias_ld, cbias_rows, _ptr(res), res_ld, scale, act_, _ptr(out), out_ld)
+            add(lib.ds_conv2d_nhwc, (C.byref(a),), name, keep=(a,))
+
+        def norm(kind, x0, c0, ld0, n, h, wd, name, x1=None, c1=0, ld1=0, groups=1, eps=1e-5, use_stats=True, gamma=None,
+                 beta=None, scale=None, shift=None, ss_ld=0, ss_rows=1, act_=DS_ACT_NONE, resample=DS_RESAMPLE_NONE,
+                 out=None, out_ld=0):
+            a = NormArgs(_ptr(x0), _ptr(x1), c0, c1, ld0, ld1, n, h, wd, groups, eps,
+                         _ptr(mean) if use_stats else None, _ptr(rstd) if use_stats else None, _ptr(gamma), _ptr(beta),
+                         _ptr(scale), _ptr(shift), ss_ld, ss_rows, act_, resample, _ptr(out), out_ld)
+            add(lib.ds_gn_stats if kind == 'stats' else lib.ds_norm_act, (C.byref(a),), name, keep=(a,))
+
+        def gemm(a_, lda, b_, ldb, c_, ldc, m_, n_, k_, name, batch=1, heads=1, a_bs=0, a_hs=0, b_bs=0, b_hs=0, c_bs=0, c_hs=0,
+                 alpha=1.0, rowbias=None, colbias=None):
+            g_ = GemmArgs(_ptr(a_), lda, a_bs, a_hs, _ptr(b_), ldb, b_bs, b_hs, _ptr(c_), ldc, c_bs, c_hs, m_, n_, k_, batch,
+                          heads, alpha, _ptr(rowbias), _ptr(colbias), DS_ACT_NONE)
+            add(lib.ds_gemm_nt_batched, (C.byref(g_),), name, keep=(g_,))
+
+        # ---- embedding path (networks_edm.py:314-324 / :429-439) -----------------------------------------------
+        pos = new(Bs, NC); e0 = new(Bs, E); emb = new(Bs, E); aff = new(Bs, self.aff_total)
+        add(lib.ds_noise_embed, (_ptr(bufs['sigma']), Bs, _ptr(w['freqs']), NC, int(spec.swap_sincos), _ptr(pos), NC), 'noise_embed')
+        if song:
+            src = pos
+            if spec.label_dim:
+                pos2 = new(Bs, NC)
+                conv(bufs['labels'], bufs['labels'].shape[1], bufs['labels'].shape[1], Bs, 1, 1, w['label.w'], NC, pos2, NC, 1,
+                     'map_label', bias=w['label.b'], res=pos, res_ld=NC)
+                src = pos2
+            conv(src, NC, NC, Bs, 1, 1, w['map0.w'], E, e0, E, 1, 'map_layer0', bias=w['map0.b'], act_=DS_ACT_SILU)
+            conv(e0, E, E, Bs, 1, 1, w['map1.w'], E, emb, E, 1, 'map_layer1', bias=w['map1.b'], act_=DS_ACT_SILU)
+        else:
+            conv(pos, NC, NC, Bs, 1, 1, w['map0.w'], E, e0, E, 1, 'map_layer0', bias=w['map0.b'], act_=DS_ACT_SILU)
+            lab = None
+            if spec.label_dim:
+                lab = new(Bs, E)
+                conv(bufs['labels'], bufs['labels'].shape[1], bufs['labels'].shape[1], Bs, 1, 1, w['label.w'], E, lab, E, 1,
+                     'map_label', bias=w['label.b'])
+            conv(e0, E, E, Bs, 1, 1, w['map1.w'], E, emb, E, 1, 'map_layer1', bias=w['map1.b'], res=lab, res_ld=E,
+                 act_=DS_ACT_SILU)
+        conv(emb, E, E, Bs, 1, 1, w['aff.w'], self.aff_total, aff, self.aff_total, 1, 'affine_all', bias=w['aff.b'])
+        bufs.update(emb=emb, aff=aff)
+
+        # ---- stem ---------------------------------------------------------------------------------------------
+        x_cur = None          # (tensor, channels)
+        skips: List[tuple] = []
+        dec_pp = [None, None]
+        dec_i = 0
+        for b in spec.blocks:
+            n, Hin, Ho = B, b.res_in, b.res_out
+            M = B * Ho * Ho
+            if b.kind == 'conv':
+                add(lib.ds_stem_im2col, (_ptr(bufs['x']), _ptr(bufs['sigma']), Bs, spec.sigma_data, B, spec.in_channels, R, R,
+                                         _ptr(act), kpad), 'stem_im2col')
+                out = new(M, b.cout)
+                conv(act, kpad, kpad, B, R, R, w[f'{b.name}.w'], b.cout, out, b.cout, 1, b.name, bias=w[f'{b.name}.b'])
+                x_cur = (out, b.cout)
+                skips.append(x_cur)
+                bufs[b.name] = out
+                continue
+            # sources of this block's input
+            x0, c0 = x_cur
+            x1, c1 = (None, 0)
+            if b.pops_skip:
+                x1, c1 = skips.pop()
+                assert c1 == b.skip_cin and c0 + c1 == b.cin
+            cin, cout = b.cin, b.cout
+            G_in, G_out = arch.num_groups(cin), arch.num_groups(cout)
+            rs = DS_RESAMPLE_DOWN if b.down else (DS_RESAMPLE_UP if b.up else DS_RESAMPLE_NONE)
+            nm = b.name
+            # norm0 + silu (+resample) -> act
+            norm('stats', x0, c0, c0, n, Hin, Hin, nm + '.norm0.stats', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps)
+            norm('apply', x0, c0, c0, n, Hin, Hin, nm + '.norm0', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps,
+                 gamma=w[f'{nm}.norm0.g'], beta=w[f'{nm}.norm0.b'], act_=DS_ACT_SILU, resample=rs, out=act, out_ld=cin)
+            # conv0 (+bias, + per-image embedding for the non-adaptive variant)
+            aoff = self.aff_off[nm]
+            if b.adaptive_scale:
+                conv(act, cin, cin, n, Ho, Ho, w[f'{nm}.conv0.w'], cout, hbuf, cout, 9, nm + '.conv0', bias=w[f'{nm}.conv0.b'])
+            else:
+                conv(act, cin, cin, n, Ho, Ho, w[f'{nm}.conv0.w'], cout, hbuf, cout, 9, nm + '.conv0', bias=w[f'{nm}.conv0.b'],
+                     cbias=aff[:, aoff:], cbias_ld=self.aff_total, cbias_rows=Bs)
+            # norm1 (+adaptive scale/shift) + silu -> act
+            norm('stats', hbuf, cout, cout, n, Ho, Ho, nm + '.norm1.stats', groups=G_out, eps=b.eps)
+            if b.adaptive_scale:
+                norm('apply', hbuf, cout, cout, n, Ho, Ho, nm + '.norm1', groups=G_out, eps=b.eps, gamma=w[f'{nm}.norm1.g'],
+                     beta=w[f'{nm}.norm1.b'], scale=aff[:, aoff:], shift=aff[:, aoff + cout:], ss_ld=self.aff_total, ss_rows=Bs,
+                     act_=DS_ACT_SILU, out=act, out_ld=cout)
+            else:
+                norm('apply', hbuf, cout, cout, n, Ho, Ho, nm + '.norm1', groups=G_out, eps=b.eps, gamma=w[f'{nm}.norm1.g'],
+                     beta=w[f'{nm}.norm1.b'], act_=DS_ACT_SILU, out=act, out_ld=cout)
+            # skip path
+            s0, sc0, s1, sc1 = x0, c0, x1, c1
+            if rs != DS_RESAMPLE_NONE:
+                norm('apply', x0, c0, c0, n, Hin, Hin, nm + '.skip.resample', x1=x1, c1=c1, ld1=c1, use_stats=False,
+                     resample=rs, out=sres, out_ld=cin)
+                s0, sc0, s1, sc1 = sres, cin, None, 0
+            if b.skip_conv:
+                conv(s0, sc0, sc0, n, Ho, Ho, w[f'{nm}.skip.w'], cout, sproj, cout, 1, nm + '.skip', x1=s1, c1=sc1, ld1=sc1,
+                     bias=w[f'{nm}.skip.b'])
+                res = sproj
+            else:
+                assert s1 is None and sc0 == cout
+                res = s0
+            # output buffer: encoder outputs are kept for the skip stack, decoder outputs ping-pong
+            if b.pushes_skip:
+                out = new(M, cout)
+            else:
+                if dec_pp[dec_i] is None or dec_pp[dec_i].numel() < M * cout:
+                    dec_pp[dec_i] = new(B * max_h)
+                out = dec_pp[dec_i]
+                dec_i ^= 1
+            if b.heads:
+                mid = out
+                out2 = None
+            conv(act, cout, cout, n, Ho, Ho, w[f'{nm}.conv1.w'], cout, out, cout, 9, nm + '.conv1', bias=w[f'{nm}.conv1.b'],
+                 res=res, res_ld=cout, scale=b.skip_scale)
+            if b.heads:
+                S = Ho * Ho
+                hd = b.heads
+                ch = cout // hd
+                norm('stats', out, cout, cout, n, Ho, Ho, nm + '.norm2.stats', groups=G_out, eps=b.eps)
+                norm('apply', out, cout, cout, n, Ho, Ho, nm + '.norm2', groups=G_out, eps=b.eps, gamma=w[f'{nm}.norm2.g'],
+                     beta=w[f'{nm}.norm2.b'], out=n2, out_ld=cout)
+                conv(n2, cout, cout, n, Ho, Ho, w[f'{nm}.qk.w'], 2 * cout, qk, 2 * cout, 1, nm + '.qk', bias=w[f'{nm}.qk.b'])
+                # V^T[b] = Wv . n2[b]^T + bv  -> [B][C][S]
+                gemm(w[f'{nm}.v.w'], cout, n2, cout, vt, S, cout, S, cout, nm + '.vT', batch=B, b_bs=S * cout, c_bs=cout * S,
+                     rowbias=w[f'{nm}.v.b'])
+                # scores[b,h] = Q K^T / sqrt(ch)
+                gemm(qk, 2 * cout, qk[cout:], 2 * cout, sc, S, S, S, ch, nm + '.qkT', batch=B, heads=hd,
+                     a_bs=S * 2 * cout, a_hs=ch, b_bs=S * 2 * cout, b_hs=ch, c_bs=hd * S * S, c_hs=S * S,
+                     alpha=1.0 / math.sqrt(ch))
+                add(lib.ds_softmax_rows, (_ptr(sc), _ptr(sc), B * hd * S, S, S), nm + '.softmax')
+                # O[b, :, h] = P[b,h] V[b,h]   (B operand = V^T rows of head h)
+                gemm(sc, S, vt, S, ao, cout, S, ch, S, nm + '.pv', batch=B, heads=hd, a_bs=hd * S * S, a_hs=S * S,
+                     b_bs=cout * S, b_hs=ch * S, c_bs=S * cout, c_hs=ch)
+                if b.pushes_skip:
+                    out2 = new(M, cout)
+                else:
+                    if dec_pp[dec_i] is None:
+                        dec_pp[dec_i] = new(B * max_h)
+                    out2 = dec_pp[dec_i]
+                    dec_i ^= 1
+                conv(ao, cout, cout, n, Ho, Ho, w[f'{nm}.proj.w'], cout, out2, cout, 1, nm + '.proj', bias=w[f'{nm}.proj.b'],
+                     res=out, res_ld=cout, scale=b.skip_scale)
+                out = out2
+            x_cur = (out, cout)
+            bufs[nm] = out
+            if b.pushes_skip:
+                skips.append(x_cur)
+        assert not skips
+        # ---- output head ------------------------------------------------------------------------------------------
+        xo, co = x_cur
+        norm('stats', xo, co, co, B, R, R, 'out.norm.stats', groups=arch.num_groups(co), eps=spec.out_eps)
+        norm('apply', xo, co, co, B, R, R, 'out.norm', groups=arch.num_groups(co), eps=spec.out_eps, gamma=w['out.g'],
+             beta=w['out.b'], act_=DS_ACT_SILU, out=act, out_ld=co)
+        conv(act, co, co, B, R, R, w['outc.w'], spec.out_channels, bufs['out'], 4, 9, 'out.conv', bias=w['outc.b'])
+        self._plans[key] = P
+        return P
+
+    # attention qk slice helper relies on 2-D views
+    def flops(self, B):
+        return arch.flops_per_image(self.spec) * B
+
+
+class EDMDenoiser:
+    """Drop-in for the reference ``EDMPrecond`` object (networks_edm.py:460-499) backed by the HIP engine.
+
+    ``net(x, sigma, class_labels=None)`` -> denoised NCHW fp32, like the reference.  The fused solvers bypass
+    the final ``c_skip x + c_out F`` pass and read the raw output through ``raw()`` instead.
+    """
+
+    def __init__(self, spec: arch.UNetSpec, params: Dict[str, torch.Tensor], device='cuda'):
+        self.spec = spec
+        self.engine = UNetEngine(spec, params, device)
+        self.device = self.engine.device
+        self.img_resolution = spec.img_resolution
+        self.img_channels = spec.in_channels
+        self.label_dim = spec.label_dim
+        self.sigma_min = spec.sigma_min
+        self.sigma_max = spec.sigma_max
+        self.sigma_data = spec.sigma_data
+        self.use_fp16 = False
+        self.bottleneck_name = None      # set by the AMED path: 'enc.8x8_block3' / 'enc.8x8_block2'
+
+    @classmethod
+    def from_config(cls, name_or_kwargs, seed=0, mode='signal', device='cuda'):
+        kw = arch.NAMED_CONFIGS[name_or_kwargs] if isinstance(name_or_kwargs, str) else name_or_kwargs
+        spec = arch.edm_precond_spec(**kw)
+        return cls(spec, arch.init_params(spec, seed=seed, mode=mode), device)
+
+    @classmethod
+    def from_reference_module(cls, net, device='cuda'):
+        """Build from a live reference ``EDMPrecond`` instance (duck-typed: pickled EDM classes are exec'd from
+        source, so ``isinstance`` is useless -- persistence.py:222-233)."""
+        spec = spec_from_module(net)
+        return cls(spec, {k: v for k, v in net.state_dict().items() if 'resample_filter' not in k}, device)
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    # -- raw evaluation: fills plan inputs, runs the plan, returns (F_nhwc4, plan) -----------------------------------
+    def _prepare(self, x, sigma, class_labels):
+        B = x.shape[0]
+        sigma = torch.as_tensor(sigma, dtype=torch.float32, device=self.device).reshape(-1)
+        per_sample = sigma.numel() > 1
+        emb_rows = B if (per_sample or self.label_dim) else 1
+        plan = self.engine.plan(B, emb_rows)
+        st = _lib.stream_ptr()
+        lib = self.engine.lib
+        xb = plan.bufs['x']
+        if x.data_ptr() != xb.data_ptr():
+            assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+            _lib.check(lib.ds_copy_rows(_ptr(x), x[0].numel(), _ptr(xb), x[0].numel(), B, x[0].numel(), st), 'copy x')
+        sb = plan.bufs['sigma']
+        if sigma.data_ptr() != sb.data_ptr():
+            rows = emb_rows
+            if sigma.numel() == 1 and rows > 1:
+                sigma = sigma.expand(rows).contiguous()
+            _lib.check(lib.ds_copy_rows(_ptr(sigma), 1, _ptr(sb), 1, rows, 1, st), 'copy sigma')
+        if self.label_dim:
+            lb = plan.bufs['labels']
+            if class_labels is None:
+                lb.zero_()
+            else:
+                cl = class_labels.to(torch.float32).reshape(-1, self.label_dim).contiguous()
+                if cl.shape[0] == 1 and B > 1:
+                    cl = cl.expand(B, -1).contiguous()
+                _lib.check(lib.ds_copy_rows(_ptr(cl), self.label_dim, _ptr(lb), lb.shape[1], B, self.label_dim, st), 'copy labels')
+        return plan, emb_rows
+
+    def raw(self, x, sigma, class_labels=None):
+        """F(c_in x; c_noise) as an NHWC [B*H*W, 4] tensor (channels 0..C-1 valid).  Engine-owned, overwritten by the
+        next evaluation at the same batch size."""
+        plan, _ = self._prepare(x, sigma, class_labels)
+        plan.run(_lib.stream_ptr())
+        return plan.bufs['out'], plan
+
+    def __call__(self, x, sigma, class_labels=None, force_fp32=False, **kwargs):
+        from . import ops
+        B, Cc, H, W = x.shape
+        x = x.to(torch.float32).contiguous()
+        plan, emb_rows = self._prepare(x, sigma, class_labels)
+        plan.run(_lib.stream_ptr())
+        out = torch.empty_like(x)
+        # D = c_skip x + c_out F, evaluated by the update kernel with cx = 0, cm = 1, store_d = 0 (m = D)
+        args = ops.make_update_args(plan.bufs['x'], plan.bufs['x'], plan.bufs['out'], B, Cc, H, W, None, raw=True, f_ld=4,
+                                    coefs=self._sigma_coefs(plan, emb_rows), coef_rows=(B if emb_rows > 1 else 1),
+                                    sigma_data=self.sigma_data, m_out=out, store_d=False)
+        ops.solver_update(args)
+        return out
+
+    def _sigma_coefs(self, plan, emb_rows):
+        """[rows][8] coefficient rows carrying sigma in slot 6 (and t = 1 in slot 5)."""
+        rows = emb_rows
+        key = ('sigcoef', rows)
+        if key not in plan.bufs:
+            plan.bufs[key] = torch.zeros(rows, 8, dtype=torch.float32, device=self.device)
+            plan.bufs[key][:, 5] = 1.0
+        cf = plan.bufs[key]
+        lib = self.engine.lib
+        _lib.check(lib.ds_copy_rows(_ptr(plan.bufs['sigma']), 1, _ptr(cf[:, 6:]), 8, rows, 1, _lib.stream_ptr()), 'sigma->coefs')
+        return cf
+
+    def bottleneck_mean(self, plan, B, class_cond):
+        """Channel mean of the AMED bottleneck tap, [B, 8, 8] (solvers_amed.py:16-17, :24-28)."""
+        from . import ops
+        name = 'enc.8x8_block2' if class_cond else 'enc.8x8_block3'
+        t = plan.bufs[name]
+        c = t.shape[1]
+        out = torch.empty(B, 8, 8, dtype=torch.float32, device=self.device)
+        ops.channel_mean(t, c, c, B * 64, out)
+        return out
+
+
+def spec_from_module(net) -> arch.UNetSpec:
+    """Recover the UNetSpec of a live reference EDMPrecond by attribute inspection."""
+    model = net.model
+    names = list(model.enc.keys())
+    song = any('aux' in k for k in model.dec.keys())
+    first = model.enc[names[0]]
+    res0 = int(net.img_resolution)
+    mc_emb = model.map_layer0.weight.shape[0]
+    blocks = [k for k in names if 'block' in k]
+    levels = sorted({int(k.split('x')[0]) for k in names}, reverse=True)
+    num_blocks = sum(1 for k in blocks if k.startswith(f'{res0}x{res0}_block'))
+    if song:
+        model_channels = first.out_channels
+        mult = [model.enc[f'{r}x{r}_block0'].out_channels // model_channels for r in levels]
+        attn = [r for r in levels if getattr(model.enc[f'{r}x{r}_block0'], 'num_heads', 0)]
+        spec = arch.song_unet_spec(res0, net.img_channels, net.img_channels, label_dim=net.label_dim,
+                                   augment_dim=(model.map_augment.weight.shape[1] if getattr(model, 'map_augment', None) is not None else 0),
+                                   model_channels=model_channels, channel_mult=mult, channel_mult_emb=mc_emb // model_channels,
+                                   num_blocks=num_blocks, attn_resolutions=attn,
+                                   channel_mult_noise=model.map_layer0.weight.shape[1] // model_channels)
+    else:
+        model_channels = model.map_layer0.weight.shape[1]
+        mult = [model.enc[f'{r}x{r}_block0'].out_channels // model_channels for r in levels]
+        attn = [r for r in levels if getattr(model.enc[f'{r}x{r}_block0'], 'num_heads', 0)]
+        spec = arch.dhariwal_unet_spec(res0, net.img_channels, net.img_channels, label_dim=net.label_dim,
+                                       augment_dim=(model.map_augment.weight.shape[1] if getattr(model, 'map_augment', None) is not None else 0),
+                                       model_channels=model_channels, channel_mult=mult, channel_mult_emb=mc_emb // model_channels,
+                                       num_blocks=num_blocks, attn_resolutions=attn)
+    spec.sigma_data = float(getattr(net, 'sigma_data', 0.5))
+    spec.sigma_min = float(getattr(net, 'sigma_min', 0.002))
+    spec.sigma_max = float(getattr(net, 'sigma_max', 80.0))
+    return spec

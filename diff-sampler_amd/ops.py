@@ -1,0 +1,129 @@
+"""Tensor-level wrappers around the C ABI (one Python function per libdsamd entry point).
+
+Each wrapper only marshals: it checks dtype/device/contiguity, fills the ctypes struct with raw device pointers and
+launches on the current HIP stream.  No arithmetic happens in Python and nothing falls back to ATen.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import (ConvArgs, GemmArgs, NormArgs, UpdateArgs, DS_ACT_NONE, DS_ACT_SILU, DS_RESAMPLE_NONE,
+                   DS_RESAMPLE_DOWN, DS_RESAMPLE_UP)
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype in (torch.float32, torch.uint8, torch.int32), (t.device, t.dtype)
+    return C.c_void_p(t.data_ptr())
+
+
+def pack_conv_weight(w: torch.Tensor, row_pad: int = 128, k_pad: int = 32) -> torch.Tensor:
+    """[Cout, Cin, kh, kw] -> [Cout_pad, kh*kw*Cin] with K index = tap*Cin + c (tap = ky*3 + kx), zero-padded rows
+    (to a multiple of the N tile) and columns (to a multiple of the K tile)."""
+    cout, cin, kh, kw = w.shape
+    m = w.permute(0, 2, 3, 1).reshape(cout, kh * kw * cin)
+    rows = -(-cout // row_pad) * row_pad
+    cols = -(-m.shape[1] // k_pad) * k_pad
+    out = torch.zeros(rows, cols, dtype=torch.float32, device=w.device)
+    out[:cout, :m.shape[1]] = m
+    return out.contiguous()
+
+
+def pack_linear_weight(w: torch.Tensor, row_pad: int = 128, k_pad: int = 32) -> torch.Tensor:
+    return pack_conv_weight(w[:, :, None, None], row_pad, k_pad)
+
+
+def conv2d_nhwc(x0, c0, ld0, n, h, w, wgt, cout, out, out_ld, *, taps=9, x1=None, c1=0, ld1=0, bias=None, cbias=None,
+                cbias_ld=0, cbias_rows=1, res=None, res_ld=0, out_scale=1.0, act=DS_ACT_NONE):
+    a = ConvArgs(_p(x0), _p(x1), c0, c1, ld0, ld1, n, h, w, taps, _p(wgt), cout, _p(bias), _p(cbias), cbias_ld,
+                 cbias_rows, _p(res), res_ld, out_scale, act, _p(out), out_ld)
+    _lib.check(_lib.load().ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr()), 'ds_conv2d_nhwc')
+
+
+def gemm_nt_batched(a, lda, b, ldb, c, ldc, m, n, k, *, batch=1, heads=1, a_bs=0, a_hs=0, b_bs=0, b_hs=0, c_bs=0,
+                    c_hs=0, alpha=1.0, rowbias=None, colbias=None, act=DS_ACT_NONE):
+    g = GemmArgs(_p(a), lda, a_bs, a_hs, _p(b), ldb, b_bs, b_hs, _p(c), ldc, c_bs, c_hs, m, n, k, batch, heads,
+                 alpha, _p(rowbias), _p(colbias), act)
+    _lib.check(_lib.load().ds_gemm_nt_batched(C.byref(g), _lib.stream_ptr()), 'ds_gemm_nt_batched')
+
+
+def _norm_args(x0, c0, ld0, n, h, w, *, x1=None, c1=0, ld1=0, groups=1, eps=1e-5, mean=None, rstd=None, gamma=None,
+               beta=None, scale=None, shift=None, ss_ld=0, ss_rows=1, act=DS_ACT_NONE, resample=DS_RESAMPLE_NONE,
+               out=None, out_ld=0):
+    return NormArgs(_p(x0), _p(x1), c0, c1, ld0, ld1, n, h, w, groups, eps, _p(mean), _p(rstd), _p(gamma), _p(beta),
+                    _p(scale), _p(shift), ss_ld, ss_rows, act, resample, _p(out), out_ld)
+
+
+def gn_stats(x0, c0, ld0, n, h, w, groups, eps, mean, rstd, *, x1=None, c1=0, ld1=0):
+    a = _norm_args(x0, c0, ld0, n, h, w, x1=x1, c1=c1, ld1=ld1, groups=groups, eps=eps, mean=mean, rstd=rstd)
+    _lib.check(_lib.load().ds_gn_stats(C.byref(a), _lib.stream_ptr()), 'ds_gn_stats')
+
+
+def norm_act(x0, c0, ld0, n, h, w, out, out_ld, **kw):
+    a = _norm_args(x0, c0, ld0, n, h, w, out=out, out_ld=out_ld, **kw)
+    _lib.check(_lib.load().ds_norm_act(C.byref(a), _lib.stream_ptr()), 'ds_norm_act')
+
+
+def softmax_rows(x, y, rows, cols, ld):
+    _lib.check(_lib.load().ds_softmax_rows(_p(x), _p(y), rows, cols, ld, _lib.stream_ptr()), 'ds_softmax_rows')
+
+
+def noise_embed(sigma, bs, freqs, nch, swap, out, out_ld):
+    _lib.check(_lib.load().ds_noise_embed(_p(sigma), bs, _p(freqs), nch, int(swap), _p(out), out_ld, _lib.stream_ptr()),
+               'ds_noise_embed')
+
+
+def stem_im2col(x, sigma, sigma_rows, sigma_data, n, c, h, w, out, kpad):
+    _lib.check(_lib.load().ds_stem_im2col(_p(x), _p(sigma), sigma_rows, sigma_data, n, c, h, w, _p(out), kpad,
+                                          _lib.stream_ptr()), 'ds_stem_im2col')
+
+
+def make_update_args(xe, xb, f, n, c, h, w, x_out, *, raw=False, f_ld=0, hist: Sequence = (), coefs=None, coef_rows=1,
+                     hcoefs=None, afs=False, sigma_data=0.5, m_out=None, store_d=True) -> UpdateArgs:
+    a = UpdateArgs()
+    a.xe, a.xb, a.f = _p(xe), _p(xb), _p(f)
+    a.raw, a.f_ld = int(raw), f_ld
+    for i in range(3):
+        a.hist[i] = _p(hist[i]) if i < len(hist) and hist[i] is not None else None
+    a.coefs, a.coef_rows = _p(coefs), coef_rows
+    if hcoefs is not None:
+        for i, v in enumerate(hcoefs):
+            a.hcoefs[i] = float(v)
+    a.afs, a.sigma_data = int(afs), sigma_data
+    a.m_out, a.store_d, a.x_out = _p(m_out), int(store_d), _p(x_out)
+    a.n, a.c, a.h, a.w = n, c, h, w
+    return a
+
+
+def solver_update(args: UpdateArgs):
+    _lib.check(_lib.load().ds_solver_update(C.byref(args), _lib.stream_ptr()), 'ds_solver_update')
+
+
+def table_select(table, row_floats, step, advance, dst):
+    _lib.check(_lib.load().ds_table_select(_p(table), row_floats, _p(step), int(advance), _p(dst), _lib.stream_ptr()),
+               'ds_table_select')
+
+
+def dynamic_threshold(x0, out, n, per, p=0.995):
+    _lib.check(_lib.load().ds_dynamic_threshold(_p(x0), _p(out), n, per, p, _lib.stream_ptr()), 'ds_dynamic_threshold')
+
+
+def scale(x, a, y):
+    _lib.check(_lib.load().ds_scale(_p(x), float(a), _p(y), x.numel(), _lib.stream_ptr()), 'ds_scale')
+
+
+def quantize_u8_nhwc(x, out, n, c, h, w):
+    _lib.check(_lib.load().ds_quantize_u8_nhwc(_p(x), _p(out), n, c, h, w, _lib.stream_ptr()), 'ds_quantize_u8_nhwc')
+
+
+def channel_mean(x, ld, c, rows, out):
+    _lib.check(_lib.load().ds_channel_mean(_p(x), ld, c, rows, _p(out), _lib.stream_ptr()), 'ds_channel_mean')
+
+
+def copy_rows(src, src_ld, dst, dst_ld, rows, cols):
+    _lib.check(_lib.load().ds_copy_rows(_p(src), src_ld, _p(dst), dst_ld, rows, cols, _lib.stream_ptr()), 'ds_copy_rows')

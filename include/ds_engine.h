@@ -1,0 +1,185 @@
+/*
+ * ds_engine.h -- C ABI of libdsamd.so, the MI355X (gfx950) engine behind the diff-sampler hot path.
+ *
+ * The reference (zju-pi/diff-sampler) is pure Python/PyTorch and has no FFI layer: the
+ * boundary it exposes is the Python surface of diff-solvers-main/{solvers.py, solver_utils.py, sample.py}.  This
+ * header is the native boundary UNDER that surface: every entry point replaces one group of ATen op sequences the
+ * reference issues (cited per function as file:line under /root/reference/diff-solvers-main unless noted), takes
+ * raw device pointers + sizes + a hipStream_t (passed as void*), returns 0 on success or a non-zero code
+ * (positive = hipError_t, negative = argument error, see DS_E_*), never allocates, never synchronises.
+ * The Python mirrors of the reference functions (diff-sampler_amd/solvers.py etc.) bind it with ctypes;
+ * INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Tensor layouts
+ *   user tensors (latents x, denoised D, history)  : NCHW fp32, exactly as the reference passes them
+ *   denoiser activations (internal)                : NHWC fp32, "rows" = pixels (n*H*W + h*W + w), ld = floats/row
+ *   conv / linear weights                          : packed [Cout_pad][taps*Cin] fp32, K index = tap*Cin + c
+ */
+#ifndef DS_ENGINE_H
+#define DS_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DS_OK 0
+#define DS_E_ARG (-1)      /* invalid argument combination            */
+#define DS_E_ALIGN (-2)    /* pointer / leading dimension not aligned */
+#define DS_E_SHAPE (-3)    /* unsupported shape (e.g. K % 32 != 0)    */
+
+#define DS_ACT_NONE 0
+#define DS_ACT_SILU 1
+
+#define DS_RESAMPLE_NONE 0
+#define DS_RESAMPLE_DOWN 1  /* 2x2 box filter, stride 2  (networks_edm.py:77 with resample_filter [1,1]) */
+#define DS_RESAMPLE_UP 2    /* nearest neighbour x2      (networks_edm.py:75 with resample_filter [1,1]) */
+
+int ds_version(void);
+const char* ds_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution / linear layer on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32; exact fp32).
+ * Replaces F.conv2d 3x3 pad 1 / 1x1 (networks_edm.py:79), Linear (networks_edm.py:32-34), torch.cat of the decoder
+ * skip (networks_edm.py:353: two sources are read in place), the bias add (:81), the embedding add (:167), the
+ * residual add and skip_scale (:170-171, :177-178).
+ *
+ *   out[m, co] = act( ( sum_{tap,c} X(m, tap, c) * W[co, tap*Ctot + c] + bias[co] + cbias[img(m), co] + res[m, co] )
+ *                     * out_scale )
+ *   X(m, tap, c): zero-padded 3x3 neighbourhood of pixel m in the channel-concatenation [x0 | x1].
+ * Constraints: c0 % 32 == 0, c1 % 32 == 0, all leading dimensions % 4 == 0, pointers 16-byte aligned,
+ * W has ceil(cout/128)*128 rows (zero padded).
+ */
+typedef struct ds_conv_args {
+    const float* x0; const float* x1;      /* sources; x1 may be NULL when c1 == 0                               */
+    int c0, c1;                            /* channels taken from each source                                   */
+    int ld0, ld1;                          /* floats per pixel row in each source                               */
+    int n, h, w;                           /* images, height, width (same for input and output)                 */
+    int taps;                              /* 9 (3x3, pad 1) or 1 (1x1 / linear)                                */
+    const float* wgt;                      /* packed weights [cout_pad][taps*(c0+c1)]                           */
+    int cout;
+    const float* bias;                     /* [cout] or NULL                                                    */
+    const float* cbias; int cbias_ld;      /* per-image channel bias [n or 1][cbias_ld] or NULL                 */
+    int cbias_rows;                        /* 1 = broadcast over images, else n                                 */
+    const float* res; int res_ld;          /* residual [M][res_ld] or NULL                                      */
+    float out_scale;
+    int act;                               /* DS_ACT_*                                                          */
+    float* out; int out_ld;
+} ds_conv_args;
+
+int ds_conv2d_nhwc(const ds_conv_args* a, void* stream);
+
+/* Batched C[z] = act(alpha * A[z] * B[z]^T + rowbias + colbias) on the same MFMA core ("NT": both operands have k
+ * contiguous).  Used for attention: S = Q K^T / sqrt(C) and O = P V (networks_edm.py:108, :176) and the transposed
+ * V projection.  z = zb * heads + zh;  X_z = X + zb*x_bstride + zh*x_hstride. Constraints: k % 32 == 0. */
+typedef struct ds_gemm_args {
+    const float* a; int lda; long long a_bstride, a_hstride;   /* A[z]: [m][lda] */
+    const float* b; int ldb; long long b_bstride, b_hstride;   /* B[z]: [n][ldb] */
+    float* c; int ldc; long long c_bstride, c_hstride;         /* C[z]: [m][ldc] */
+    int m, n, k;
+    int batch, heads;
+    float alpha;
+    const float* rowbias;                  /* [m] or NULL  */
+    const float* colbias;                  /* [n] or NULL  */
+    int act;
+} ds_gemm_args;
+
+int ds_gemm_nt_batched(const ds_gemm_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * GroupNorm statistics + fused normalise / affine / SiLU / resample pass (networks_edm.py:88-98, :160, :165-167).
+ * ds_gn_stats: per (image, group) mean and 1/sqrt(var + eps) over the channel-concatenation [x0 | x1].
+ * ds_norm_act: y = resample( act( (x - mean) * rstd * gamma * (1 + scale) + beta * (1 + scale) + shift ) ),
+ *              any of {mean/rstd, gamma/beta, scale/shift} may be NULL (identity), so the same kernel is the raw
+ *              resampler of the skip path.  Output is a single NHWC tensor with ld = out_ld.
+ */
+typedef struct ds_norm_args {
+    const float* x0; const float* x1; int c0, c1; int ld0, ld1;
+    int n, h, w;                           /* input geometry                                                    */
+    int groups; float eps;
+    float* mean; float* rstd;              /* [n][groups]  (outputs of ds_gn_stats, inputs of ds_norm_act)      */
+    const float* gamma; const float* beta; /* [c0+c1]                                                           */
+    const float* scale; const float* shift; int ss_ld; int ss_rows;  /* adaptive scale/shift [ss_rows][ss_ld]   */
+    int act; int resample;
+    float* out; int out_ld;
+} ds_norm_args;
+
+int ds_gn_stats(const ds_norm_args* a, void* stream);
+int ds_norm_act(const ds_norm_args* a, void* stream);
+
+/* Row softmax, in place or out of place: y[r, :] = softmax(x[r, :cols]) (networks_edm.py:108). */
+int ds_softmax_rows(const float* x, float* y, long long rows, int cols, int ld, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Noise embedding front end (networks_edm.py:185-198, :314-315, :488-491).
+ * sigma: [bs] device.  out[b, :] = PositionalEmbedding(ln(sigma_b)/4) with the precomputed freqs table
+ * [nch/2]; swap=1 gives [sin | cos] (SongUNet), swap=0 [cos | sin] (DhariwalUNet).
+ */
+int ds_noise_embed(const float* sigma, int bs, const float* freqs, int nch, int swap, float* out, int out_ld, void* stream);
+
+/* First-layer input: im2col of c_in(sigma) * x for the 3x3 stem conv, written as [n*h*w][kpad] rows with
+ * k = tap*c + ch (zero padded to kpad, a multiple of 32), so that the stem runs as a 1x1 on the MFMA kernel.
+ * x: NCHW [n][c][h][w]; sigma: [n] or [1] (sigma_rows).  Fuses networks_edm.py:490,493 (c_in * x). */
+int ds_stem_im2col(const float* x, const float* sigma, int sigma_rows, float sigma_data, int n, int c, int h, int w,
+                   float* out, int kpad, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Solver side (solvers.py / solver_utils.py).  All tensors NCHW fp32 with `per` = C*H*W elements per sample.
+ *
+ * ds_solver_update: one fused pass replacing 4-8 ATen elementwise launches per step (solvers.py:76-81, :156-168,
+ * :245-258, :344-352, :574-585; solver_utils.py:102-163 after thresholding):
+ *     D      = raw ? c_skip(sig) * xe + c_out(sig) * F_nhwc   (EDMPrecond epilogue, networks_edm.py:495)
+ *                  : F                                        (already a denoised NCHW tensor)
+ *     d      = afs ? xe / sqrt(1 + t^2) : (xe - D) / t         (solvers.py:77 / :80)
+ *     m      = store_d ? d : D                                 (what the multistep history keeps)
+ *     x_out  = cx * xb + cm * m + sum_k ch[k] * hist[k]
+ * xe = the point the network was evaluated at, xb = the base point of the update (they differ in 2-stage solvers).
+ * Per-sample coefficient arrays (AMED) are used when coef_rows == n: each of cx, cm, ch[k], t, sig is then read from
+ * coefs[sample*8 + slot]; with coef_rows == 1 the same 8 floats are shared (device-resident: hipGraph replay reads
+ * the row a ds_table_select node copied in); coefs == NULL takes the 8 floats by value from hcoefs.
+ * Slots: 0 cx, 1 cm, 2..4 ch[0..2], 5 t (divisor of d), 6 sigma (precond), 7 unused.
+ */
+typedef struct ds_update_args {
+    const float* xe; const float* xb;      /* NCHW                                                               */
+    const float* f;                        /* raw: NHWC [n*h*w][f_ld] network output; else NCHW denoised          */
+    int raw; int f_ld;
+    const float* hist[3];                  /* NCHW history tensors or NULL                                       */
+    const float* coefs; int coef_rows;     /* device [coef_rows][8]; NULL -> use hcoefs (host scalars by value)  */
+    float hcoefs[8];
+    int afs;
+    float sigma_data;
+    float* m_out;                          /* optional: write m (d or D) here, NCHW                              */
+    int store_d;
+    float* x_out;
+    int n, c, h, w;
+} ds_update_args;
+
+int ds_solver_update(const ds_update_args* a, void* stream);
+
+/* dst[0..row_floats) = table[(*step) * row_floats ...]; then optionally (*step)++ when advance != 0.  The only
+ * per-step state of a captured sampler step: every kernel of the step reads its scalars (sigma, coefficients) from
+ * `dst`, so one hipGraph replays for all steps. */
+int ds_table_select(const float* table, int row_floats, int* step, int advance, float* dst, void* stream);
+
+/* x0 <- clamp(x0, -s, s) / s with s = max(quantile_{0.995}(|x0|) per sample, 1): solver_utils.py:77-86, exact
+ * torch.quantile semantics (linear interpolation between the two order statistics around p*(n-1)). */
+int ds_dynamic_threshold(const float* x0, float* out, int n, int per, float p, void* stream);
+
+/* y = a * x (latents * t_steps[0], solvers.py:68). */
+int ds_scale(const float* x, float a, float* y, long long count, void* stream);
+
+/* images uint8 NHWC <- clip(x * 127.5 + 128, 0, 255), x NCHW (sample.py:311). */
+int ds_quantize_u8_nhwc(const float* x, uint8_t* out, int n, int c, int h, int w, void* stream);
+
+/* dst[r, 0:cols] = src[r, 0:cols] for r < rows (strided 2-D copy; pads/gathers label and sigma rows). */
+int ds_copy_rows(const float* src, int src_ld, float* dst, int dst_ld, long long rows, int cols, void* stream);
+
+/* Channel mean of an NHWC tensor: out[n][h*w] = mean_c x[n, hw, c] (AMED bottleneck tap, solvers_amed.py:24-28). */
+int ds_channel_mean(const float* x, int ld, int c, long long rows, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DS_ENGINE_H */

@@ -1,0 +1,72 @@
+"""GPU parity: the HIP denoiser (through the C ABI) against the CPU oracle and the golden vectors.
+
+Tolerance (stated, fp32 path): the MFMA kernel is an exact fp32 FMA chain but sums K in a different order than
+ATen's CPU convolution, and GroupNorm/SiLU/softmax use fast exp; per-evaluation error is bounded by
+``atol = rtol = 2e-4`` relative to the output scale (observed ~1e-5)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+import diff_sampler_amd.arch as arch  # noqa: E402
+
+G = os.path.join(ROOT, 'tests', 'golden')
+TOL = 2e-4
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-6))
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return torch.device('cuda')
+
+
+@pytest.mark.parametrize('name', ['tiny_song', 'tiny_song_cond', 'tiny_adm', 'tiny_song_amed', 'cifar10'])
+def test_denoiser_matches_golden(name, dev):
+    from diff_sampler_amd.engine import EDMDenoiser
+    z = np.load(os.path.join(G, f'net_{name}.npz'))
+    net = EDMDenoiser.from_config(name, seed=int(z['seed']))
+    x = torch.from_numpy(z['x']).to(dev)
+    lab = torch.from_numpy(z['labels']).to(dev) if z['labels'].size else None
+    out_vec = net(x, torch.from_numpy(z['sigma']).to(dev), class_labels=lab)
+    out_sc = net(x, torch.tensor(0.6), class_labels=lab)
+    torch.cuda.synchronize()
+    assert _rel(out_vec.cpu(), torch.from_numpy(z['out_vec'])) < TOL
+    assert _rel(out_sc.cpu(), torch.from_numpy(z['out_scalar'])) < TOL
+
+
+def test_block_taps_match_oracle(dev):
+    """Every encoder block output of the tiny nets against the oracle's taps (localises a wrong kernel)."""
+    from diff_sampler_amd.engine import EDMDenoiser
+    from oracle.edm_net import edm_denoise
+    for name in ['tiny_song', 'tiny_adm']:
+        kw = dict(arch.NAMED_CONFIGS[name])
+        spec = arch.edm_precond_spec(**kw)
+        params = arch.init_params(spec, seed=3)
+        net = EDMDenoiser(spec, params)
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(2, 3, 16, 16, generator=g) * 2
+        lab = torch.eye(10)[torch.tensor([3, 8])] if kw['label_dim'] else None
+        sig = torch.tensor([1.3, 0.2])
+        taps = {}
+        with torch.no_grad():
+            ref = edm_denoise(params, kw, x, sig, lab, taps=taps)
+        out = net(x.to(dev), sig.to(dev), class_labels=(lab.to(dev) if lab is not None else None))
+        plan = net.engine.plan(2, 2)
+        torch.cuda.synchronize()
+        for b in spec.blocks:
+            if not b.pushes_skip:      # decoder outputs ping-pong between two workspaces and are overwritten
+                continue
+            got = plan.bufs[b.name][:2 * b.res_out ** 2 * b.cout].reshape(2, b.res_out, b.res_out, b.cout).permute(0, 3, 1, 2).cpu()
+            assert _rel(got, taps[b.name]) < TOL, (name, b.name)
+        assert _rel(out.cpu(), ref) < TOL

@@ -1,0 +1,48 @@
+"""Time one denoiser evaluation (raw plan) on the GPU: ms, TFLOP/s; optional per-op breakdown."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import diff_sampler_amd.arch as arch  # noqa: E402
+from diff_sampler_amd import _lib  # noqa: E402
+from diff_sampler_amd.engine import EDMDenoiser  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--config', default='cifar10')
+ap.add_argument('--batch', type=int, nargs='+', default=[64, 256])
+ap.add_argument('--iters', type=int, default=5)
+ap.add_argument('--breakdown', action='store_true')
+args = ap.parse_args()
+
+net = EDMDenoiser.from_config(args.config, seed=0)
+spec = net.spec
+for B in args.batch:
+    x = torch.randn(B, spec.in_channels, spec.img_resolution, spec.img_resolution, device='cuda')
+    sig = torch.tensor(1.5)
+    lab = torch.eye(spec.label_dim, device='cuda')[torch.randint(spec.label_dim, (B,), device='cuda')] if spec.label_dim else None
+    net.raw(x, sig, lab)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.iters):
+        out, plan = net.raw(x, sig, lab)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / args.iters
+    fl = arch.flops_per_image(spec) * B
+    print(f'{args.config} B={B}: {dt*1e3:.2f} ms/eval  {fl/dt/1e12:.1f} TFLOP/s  {B/dt:.0f} img-evals/s  ({len(plan.ops)} launches)', flush=True)
+    if args.breakdown:
+        st = _lib.stream_ptr()
+        tot = {}
+        for op in plan.ops:
+            torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            op.fn(*op.args, st)
+            e1.record(); torch.cuda.synchronize()
+            kind = op.name.split('.')[-1]
+            tot[kind] = tot.get(kind, 0.0) + e0.elapsed_time(e1)
+        for k, v in sorted(tot.items(), key=lambda kv: -kv[1]):
+            print(f'   {k:16s} {v:8.2f} ms')
