@@ -1,0 +1,251 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec at NFE=10 on the EDM CIFAR-10 denoiser (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full sampler call (DPM-Solver++(2M), 10 network evaluations, logSNR schedule -- BASELINE configs[1]
+at the NFE the metric is quoted on) over a batch of synthetic N(0,1) latents already resident in HBM, on the
+random-init (signal-carrying) CIFAR-10 SongUNet.  Ranks shard images, nothing is exchanged during sampling
+(SURVEY.md section 8e), so scaling is weak: every rank runs ``--batch`` images per step.
+
+Prints ONE JSON line on rank 0 with the driver's contract fields plus
+  roofline      dominant kernel (fp32-MFMA implicit-GEMM conv): algorithmic FLOPs of its launches in one sampler
+                step / their summed duration, measured with HIP events on the launch stream in an instrumented
+                replay of the timed workload; peak = 157.3 TFLOP/s (MI355X fp32 matrix, MI355X_MICROARCH.md)
+  roofline_update   the fused solver-update kernel against HBM 8 TB/s
+  cpu_baseline  the oracle (CPU restatement of the reference, ``oracle/``) timed on this host's cores on a bounded
+                sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=256, help='images per GPU per sampler call')
+    ap.add_argument('--nfe', type=int, default=10)
+    ap.add_argument('--solver', default='dpmpp', choices=['dpmpp', 'euler', 'ipndm', 'heun'])
+    ap.add_argument('--config', default='cifar10')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=8)
+    ap.add_argument('--cpu-calls', type=int, default=2)
+    return ap.parse_args()
+
+
+def sampler_call(solvers, solver, net, latents, nfe):
+    if solver == 'dpmpp':
+        return solvers.dpm_pp_sampler(net, latents, num_steps=nfe + 1, sigma_min=0.002, sigma_max=80., schedule_type='logsnr',
+                                      schedule_rho=7, max_order=2, predict_x0=True, lower_order_final=True)
+    if solver == 'euler':
+        return solvers.euler_sampler(net, latents, num_steps=nfe + 1, sigma_min=0.002, sigma_max=80.)
+    if solver == 'ipndm':
+        return solvers.ipndm_sampler(net, latents, num_steps=nfe + 1, sigma_min=0.002, sigma_max=80., max_order=4)
+    if solver == 'heun':
+        return solvers.heun_sampler(net, latents, num_steps=nfe // 2 + 1, sigma_min=0.002, sigma_max=80.)
+    raise ValueError(solver)
+
+
+def instrumented_pass(net, solvers, solver, latents, nfe):
+    """Replay one sampler call with every launch bracketed by HIP events on the launch stream."""
+    from diff_sampler_amd import _lib, engine, ops
+    import diff_sampler_amd.arch as arch
+    rec = {}          # kernel class -> [time_ms, launches]
+    plan_run = engine._Plan.run
+    upd = ops.solver_update
+    thr = ops.dynamic_threshold
+
+    def add(kind, ms):
+        r = rec.setdefault(kind, [0.0, 0])
+        r[0] += ms
+        r[1] += 1
+
+    def timed_plan_run(self, stream):
+        evs = []
+        for op in self.ops:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = op.fn(*op.args, stream)
+            e1.record()
+            if rc:
+                _lib.check(rc, op.name)
+            evs.append((op, e0, e1))
+        torch.cuda.synchronize()
+        for op, e0, e1 in evs:
+            if op.fn is self_lib.ds_conv2d_nhwc:
+                kind = 'igemm_conv'
+            elif op.fn is self_lib.ds_gemm_nt_batched:
+                kind = 'igemm_gemm'
+            elif op.fn is self_lib.ds_gn_stats:
+                kind = 'gn_stats'
+            elif op.fn is self_lib.ds_norm_act:
+                kind = 'norm_act'
+            else:
+                kind = 'other'
+            add(kind, e0.elapsed_time(e1))
+
+    def timed_call(kind, fn):
+        def w(*a, **k):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(); r = fn(*a, **k); e1.record(); torch.cuda.synchronize()
+            add(kind, e0.elapsed_time(e1))
+            return r
+        return w
+
+    self_lib = _lib.load()
+    engine._Plan.run = timed_plan_run
+    ops.solver_update = timed_call('solver_update', upd)
+    ops.dynamic_threshold = timed_call('dynamic_threshold', thr)
+    try:
+        sampler_call(solvers, solver, net, latents, nfe)
+        torch.cuda.synchronize()
+    finally:
+        engine._Plan.run = plan_run
+        ops.solver_update = upd
+        ops.dynamic_threshold = thr
+    return rec
+
+
+def conv_flops_per_eval(spec, B):
+    """Algorithmic FLOPs (2 x MAC) executed by ds_conv2d_nhwc launches in one network evaluation."""
+    import diff_sampler_amd.arch as arch
+    f = 0.0
+    for b in spec.blocks:
+        hw = b.res_out ** 2
+        if b.kind == 'conv':
+            f += 2.0 * hw * 9 * b.cin * b.cout
+            continue
+        f += 2.0 * hw * 9 * (b.cin + b.cout) * b.cout
+        if b.skip_conv:
+            f += 2.0 * hw * b.cin * b.cout
+        if b.heads:
+            f += 2.0 * hw * b.cout * 2 * b.cout + 2.0 * hw * b.cout * b.cout       # qk projection + proj
+    f += 2.0 * spec.img_resolution ** 2 * 9 * spec.blocks[-1].cout * spec.out_channels
+    return f * B
+
+
+def cpu_baseline(args, nfe):
+    """Oracle (kind 'port') on the host cores: same net, same sampler, bounded sample."""
+    from oracle import solvers_ref
+    from oracle.edm_net import OracleNet
+    import diff_sampler_amd.arch as arch
+    kw = dict(arch.NAMED_CONFIGS[args.config])
+    spec = arch.edm_precond_spec(**kw)
+    net = OracleNet(arch.init_params(spec, seed=0), kw)
+    threads = torch.get_num_threads()
+    g = torch.Generator().manual_seed(0)
+    lat = torch.randn(args.cpu_batch, 3, spec.img_resolution, spec.img_resolution, generator=g)
+    ts = solvers_ref.schedule(nfe + 1, 0.002, 80., kind='logsnr' if args.solver == 'dpmpp' else 'polynomial', rho=7)
+    name = {'dpmpp': 'dpm_pp', 'euler': 'euler', 'ipndm': 'ipndm', 'heun': 'heun'}[args.solver]
+    kws = dict(max_order=2, predict_x0=True, lower_order_final=True, num_steps=nfe + 1) if args.solver == 'dpmpp' else \
+        (dict(max_order=4) if args.solver == 'ipndm' else {})
+    with torch.no_grad():
+        t0 = time.time()
+        for _ in range(args.cpu_calls):
+            solvers_ref.sample(name, net, lat, ts, **kws)
+        dt = time.time() - t0
+    return dict(value=round(args.cpu_batch * args.cpu_calls / dt, 3), unit='images/sec', cores=threads, kind='port',
+                sample=f'{args.cpu_calls} sampler calls x batch {args.cpu_batch}, NFE={nfe}, same net/solver ({dt:.1f} s of CPU work)')
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', init_method='env://')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    import diff_sampler_amd.arch as arch
+    from diff_sampler_amd import solvers
+    from diff_sampler_amd.engine import EDMDenoiser
+
+    net = EDMDenoiser.from_config(args.config, seed=0, device=dev)
+    spec = net.spec
+    B = args.batch
+    g = torch.Generator(device='cpu').manual_seed(1234 + rank)
+    latents = torch.randn(B, spec.in_channels, spec.img_resolution, spec.img_resolution, generator=g).to(dev)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, args.nfe)
+
+    for _ in range(args.warmup):
+        sampler_call(solvers, args.solver, net, latents, args.nfe)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = sampler_call(solvers, args.solver, net, latents, args.nfe)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(out).all()
+
+    roof = roof_u = None
+    if rank == 0:
+        rec = instrumented_pass(net, solvers, args.solver, latents, args.nfe)
+        ms, launches = rec['igemm_conv']
+        fl = conv_flops_per_eval(spec, B) * args.nfe
+        ach = fl / (ms * 1e-3) / 1e12
+        roof = dict(bound='mfma', kernel='igemm_f32_kernel<conv> (ds_conv2d_nhwc)', achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS,
+                    unit='TFLOP/s', frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None, launches_per_step=launches,
+                    avg_launch_ms=round(ms / launches, 4), share_of_step=round(ms / (dt / args.steps * 1e3), 3))
+        if 'solver_update' in rec:
+            ums, ul = rec['solver_update']
+            per = spec.in_channels * spec.img_resolution ** 2 * 4
+            # DPM-Solver++(2M), x0 form: D pass (x, F read; m written) + combine (x, m0, m1 read; x written) = 7 passes/image/step
+            passes = {'dpmpp': 7, 'euler': 3, 'ipndm': 7, 'heun': 3.5}[args.solver]
+            byts = passes * per * B * args.nfe
+            gbs = byts / (ums * 1e-3) / 1e9
+            roof_u = dict(bound='hbm', kernel='solver_update_kernel', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s',
+                          frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, launches_per_step=ul, avg_launch_ms=round(ums / ul, 4))
+
+    if rank == 0:
+        total_images = B * world * args.steps
+        line = {
+            'metric': 'images/sec (whole node) at NFE=%d, EDM CIFAR-10' % args.nfe,
+            'value': round(total_images / dt, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'fp32', 'data': 'synthetic N(0,1) latents, random-init (signal-carrying) weights',
+            'config': {'workload': 'EDM CIFAR-10 32x32 SongUNet (55.7M params), %s NFE=%d, batch %d/GPU' %
+                       ({'dpmpp': 'DPM-Solver++(2M) logSNR', 'euler': 'Euler', 'ipndm': 'iPNDM-4', 'heun': 'Heun'}[args.solver], args.nfe, B),
+                       'images_per_step': B * world, 'sharding': 'independent image batches per rank, no collective'},
+            'roofline': roof, 'roofline_update': roof_u, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

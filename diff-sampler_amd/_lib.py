@@ -63,6 +63,7 @@ _SIGNATURES = {
     'ds_dynamic_threshold': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp]),
     'ds_scale': (C.c_int, [vp, C.c_float, vp, C.c_longlong, vp]),
     'ds_quantize_u8_nhwc': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'ds_fill': (C.c_int, [vp, C.c_float, C.c_longlong, vp]),
     'ds_copy_rows': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_longlong, C.c_int, vp]),
     'ds_channel_mean': (C.c_int, [vp, C.c_int, C.c_int, C.c_longlong, vp, vp]),
 }
@@ -80,6 +81,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so.7; importing it FIRST makes libdsamd.so bind to that same runtime instance
+    # (same SONAME), so that torch's stream handles and allocations are valid in our launches.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise DsError(f'{LIB_PATH} is missing: build it with `python diff-sampler_amd/build.py` '
                       f'(or __graft_entry__.build()).  The HIP engine has no CPU fallback.')

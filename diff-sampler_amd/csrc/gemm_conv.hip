@@ -215,6 +215,7 @@ int launch(const KParams& p, int batch, hipStream_t stream) {
 }  // namespace
 
 extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated runtime calls
     if (!a || !a->x0 || !a->wgt || !a->out) return DS_E_ARG;
     if (a->taps != 1 && a->taps != 9) return DS_E_ARG;
     if (a->c0 <= 0 || a->c0 % 32 || a->c1 < 0 || a->c1 % 32) return DS_E_SHAPE;
@@ -238,6 +239,7 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
 }
 
 extern "C" int ds_gemm_nt_batched(const ds_gemm_args* a, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated runtime calls
     if (!a || !a->a || !a->b || !a->c) return DS_E_ARG;
     if (a->m <= 0 || a->n <= 0 || a->k <= 0 || a->batch <= 0 || a->heads <= 0) return DS_E_ARG;
     if (a->k % 32) return DS_E_SHAPE;

@@ -206,6 +206,7 @@ int norm_geometry(const ds_norm_args* a, int* CQ, int* PL) {
 }  // namespace
 
 extern "C" int ds_gn_stats(const ds_norm_args* a, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated runtime calls
     if (!a || !a->x0 || !a->mean || !a->rstd) return DS_E_ARG;
     if (a->groups <= 0 || a->groups > 64 || (a->c0 + a->c1) % a->groups) return DS_E_SHAPE;
     if ((a->ld0 & 3) || (a->c1 && (a->ld1 & 3))) return DS_E_ALIGN;
@@ -221,6 +222,7 @@ extern "C" int ds_gn_stats(const ds_norm_args* a, void* stream) {
 }
 
 extern "C" int ds_norm_act(const ds_norm_args* a, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated runtime calls
     if (!a || !a->x0 || !a->out) return DS_E_ARG;
     if ((a->mean == nullptr) != (a->rstd == nullptr)) return DS_E_ARG;
     if ((a->scale == nullptr) != (a->shift == nullptr)) return DS_E_ARG;
@@ -247,6 +249,7 @@ extern "C" int ds_norm_act(const ds_norm_args* a, void* stream) {
 }
 
 extern "C" int ds_softmax_rows(const float* x, float* y, long long rows, int cols, int ld, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated runtime calls
     if (!x || !y || rows <= 0 || cols <= 0 || ld < cols) return DS_E_ARG;
     const long long blocks = (rows + 3) / 4;
     if (blocks > 0x7fffffffLL) return DS_E_SHAPE;
@@ -257,6 +260,7 @@ extern "C" int ds_softmax_rows(const float* x, float* y, long long rows, int col
 
 extern "C" int ds_noise_embed(const float* sigma, int bs, const float* freqs, int nch, int swap, float* out, int out_ld,
                               void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated runtime calls
     if (!sigma || !freqs || !out || bs <= 0 || nch <= 0 || (nch & 1)) return DS_E_ARG;
     const int total = bs * (nch / 2);
     hipLaunchKernelGGL(noise_embed_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, sigma, bs, freqs, nch,
@@ -267,6 +271,7 @@ extern "C" int ds_noise_embed(const float* sigma, int bs, const float* freqs, in
 
 extern "C" int ds_stem_im2col(const float* x, const float* sigma, int sigma_rows, float sigma_data, int n, int c, int h, int w,
                               float* out, int kpad, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated runtime calls
     if (!x || !sigma || !out || n <= 0 || c <= 0 || kpad < 9 * c || (kpad % 32)) return DS_E_ARG;
     const long long total = (long long)n * h * w * kpad;
     long long blocks = (total + 255) / 256;
@@ -278,6 +283,7 @@ extern "C" int ds_stem_im2col(const float* x, const float* sigma, int sigma_rows
 }
 
 extern "C" int ds_channel_mean(const float* x, int ld, int c, long long rows, float* out, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated runtime calls
     if (!x || !out || rows <= 0 || c <= 0) return DS_E_ARG;
     hipLaunchKernelGGL(channel_mean_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ld, c, rows, out);
     DS_CHECK_LAUNCH();

@@ -128,6 +128,10 @@ __global__ void __launch_bounds__(256) scale_kernel(const float* __restrict__ x,
     for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) y[i] = a * x[i];
 }
 
+__global__ void __launch_bounds__(256) fill_kernel(float* __restrict__ dst, float v, long long count) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) dst[i] = v;
+}
+
 __global__ void __launch_bounds__(256) copy_rows_kernel(const float* __restrict__ src, int src_ld, float* __restrict__ dst, int dst_ld,
                                                         long long rows, int cols) {
     const long long total = rows * cols;
@@ -223,6 +227,7 @@ __global__ void __launch_bounds__(512) dynamic_threshold_kernel(const float* __r
 }  // namespace
 
 extern "C" int ds_solver_update(const ds_update_args* a, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated runtime calls
     if (!a || !a->xe || !a->xb) return DS_E_ARG;
     if (!a->afs && !a->f) return DS_E_ARG;
     if (!a->x_out && !a->m_out) return DS_E_ARG;
@@ -242,6 +247,7 @@ extern "C" int ds_solver_update(const ds_update_args* a, void* stream) {
 }
 
 extern "C" int ds_table_select(const float* table, int row_floats, int* step, int advance, float* dst, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated runtime calls
     if (!table || !step || !dst || row_floats <= 0) return DS_E_ARG;
     hipLaunchKernelGGL(table_select_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, table, row_floats, step, advance, dst);
     DS_CHECK_LAUNCH();
@@ -249,6 +255,7 @@ extern "C" int ds_table_select(const float* table, int row_floats, int* step, in
 }
 
 extern "C" int ds_dynamic_threshold(const float* x0, float* out, int n, int per, float p, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated runtime calls
     if (!x0 || !out || n <= 0 || per <= 1) return DS_E_ARG;
     const size_t smem = ((size_t)per + 256) * sizeof(unsigned);
     if (smem > 150 * 1024) return DS_E_SHAPE;
@@ -265,6 +272,7 @@ extern "C" int ds_dynamic_threshold(const float* x0, float* out, int n, int per,
 }
 
 extern "C" int ds_scale(const float* x, float a, float* y, long long count, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated runtime calls
     if (!x || !y || count <= 0) return DS_E_ARG;
     if (!ds_aligned16(x) || !ds_aligned16(y)) return DS_E_ALIGN;
     long long blocks = ((count >> 2) + 255) / 256;
@@ -276,6 +284,7 @@ extern "C" int ds_scale(const float* x, float a, float* y, long long count, void
 }
 
 extern "C" int ds_quantize_u8_nhwc(const float* x, uint8_t* out, int n, int c, int h, int w, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated runtime calls
     if (!x || !out || n <= 0 || c <= 0) return DS_E_ARG;
     long long blocks = ((long long)n * h * w + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -284,7 +293,18 @@ extern "C" int ds_quantize_u8_nhwc(const float* x, uint8_t* out, int n, int c, i
     return DS_OK;
 }
 
+extern "C" int ds_fill(float* dst, float value, long long count, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated runtime calls
+    if (!dst || count <= 0) return DS_E_ARG;
+    long long blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dst, value, count);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
 extern "C" int ds_copy_rows(const float* src, int src_ld, float* dst, int dst_ld, long long rows, int cols, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated runtime calls
     if (!src || !dst || rows <= 0 || cols <= 0) return DS_E_ARG;
     long long blocks = (rows * cols + 255) / 256;
     if (blocks > 4096) blocks = 4096;

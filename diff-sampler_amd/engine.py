@@ -45,6 +45,7 @@ class _Plan:
     def __init__(self):
         self.ops: List[_Op] = []
         self.bufs: Dict[str, torch.Tensor] = {}
+        self.keep: List[torch.Tensor] = []      # every workspace tensor the launch arguments point into
 
     def run(self, stream):
         for op in self.ops:
@@ -129,7 +130,12 @@ class UNetEngine:
             return self._plans[key]
         spec, dev, w, lib = self.spec, self.device, self.w, self.lib
         P = _Plan()
-        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        def new(*shape):
+            # The argument structs hold raw pointers: the plan must own every tensor they point into, otherwise the
+            # caching allocator would hand the memory to the next torch.empty() while the plan still uses it.
+            t = torch.empty(*shape, dtype=torch.float32, device=dev)
+            P.keep.append(t)
+            return t
         R = spec.img_resolution
         Bs = emb_rows
         E, NC = spec.emb_channels, spec.noise_channels
@@ -381,22 +387,26 @@ class EDMDenoiser:
     # -- raw evaluation: fills plan inputs, runs the plan, returns (F_nhwc4, plan) -----------------------------------
     def _prepare(self, x, sigma, class_labels):
         B = x.shape[0]
-        sigma = torch.as_tensor(sigma, dtype=torch.float32, device=self.device).reshape(-1)
-        per_sample = sigma.numel() > 1
-        emb_rows = B if (per_sample or self.label_dim) else 1
-        plan = self.engine.plan(B, emb_rows)
-        st = _lib.stream_ptr()
         lib = self.engine.lib
+        st = _lib.stream_ptr()
+        host_scalar = isinstance(sigma, (int, float))
+        if host_scalar:
+            emb_rows = B if self.label_dim else 1
+        else:
+            sigma = torch.as_tensor(sigma, dtype=torch.float32, device=self.device).reshape(-1).contiguous()
+            emb_rows = B if (sigma.numel() > 1 or self.label_dim) else 1
+        plan = self.engine.plan(B, emb_rows)
         xb = plan.bufs['x']
         if x.data_ptr() != xb.data_ptr():
             assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
             _lib.check(lib.ds_copy_rows(_ptr(x), x[0].numel(), _ptr(xb), x[0].numel(), B, x[0].numel(), st), 'copy x')
         sb = plan.bufs['sigma']
-        if sigma.data_ptr() != sb.data_ptr():
-            rows = emb_rows
-            if sigma.numel() == 1 and rows > 1:
-                sigma = sigma.expand(rows).contiguous()
-            _lib.check(lib.ds_copy_rows(_ptr(sigma), 1, _ptr(sb), 1, rows, 1, st), 'copy sigma')
+        if host_scalar:      # no H2D copy: the sigma rows are written by a kernel
+            _lib.check(lib.ds_fill(_ptr(sb), float(sigma), emb_rows, st), 'fill sigma')
+        elif sigma.data_ptr() != sb.data_ptr():
+            if sigma.numel() == 1 and emb_rows > 1:
+                sigma = sigma.expand(emb_rows).contiguous()
+            _lib.check(lib.ds_copy_rows(_ptr(sigma), 1, _ptr(sb), 1, emb_rows, 1, st), 'copy sigma')
         if self.label_dim:
             lb = plan.bufs['labels']
             if class_labels is None:

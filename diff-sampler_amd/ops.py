@@ -127,3 +127,7 @@ def channel_mean(x, ld, c, rows, out):
 
 def copy_rows(src, src_ld, dst, dst_ld, rows, cols):
     _lib.check(_lib.load().ds_copy_rows(_p(src), src_ld, _p(dst), dst_ld, rows, cols, _lib.stream_ptr()), 'ds_copy_rows')
+
+
+def fill(dst, value, count=None):
+    _lib.check(_lib.load().ds_fill(_p(dst), float(value), dst.numel() if count is None else count, _lib.stream_ptr()), 'ds_fill')

@@ -173,6 +173,9 @@ int ds_scale(const float* x, float a, float* y, long long count, void* stream);
 /* images uint8 NHWC <- clip(x * 127.5 + 128, 0, 255), x NCHW (sample.py:311). */
 int ds_quantize_u8_nhwc(const float* x, uint8_t* out, int n, int c, int h, int w, void* stream);
 
+/* dst[0..count) = value. */
+int ds_fill(float* dst, float value, long long count, void* stream);
+
 /* dst[r, 0:cols] = src[r, 0:cols] for r < rows (strided 2-D copy; pads/gathers label and sigma rows). */
 int ds_copy_rows(const float* src, int src_ld, float* dst, int dst_ld, long long rows, int cols, void* stream);
 
