@@ -1,0 +1,240 @@
+"""Batched generation CLI -- the reference's ``sample.py`` surface on the HIP engine.
+
+Same click options, defaults, seed sharding, per-seed RNG, NFE bookkeeping and output tree as
+diff-solvers-main/sample.py:125-320 (+ the GITS ``--dp/--metric/...`` and AMED ``--predictor_path`` options are
+accepted where they only select a schedule / predictor).  Differences, all host-side:
+  * the network object is an ``engine.EDMDenoiser`` (built from the unpickled EDM network when a pickle is given, or
+    from the stated architecture with ``--random_init`` -- no pretrained weights exist in this environment);
+  * uint8 conversion runs in a HIP kernel and PNG encoding is off the critical path only in the sense that it stays
+    where the reference has it (one file per seed, ``<outdir>/<seed-seed%1000:06d>/<seed:06d>.png``);
+  * ``torch.distributed`` is initialised here (env://, backend nccl = RCCL) instead of ``torch_utils.distributed``.
+"""
+from __future__ import annotations
+
+import ast
+import os
+import pickle
+import re
+from typing import List
+
+import torch
+
+try:
+    import click
+except ImportError:                        # pragma: no cover
+    click = None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class StackedRandomGenerator:
+    """One generator per sample, seeded ``seed % 2**32`` (sample.py:22-36): a batch is reproducible per image
+    regardless of how seeds are grouped into batches or sharded over ranks."""
+
+    def __init__(self, device, seeds):
+        self.generators = [torch.Generator(device).manual_seed(int(seed) % (1 << 32)) for seed in seeds]
+
+    def randn(self, size, **kwargs):
+        assert size[0] == len(self.generators)
+        return torch.stack([torch.randn(size[1:], generator=g, **kwargs) for g in self.generators])
+
+    def randn_like(self, input):
+        return self.randn(input.shape, dtype=input.dtype, layout=input.layout, device=input.device)
+
+    def randint(self, *args, size, **kwargs):
+        assert size[0] == len(self.generators)
+        return torch.stack([torch.randint(*args, size=size[1:], generator=g, **kwargs) for g in self.generators])
+
+
+def parse_int_list(s):
+    """'1,2,5-10' -> [1, 2, 5, 6, 7, 8, 9, 10] (sample.py:42-52)."""
+    if isinstance(s, list):
+        return s
+    out: List[int] = []
+    for part in s.split(','):
+        m = re.match(r'^(\d+)-(\d+)$', part)
+        out.extend(range(int(m.group(1)), int(m.group(2)) + 1) if m else [int(part)])
+    return out
+
+
+def shard_seeds(seeds, max_batch_size: int, rank: int, world: int):
+    """The reference partition (sample.py:167-169): ``ceil(len/(B*W))*W`` near-equal batches, rank r takes r::W."""
+    num_batches = ((len(seeds) - 1) // (max_batch_size * world) + 1) * world
+    all_batches = torch.as_tensor(seeds).tensor_split(num_batches)
+    return all_batches[rank::world]
+
+
+def compute_nfe(solver, num_steps, afs, denoise_to_zero, dataset_name):
+    """sample.py:211-219."""
+    if solver in ('dpm', 'heun'):
+        nfe = 2 * (num_steps - 1) - 1 if afs else 2 * (num_steps - 1)
+    else:
+        nfe = num_steps - 2 if afs else num_steps - 1
+    if denoise_to_zero:
+        nfe += 1
+    return 2 * nfe if dataset_name in ['ms_coco'] else nfe
+
+
+SOLVER_FNS = dict(euler='euler_sampler', heun='heun_sampler', dpm='dpm_2_sampler', ipndm='ipndm_sampler',
+                  ipndm_v='ipndm_v_sampler', dpmpp='dpm_pp_sampler', unipc='unipc_sampler', deis='deis_sampler')
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def create_model(dataset_name=None, model_path=None, random_init=False, device=None, seed=0):
+    """EDM networks only (cifar10 / ffhq / afhqv2 / imagenet64; sample.py:80-85).  Returns (net, 'edm')."""
+    from . import arch
+    from .engine import EDMDenoiser
+    if dataset_name not in arch.NAMED_CONFIGS:
+        raise ValueError(f'dataset {dataset_name!r}: only the EDM networks are in scope of the HIP engine '
+                         f'({sorted(k for k in arch.NAMED_CONFIGS if not k.startswith("tiny"))}); CM/ADM/LDM models run on the reference')
+    if random_init or model_path is None:
+        net = EDMDenoiser.from_config(dataset_name, seed=seed, device=device)
+    else:
+        with open(model_path, 'rb') as f:       # needs the reference's torch_utils/dnnlib importable for unpickling
+            ref = pickle.load(f)['ema']
+        net = EDMDenoiser.from_reference_module(ref, device=device)
+    net.sigma_min, net.sigma_max = 0.002, 80.0
+    return net, 'edm'
+
+
+def save_images(images: torch.Tensor, batch_seeds, outdir, subdirs=True):
+    """uint8 NHWC conversion on the GPU (sample.py:311), then one PNG per seed (sample.py:312-316)."""
+    import PIL.Image
+    from . import ops
+    B, C, H, W = images.shape
+    u8 = torch.empty(B, H, W, C, dtype=torch.uint8, device=images.device)
+    ops.quantize_u8_nhwc(images.contiguous(), u8, B, C, H, W)
+    arr = u8.cpu().numpy()
+    for seed, img in zip(batch_seeds, arr):
+        seed = int(seed)
+        d = os.path.join(outdir, f'{seed - seed % 1000:06d}') if subdirs else outdir
+        os.makedirs(d, exist_ok=True)
+        PIL.Image.fromarray(img, 'RGB').save(os.path.join(d, f'{seed:06d}.png'))
+
+
+def save_grid(images: torch.Tensor, outdir):
+    import PIL.Image
+    x = torch.clamp(images / 2 + 0.5, 0, 1)
+    n = int(x.shape[0] ** 0.5)
+    rows = [torch.cat(list(x[r * n:(r + 1) * n]), dim=2) for r in range(max(1, x.shape[0] // n))]
+    grid = (torch.cat(rows, dim=1) * 255 + 0.5).clamp(0, 255).to(torch.uint8).permute(1, 2, 0).cpu().numpy()
+    os.makedirs(outdir, exist_ok=True)
+    PIL.Image.fromarray(grid, 'RGB').save(os.path.join(outdir, 'grid.png'))
+
+
+def _dist():
+    import torch.distributed as dist
+    if 'RANK' in os.environ and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl' if torch.cuda.is_available() else 'gloo', init_method='env://')
+    if dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+def run(dataset_name, max_batch_size=64, seeds='0-63', grid=False, outdir=None, subdirs=True, t_steps=None, model_path=None,
+        random_init=False, device=None, **solver_kwargs):
+    """Body of the CLI, importable (the tests call it directly)."""
+    from . import solvers, solver_utils
+    seeds = parse_int_list(seeds)
+    dist, rank, world = _dist()
+    device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0))) if device is None else torch.device(device)
+    torch.cuda.set_device(device)
+    rank_batches = shard_seeds(seeds, max_batch_size, rank, world)
+    log = print if rank == 0 else (lambda *a, **k: None)
+
+    if dist is not None and rank != 0:
+        dist.barrier()                                              # rank 0 goes first (sample.py:183-193)
+    net, solver_kwargs['model_source'] = create_model(dataset_name, model_path, random_init, device)
+    if dist is not None and rank == 0:
+        dist.barrier()
+
+    solver_kwargs.setdefault('num_steps', 6)
+    for k, v in dict(afs=False, denoise_to_zero=False, schedule_type='polynomial', schedule_rho=7, predict_x0=True,
+                     lower_order_final=True, variant='bh2', deis_mode='tab', max_order=None, prompt=None,
+                     guidance_type=None, guidance_rate=None, return_inters=False).items():
+        solver_kwargs.setdefault(k, v)
+    solver_kwargs['sigma_min'], solver_kwargs['sigma_max'] = net.sigma_min, net.sigma_max
+    if t_steps is None:
+        t_steps = solver_utils.get_schedule(solver_kwargs['num_steps'], net.sigma_min, net.sigma_max, device=device,
+                                            schedule_type=solver_kwargs['schedule_type'], schedule_rho=solver_kwargs['schedule_rho'],
+                                            net=net)
+    else:
+        t_list = ast.literal_eval(t_steps) if isinstance(t_steps, str) else list(t_steps)
+        t_steps = torch.tensor(t_list, device=device)               # all-int lists give an int64 tensor, as in the reference
+        solver_kwargs['num_steps'] = t_steps.shape[0]
+        solver_kwargs['sigma_max'], solver_kwargs['sigma_min'] = t_list[0], t_list[-1]
+        solver_kwargs['schedule_type'] = solver_kwargs['schedule_rho'] = None
+        log('Pre-specified t_steps:', t_list)
+    solver_kwargs['t_steps'] = t_steps
+    solver = solver_kwargs['solver']
+    nfe = compute_nfe(solver, solver_kwargs['num_steps'], solver_kwargs['afs'], solver_kwargs['denoise_to_zero'], dataset_name)
+    solver_kwargs['nfe'] = nfe
+    sampler_fn = getattr(solvers, SOLVER_FNS[solver])
+    if solver == 'deis':
+        solver_kwargs['coeff_list'] = solver_utils.get_deis_coeff_list(t_steps, solver_kwargs['max_order'],
+                                                                       deis_mode=solver_kwargs['deis_mode'])
+    if outdir is None:
+        outdir = os.path.join(f'./samples/grids/{dataset_name}' if grid else f'./samples/{dataset_name}', f'{solver}_nfe{nfe}')
+    log(f'Generating {len(seeds)} images to "{outdir}"...')
+
+    n_done = 0
+    for batch_seeds in rank_batches:
+        if dist is not None:
+            dist.barrier()                                          # per-batch barrier, as the reference (sample.py:268)
+        B = len(batch_seeds)
+        if B == 0:
+            continue
+        rnd = StackedRandomGenerator(device, batch_seeds)
+        latents = rnd.randn([B, net.img_channels, net.img_resolution, net.img_resolution], device=device)
+        class_labels = None
+        if net.label_dim:
+            class_labels = torch.eye(net.label_dim, device=device)[rnd.randint(net.label_dim, size=[B], device=device)]
+        with torch.no_grad():
+            images = sampler_fn(net, latents, class_labels=class_labels, **solver_kwargs)
+        if solver_kwargs.get('return_inters'):
+            images = images[-1]
+        if grid:
+            save_grid(images, outdir)
+        else:
+            save_images(images, batch_seeds, outdir, subdirs)
+        n_done += B
+    if dist is not None:
+        dist.barrier()
+    log('Done.')
+    return outdir, n_done
+
+
+if click is not None:
+    @click.command()
+    @click.option('--dataset_name', help='Name of the dataset', metavar='STR', type=str, required=True)
+    @click.option('--model_path', help='Network filepath', metavar='PATH|URL', type=str)
+    @click.option('--batch', 'max_batch_size', help='Maximum batch size', metavar='INT', type=click.IntRange(min=1), default=64, show_default=True)
+    @click.option('--seeds', help='Random seeds (e.g. 1,2,5-10)', metavar='LIST', type=parse_int_list, default='0-63', show_default=True)
+    @click.option('--prompt', help='Prompt for Stable Diffusion sampling', metavar='STR', type=str)
+    @click.option('--solver', help='Name of the solver', metavar='many solvers', type=click.Choice(list(SOLVER_FNS)))
+    @click.option('--num_steps', help='Number of sampling steps', metavar='INT', type=click.IntRange(min=1), default=6, show_default=True)
+    @click.option('--afs', help='Whether to use AFS', metavar='BOOL', type=bool, default=False, show_default=True)
+    @click.option('--guidance_type', help='Guidance type', type=click.Choice(['cg', 'cfg', 'uncond', None]), default=None, show_default=True)
+    @click.option('--guidance_rate', help='Guidance rate', type=float)
+    @click.option('--denoise_to_zero', help='Whether to denoise from the last time step to 0', type=bool, default=False)
+    @click.option('--return_inters', help='Whether to save intermediate outputs', metavar='BOOL', type=bool, default=False)
+    @click.option('--use_fp16', help='Whether to use mixed precision', metavar='BOOL', type=bool, default=False)
+    @click.option('--max_order', help='Max order for solvers', metavar='INT', type=click.IntRange(min=1))
+    @click.option('--predict_x0', help='Whether to use data prediction mode', metavar='BOOL', type=bool, default=True)
+    @click.option('--lower_order_final', help='Whether to lower the order at final stages', metavar='BOOL', type=bool, default=True)
+    @click.option('--variant', help='Type of UniPC solver', metavar='STR', type=click.Choice(['bh1', 'bh2']), default='bh2')
+    @click.option('--deis_mode', help='Type of DEIS solver', metavar='STR', type=click.Choice(['tab', 'rhoab']), default='tab')
+    @click.option('--sigma_min', help='Lowest noise level', metavar='FLOAT', type=click.FloatRange(min=0, min_open=True), default=0.002)
+    @click.option('--sigma_max', help='Highest noise level', metavar='FLOAT', type=click.FloatRange(min=0, min_open=True), default=80.)
+    @click.option('--schedule_type', help='Time discretization schedule', metavar='STR', type=click.Choice(['polynomial', 'logsnr', 'time_uniform', 'discrete']), default='polynomial', show_default=True)
+    @click.option('--schedule_rho', help='Time step exponent', metavar='FLOAT', type=click.FloatRange(min=0, min_open=True), default=7, show_default=True)
+    @click.option('--t_steps', help='Pre-specified time schedule', metavar='STR', type=str, default=None)
+    @click.option('--outdir', help='Where to save the output images', metavar='DIR', type=str)
+    @click.option('--grid', help='Whether to make grid', type=bool, default=False)
+    @click.option('--subdirs', help='Create subdirectory for every 1000 seeds', type=bool, default=True, is_flag=True)
+    @click.option('--random_init', help='Use a random-init network of the named architecture (no checkpoint)', type=bool, default=False)
+    def main(**kw):
+        run(**kw)
+
+    if __name__ == '__main__':
+        main()

@@ -1,0 +1,154 @@
+"""CPU-only tests of the host logic: seed sharding (property test + 2 gloo ranks), CLI helpers, coefficient compilers
+against the oracle's tensor arithmetic, FID moments + all-reduce on gloo (world_size 2)."""
+import math
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+from diff_sampler_amd import sample as S, solver_utils as U, fid as F  # noqa: E402
+from oracle import solvers_ref  # noqa: E402
+
+
+# ---------------------------------------------------------------------------------------------------- sharding
+@settings(max_examples=200, deadline=None)
+@given(n=st.integers(1, 3000), batch=st.integers(1, 700), world=st.integers(1, 9))
+def test_shard_seeds_partitions_every_seed_exactly_once(n, batch, world):
+    seeds = list(range(100, 100 + n))
+    got = []
+    for r in range(world):
+        for b in S.shard_seeds(seeds, batch, r, world):
+            assert len(b) <= batch
+            got.extend(b.tolist())
+    assert sorted(got) == seeds
+
+
+def test_shard_seeds_is_the_reference_rule():
+    seeds = list(range(0, 50000))
+    for world in (1, 2, 4, 8):
+        nb = ((len(seeds) - 1) // (64 * world) + 1) * world
+        allb = torch.as_tensor(seeds).tensor_split(nb)
+        for r in range(world):
+            mine = S.shard_seeds(seeds, 64, r, world)
+            ref = allb[r::world]
+            assert len(mine) == len(ref) and all(torch.equal(a, b) for a, b in zip(mine, ref))
+
+
+def test_cli_helpers():
+    assert S.parse_int_list('1,2,5-10') == [1, 2, 5, 6, 7, 8, 9, 10]
+    assert S.parse_int_list([3, 4]) == [3, 4]
+    assert S.compute_nfe('euler', 11, False, False, 'cifar10') == 10
+    assert S.compute_nfe('heun', 6, True, False, 'cifar10') == 9
+    assert S.compute_nfe('dpm', 6, False, True, 'cifar10') == 11
+    assert S.compute_nfe('ipndm', 6, True, False, 'ms_coco') == 8
+    assert set(S.SOLVER_FNS) == {'euler', 'ipndm', 'ipndm_v', 'heun', 'dpm', 'dpmpp', 'deis', 'unipc'}
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _rank_shard(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    seeds = list(range(1000, 1000 + 777))
+    mine = torch.cat(list(S.shard_seeds(seeds, 50, rank, world))).to(torch.int64)
+    # FID moments: every rank accumulates its shard, then the reference's two all-reduces
+    g = torch.Generator().manual_seed(0)
+    feats = torch.randn(777, 32, generator=g, dtype=torch.float64)
+    mu, sigma = F.calculate_inception_stats(lambda b: b, feats, max_batch_size=50, device='cpu', feature_dim=32)
+    gathered = [torch.zeros(500, dtype=torch.int64) for _ in range(world)]
+    pad = torch.full((500,), -1, dtype=torch.int64); pad[:len(mine)] = mine
+    dist.all_gather(gathered, pad)
+    if rank == 0:
+        q.put((torch.cat(gathered).tolist(), mu, sigma))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_gloo_ranks_shard_and_allreduce_moments():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_shard, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    allseeds, mu, sigma = q.get(timeout=120)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert sorted(s for s in allseeds if s >= 0) == list(range(1000, 1777))
+    g = torch.Generator().manual_seed(0)
+    feats = torch.randn(777, 32, generator=g, dtype=torch.float64).numpy()
+    assert np.allclose(mu, feats.mean(0), atol=1e-12)
+    assert np.allclose(sigma, np.cov(feats, rowvar=False), atol=1e-10)
+    assert abs(F.calculate_fid_from_inception_stats(mu, sigma, mu, sigma)) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------- coefficient compilers
+def _lin_from_oracle(order, px0, scale, ts, tn):
+    """Coefficients of (x, m0, m1, m2) implied by the oracle's tensor code, extracted by probing with unit tensors."""
+    def run(x, ms):
+        X = torch.full((1, 1, 1, 1), x, dtype=torch.float64)
+        M = [torch.full((1, 1, 1, 1), v, dtype=torch.float64) for v in ms]
+        T = [torch.tensor(v, dtype=torch.float64) for v in ts]
+        return float(solvers_ref.dpmpp_step(X, M, T, torch.tensor(tn, dtype=torch.float64), order, predict_x0=px0, scale=scale,
+                                            scaled_form=(scale != 1)))
+    base = [0.0, 0.0, 0.0]
+    cx = run(1.0, base)
+    cm = []
+    for j in range(order):
+        ms = list(base); ms[2 - j] = 1.0          # ms is oldest..newest; m_j newest-first
+        cm.append(run(0.0, ms))
+    return cx, cm
+
+
+@pytest.mark.parametrize('order', [1, 2, 3])
+@pytest.mark.parametrize('px0', [True, False])
+@pytest.mark.parametrize('scale', [1, 0.93])
+def test_dpmpp_coefficient_compiler(order, px0, scale):
+    ts, tn = [9.6, 3.3, 1.15], 0.4
+    cx, cm = U.dpmpp_coeffs(ts[-order:] if order < 3 else ts, tn, order, px0, scale)
+    rx, rm = _lin_from_oracle(order, px0, scale, ts, tn)
+    assert math.isclose(cx, rx, rel_tol=1e-12)
+    assert np.allclose(cm, rm, rtol=1e-10, atol=1e-14)
+
+
+def test_ipndm_v_coefficients_reduce_to_fixed_step_ab_on_uniform_grid():
+    # orders 1-3 are the classical variable-step AB weights; the reference's order-4 expression (solvers.py:470-476)
+    # does NOT reduce to AB4 on a uniform grid (57/24 instead of 55/24 ...) -- it is reproduced as is and pinned by the
+    # golden trajectories (tests/test_hip_samplers.py, case 'ipndmv4').
+    ts = [5.0, 4.0, 3.0, 2.0, 1.0]
+    for order in (1, 2, 3):
+        i = order - 1
+        assert np.allclose(U.ipndm_v_coeffs(order, ts, i), U.ipndm_coeffs(order, ts[i + 1] - ts[i]), rtol=1e-12)
+
+
+def test_unipc_coefficients_against_reference_formulas():
+    """order-1 corrector and order-2 predictor use the reference's hard-coded 0.5 (solver_utils.py:233-243)."""
+    th, tn = [3.0, 1.2], 0.5
+    k1 = U.unipc_coeffs(th[-1:], tn, 1, predict_x0=True, variant='bh2', use_corrector=True)
+    h = -math.log(tn) + math.log(th[-1]); hh = -h
+    assert math.isclose(k1['cx'], tn / th[-1])
+    assert math.isclose(k1['pred'][0], -math.expm1(hh))
+    assert math.isclose(k1['corr'][-1], -math.expm1(hh) * 0.5)
+    assert math.isclose(k1['corr'][0], -math.expm1(hh) + math.expm1(hh) * 0.5)
+    k2 = U.unipc_coeffs(th, tn, 2, predict_x0=False, variant='bh1', use_corrector=False)
+    assert k2['corr'] is None and len(k2['pred']) == 2 and k2['cx'] == 1.0
+
+
+def test_get_schedule_errors_and_types():
+    with pytest.raises(ValueError, match='Got wrong schedule type'):
+        U.get_schedule(5, 0.002, 80., schedule_type='nope')
+    t = U.get_schedule(6, 0.002, 80.)
+    assert t.dtype == torch.float32 and t.shape == (6,) and float(t[0]) == pytest.approx(79.99998474, rel=1e-7)
+    assert torch.all(t[:-1] > t[1:])
