@@ -2,9 +2,13 @@
 //
 // One kernel core serves every contraction of the denoiser (3x3 conv, 1x1 conv, Linear, QK^T, PV):
 //     C[m, n] = sum_k A(m, k) * B(n, k)          (both operands k-contiguous in memory: "NT")
-//   conv mode : A(m, k) is gathered on the fly from the NHWC activation(s): k = tap*Ctot + c addresses the
-//               zero-padded 3x3 neighbour `tap` of output pixel m, channel c of the concatenation [x0 | x1]
-//               (the decoder's torch.cat is never materialised);  B = packed weights [Cout_pad][K].
+//   conv mode : A(m, k) is gathered on the fly from the NHWC activation(s).  K is ordered CHUNK-MAJOR, TAP-MINOR:
+//               k = (chunk * taps + tap) * 32 + cc, where chunk indexes 32-channel slabs of the concatenation
+//               [x0 | x1] (the decoder's torch.cat is never materialised) and tap the zero-padded 3x3 neighbour.
+//               All 9 taps of one 32-channel slab are consumed back to back, so a block's working set per slab is
+//               128 pixels x 128 B (+halo) = L1-resident: every activation byte leaves L2 once per block instead of
+//               nine times (round-1 PMC: 5.5x the algorithmic HBM bytes with the tap-major order).
+//               B = packed weights [Cout_pad][K] in the same K order.
 //   gemm mode : A, B plain strided row-major matrices, batched over blockIdx.z (attention).
 //
 // Tiling (CDNA4, wave64): block tile 128(M) x 128(N) x 32(K), 256 threads = 4 waves in a 2x2 grid, each wave
@@ -16,12 +20,21 @@
 // Fragment trick: lane l of an MFMA holds A[row = l&31][kslot = l>>5]; one ds_read_b128 fetches 4 consecutive k
 // for that lane, and register r of the read feeds MFMA number r, i.e. MFMA r contracts k = {8*ks + r, 8*ks+4+r}.
 // A and B use the same k permutation, so the sum over k is unchanged.
+//
+// Tile -> workgroup mapping (conv): 1-D grid; the dispatcher places workgroup b on XCD b % 8, so ids are decoded as
+// (group of 8*NT ids) -> m-tile = group*8 + (b % 8), n-tile = (b / 8) % NT: the NT column tiles that share an A
+// slab run on the SAME XCD (same L2) at nearly the same time.  Placement only affects speed, never results.
+//
+// Epilogue: accumulators are transposed through LDS (free after the K loop) so that bias / residual / output are
+// accessed as float4 rows (16 B per lane, 256 B contiguous per 16 lanes) instead of 64 dword accesses per lane.
 #include "ds_common.h"
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32, LDSK = 36;
+constexpr int EPI_LD = 68;                                              // 64 + 4 floats: epilogue staging row
 constexpr int SMEM_BYTES = 2 * (BM + BN) * LDSK * (int)sizeof(float);   // 73,728 B -> 2 blocks / CU
+static_assert(4 * 64 * EPI_LD * (int)sizeof(float) <= SMEM_BYTES, "epilogue staging must fit in the tile buffers");
 
 struct KParams {
     // A side (conv gather)
@@ -31,13 +44,17 @@ struct KParams {
     // B side
     const float* b; int ldb; long long b_bs, b_hs; int nrows_b;   // rows of B that may be read
     int M, N, K;
+    int mtiles, ntiles;
     // epilogue
     float* out; int ldo; long long o_bs, o_hs;
     const float* colbias; const float* rowbias;
     const float* cbias; int cbias_ld; int cbias_bcast;
     const float* res; int res_ld;
     float scale; int act; int heads;
+    int vec_ok;                                                    // float4 epilogue allowed (alignment, ld % 4)
 };
+
+__device__ float g_zero_page[64];     // zero-initialised; target of the predicated-off staging loads
 
 template <int MODE>   // 0 = conv gather, 1 = batched gemm
 __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(const KParams p) {
@@ -47,7 +64,18 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(const KParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    int mt, nt;
+    if (MODE == 0) {
+        const int b = blockIdx.x;
+        const int per = 8 * p.ntiles;
+        const int g = b / per, r = b - g * per;
+        mt = g * 8 + (r & 7);
+        nt = r >> 3;
+        if (mt >= p.mtiles) return;           // padding ids of the last group (uniform per block)
+    } else {
+        mt = blockIdx.x; nt = blockIdx.y;
+    }
+    const int m0 = mt * BM, n0 = nt * BN;
     const int ld_row = tid >> 3, ld_col = (tid & 7) * 4;
 
     const float* a_base = p.a0;
@@ -84,41 +112,30 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(const KParams p) {
         b_ok[i] = n < p.nrows_b;
         b_off[i] = (size_t)n * p.ldb + ld_col;
     }
-    const int Ctot = p.c0 + p.c1;
 
+    // Staging is branch-free: out-of-image taps, rows past M and weight rows past N read from a zero page instead of
+    // being predicated, so the whole K-tile body is ONE basic block and the scheduler can interleave the address
+    // arithmetic, the 8 global loads and the 8 LDS stores with the 64 MFMAs (each MFMA leaves ~16 issue slots).
     f32x4 ra[4], rb[4];
-    auto load_tiles = [&](int kt) {
-        const int k0 = kt * BK;
+    const float* zero = g_zero_page;
+    auto a_addr = [&](int kt, int i) -> const float* {
         if (MODE == 0) {
-            const int tap = k0 / Ctot;
-            const int c = k0 - tap * Ctot;
-            int dy = 0, dx = 0;
-            if (p.taps == 9) { const int ty = tap / 3; dy = ty - 1; dx = tap - ty * 3 - 1; }
-            const float* src; int ld;
-            if (c < p.c0) { src = p.a0 + c + ld_col; ld = p.lda0; } else { src = p.a1 + (c - p.c0) + ld_col; ld = p.lda1; }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ih = a_oh[i] + dy, iw = a_ow[i] + dx;
-                const bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (ok) v = *reinterpret_cast<const f32x4*>(src + (a_off[i] + (size_t)(ih * p.W + iw)) * ld);
-                ra[i] = v;
-            }
+            const int chunk = kt / p.taps;
+            const int tap = kt - chunk * p.taps;
+            const int c = chunk * BK;
+            const int ty = (p.taps == 9) ? tap / 3 : 1;
+            const int dy = ty - 1, dx = (p.taps == 9) ? tap - ty * 3 - 1 : 0;
+            const bool first = c < p.c0;
+            const float* src = first ? p.a0 + c + ld_col : p.a1 + (c - p.c0) + ld_col;
+            const int ld = first ? p.lda0 : p.lda1;
+            const int ih = a_oh[i] + dy, iw = a_ow[i] + dx;
+            const bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            return ok ? src + (a_off[i] + (size_t)(ih * p.W + iw)) * ld : zero;
         } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (a_ok[i]) v = *reinterpret_cast<const f32x4*>(a_base + a_off[i] + k0);
-                ra[i] = v;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (b_ok[i]) v = *reinterpret_cast<const f32x4*>(b_base + b_off[i] + k0);
-            rb[i] = v;
+            return a_ok[i] ? a_base + a_off[i] + kt * BK : zero;
         }
     };
+    auto b_addr = [&](int kt, int i) -> const float* { return b_ok[i] ? b_base + b_off[i] + kt * BK : zero; };
     auto store_tiles = [&](int buf) {
         float* as = As + buf * BM * LDSK + ld_row * LDSK + ld_col;
         float* bs = Bs + buf * BN * LDSK + ld_row * LDSK + ld_col;
@@ -138,16 +155,18 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(const KParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int KT = p.K / BK;
-    load_tiles(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ra[i] = *reinterpret_cast<const f32x4*>(a_addr(0, i));
+        rb[i] = *reinterpret_cast<const f32x4*>(b_addr(0, i));
+    }
     store_tiles(0);
     __syncthreads();
 
     const int frag_off = (lane & 31) * LDSK + (lane >> 5) * 4;
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = kt & 1;
-        const bool more = (kt + 1) < KT;
-        if (more) load_tiles(kt + 1);
-
+        const int nxt = min(kt + 1, KT - 1);      // the last iteration re-stages its own tile (harmless, keeps the body branch-free)
         const float* as = As + cur * BM * LDSK + wr * 64 * LDSK + frag_off;
         const float* bs = Bs + cur * BN * LDSK + wc * 64 * LDSK + frag_off;
 #pragma unroll
@@ -156,6 +175,14 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(const KParams p) {
             const f32x4 a1 = *reinterpret_cast<const f32x4*>(as + 32 * LDSK + ks * 8);
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(bs + ks * 8);
             const f32x4 b1 = *reinterpret_cast<const f32x4*>(bs + 32 * LDSK + ks * 8);
+            // two of the eight staging loads ride in the shadow of each 16-MFMA group
+            if (ks < 2) {
+                ra[2 * ks] = *reinterpret_cast<const f32x4*>(a_addr(nxt, 2 * ks));
+                ra[2 * ks + 1] = *reinterpret_cast<const f32x4*>(a_addr(nxt, 2 * ks + 1));
+            } else {
+                rb[2 * (ks - 2)] = *reinterpret_cast<const f32x4*>(b_addr(nxt, 2 * (ks - 2)));
+                rb[2 * (ks - 2) + 1] = *reinterpret_cast<const f32x4*>(b_addr(nxt, 2 * (ks - 2) + 1));
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[r], b0[r], acc[0][0], 0, 0, 0);
@@ -164,21 +191,63 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(const KParams p) {
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], b1[r], acc[1][1], 0, 0, 0);
             }
         }
-        if (more) store_tiles(cur ^ 1);
+        store_tiles(cur ^ 1);
         __syncthreads();
     }
 
-    // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    // ---- epilogue ---------------------------------------------------------------------------------------------
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    const int wm0 = m0 + wr * 64, wn0 = n0 + wc * 64;
+    const bool full_cols = (wn0 + 64 <= p.N);
+    if (p.vec_ok && full_cols) {
+        // stage this wave's 64x64 tile in LDS (all tile reads finished at the loop's last barrier), read it back
+        // row-major: lane -> (row = pass*4 + lane/16, 4 columns at (lane%16)*4)
+        float* st = smem + wave * 64 * EPI_LD;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    st[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_LD + j * 32 + (lane & 31)] = acc[i][j][r];
+        const int c4 = (lane & 15) * 4;
+        const int col = wn0 + c4;
+        f32x4 cb = {0.f, 0.f, 0.f, 0.f};
+        if (p.colbias) cb = *reinterpret_cast<const f32x4*>(p.colbias + col);
+#pragma unroll 4
+        for (int pass = 0; pass < 16; ++pass) {
+            const int rr = pass * 4 + (lane >> 4);
+            const int row = wm0 + rr;
+            if (row >= p.M) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(st + rr * EPI_LD + c4);
+            if (MODE == 1) v *= p.scale;
+            v += cb;
+            if (p.rowbias) v += p.rowbias[row];
+            if (p.cbias) {
+                const int img = p.cbias_bcast ? 0 : row / p.HW;
+                v += *reinterpret_cast<const f32x4*>(p.cbias + (size_t)img * p.cbias_ld + col);
+            }
+            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.res_ld + col);
+            if (MODE == 0) v *= p.scale;
+            if (p.act == DS_ACT_SILU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = ds_silu(v[q]);
+            }
+            *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col) = v;
+        }
+        return;
+    }
+    // scalar fallback (ragged N such as the 3-channel output conv, or unaligned leading dimensions)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wc * 64 + j * 32 + (lane & 31);
+        const int col = wn0 + j * 32 + (lane & 31);
         if (col >= p.N) continue;
         const float cb = p.colbias ? p.colbias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row >= p.M) continue;
                 float v = acc[i][j][r];
                 if (MODE == 1) v *= p.scale;          // gemm: alpha scales the product, biases added after
@@ -198,7 +267,7 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(const KParams p) {
 }
 
 template <int MODE>
-int launch(const KParams& p, int batch, hipStream_t stream) {
+int launch(KParams& p, int batch, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f32_kernel<MODE>),
@@ -206,10 +275,23 @@ int launch(const KParams& p, int batch, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, batch);
+    p.mtiles = (p.M + BM - 1) / BM;
+    p.ntiles = (p.N + BN - 1) / BN;
+    dim3 grid;
+    if (MODE == 0) grid = dim3(((p.mtiles + 7) / 8) * 8 * p.ntiles, 1, 1);
+    else grid = dim3(p.mtiles, p.ntiles, batch);
     hipLaunchKernelGGL(igemm_f32_kernel<MODE>, grid, dim3(256), SMEM_BYTES, stream, p);
     DS_CHECK_LAUNCH();
     return DS_OK;
+}
+
+bool vec_epilogue_ok(const KParams& p) {
+    auto a16 = [](const void* q) { return q == nullptr || ds_aligned16(q); };
+    if ((p.ldo & 3) || !a16(p.out) || (p.o_bs & 3) || (p.o_hs & 3)) return false;
+    if (p.res && ((p.res_ld & 3) || !a16(p.res))) return false;
+    if (p.cbias && ((p.cbias_ld & 3) || !a16(p.cbias))) return false;
+    if (!a16(p.colbias)) return false;
+    return true;
 }
 
 }  // namespace
@@ -235,6 +317,7 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     p.cbias = a->cbias; p.cbias_ld = a->cbias_ld; p.cbias_bcast = (a->cbias_rows == 1);
     p.res = a->res; p.res_ld = a->res_ld;
     p.scale = a->out_scale; p.act = a->act; p.heads = 1;
+    p.vec_ok = vec_epilogue_ok(p) ? 1 : 0;
     return launch<0>(p, 1, (hipStream_t)stream);
 }
 
@@ -253,5 +336,6 @@ extern "C" int ds_gemm_nt_batched(const ds_gemm_args* a, void* stream) {
     p.M = a->m; p.N = a->n; p.K = a->k; p.HW = 1; p.H = p.W = 1; p.taps = 1; p.c0 = a->k; p.c1 = 0;
     p.colbias = a->colbias; p.rowbias = a->rowbias; p.cbias = nullptr; p.res = nullptr;
     p.scale = a->alpha; p.act = a->act; p.heads = a->heads;
+    p.vec_ok = vec_epilogue_ok(p) ? 1 : 0;
     return launch<1>(p, a->batch * a->heads, (hipStream_t)stream);
 }

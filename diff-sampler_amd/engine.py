@@ -26,7 +26,7 @@ import torch
 from . import _lib, arch
 from ._lib import (ConvArgs, GemmArgs, NormArgs, DS_ACT_NONE, DS_ACT_SILU, DS_RESAMPLE_NONE, DS_RESAMPLE_DOWN,
                    DS_RESAMPLE_UP)
-from .ops import pack_conv_weight, pack_linear_weight
+from .ops import pack_conv_weight, pack_linear_weight, pack_stem_weight
 
 
 def _ptr(t):
@@ -99,7 +99,7 @@ class UNetEngine:
         for b in spec.blocks:
             p = f'{m}.{b.name}'
             if b.kind == 'conv':
-                w[f'{b.name}.w'] = pack_conv_weight(g(f'{p}.weight')); w[f'{b.name}.b'] = g(f'{p}.bias')
+                w[f'{b.name}.w'] = pack_stem_weight(g(f'{p}.weight')); w[f'{b.name}.b'] = g(f'{p}.bias')
                 continue
             for leaf in ('norm0', 'norm1'):
                 w[f'{b.name}.{leaf}.g'] = g(f'{p}.{leaf}.weight'); w[f'{b.name}.{leaf}.b'] = g(f'{p}.{leaf}.bias')

@@ -23,8 +23,26 @@ def _p(t: Optional[torch.Tensor]):
 
 
 def pack_conv_weight(w: torch.Tensor, row_pad: int = 128, k_pad: int = 32) -> torch.Tensor:
-    """[Cout, Cin, kh, kw] -> [Cout_pad, kh*kw*Cin] with K index = tap*Cin + c (tap = ky*3 + kx), zero-padded rows
-    (to a multiple of the N tile) and columns (to a multiple of the K tile)."""
+    """[Cout, Cin, kh, kw] -> [Cout_pad, K] in the kernel's K order, rows zero-padded to a multiple of the N tile.
+
+    3x3: K = (chunk*9 + tap)*32 + cc with c = chunk*32 + cc, tap = ky*3 + kx  (chunk-major, tap-minor; Cin % 32 == 0).
+    1x1 / linear: K = c, zero-padded to a multiple of 32."""
+    cout, cin, kh, kw = w.shape
+    taps = kh * kw
+    if taps == 1:
+        m = w.reshape(cout, cin)
+    else:
+        assert cin % k_pad == 0, 'use pack_stem_weight for the 3-channel stem'
+        m = w.permute(0, 2, 3, 1).reshape(cout, taps, cin // k_pad, k_pad).permute(0, 2, 1, 3).reshape(cout, taps * cin)
+    rows = -(-cout // row_pad) * row_pad
+    cols = -(-m.shape[1] // k_pad) * k_pad
+    out = torch.zeros(rows, cols, dtype=torch.float32, device=w.device)
+    out[:cout, :m.shape[1]] = m
+    return out.contiguous()
+
+
+def pack_stem_weight(w: torch.Tensor, row_pad: int = 128, k_pad: int = 32) -> torch.Tensor:
+    """Stem conv [Cout, C, 3, 3] for the im2col'd input of ds_stem_im2col: K = tap*C + c, zero-padded to 32."""
     cout, cin, kh, kw = w.shape
     m = w.permute(0, 2, 3, 1).reshape(cout, kh * kw * cin)
     rows = -(-cout // row_pad) * row_pad

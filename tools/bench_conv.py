@@ -1,0 +1,74 @@
+"""Micro-benchmark of the implicit-GEMM conv kernel on the CIFAR-10 denoiser's shapes (B images).
+
+    python tools/bench_conv.py --batch 256 [--entry ds_conv2d_nhwc] [--check]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diff_sampler_amd import _lib, ops  # noqa: E402
+from diff_sampler_amd._lib import ConvArgs  # noqa: E402
+
+SHAPES = [  # (res, c0, c1, cout, taps, share of FLOPs label)
+    (32, 256, 0, 256, 9), (32, 256, 256, 256, 9), (32, 256, 128, 256, 9), (32, 128, 0, 256, 9),
+    (16, 256, 0, 256, 9), (16, 256, 256, 256, 9), (8, 256, 0, 256, 9), (8, 256, 256, 256, 9),
+    (32, 256, 256, 256, 1), (16, 256, 0, 512, 1), (32, 256, 0, 3, 9),
+]
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--batch', type=int, default=256)
+ap.add_argument('--entry', default='ds_conv2d_nhwc')
+ap.add_argument('--iters', type=int, default=10)
+ap.add_argument('--check', action='store_true')
+ap.add_argument('--only', type=int, nargs='*')
+args = ap.parse_args()
+
+lib = _lib.load()
+fn = getattr(lib, args.entry)
+fn.restype, fn.argtypes = C.c_int, [C.POINTER(ConvArgs), C.c_void_p]
+B = args.batch
+dev = 'cuda'
+tot_fl = tot_t = 0.0
+for si, (res, c0, c1, cout, taps) in enumerate(SHAPES):
+    if args.only and si not in args.only:
+        continue
+    M = B * res * res
+    x0 = torch.randn(M, c0, device=dev)
+    x1 = torch.randn(M, c1, device=dev) if c1 else None
+    w = torch.randn(cout, c0 + c1, 3 if taps == 9 else 1, 3 if taps == 9 else 1, device=dev) / (taps * (c0 + c1)) ** 0.5
+    wp = ops.pack_conv_weight(w)
+    bias = torch.randn(cout, device=dev)
+    res_t = torch.randn(M, cout, device=dev)
+    old = 4 if cout < 4 else cout
+    out = torch.zeros(M, old, device=dev)
+    a = ConvArgs(x0.data_ptr(), x1.data_ptr() if c1 else None, c0, c1, c0, c1, B, res, res, taps, wp.data_ptr(), cout, bias.data_ptr(),
+                 None, 0, 1, res_t.data_ptr() if cout >= 4 else None, cout, 0.70710678, 0, out.data_ptr(), old)
+    st = _lib.stream_ptr()
+    rc = fn(C.byref(a), st); assert rc == 0, rc
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.iters):
+        fn(C.byref(a), st)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.iters
+    fl = 2.0 * M * taps * (c0 + c1) * cout
+    tot_fl += fl; tot_t += ms
+    msg = f'[{si}] {res}x{res} {c0}+{c1}->{cout} taps={taps} M={M}: {ms:8.3f} ms  {fl/ms/1e9:7.1f} TFLOP/s'
+    if args.check:
+        xin = torch.cat([x0, x1], 1) if c1 else x0
+        xin = xin.reshape(B, res, res, c0 + c1).permute(0, 3, 1, 2)
+        ref = torch.nn.functional.conv2d(xin, w, bias, padding=(1 if taps == 9 else 0))
+        ref = ref.permute(0, 2, 3, 1).reshape(M, cout)
+        if cout >= 4:
+            ref = (ref + res_t) * 0.70710678
+        else:
+            ref = ref * 0.70710678
+        err = float((out[:, :cout] - ref).abs().max() / ref.abs().max())
+        msg += f'  relerr {err:.2e}'
+    print(msg, flush=True)
+print(f'total {tot_t:.3f} ms, {tot_fl/tot_t/1e9:.1f} TFLOP/s aggregate (unweighted by layer counts)')
