@@ -1,58 +1,28 @@
-// Implicit-GEMM convolution / batched NT GEMM on the gfx950 fp32 matrix pipe.
+// Generic implicit-GEMM / batched NT GEMM on the gfx950 fp32 matrix pipe, and the C-ABI entry points of both
+// contraction kernels (3x3 convolutions that fit the halo geometry are routed to conv3x3_halo.hip).
 //
-// One kernel core serves every contraction of the denoiser (3x3 conv, 1x1 conv, Linear, QK^T, PV):
+// One kernel core serves 1x1 convolutions, Linear layers, QK^T, PV and any 3x3 convolution the halo kernel rejects:
 //     C[m, n] = sum_k A(m, k) * B(n, k)          (both operands k-contiguous in memory: "NT")
 //   conv mode : A(m, k) is gathered on the fly from the NHWC activation(s).  K is ordered CHUNK-MAJOR, TAP-MINOR:
 //               k = (chunk * taps + tap) * 32 + cc, where chunk indexes 32-channel slabs of the concatenation
 //               [x0 | x1] (the decoder's torch.cat is never materialised) and tap the zero-padded 3x3 neighbour.
-//               All 9 taps of one 32-channel slab are consumed back to back, so a block's working set per slab is
-//               128 pixels x 128 B (+halo) = L1-resident: every activation byte leaves L2 once per block instead of
-//               nine times (round-1 PMC: 5.5x the algorithmic HBM bytes with the tap-major order).
 //               B = packed weights [Cout_pad][K] in the same K order.
 //   gemm mode : A, B plain strided row-major matrices, batched over blockIdx.z (attention).
 //
 // Tiling (CDNA4, wave64): block tile 128(M) x 128(N) x 32(K), 256 threads = 4 waves in a 2x2 grid, each wave
 // owns a 64x64 sub-tile = 2x2 MFMA tiles of v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 64 cycles each,
-// 157 TFLOP/s chip peak).  Global -> register -> LDS staging with double-buffered LDS (one barrier per K tile):
-// the global loads of tile k+1 are issued before the 64 MFMAs of tile k and written to the other LDS buffer
-// after them.  LDS rows are padded to 36 floats so that the ds_read_b128 fragment reads (16 distinct rows per
-// lane group, stride 144 B) hit 16 distinct 16-B bank slots: conflict free.
+// 157 TFLOP/s chip peak).  Global -> register -> LDS staging with double-buffered LDS (one barrier per K tile).
+// LDS rows are padded to 36 floats so that the ds_read_b128 fragment reads (16 distinct rows per lane group,
+// stride 144 B) hit 16 distinct 16-B bank slots: conflict free.
 // Fragment trick: lane l of an MFMA holds A[row = l&31][kslot = l>>5]; one ds_read_b128 fetches 4 consecutive k
 // for that lane, and register r of the read feeds MFMA number r, i.e. MFMA r contracts k = {8*ks + r, 8*ks+4+r}.
 // A and B use the same k permutation, so the sum over k is unchanged.
-//
-// Tile -> workgroup mapping (conv): 1-D grid; the dispatcher places workgroup b on XCD b % 8, so ids are decoded as
-// (group of 8*NT ids) -> m-tile = group*8 + (b % 8), n-tile = (b / 8) % NT: the NT column tiles that share an A
-// slab run on the SAME XCD (same L2) at nearly the same time.  Placement only affects speed, never results.
-//
-// Epilogue: accumulators are transposed through LDS (free after the K loop) so that bias / residual / output are
-// accessed as float4 rows (16 B per lane, 256 B contiguous per 16 lanes) instead of 64 dword accesses per lane.
-#include "ds_common.h"
+// Staging is branch-free: out-of-image taps, rows past M and B rows past N read from a zero page instead of being
+// predicated, so the K-tile body is one basic block and the staging loads ride in the shadow of the MFMAs.
+#include "igemm_common.h"
 
+namespace igemm {
 namespace {
-
-constexpr int BM = 128, BN = 128, BK = 32, LDSK = 36;
-constexpr int EPI_LD = 68;                                              // 64 + 4 floats: epilogue staging row
-constexpr int SMEM_BYTES = 2 * (BM + BN) * LDSK * (int)sizeof(float);   // 73,728 B -> 2 blocks / CU
-static_assert(4 * 64 * EPI_LD * (int)sizeof(float) <= SMEM_BYTES, "epilogue staging must fit in the tile buffers");
-
-struct KParams {
-    // A side (conv gather)
-    const float* a0; const float* a1; int c0, c1, lda0, lda1; int H, W, HW, taps;
-    // A side (gemm) uses a0/lda0 plus batch strides
-    long long a_bs, a_hs;
-    // B side
-    const float* b; int ldb; long long b_bs, b_hs; int nrows_b;   // rows of B that may be read
-    int M, N, K;
-    int mtiles, ntiles;
-    // epilogue
-    float* out; int ldo; long long o_bs, o_hs;
-    const float* colbias; const float* rowbias;
-    const float* cbias; int cbias_ld; int cbias_bcast;
-    const float* res; int res_ld;
-    float scale; int act; int heads;
-    int vec_ok;                                                    // float4 epilogue allowed (alignment, ld % 4)
-};
 
 __device__ float g_zero_page[64];     // zero-initialised; target of the predicated-off staging loads
 
@@ -66,12 +36,7 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(const KParams p) {
     const int wr = wave >> 1, wc = wave & 1;
     int mt, nt;
     if (MODE == 0) {
-        const int b = blockIdx.x;
-        const int per = 8 * p.ntiles;
-        const int g = b / per, r = b - g * per;
-        mt = g * 8 + (r & 7);
-        nt = r >> 3;
-        if (mt >= p.mtiles) return;           // padding ids of the last group (uniform per block)
+        if (!decode_tile(blockIdx.x, p.mtiles, p.ntiles, mt, nt)) return;
     } else {
         mt = blockIdx.x; nt = blockIdx.y;
     }
@@ -113,9 +78,6 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(const KParams p) {
         b_off[i] = (size_t)n * p.ldb + ld_col;
     }
 
-    // Staging is branch-free: out-of-image taps, rows past M and weight rows past N read from a zero page instead of
-    // being predicated, so the whole K-tile body is ONE basic block and the scheduler can interleave the address
-    // arithmetic, the 8 global loads and the 8 LDS stores with the 64 MFMAs (each MFMA leaves ~16 issue slots).
     f32x4 ra[4], rb[4];
     const float* zero = g_zero_page;
     auto a_addr = [&](int kt, int i) -> const float* {
@@ -195,75 +157,7 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(const KParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue ---------------------------------------------------------------------------------------------
-    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-    const int wm0 = m0 + wr * 64, wn0 = n0 + wc * 64;
-    const bool full_cols = (wn0 + 64 <= p.N);
-    if (p.vec_ok && full_cols) {
-        // stage this wave's 64x64 tile in LDS (all tile reads finished at the loop's last barrier), read it back
-        // row-major: lane -> (row = pass*4 + lane/16, 4 columns at (lane%16)*4)
-        float* st = smem + wave * 64 * EPI_LD;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    st[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_LD + j * 32 + (lane & 31)] = acc[i][j][r];
-        const int c4 = (lane & 15) * 4;
-        const int col = wn0 + c4;
-        f32x4 cb = {0.f, 0.f, 0.f, 0.f};
-        if (p.colbias) cb = *reinterpret_cast<const f32x4*>(p.colbias + col);
-#pragma unroll 4
-        for (int pass = 0; pass < 16; ++pass) {
-            const int rr = pass * 4 + (lane >> 4);
-            const int row = wm0 + rr;
-            if (row >= p.M) continue;
-            f32x4 v = *reinterpret_cast<const f32x4*>(st + rr * EPI_LD + c4);
-            if (MODE == 1) v *= p.scale;
-            v += cb;
-            if (p.rowbias) v += p.rowbias[row];
-            if (p.cbias) {
-                const int img = p.cbias_bcast ? 0 : row / p.HW;
-                v += *reinterpret_cast<const f32x4*>(p.cbias + (size_t)img * p.cbias_ld + col);
-            }
-            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.res_ld + col);
-            if (MODE == 0) v *= p.scale;
-            if (p.act == DS_ACT_SILU) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = ds_silu(v[q]);
-            }
-            *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col) = v;
-        }
-        return;
-    }
-    // scalar fallback (ragged N such as the 3-channel output conv, or unaligned leading dimensions)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = wn0 + j * 32 + (lane & 31);
-        if (col >= p.N) continue;
-        const float cb = p.colbias ? p.colbias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row >= p.M) continue;
-                float v = acc[i][j][r];
-                if (MODE == 1) v *= p.scale;          // gemm: alpha scales the product, biases added after
-                v += cb;
-                if (p.rowbias) v += p.rowbias[row];
-                if (p.cbias) {
-                    const int img = p.cbias_bcast ? 0 : row / p.HW;
-                    v += p.cbias[(size_t)img * p.cbias_ld + col];
-                }
-                if (p.res) v += p.res[(size_t)row * p.res_ld + col];
-                if (MODE == 0) v *= p.scale;          // conv: (acc + bias + residual) * skip_scale
-                if (p.act == DS_ACT_SILU) v = ds_silu(v);
-                o_base[(size_t)row * p.ldo + col] = v;
-            }
-        }
-    }
+    epilogue<MODE>(p, acc, smem + wave * 64 * EPI_LD, lane, m0 + wr * 64, n0 + wc * 64, o_base);
 }
 
 template <int MODE>
@@ -278,7 +172,7 @@ int launch(KParams& p, int batch, hipStream_t stream) {
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = (p.N + BN - 1) / BN;
     dim3 grid;
-    if (MODE == 0) grid = dim3(((p.mtiles + 7) / 8) * 8 * p.ntiles, 1, 1);
+    if (MODE == 0) grid = dim3(grid_1d(p.mtiles, p.ntiles), 1, 1);
     else grid = dim3(p.mtiles, p.ntiles, batch);
     hipLaunchKernelGGL(igemm_f32_kernel<MODE>, grid, dim3(256), SMEM_BYTES, stream, p);
     DS_CHECK_LAUNCH();
@@ -294,7 +188,15 @@ bool vec_epilogue_ok(const KParams& p) {
     return true;
 }
 
+int g_force_generic = 0;
+
 }  // namespace
+}  // namespace igemm
+
+using namespace igemm;
+
+// Debug/benchmark switch: 1 = route 3x3 convolutions through the generic gather kernel instead of the halo kernel.
+extern "C" int ds_debug_force_generic_conv(int v) { g_force_generic = v; return DS_OK; }
 
 extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     (void)hipGetLastError();   // drop stale errors of unrelated runtime calls
@@ -318,6 +220,7 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     p.res = a->res; p.res_ld = a->res_ld;
     p.scale = a->out_scale; p.act = a->act; p.heads = 1;
     p.vec_ok = vec_epilogue_ok(p) ? 1 : 0;
+    if (!g_force_generic && conv3x3_halo_supported(p)) return launch_conv3x3_halo(p, (hipStream_t)stream);
     return launch<0>(p, 1, (hipStream_t)stream);
 }
 

@@ -1,0 +1,125 @@
+// Shared pieces of the fp32-MFMA contraction kernels (gemm_conv.hip, conv3x3_halo.hip): tile constants, kernel
+// parameter block, fused epilogue.
+#pragma once
+#include "ds_common.h"
+
+namespace igemm {
+
+constexpr int BM = 128, BN = 128, BK = 32, LDSK = 36;
+constexpr int EPI_LD = 68;                                              // 64 + 4 floats: epilogue staging row
+constexpr int SMEM_BYTES = 2 * (BM + BN) * LDSK * (int)sizeof(float);   // 73,728 B -> 2 blocks / CU
+static_assert(4 * 64 * EPI_LD * (int)sizeof(float) <= SMEM_BYTES, "epilogue staging must fit in the tile buffers");
+
+struct KParams {
+    // A side (conv gather)
+    const float* a0; const float* a1; int c0, c1, lda0, lda1; int H, W, HW, taps;
+    // A side (gemm) uses a0/lda0 plus batch strides
+    long long a_bs, a_hs;
+    // B side
+    const float* b; int ldb; long long b_bs, b_hs; int nrows_b;   // rows of B that may be read
+    int M, N, K;
+    int mtiles, ntiles;
+    // halo kernel geometry: a 128-pixel M tile = nimg image slots x TH rows x W columns
+    int TH, nimg, HP, WP, NP;      // HP = TH + 2, WP = W + 2, NP = nimg * HP * WP halo pixels
+    // epilogue
+    float* out; int ldo; long long o_bs, o_hs;
+    const float* colbias; const float* rowbias;
+    const float* cbias; int cbias_ld; int cbias_bcast;
+    const float* res; int res_ld;
+    float scale; int act; int heads;
+    int vec_ok;                                                    // float4 epilogue allowed (alignment, ld % 4)
+};
+
+// Fused epilogue of one wave's 64x64 accumulator tile (2x2 MFMA 32x32 tiles).
+//   conv (MODE 0): out = act((acc + colbias + cbias[img] + res) * scale)
+//   gemm (MODE 1): out = act(acc * scale + colbias + rowbias)
+// C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+// Vector path: the tile is transposed through LDS (`stage`, 64 x EPI_LD floats owned by this wave, free once every
+// wave of the block has passed the K loop's last barrier) so that bias / residual / output are accessed as float4
+// rows (16 B per lane, 256 B contiguous per 16 lanes) instead of 64 dword accesses per lane.
+template <int MODE>
+__device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2][2], float* stage, int lane, int wm0, int wn0,
+                                         float* o_base) {
+    const bool full_cols = (wn0 + 64 <= p.N);
+    if (p.vec_ok && full_cols) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_LD + j * 32 + (lane & 31)] = acc[i][j][r];
+        const int c4 = (lane & 15) * 4;
+        const int col = wn0 + c4;
+        f32x4 cb = {0.f, 0.f, 0.f, 0.f};
+        if (p.colbias) cb = *reinterpret_cast<const f32x4*>(p.colbias + col);
+#pragma unroll 4
+        for (int pass = 0; pass < 16; ++pass) {
+            const int rr = pass * 4 + (lane >> 4);
+            const int row = wm0 + rr;
+            if (row >= p.M) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * EPI_LD + c4);
+            if (MODE == 1) v *= p.scale;
+            v += cb;
+            if (p.rowbias) v += p.rowbias[row];
+            if (p.cbias) {
+                const int img = p.cbias_bcast ? 0 : row / p.HW;
+                v += *reinterpret_cast<const f32x4*>(p.cbias + (size_t)img * p.cbias_ld + col);
+            }
+            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.res_ld + col);
+            if (MODE == 0) v *= p.scale;
+            if (p.act == DS_ACT_SILU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = ds_silu(v[q]);
+            }
+            *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col) = v;
+        }
+        return;
+    }
+    // scalar fallback (ragged N such as the 3-channel output conv, or unaligned leading dimensions)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = wn0 + j * 32 + (lane & 31);
+        if (col >= p.N) continue;
+        const float cb = p.colbias ? p.colbias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= p.M) continue;
+                float v = acc[i][j][r];
+                if (MODE == 1) v *= p.scale;
+                v += cb;
+                if (p.rowbias) v += p.rowbias[row];
+                if (p.cbias) {
+                    const int img = p.cbias_bcast ? 0 : row / p.HW;
+                    v += p.cbias[(size_t)img * p.cbias_ld + col];
+                }
+                if (p.res) v += p.res[(size_t)row * p.res_ld + col];
+                if (MODE == 0) v *= p.scale;
+                if (p.act == DS_ACT_SILU) v = ds_silu(v);
+                o_base[(size_t)row * p.ldo + col] = v;
+            }
+        }
+    }
+}
+
+// XCD-aware decode of a 1-D workgroup id into (m tile, n tile): the dispatcher places workgroup b on XCD b % 8, so
+// within each group of 8*NT ids the NT column tiles that share an A slab get the SAME b % 8 (same L2) and are
+// dispatched back to back.  Placement only affects speed, never results.
+__device__ __forceinline__ bool decode_tile(int b, int mtiles, int ntiles, int& mt, int& nt) {
+    const int per = 8 * ntiles;
+    const int g = b / per, r = b - g * per;
+    mt = g * 8 + (r & 7);
+    nt = r >> 3;
+    return mt < mtiles;
+}
+
+inline unsigned grid_1d(int mtiles, int ntiles) { return (unsigned)(((mtiles + 7) / 8) * 8 * ntiles); }
+
+// conv3x3_halo.hip
+bool conv3x3_halo_supported(const KParams& p);
+int launch_conv3x3_halo(KParams& p, hipStream_t stream);
+
+}  // namespace igemm

@@ -71,6 +71,10 @@ typedef struct ds_conv_args {
 
 int ds_conv2d_nhwc(const ds_conv_args* a, void* stream);
 
+/* Benchmark/debug switch: v != 0 routes 3x3 convolutions through the generic gather kernel instead of the
+ * LDS-halo kernel (both are exact fp32; used for A/B measurements and as a cross-check in the tests). */
+int ds_debug_force_generic_conv(int v);
+
 /* Batched C[z] = act(alpha * A[z] * B[z]^T + rowbias + colbias) on the same MFMA core ("NT": both operands have k
  * contiguous).  Used for attention: S = Q K^T / sqrt(C) and O = P V (networks_edm.py:108, :176) and the transposed
  * V projection.  z = zb * heads + zh;  X_z = X + zb*x_bstride + zh*x_hstride. Constraints: k % 32 == 0. */
