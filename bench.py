@@ -43,6 +43,7 @@ def parse():
     ap.add_argument('--solver', default='dpmpp', choices=['dpmpp', 'euler', 'ipndm', 'heun'])
     ap.add_argument('--config', default='cifar10')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', action='store_true', help='replay the sampler call from a captured hipGraph')
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--cpu-calls', type=int, default=2)
     return ap.parse_args()
@@ -190,15 +191,25 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, args.nfe)
 
+    run_step = lambda: sampler_call(solvers, args.solver, net, latents, args.nfe)
+    if args.graph:
+        from diff_sampler_amd.graph import GraphedSampler
+
+        class _Rec:        # records the sampler function and kwargs sampler_call() would use
+            def __getattr__(self, name):
+                return lambda net_, lat_, **kw: (getattr(solvers, name), kw)
+        fn, kw = sampler_call(_Rec(), args.solver, net, latents, args.nfe)
+        graphed = GraphedSampler(fn, net, tuple(latents.shape), device=dev, **kw)
+        run_step = lambda: graphed(latents, clone=False)
     for _ in range(args.warmup):
-        sampler_call(solvers, args.solver, net, latents, args.nfe)
+        run_step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = sampler_call(solvers, args.solver, net, latents, args.nfe)
+        out = run_step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -238,7 +249,7 @@ def main():
             'dtype': 'fp32', 'data': 'synthetic N(0,1) latents, random-init (signal-carrying) weights',
             'config': {'workload': 'EDM CIFAR-10 32x32 SongUNet (55.7M params), %s NFE=%d, batch %d/GPU' %
                        ({'dpmpp': 'DPM-Solver++(2M) logSNR', 'euler': 'Euler', 'ipndm': 'iPNDM-4', 'heun': 'Heun'}[args.solver], args.nfe, B),
-                       'images_per_step': B * world, 'sharding': 'independent image batches per rank, no collective'},
+                       'images_per_step': B * world, 'sharding': 'independent image batches per rank, no collective', 'launch': 'hipGraph replay' if args.graph else 'eager'},
             'roofline': roof, 'roofline_update': roof_u, 'cpu_baseline': cpu,
         }
         print(json.dumps(line), flush=True)

@@ -48,6 +48,18 @@ class UpdateArgs(C.Structure):
                 ('n', C.c_int), ('c', C.c_int), ('h', C.c_int), ('w', C.c_int)]
 
 
+class AmedPredictor(C.Structure):
+    _fields_ = [('map0_w', vp), ('map0_b', vp), ('enc0_w', vp), ('enc0_b', vp), ('enc1_w', vp), ('enc1_b', vp),
+                ('fc_r_w', vp), ('fc_r_b', vp), ('fc_sd_w', vp), ('fc_sd_b', vp), ('fc_st_w', vp), ('fc_st_b', vp),
+                ('nc', C.c_int), ('in_dim', C.c_int), ('hidden', C.c_int), ('out_dim', C.c_int),
+                ('scale_dir', C.c_float), ('scale_time', C.c_float)]
+
+
+class AmedCoefArgs(C.Structure):
+    _fields_ = [('pred', vp), ('t_cur', C.c_float), ('t_next', C.c_float), ('mode', C.c_int), ('stage', C.c_int),
+                ('order', C.c_int), ('predict_x0', C.c_int), ('thist', vp), ('coefs', vp), ('sigma2', vp), ('n', C.c_int)]
+
+
 _SIGNATURES = {
     'ds_version': (C.c_int, []),
     'ds_error_string': (C.c_char_p, [C.c_int]),
@@ -66,6 +78,8 @@ _SIGNATURES = {
     'ds_quantize_u8_nhwc': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'ds_fill': (C.c_int, [vp, C.c_float, C.c_longlong, vp]),
     'ds_copy_rows': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_longlong, C.c_int, vp]),
+    'ds_amed_predict': (C.c_int, [C.POINTER(AmedPredictor), vp, C.c_int, C.c_float, C.c_float, vp, vp]),
+    'ds_amed_coefs': (C.c_int, [C.POINTER(AmedCoefArgs), vp]),
     'ds_channel_mean': (C.c_int, [vp, C.c_int, C.c_int, C.c_longlong, vp, vp]),
 }
 

@@ -65,7 +65,8 @@ class _Run:
     # -- network evaluation at (x, sigma): remembers F (raw) or D (denoised) for the next update --------------------
     def evaluate(self, x, sigma: float):
         if self.fused:
-            self._f, _ = self.net.raw(x, sigma, self.cl)
+            # sigma: Python float (uniform) or a device tensor [B] (per-sample, AMED second stage)
+            self._f, self._plan = self.net.raw(x, sigma, self.cl)
             self._raw = True
         else:
             t = torch.tensor(sigma, dtype=torch.float32, device=x.device)
@@ -83,7 +84,9 @@ class _Run:
         return out
 
     # -- one fused launch ---------------------------------------------------------------------------------------------
-    def update(self, xe, xb, t, sigma, cx, cm, x_out, hist=(), ch=(), m_out=None, store_d=True, afs=False, f=None, raw=None):
+    def update(self, xe, xb, t, sigma, cx, cm, x_out, hist=(), ch=(), m_out=None, store_d=True, afs=False, f=None, raw=None,
+               coefs=None):
+        """coefs: optional device tensor [B, 8] of per-sample coefficient rows (AMED); overrides t/sigma/cx/cm/ch."""
         hc = [0.0] * 8
         hc[0], hc[1], hc[5], hc[6] = cx, cm, t, sigma
         for i, c in enumerate(ch):
@@ -92,7 +95,7 @@ class _Run:
         raw = self._raw if raw is None else raw
         a = ops.make_update_args(xe, xb, None if afs else f, self.B, self.C, self.H, self.W, x_out, raw=(raw and not afs),
                                  f_ld=4, hist=list(hist), hcoefs=hc, afs=afs, sigma_data=self.sigma_data, m_out=m_out,
-                                 store_d=store_d)
+                                 store_d=store_d, coefs=coefs, coef_rows=(self.B if coefs is not None else 1))
         ops.solver_update(a)
 
     def record(self, x, d=None):

@@ -186,6 +186,50 @@ int ds_copy_rows(const float* src, int src_ld, float* dst, int dst_ld, long long
 /* Channel mean of an NHWC tensor: out[n][h*w] = mean_c x[n, hw, c] (AMED bottleneck tap, solvers_amed.py:24-28). */
 int ds_channel_mean(const float* x, int ld, int c, long long rows, float* out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * AMED-Solver (amed-solver-main/solvers_amed.py, amed-solver-main/training/networks.py:56-155).
+ *
+ * ds_amed_predict: the AMED_predictor MLP.  bottleneck_mean: [n][in_dim] channel mean of the U-Net bottleneck (zeros
+ * under AFS); out[n][4] = {r, scale_dir, scale_time, t_mid = t_next^r * t_cur^(1-r)} per sample.
+ * Weight pointers are row-major [out][in] fp32 device arrays of the predictor's state_dict; fc_sd_* / fc_st_* may be
+ * NULL (scale_dir = 0 / scale_time = 0 at training time: the head does not exist and the factor is 1).
+ */
+typedef struct ds_amed_predictor {
+    const float* map0_w; const float* map0_b;      /* map_layer0: [nc][nc], [nc]                  */
+    const float* enc0_w; const float* enc0_b;      /* enc_layer0: [hidden][in_dim], [hidden]      */
+    const float* enc1_w; const float* enc1_b;      /* enc_layer1: [out_dim][hidden], [out_dim]    */
+    const float* fc_r_w; const float* fc_r_b;      /* [1][out_dim + 2 nc], [1]                    */
+    const float* fc_sd_w; const float* fc_sd_b;
+    const float* fc_st_w; const float* fc_st_b;
+    int nc, in_dim, hidden, out_dim;
+    float scale_dir, scale_time;
+} ds_amed_predictor;
+
+int ds_amed_predict(const ds_amed_predictor* p, const float* bottleneck_mean, int n, float t_cur, float t_next, float* out,
+                    void* stream);
+
+#define DS_AMED_AMED 0     /* amed_sampler           solvers_amed.py:69-159  */
+#define DS_AMED_EULER 1    /* euler plugin           :163-257                */
+#define DS_AMED_IPNDM 2    /* iPNDM plugin           :262-396                */
+#define DS_AMED_DPM2 3     /* DPM-Solver-2 plugin    :400-494                */
+#define DS_AMED_DPMPP 4    /* DPM-Solver++ plugin    :498-631                */
+
+/* Per-sample coefficient rows ([n][8], the layout ds_solver_update reads) of stage 1 (step from t_cur to the learned
+ * t_mid) or stage 2 (step to t_next after the evaluation at scale_time * t_mid).  `order` = the multistep order of this
+ * stage (host bookkeeping).  thist: [n][4] floats {count, t_oldest, .., t_newest}, the per-sample DPM-Solver++ time
+ * history (t_mid differs per sample); updated in place.  sigma2 (stage 1 only): [n] <- scale_time * t_mid. */
+typedef struct ds_amed_coef_args {
+    const float* pred;          /* [n][4] from ds_amed_predict */
+    float t_cur, t_next;
+    int mode, stage, order, predict_x0;
+    float* thist;
+    float* coefs;
+    float* sigma2;
+    int n;
+} ds_amed_coef_args;
+
+int ds_amed_coefs(const ds_amed_coef_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,87 @@
+"""GPU parity of the AMED-Solver / AMED-Plugin samplers against trajectories produced by the real reference
+(amed-solver-main/solvers_amed.py with a random-init AMED_predictor; tests/golden/sampler_tiny_song_amed*.npz).
+
+Tolerance 1e-3 of the trajectory scale: the predictor outputs (r, scale_dir, scale_time) feed powf/expm1f per sample
+on the device in fp32, and t_mid enters the second network evaluation, so rounding differences are amplified a little
+more than in the fixed-schedule samplers (observed ~1e-5)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cases  # noqa: E402
+
+G = os.path.join(ROOT, 'tests', 'golden')
+TOL = 1e-3
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-6))
+
+
+@pytest.mark.parametrize('netname', ['tiny_song_amed', 'tiny_song_amed_cond'])
+def test_amed_samplers_match_reference(netname):
+    from diff_sampler_amd import solvers_amed
+    from diff_sampler_amd.engine import EDMDenoiser
+    dev = torch.device('cuda')
+    z = np.load(os.path.join(G, f'sampler_{netname}.npz'))
+    net = EDMDenoiser.from_config(netname, seed=int(z['seed']))
+    latents = torch.from_numpy(z['latents']).to(dev)
+    lab = torch.from_numpy(z['labels']).to(dev) if z['labels'].size else None
+    fns = dict(amed=solvers_amed.amed_sampler, euler=solvers_amed.euler_sampler, ipndm=solvers_amed.ipndm_sampler,
+               dpm=solvers_amed.dpm_2_sampler, dpmpp=solvers_amed.dpm_pp_sampler)
+    checked = 0
+    for tag, stu, n, kind, rho, afs, pk, sk in cases.AMED_CASES:
+        if f'{tag}_inters' not in z.files:
+            continue
+        pp = cases.amed_predictor_params(int(z[f'{tag}_pseed']), pk['scale_dir'], pk['scale_time'])
+        pred = solvers_amed.AMEDPredictor(pp, device=dev, num_steps=n, sampler_stu=stu, schedule_type=kind, schedule_rho=rho,
+                                          afs=afs, **pk)
+        inters = fns[stu](net, latents, class_labels=lab, num_steps=n, sigma_min=0.002, sigma_max=80., schedule_type=kind,
+                          schedule_rho=rho, afs=afs, return_inters=True, AMED_predictor=pred, **sk)
+        torch.cuda.synchronize()
+        gold = torch.from_numpy(z[f'{tag}_inters'])
+        assert tuple(inters.shape) == tuple(gold.shape), (tag, inters.shape)
+        err = _rel(inters.cpu(), gold)
+        assert err < TOL, (netname, tag, err)
+        out = fns[stu](net, latents, class_labels=lab, num_steps=n, sigma_min=0.002, sigma_max=80., schedule_type=kind,
+                       schedule_rho=rho, afs=afs, AMED_predictor=pred, **sk)
+        assert _rel(out.cpu(), gold[-1]) < TOL
+        checked += 1
+    assert checked >= 2
+
+
+def test_amed_predictor_kernel_matches_oracle():
+    from diff_sampler_amd import solvers_amed
+    from oracle import solvers_ref
+    dev = torch.device('cuda')
+    for sd, st in [(0.01, 0), (0.05, 0.05), (0, 0)]:
+        pp = cases.amed_predictor_params(77, sd, st)
+        pred = solvers_amed.AMEDPredictor(pp, device=dev, scale_dir=sd, scale_time=st)
+        g = torch.Generator().manual_seed(2)
+        bott = torch.randn(5, 8, 8, generator=g)
+        out = torch.empty(5, 4, device=dev)
+        pred.predict(bott.to(dev), 3.3, 0.9, out)
+        r, sdir, stime = solvers_ref.amed_predict(pp, dict(scale_dir=sd, scale_time=st), bott, torch.tensor(3.3), torch.tensor(0.9))
+        o = out.cpu()
+        assert torch.allclose(o[:, 0], r.flatten(), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(o[:, 1], sdir.flatten(), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(o[:, 2], stime.flatten(), rtol=1e-5, atol=1e-6)
+        tm = (torch.tensor(0.9) ** r.flatten()) * (torch.tensor(3.3) ** (1 - r.flatten()))
+        assert torch.allclose(o[:, 3], tm, rtol=1e-5)
+
+
+def test_amed_requires_hip_denoiser():
+    from diff_sampler_amd import solvers_amed
+    pp = cases.amed_predictor_params(1, 0.01, 0)
+    pred = solvers_amed.AMEDPredictor(pp, device='cuda', scale_dir=0.01)
+    with pytest.raises(RuntimeError, match='bottleneck tap'):
+        solvers_amed.amed_sampler(lambda x, t, class_labels=None: x, torch.zeros(1, 3, 16, 16, device='cuda'), num_steps=3,
+                                  AMED_predictor=pred)
