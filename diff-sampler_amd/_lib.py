@@ -22,7 +22,9 @@ class ConvArgs(C.Structure):
     _fields_ = [('x0', vp), ('x1', vp), ('c0', C.c_int), ('c1', C.c_int), ('ld0', C.c_int), ('ld1', C.c_int),
                 ('n', C.c_int), ('h', C.c_int), ('w', C.c_int), ('taps', C.c_int), ('wgt', vp), ('cout', C.c_int),
                 ('bias', vp), ('cbias', vp), ('cbias_ld', C.c_int), ('cbias_rows', C.c_int), ('res', vp),
-                ('res_ld', C.c_int), ('out_scale', C.c_float), ('act', C.c_int), ('out', vp), ('out_ld', C.c_int)]
+                ('res_ld', C.c_int), ('out_scale', C.c_float), ('act', C.c_int), ('out', vp), ('out_ld', C.c_int),
+                ('norm_coefs', vp), ('norm_act', C.c_int),
+                ('e0', vp), ('e1', vp), ('ec0', C.c_int), ('ec1', C.c_int), ('eld0', C.c_int), ('eld1', C.c_int)]
 
 
 class GemmArgs(C.Structure):
@@ -38,7 +40,7 @@ class NormArgs(C.Structure):
                 ('n', C.c_int), ('h', C.c_int), ('w', C.c_int), ('groups', C.c_int), ('eps', C.c_float),
                 ('mean', vp), ('rstd', vp), ('gamma', vp), ('beta', vp), ('scale', vp), ('shift', vp),
                 ('ss_ld', C.c_int), ('ss_rows', C.c_int), ('act', C.c_int), ('resample', C.c_int), ('out', vp),
-                ('out_ld', C.c_int)]
+                ('out_ld', C.c_int), ('coefs', vp)]
 
 
 class UpdateArgs(C.Structure):
@@ -65,6 +67,7 @@ _SIGNATURES = {
     'ds_error_string': (C.c_char_p, [C.c_int]),
     'ds_conv2d_nhwc': (C.c_int, [C.POINTER(ConvArgs), vp]),
     'ds_debug_force_generic_conv': (C.c_int, [C.c_int]),
+    'ds_conv3x3_halo_supported': (C.c_int, [C.c_int, C.c_int]),
     'ds_gemm_nt_batched': (C.c_int, [C.POINTER(GemmArgs), vp]),
     'ds_gn_stats': (C.c_int, [C.POINTER(NormArgs), vp]),
     'ds_norm_act': (C.c_int, [C.POINTER(NormArgs), vp]),

@@ -7,37 +7,46 @@
 // activations shifted by one pixel, so this kernel stages each 32-channel slab of the input ONCE per M tile as a
 // halo tile in LDS and derives all 9 tap operands from it:
 //
-//   M tile  = 128 output pixels = nimg image slots x TH rows x W columns (TH*W*nimg = 128)
+//   M tile  = BM output pixels = nimg image slots x TH rows x W columns (TH*W*nimg = BM)
 //   halo    = nimg x (TH+2) x (W+2) pixels x 32 channels, rows padded to 36 floats (same conflict-free ds_read_b128
 //             pattern as the generic kernel); out-of-image halo pixels are zero (loaded from a zero page)
 //   tap (dy,dx) operand of output pixel (s,r,c) = halo[(s*(TH+2) + r+1+dy)*(W+2) + c+1+dx]  -> one uniform LDS
 //             offset per tap added to a per-lane base: no per-tap address arithmetic, no per-tap global loads for A
 //   weights = [Cout_pad][K], K = (chunk*9 + tap)*32 + cc, double-buffered per tap exactly like the generic kernel
 //
-// Global bytes per 32-channel slab and tile: halo 26 KB (W=32) + weights 9 x 16 KB = 170 KB instead of 288 KB, and
-// the number of vector-memory instructions per MFMA drops by the same factor.  The halo for slab c+1 is loaded into
-// registers while slab c is multiplied and written to LDS at the slab boundary (one extra barrier per 576 MFMAs).
+// Two tile shapes (template WM = wave rows; every wave owns 64x64 outputs = 2x2 MFMA 32x32x2 tiles):
+//   WM = 2: BM = 128, 4 waves, 2 workgroups per CU.  Global bytes per slab and tile: halo 26 KB (W=32) + weights
+//           9 x 16 KB = 170 KB (the generic kernel moves 288 KB) -> 124-137 TFLOP/s.
+//   WM = 4: BM = 256, 8 waves, 1 workgroup per CU.  The weight tile is shared by twice as many pixels:
+//           (43.5 + 144) KB per 2x the FLOPs = 94 KB per 128x128-equivalent.  Used when the layer has enough 256-pixel
+//           tiles to fill the chip.
+// The halo for slab c+1 is loaded into registers while slab c is multiplied and written to LDS at the slab boundary
+// (one extra barrier per 576 MFMAs per wave).
 #include "igemm_common.h"
 
 namespace igemm {
 namespace {
 
-constexpr int NS_MAX = 10;               // halo float4 slots per thread (256 threads x 10 x 16 B = 320 pixels x 128 B)
-constexpr int HALO_MAX = NS_MAX * 32;    // 320 halo pixels
-constexpr int B_BYTES = 2 * BN * LDSK * (int)sizeof(float);
+constexpr int B_FLOATS = 2 * BN * LDSK;                       // double-buffered weight tile
+constexpr int B_BYTES = B_FLOATS * (int)sizeof(float);
+constexpr int NS_MAX = 10;                                    // halo float4 slots per thread (upper bound, both shapes)
 
 __device__ float g_zero_page_halo[64];   // zero-initialised
 
-__global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(const KParams p) {
+template <int WM>
+__global__ void __launch_bounds__(128 * WM, 2) conv3x3_halo_kernel(const KParams p) {
+    constexpr int T = 128 * WM;            // threads
+    constexpr int TBM = 64 * WM;           // output pixels per tile
+    constexpr int BROWS = 1024 / T;        // weight float4 per thread per tap (4 or 2)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Bs = smem;                               // [2][BN][LDSK]
-    float* Ah = smem + 2 * BN * LDSK;               // [NP][LDSK]
+    float* Ah = smem + B_FLOATS;                    // [NP][LDSK]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     int mt, nt;
     if (!decode_tile(blockIdx.x, p.mtiles, p.ntiles, mt, nt)) return;
-    const int m0 = mt * BM, n0 = nt * BN;
+    const int m0 = mt * TBM, n0 = nt * BN;
     const int ld_row = tid >> 3, ld_col = (tid & 7) * 4;
     const float* zero = g_zero_page_halo;
 
@@ -45,13 +54,13 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(const KParams p) {
     const int img0 = m0 / p.HW;
     const int r0 = (p.nimg == 1) ? (m0 - img0 * p.HW) / p.W : 0;
     const int n_images = p.M / p.HW;
-    const int ns = (p.NP * 8 + 255) >> 8;           // halo slots per thread actually used (uniform)
+    const int ns = (p.NP * 8 + T - 1) / T;          // halo slots per thread actually used (uniform)
 
     // per-thread halo slots: pixel index in the image tensor (or -1: zero) -- fixed for the whole K loop
     int h_pix[NS_MAX];
 #pragma unroll
     for (int j = 0; j < NS_MAX; ++j) {
-        const int q = tid + j * 256;
+        const int q = tid + j * T;
         const int hp = q >> 3;
         const int s = hp / (p.HP * p.WP);
         const int rem = hp - s * p.HP * p.WP;
@@ -71,22 +80,29 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(const KParams p) {
         a_foff[i] = ((s * p.HP + r + 1) * p.WP + c + 1) * LDSK + (lane >> 5) * 4;
     }
     // weight rows staged by this thread
-    size_t b_off[4];
-    bool b_ok[4];
+    size_t b_off[BROWS];
+    bool b_ok[BROWS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = n0 + ld_row + 32 * i;
+    for (int i = 0; i < BROWS; ++i) {
+        const int n = n0 + ld_row + (T / 8) * i;
         b_ok[i] = n < p.nrows_b;
         b_off[i] = (size_t)n * p.ldb + ld_col;
     }
 
     f32x4 hreg[NS_MAX];
-    f32x4 rb[4];
+    f32x4 rb[BROWS];
+    const int nchunks = (p.c0 + p.c1) / BK;         // 3x3 slabs
+    const int nextra = (p.ec0 + p.ec1) / BK;        // appended 1x1 slabs (fused skip projection)
+    const int Ctot = p.c0 + p.c1;
     auto halo_load = [&](int chunk) {
-        const int c = chunk * BK;
-        const bool first = c < p.c0;
-        const float* src = first ? p.a0 + c + ld_col : p.a1 + (c - p.c0) + ld_col;
-        const int ld = first ? p.lda0 : p.lda1;
+        const bool extra = chunk >= nchunks;
+        const int c = (extra ? chunk - nchunks : chunk) * BK;
+        const int cc0 = extra ? p.ec0 : p.c0;
+        const bool first = c < cc0;
+        const float* s0 = extra ? p.e0 : p.a0;
+        const float* s1 = extra ? p.e1 : p.a1;
+        const float* src = first ? s0 + c + ld_col : s1 + (c - cc0) + ld_col;
+        const int ld = first ? (extra ? p.elda0 : p.lda0) : (extra ? p.elda1 : p.lda1);
 #pragma unroll
         for (int j = 0; j < NS_MAX; ++j) {
             if (j < ns) {
@@ -95,12 +111,28 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(const KParams p) {
             }
         }
     };
-    auto halo_store = [&]() {
+    // LDS <- registers; the GroupNorm affine + SiLU of the consumer layer is applied here, once per element and slab
+    // (the reference materialises silu(norm(x)) as a tensor, networks_edm.py:160,167); padding pixels stay zero.
+    auto halo_store = [&](int chunk) {
+        const bool do_norm = p.norm != nullptr && chunk < nchunks;
+        const int cq = chunk * BK + ld_col;
 #pragma unroll
         for (int j = 0; j < NS_MAX; ++j) {
             if (j < ns) {
-                const int q = tid + j * 256;
-                if ((q >> 3) < p.NP) *reinterpret_cast<f32x4*>(Ah + (q >> 3) * LDSK + (q & 7) * 4) = hreg[j];
+                const int q = tid + j * T;
+                f32x4 v = hreg[j];
+                if (do_norm && h_pix[j] >= 0) {
+                    const float* cp = p.norm + (size_t)(h_pix[j] / p.HW) * 3 * Ctot + cq;
+                    const f32x4 mu = *reinterpret_cast<const f32x4*>(cp);
+                    const f32x4 ga = *reinterpret_cast<const f32x4*>(cp + Ctot);
+                    const f32x4 be = *reinterpret_cast<const f32x4*>(cp + 2 * Ctot);
+                    v = (v - mu) * ga + be;
+                    if (p.norm_act == DS_ACT_SILU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = ds_silu(v[e]);
+                    }
+                }
+                if ((q >> 3) < p.NP) *reinterpret_cast<f32x4*>(Ah + (q >> 3) * LDSK + (q & 7) * 4) = v;
             }
         }
     };
@@ -108,7 +140,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(const KParams p) {
     auto b_store = [&](int buf) {
         float* bs = Bs + buf * BN * LDSK + ld_row * LDSK + ld_col;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(bs + 32 * i * LDSK) = rb[i];
+        for (int i = 0; i < BROWS; ++i) *reinterpret_cast<f32x4*>(bs + (T / 8) * i * LDSK) = rb[i];
     };
 
     f32x16 acc[2][2];
@@ -119,22 +151,24 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(const KParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nchunks = (p.c0 + p.c1) / BK;
-    const int KT = nchunks * 9;
+    const int NCH = nchunks + nextra;                // slabs: 3x3 ones (9 taps each) then 1x1 ones (centre tap only)
+    const int KT = nchunks * 9 + nextra;
 
     // ---- prologue ----------------------------------------------------------------------------------------------
     halo_load(0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b_addr(0, i));
-    halo_store();
+    for (int i = 0; i < BROWS; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b_addr(0, i));
+    halo_store(0);
     b_store(0);
-    if (nchunks > 1) halo_load(1);
+    if (NCH > 1) halo_load(1);
     __syncthreads();
 
     const int b_foff = (wc * 64 + (lane & 31)) * LDSK + (lane >> 5) * 4;
     int kt = 0;
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        for (int tap = 0; tap < 9; ++tap, ++kt) {
+    for (int chunk = 0; chunk < NCH; ++chunk) {
+        const int ntaps = chunk < nchunks ? 9 : 1;
+        for (int t9 = 0; t9 < ntaps; ++t9, ++kt) {
+            const int tap = ntaps == 9 ? t9 : 4;
             const int ty = tap / 3;
             const int toff = ((ty - 1) * p.WP + (tap - ty * 3 - 1)) * LDSK;
             const int cur = kt & 1;
@@ -148,7 +182,9 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(const KParams p) {
                 const f32x4 a1 = *reinterpret_cast<const f32x4*>(as1 + ks * 8);
                 const f32x4 b0 = *reinterpret_cast<const f32x4*>(bs + ks * 8);
                 const f32x4 b1 = *reinterpret_cast<const f32x4*>(bs + 32 * LDSK + ks * 8);
-                rb[ks] = *reinterpret_cast<const f32x4*>(b_addr(nxt, ks));     // one weight-staging load per 16 MFMAs
+                // the weight-staging loads ride in the shadow of the MFMA groups
+                if (BROWS == 4) rb[ks] = *reinterpret_cast<const f32x4*>(b_addr(nxt, ks));
+                else if (ks < BROWS) rb[ks] = *reinterpret_cast<const f32x4*>(b_addr(nxt, ks));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[r], b0[r], acc[0][0], 0, 0, 0);
@@ -160,49 +196,73 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(const KParams p) {
             b_store(cur ^ 1);
             __syncthreads();
         }
-        if (chunk + 1 < nchunks) {
-            // every wave has passed the barrier of tap 8: the halo of this slab is dead, publish the next one
-            halo_store();
-            if (chunk + 2 < nchunks) halo_load(chunk + 2);
+        if (chunk + 1 < NCH) {
+            // every wave has passed the barrier of the slab's last tap: its halo is dead, publish the next one
+            halo_store(chunk + 1);
+            if (chunk + 2 < NCH) halo_load(chunk + 2);
             __syncthreads();
         }
     }
 
-    // epilogue staging overlays the whole LDS allocation (>= 4 * 64 * EPI_LD floats, see the launcher)
-    epilogue<0>(p, acc, smem + wave * 64 * EPI_LD, lane, m0 + wr * 64, n0 + wc * 64, p.out);
+    // epilogue staging overlays the LDS allocation (the launcher sizes it for 4 x 64 or 8 x 32 staging rows per wave)
+    if (WM == 2) epilogue<0, false>(p, acc, smem + wave * 64 * EPI_LD, lane, m0 + wr * 64, n0 + wc * 64, p.out);
+    else epilogue<0, true>(p, acc, smem + wave * 32 * EPI_LD, lane, m0 + wr * 64, n0 + wc * 64, p.out);
+}
+
+struct Geo { int TH, nimg, NP; bool ok; };
+
+Geo geometry(const KParams& p, int tbm) {
+    Geo g{0, 0, 0, false};
+    if (p.taps != 9 || p.W < 4 || p.W > 64) return g;
+    if (p.HW >= tbm) { if (tbm % p.W || p.HW % tbm) return g; g.TH = tbm / p.W; g.nimg = 1; }
+    else { if (tbm % p.HW) return g; g.TH = p.H; g.nimg = tbm / p.HW; }
+    g.NP = g.nimg * (g.TH + 2) * (p.W + 2);
+    const int threads = tbm * 2;                      // 128 * WM
+    g.ok = (g.NP * 8 + threads - 1) / threads <= NS_MAX;
+    return g;
+}
+
+int g_tile_override = 0;       // 0 = heuristic, 128 / 256 = forced (benchmarks)
+
+template <int WM>
+int launch_wm(KParams& p, const Geo& g, hipStream_t stream) {
+    constexpr int TBM = 64 * WM;
+    p.TH = g.TH; p.nimg = g.nimg; p.HP = g.TH + 2; p.WP = p.W + 2; p.NP = g.NP;
+    p.mtiles = (p.M + TBM - 1) / TBM;
+    p.ntiles = (p.N + BN - 1) / BN;
+    int smem = B_BYTES + p.NP * LDSK * (int)sizeof(float);
+    const int epi = 4 * 64 * EPI_LD * (int)sizeof(float);       // = 8 x 32 x EPI_LD for the 8-wave shape
+    if (smem < epi) smem = epi;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3x3_halo_kernel<WM>, dim3(grid_1d(p.mtiles, p.ntiles)), dim3(128 * WM), smem, stream, p);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
 }
 
 }  // namespace
 
-bool conv3x3_halo_supported(const KParams& p) {
-    if (p.taps != 9) return false;
-    if (p.W < 4 || p.W > 64) return false;
-    if (p.HW >= BM) { if (BM % p.W || p.HW % BM) return false; }
-    else if (BM % p.HW) return false;
-    const int TH = (p.HW >= BM) ? BM / p.W : p.H;
-    const int nimg = (p.HW >= BM) ? 1 : BM / p.HW;
-    return nimg * (TH + 2) * (p.W + 2) <= HALO_MAX;
-}
+bool conv3x3_halo_supported(const KParams& p) { return geometry(p, 128).ok; }
+
+void conv3x3_halo_set_tile(int tile) { g_tile_override = tile; }
 
 int launch_conv3x3_halo(KParams& p, hipStream_t stream) {
-    p.TH = (p.HW >= BM) ? BM / p.W : p.H;
-    p.nimg = (p.HW >= BM) ? 1 : BM / p.HW;
-    p.HP = p.TH + 2; p.WP = p.W + 2; p.NP = p.nimg * p.HP * p.WP;
-    p.mtiles = (p.M + BM - 1) / BM;
-    p.ntiles = (p.N + BN - 1) / BN;
-    int smem = B_BYTES + p.NP * LDSK * (int)sizeof(float);
-    const int epi = 4 * 64 * EPI_LD * (int)sizeof(float);
-    if (smem < epi) smem = epi;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, B_BYTES + HALO_MAX * LDSK * (int)sizeof(float));
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
+    const Geo g128 = geometry(p, 128), g256 = geometry(p, 256);
+    bool use256 = false;
+    if (g256.ok) {
+        // one 8-wave workgroup per CU: worth it when the 256-pixel tiles alone cover the 256 CUs at least twice
+        const long long blocks256 = (long long)((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
+        use256 = blocks256 >= 512;
+        if (g_tile_override == 256) use256 = true;
+        if (g_tile_override == 128) use256 = false;
     }
-    hipLaunchKernelGGL(conv3x3_halo_kernel, dim3(grid_1d(p.mtiles, p.ntiles)), dim3(256), smem, stream, p);
-    DS_CHECK_LAUNCH();
-    return DS_OK;
+    if (use256) return launch_wm<4>(p, g256, stream);
+    return launch_wm<2>(p, g128, stream);
 }
 
 }  // namespace igemm

@@ -82,14 +82,19 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(const KParams p) {
     const float* zero = g_zero_page;
     auto a_addr = [&](int kt, int i) -> const float* {
         if (MODE == 0) {
-            const int chunk = kt / p.taps;
-            const int tap = kt - chunk * p.taps;
+            const int nmain = p.taps * ((p.c0 + p.c1) / BK);
+            const bool extra = kt >= nmain;                       // appended 1x1 sources (centre tap)
+            const int chunk = extra ? kt - nmain : kt / p.taps;
+            const int tap = extra ? 4 : kt - chunk * p.taps;
             const int c = chunk * BK;
             const int ty = (p.taps == 9) ? tap / 3 : 1;
             const int dy = ty - 1, dx = (p.taps == 9) ? tap - ty * 3 - 1 : 0;
-            const bool first = c < p.c0;
-            const float* src = first ? p.a0 + c + ld_col : p.a1 + (c - p.c0) + ld_col;
-            const int ld = first ? p.lda0 : p.lda1;
+            const int cc0 = extra ? p.ec0 : p.c0;
+            const bool first = c < cc0;
+            const float* s0 = extra ? p.e0 : p.a0;
+            const float* s1 = extra ? p.e1 : p.a1;
+            const float* src = first ? s0 + c + ld_col : s1 + (c - cc0) + ld_col;
+            const int ld = first ? (extra ? p.elda0 : p.lda0) : (extra ? p.elda1 : p.lda1);
             const int ih = a_oh[i] + dy, iw = a_ow[i] + dx;
             const bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
             return ok ? src + (a_off[i] + (size_t)(ih * p.W + iw)) * ld : zero;
@@ -196,7 +201,12 @@ int g_force_generic = 0;
 using namespace igemm;
 
 // Debug/benchmark switch: 1 = route 3x3 convolutions through the generic gather kernel instead of the halo kernel.
-extern "C" int ds_debug_force_generic_conv(int v) { g_force_generic = v; return DS_OK; }
+// v = 128 / 256 keeps the halo kernel but forces its M tile; v = 0 restores the defaults.
+extern "C" int ds_debug_force_generic_conv(int v) {
+    g_force_generic = (v == 1);
+    conv3x3_halo_set_tile((v == 128 || v == 256) ? v : 0);
+    return DS_OK;
+}
 
 extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     (void)hipGetLastError();   // drop stale errors of unrelated runtime calls
@@ -212,8 +222,16 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     KParams p{};
     p.a0 = a->x0; p.a1 = a->x1; p.c0 = a->c0; p.c1 = a->c1; p.lda0 = a->ld0; p.lda1 = a->ld1;
     p.H = a->h; p.W = a->w; p.HW = a->h * a->w; p.taps = a->taps;
-    p.M = (int)M; p.N = a->cout; p.K = a->taps * (a->c0 + a->c1);
+    if (a->ec0 < 0 || a->ec1 < 0 || a->ec0 % 32 || a->ec1 % 32 || (a->ec1 && !a->ec0)) return DS_E_SHAPE;
+    if (a->ec0) {
+        if (a->taps != 9 || !a->e0 || (a->ec1 && !a->e1)) return DS_E_ARG;
+        if ((a->eld0 & 3) || (a->ec1 && (a->eld1 & 3)) || !ds_aligned16(a->e0) || (a->ec1 && !ds_aligned16(a->e1))) return DS_E_ALIGN;
+    }
+    if (a->norm_coefs && (a->taps != 9 || !ds_aligned16(a->norm_coefs))) return DS_E_ARG;
+    p.M = (int)M; p.N = a->cout; p.K = a->taps * (a->c0 + a->c1) + a->ec0 + a->ec1;
     p.b = a->wgt; p.ldb = p.K; p.nrows_b = ((a->cout + BN - 1) / BN) * BN;   // weights are row-padded
+    p.norm = a->norm_coefs; p.norm_act = a->norm_act;
+    p.e0 = a->e0; p.e1 = a->e1; p.ec0 = a->ec0; p.ec1 = a->ec1; p.elda0 = a->eld0; p.elda1 = a->eld1;
     p.out = a->out; p.ldo = a->out_ld;
     p.colbias = a->bias; p.rowbias = nullptr;
     p.cbias = a->cbias; p.cbias_ld = a->cbias_ld; p.cbias_bcast = (a->cbias_rows == 1);
@@ -221,7 +239,14 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     p.scale = a->out_scale; p.act = a->act; p.heads = 1;
     p.vec_ok = vec_epilogue_ok(p) ? 1 : 0;
     if (!g_force_generic && conv3x3_halo_supported(p)) return launch_conv3x3_halo(p, (hipStream_t)stream);
+    if (p.norm) return DS_E_SHAPE;           // fused input normalisation exists only in the halo kernel
     return launch<0>(p, 1, (hipStream_t)stream);
+}
+
+extern "C" int ds_conv3x3_halo_supported(int h, int w) {
+    KParams p{};
+    p.taps = 9; p.H = h; p.W = w; p.HW = h * w;
+    return conv3x3_halo_supported(p) ? 1 : 0;
 }
 
 extern "C" int ds_gemm_nt_batched(const ds_gemm_args* a, void* stream) {

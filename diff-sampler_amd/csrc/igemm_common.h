@@ -21,6 +21,10 @@ struct KParams {
     int mtiles, ntiles;
     // halo kernel geometry: a 128-pixel M tile = nimg image slots x TH rows x W columns
     int TH, nimg, HP, WP, NP;      // HP = TH + 2, WP = W + 2, NP = nimg * HP * WP halo pixels
+    // fused input normalisation of the 3x3 sources: planes [n][3][c0+c1] = {mu, A, B}; in = act((x - mu) * A + B)
+    const float* norm; int norm_act;
+    // extra 1x1 sources appended along K after the 9*(c0+c1) columns (skip projection fused into the conv)
+    const float* e0; const float* e1; int ec0, ec1, elda0, elda1;
     // epilogue
     float* out; int ldo; long long o_bs, o_hs;
     const float* colbias; const float* rowbias;
@@ -37,42 +41,49 @@ struct KParams {
 // Vector path: the tile is transposed through LDS (`stage`, 64 x EPI_LD floats owned by this wave, free once every
 // wave of the block has passed the K loop's last barrier) so that bias / residual / output are accessed as float4
 // rows (16 B per lane, 256 B contiguous per 16 lanes) instead of 64 dword accesses per lane.
-template <int MODE>
+template <int MODE, bool HALF = false>
 __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2][2], float* stage, int lane, int wm0, int wn0,
                                          float* o_base) {
+    // HALF: the staging area holds 32 x EPI_LD floats per wave (8-wave blocks) and the two 32-row halves go one after
+    // the other; otherwise 64 x EPI_LD and the whole tile is staged at once.
     const bool full_cols = (wn0 + 64 <= p.N);
     if (p.vec_ok && full_cols) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_LD + j * 32 + (lane & 31)] = acc[i][j][r];
         const int c4 = (lane & 15) * 4;
         const int col = wn0 + c4;
         f32x4 cb = {0.f, 0.f, 0.f, 0.f};
         if (p.colbias) cb = *reinterpret_cast<const f32x4*>(p.colbias + col);
-#pragma unroll 4
-        for (int pass = 0; pass < 16; ++pass) {
-            const int rr = pass * 4 + (lane >> 4);
-            const int row = wm0 + rr;
-            if (row >= p.M) continue;
-            f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * EPI_LD + c4);
-            if (MODE == 1) v *= p.scale;
-            v += cb;
-            if (p.rowbias) v += p.rowbias[row];
-            if (p.cbias) {
-                const int img = p.cbias_bcast ? 0 : row / p.HW;
-                v += *reinterpret_cast<const f32x4*>(p.cbias + (size_t)img * p.cbias_ld + col);
-            }
-            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.res_ld + col);
-            if (MODE == 0) v *= p.scale;
-            if (p.act == DS_ACT_SILU) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = ds_silu(v[q]);
+        for (int half = 0; half < (HALF ? 2 : 1); ++half) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (HALF && i != half) continue;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        stage[((HALF ? 0 : i * 32) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_LD + j * 32 + (lane & 31)] = acc[i][j][r];
             }
-            *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col) = v;
+#pragma unroll 4
+            for (int pass = 0; pass < (HALF ? 8 : 16); ++pass) {
+                const int rr = pass * 4 + (lane >> 4);
+                const int row = wm0 + (HALF ? half * 32 : 0) + rr;
+                if (row >= p.M) continue;
+                f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * EPI_LD + c4);
+                if (MODE == 1) v *= p.scale;
+                v += cb;
+                if (p.rowbias) v += p.rowbias[row];
+                if (p.cbias) {
+                    const int img = p.cbias_bcast ? 0 : row / p.HW;
+                    v += *reinterpret_cast<const f32x4*>(p.cbias + (size_t)img * p.cbias_ld + col);
+                }
+                if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.res_ld + col);
+                if (MODE == 0) v *= p.scale;
+                if (p.act == DS_ACT_SILU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = ds_silu(v[q]);
+                }
+                *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col) = v;
+            }
         }
         return;
     }
@@ -121,5 +132,6 @@ inline unsigned grid_1d(int mtiles, int ntiles) { return (unsigned)(((mtiles + 7
 // conv3x3_halo.hip
 bool conv3x3_halo_supported(const KParams& p);
 int launch_conv3x3_halo(KParams& p, hipStream_t stream);
+void conv3x3_halo_set_tile(int tile);     // 0 = heuristic, 128 / 256 = forced M tile (benchmarks)
 
 }  // namespace igemm

@@ -52,6 +52,26 @@ __global__ void __launch_bounds__(1024) gn_stats_kernel(const ds_norm_args a, in
         if (var < 0.0) var = 0.0;
         a.mean[(size_t)n * a.groups + tid] = (float)mean;
         a.rstd[(size_t)n * a.groups + tid] = (float)(1.0 / sqrt(var + (double)a.eps));
+        s_sum[tid] = mean;                                        // reuse as broadcast slots for the coefficient pass
+        s_sq[tid] = 1.0 / sqrt(var + (double)a.eps);
+    }
+    if (a.coefs) {
+        // per-(image, channel) planes {mu, A, B} for the convolution's fused input normalisation
+        __syncthreads();
+        float* cp = a.coefs + (size_t)n * 3 * C;
+        for (int c = tid; c < C; c += blockDim.x) {
+            const int g = c / cpg;
+            const float m = (float)s_sum[g], r = (float)s_sq[g];
+            const float gm = a.gamma ? a.gamma[c] : 1.f;
+            const float bt = a.beta ? a.beta[c] : 0.f;
+            float sc1 = 1.f, sh = 0.f;
+            if (a.scale) {
+                const size_t row = (a.ss_rows == 1) ? 0 : (size_t)n;
+                sc1 = a.scale[row * a.ss_ld + c] + 1.f;
+                sh = a.shift[row * a.ss_ld + c];
+            }
+            cp[c] = m; cp[C + c] = r * gm * sc1; cp[2 * C + c] = bt * sc1 + sh;
+        }
     }
 }
 

@@ -106,7 +106,10 @@ class UNetEngine:
             w[f'{b.name}.conv0.w'] = pack_conv_weight(g(f'{p}.conv0.weight')); w[f'{b.name}.conv0.b'] = g(f'{p}.conv0.bias')
             w[f'{b.name}.conv1.w'] = pack_conv_weight(g(f'{p}.conv1.weight')); w[f'{b.name}.conv1.b'] = g(f'{p}.conv1.bias')
             if b.skip_conv:
-                w[f'{b.name}.skip.w'] = pack_conv_weight(g(f'{p}.skip.weight')); w[f'{b.name}.skip.b'] = g(f'{p}.skip.bias')
+                # skip projection fused into conv1: [3x3 columns | 1x1 columns] along K, biases summed
+                w[f'{b.name}.conv1s.w'] = torch.cat([w[f'{b.name}.conv1.w'], pack_conv_weight(g(f'{p}.skip.weight'))], dim=1).contiguous()
+                w[f'{b.name}.conv1s.b'] = (g(f'{p}.conv1.bias') + g(f'{p}.skip.bias')).contiguous()
+                del w[f'{b.name}.conv1.w']
             if b.heads:
                 c, h = b.cout, b.heads
                 ch = c // h
@@ -172,6 +175,7 @@ class UNetEngine:
         sres = new(B * max_h)            # resampled skip-path input
         sproj = new(B * max_h)           # projected skip
         mean = new(B * 64); rstd = new(B * 64)
+        ncoef = new(B * 3 * max(max(b.cin, b.cout) for b in spec.blocks))      # {mu, A, B} planes of the fused GroupNorm
         if max_attn:
             n2 = new(B * max_attn // 2); qk = new(B * max_attn); vt = new(B * max_attn // 2)
             ao = new(B * max_attn // 2); sc = new(B * max_sc)
@@ -181,17 +185,19 @@ class UNetEngine:
             P.ops.append(_Op(fn, args, name, keep))
 
         def conv(x0, c0, ld0, n, h, wd, wgt, cout, out, out_ld, taps, name, x1=None, c1=0, ld1=0, bias=None, cbias=None,
-                 cbias_ld=0, cbias_rows=1, res=None, res_ld=0, scale=1.0, act_=DS_ACT_NONE):
+                 cbias_ld=0, cbias_rows=1, res=None, res_ld=0, scale=1.0, act_=DS_ACT_NONE, norm_coefs=None, norm_act=DS_ACT_NONE,
+                 e0=None, ec0=0, e1=None, ec1=0):
             a = ConvArgs(_ptr(x0), _ptr(x1), c0, c1, ld0, ld1, n, h, wd, taps, _ptr(wgt), cout, _ptr(bias), _ptr(cbias),
-                         cbias_ld, cbias_rows, _ptr(res), res_ld, scale, act_, _ptr(out), out_ld)
+                         cbias_ld, cbias_rows, _ptr(res), res_ld, scale, act_, _ptr(out), out_ld, _ptr(norm_coefs), norm_act,
+                         _ptr(e0), _ptr(e1), ec0, ec1, ec0, ec1)
             add(lib.ds_conv2d_nhwc, (C.byref(a),), name, keep=(a,))
 
         def norm(kind, x0, c0, ld0, n, h, wd, name, x1=None, c1=0, ld1=0, groups=1, eps=1e-5, use_stats=True, gamma=None,
                  beta=None, scale=None, shift=None, ss_ld=0, ss_rows=1, act_=DS_ACT_NONE, resample=DS_RESAMPLE_NONE,
-                 out=None, out_ld=0):
+                 out=None, out_ld=0, coefs=None):
             a = NormArgs(_ptr(x0), _ptr(x1), c0, c1, ld0, ld1, n, h, wd, groups, eps,
                          _ptr(mean) if use_stats else None, _ptr(rstd) if use_stats else None, _ptr(gamma), _ptr(beta),
-                         _ptr(scale), _ptr(shift), ss_ld, ss_rows, act_, resample, _ptr(out), out_ld)
+                         _ptr(scale), _ptr(shift), ss_ld, ss_rows, act_, resample, _ptr(out), out_ld, _ptr(coefs))
             add(lib.ds_gn_stats if kind == 'stats' else lib.ds_norm_act, (C.byref(a),), name, keep=(a,))
 
         def gemm(a_, lda, b_, ldb, c_, ldc, m_, n_, k_, name, batch=1, heads=1, a_bs=0, a_hs=0, b_bs=0, b_hs=0, c_bs=0, c_hs=0,
@@ -251,39 +257,44 @@ class UNetEngine:
             G_in, G_out = arch.num_groups(cin), arch.num_groups(cout)
             rs = DS_RESAMPLE_DOWN if b.down else (DS_RESAMPLE_UP if b.up else DS_RESAMPLE_NONE)
             nm = b.name
-            # norm0 + silu (+resample) -> act
-            norm('stats', x0, c0, c0, n, Hin, Hin, nm + '.norm0.stats', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps)
-            norm('apply', x0, c0, c0, n, Hin, Hin, nm + '.norm0', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps,
-                 gamma=w[f'{nm}.norm0.g'], beta=w[f'{nm}.norm0.b'], act_=DS_ACT_SILU, resample=rs, out=act, out_ld=cin)
-            # conv0 (+bias, + per-image embedding for the non-adaptive variant)
+            fuse = bool(lib.ds_conv3x3_halo_supported(Ho, Ho))     # GroupNorm+SiLU applied by the conv's halo loader
             aoff = self.aff_off[nm]
-            if b.adaptive_scale:
-                conv(act, cin, cin, n, Ho, Ho, w[f'{nm}.conv0.w'], cout, hbuf, cout, 9, nm + '.conv0', bias=w[f'{nm}.conv0.b'])
+            cb = dict(cbias=aff[:, aoff:], cbias_ld=self.aff_total, cbias_rows=Bs) if not b.adaptive_scale else {}
+            # norm0 + silu (+resample) -> conv0 (+bias, + per-image embedding for the non-adaptive variant)
+            if fuse and rs == DS_RESAMPLE_NONE:
+                norm('stats', x0, c0, c0, n, Hin, Hin, nm + '.norm0.stats', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps,
+                     gamma=w[f'{nm}.norm0.g'], beta=w[f'{nm}.norm0.b'], coefs=ncoef)
+                conv(x0, c0, c0, n, Ho, Ho, w[f'{nm}.conv0.w'], cout, hbuf, cout, 9, nm + '.conv0', x1=x1, c1=c1, ld1=c1,
+                     bias=w[f'{nm}.conv0.b'], norm_coefs=ncoef, norm_act=DS_ACT_SILU, **cb)
             else:
-                conv(act, cin, cin, n, Ho, Ho, w[f'{nm}.conv0.w'], cout, hbuf, cout, 9, nm + '.conv0', bias=w[f'{nm}.conv0.b'],
-                     cbias=aff[:, aoff:], cbias_ld=self.aff_total, cbias_rows=Bs)
-            # norm1 (+adaptive scale/shift) + silu -> act
-            norm('stats', hbuf, cout, cout, n, Ho, Ho, nm + '.norm1.stats', groups=G_out, eps=b.eps)
-            if b.adaptive_scale:
-                norm('apply', hbuf, cout, cout, n, Ho, Ho, nm + '.norm1', groups=G_out, eps=b.eps, gamma=w[f'{nm}.norm1.g'],
-                     beta=w[f'{nm}.norm1.b'], scale=aff[:, aoff:], shift=aff[:, aoff + cout:], ss_ld=self.aff_total, ss_rows=Bs,
-                     act_=DS_ACT_SILU, out=act, out_ld=cout)
+                norm('stats', x0, c0, c0, n, Hin, Hin, nm + '.norm0.stats', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps)
+                norm('apply', x0, c0, c0, n, Hin, Hin, nm + '.norm0', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps,
+                     gamma=w[f'{nm}.norm0.g'], beta=w[f'{nm}.norm0.b'], act_=DS_ACT_SILU, resample=rs, out=act, out_ld=cin)
+                conv(act, cin, cin, n, Ho, Ho, w[f'{nm}.conv0.w'], cout, hbuf, cout, 9, nm + '.conv0', bias=w[f'{nm}.conv0.b'], **cb)
+            # norm1 (+adaptive scale/shift) + silu
+            ss = dict(scale=aff[:, aoff:], shift=aff[:, aoff + cout:], ss_ld=self.aff_total, ss_rows=Bs) if b.adaptive_scale else {}
+            if fuse:
+                norm('stats', hbuf, cout, cout, n, Ho, Ho, nm + '.norm1.stats', groups=G_out, eps=b.eps, gamma=w[f'{nm}.norm1.g'],
+                     beta=w[f'{nm}.norm1.b'], coefs=ncoef, **ss)
+                c1_in, c1_norm = hbuf, dict(norm_coefs=ncoef, norm_act=DS_ACT_SILU)
             else:
+                norm('stats', hbuf, cout, cout, n, Ho, Ho, nm + '.norm1.stats', groups=G_out, eps=b.eps)
                 norm('apply', hbuf, cout, cout, n, Ho, Ho, nm + '.norm1', groups=G_out, eps=b.eps, gamma=w[f'{nm}.norm1.g'],
-                     beta=w[f'{nm}.norm1.b'], act_=DS_ACT_SILU, out=act, out_ld=cout)
-            # skip path
+                     beta=w[f'{nm}.norm1.b'], act_=DS_ACT_SILU, out=act, out_ld=cout, **ss)
+                c1_in, c1_norm = act, {}
+            # skip path: raw (resampled) input, projected by a 1x1 that is fused into conv1 as extra K columns
             s0, sc0, s1, sc1 = x0, c0, x1, c1
             if rs != DS_RESAMPLE_NONE:
                 norm('apply', x0, c0, c0, n, Hin, Hin, nm + '.skip.resample', x1=x1, c1=c1, ld1=c1, use_stats=False,
                      resample=rs, out=sres, out_ld=cin)
                 s0, sc0, s1, sc1 = sres, cin, None, 0
             if b.skip_conv:
-                conv(s0, sc0, sc0, n, Ho, Ho, w[f'{nm}.skip.w'], cout, sproj, cout, 1, nm + '.skip', x1=s1, c1=sc1, ld1=sc1,
-                     bias=w[f'{nm}.skip.b'])
-                res = sproj
+                c1_w, c1_b = w[f'{nm}.conv1s.w'], w[f'{nm}.conv1s.b']
+                c1_skip = dict(e0=s0, ec0=sc0, e1=s1, ec1=sc1)
             else:
                 assert s1 is None and sc0 == cout
-                res = s0
+                c1_w, c1_b = w[f'{nm}.conv1.w'], w[f'{nm}.conv1.b']
+                c1_skip = dict(res=s0, res_ld=cout)
             # output buffer: encoder outputs are kept for the skip stack, decoder outputs ping-pong
             if b.pushes_skip:
                 out = new(M, cout)
@@ -295,8 +306,8 @@ class UNetEngine:
             if b.heads:
                 mid = out
                 out2 = None
-            conv(act, cout, cout, n, Ho, Ho, w[f'{nm}.conv1.w'], cout, out, cout, 9, nm + '.conv1', bias=w[f'{nm}.conv1.b'],
-                 res=res, res_ld=cout, scale=b.skip_scale)
+            conv(c1_in, cout, cout, n, Ho, Ho, c1_w, cout, out, cout, 9, nm + '.conv1', bias=c1_b, scale=b.skip_scale,
+                 **c1_norm, **c1_skip)
             if b.heads:
                 S = Ho * Ho
                 hd = b.heads
@@ -333,10 +344,16 @@ class UNetEngine:
         assert not skips
         # ---- output head ------------------------------------------------------------------------------------------
         xo, co = x_cur
-        norm('stats', xo, co, co, B, R, R, 'out.norm.stats', groups=arch.num_groups(co), eps=spec.out_eps)
-        norm('apply', xo, co, co, B, R, R, 'out.norm', groups=arch.num_groups(co), eps=spec.out_eps, gamma=w['out.g'],
-             beta=w['out.b'], act_=DS_ACT_SILU, out=act, out_ld=co)
-        conv(act, co, co, B, R, R, w['outc.w'], spec.out_channels, bufs['out'], 4, 9, 'out.conv', bias=w['outc.b'])
+        if lib.ds_conv3x3_halo_supported(R, R):
+            norm('stats', xo, co, co, B, R, R, 'out.norm.stats', groups=arch.num_groups(co), eps=spec.out_eps, gamma=w['out.g'],
+                 beta=w['out.b'], coefs=ncoef)
+            conv(xo, co, co, B, R, R, w['outc.w'], spec.out_channels, bufs['out'], 4, 9, 'out.conv', bias=w['outc.b'],
+                 norm_coefs=ncoef, norm_act=DS_ACT_SILU)
+        else:
+            norm('stats', xo, co, co, B, R, R, 'out.norm.stats', groups=arch.num_groups(co), eps=spec.out_eps)
+            norm('apply', xo, co, co, B, R, R, 'out.norm', groups=arch.num_groups(co), eps=spec.out_eps, gamma=w['out.g'],
+                 beta=w['out.b'], act_=DS_ACT_SILU, out=act, out_ld=co)
+            conv(act, co, co, B, R, R, w['outc.w'], spec.out_channels, bufs['out'], 4, 9, 'out.conv', bias=w['outc.b'])
         self._plans[key] = P
         return P
 

@@ -67,9 +67,21 @@ typedef struct ds_conv_args {
     float out_scale;
     int act;                               /* DS_ACT_*                                                          */
     float* out; int out_ld;
+    /* Fused input normalisation (taps == 9 only): the kernel reads in = act_in((x - mu) * A + B) instead of x, with
+     * per-(image, channel) coefficient planes [n][3][c0+c1] = {mu, A, B} written by ds_gn_stats (coefs output).
+     * Zero padding stays zero (it pads the NORMALISED tensor, networks_edm.py:160,167).  NULL = raw input.
+     * Requires ds_conv3x3_halo_supported(h, w); otherwise DS_E_SHAPE. */
+    const float* norm_coefs; int norm_act;
+    /* Extra 1x1 sources appended along K (the skip projection fused into conv1, networks_edm.py:170): after the
+     * 9*(c0+c1) columns the weight rows carry ec0+ec1 more columns that multiply [e0 | e1] at the output pixel.
+     * ec0 == 0 = none.  Same constraints as c0/c1 (multiples of 32, ld % 4 == 0). */
+    const float* e0; const float* e1; int ec0, ec1; int eld0, eld1;
 } ds_conv_args;
 
 int ds_conv2d_nhwc(const ds_conv_args* a, void* stream);
+
+/* 1 if a 3x3 convolution on h x w images runs on the LDS-halo kernel (needed for norm_coefs), else 0. */
+int ds_conv3x3_halo_supported(int h, int w);
 
 /* Benchmark/debug switch: v != 0 routes 3x3 convolutions through the generic gather kernel instead of the
  * LDS-halo kernel (both are exact fp32; used for A/B measurements and as a cross-check in the tests). */
@@ -108,6 +120,9 @@ typedef struct ds_norm_args {
     const float* scale; const float* shift; int ss_ld; int ss_rows;  /* adaptive scale/shift [ss_rows][ss_ld]   */
     int act; int resample;
     float* out; int out_ld;
+    float* coefs;                          /* ds_gn_stats only, optional: [n][3][c0+c1] planes {mu, A, B} with
+                                              A = rstd*gamma*(1+scale), B = beta*(1+scale)+shift, for ds_conv2d_nhwc's
+                                              fused input normalisation */
 } ds_norm_args;
 
 int ds_gn_stats(const ds_norm_args* a, void* stream);
