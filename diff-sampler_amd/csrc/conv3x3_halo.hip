@@ -113,8 +113,21 @@ __global__ void __launch_bounds__(128 * WM, 2) conv3x3_halo_kernel(const KParams
     };
     // LDS <- registers; the GroupNorm affine + SiLU of the consumer layer is applied here, once per element and slab
     // (the reference materialises silu(norm(x)) as a tensor, networks_edm.py:160,167); padding pixels stay zero.
+    // When the tile lies in one image (nimg == 1) the three coefficient quads of this thread's channels are
+    // prefetched together with the halo (coef_load), so nothing at the slab boundary waits on memory.
+    const bool norm_on = p.norm != nullptr;
+    const bool one_img = p.nimg == 1;
+    f32x4 cmu = {0.f, 0.f, 0.f, 0.f}, cga = {1.f, 1.f, 1.f, 1.f}, cbe = {0.f, 0.f, 0.f, 0.f};
+    auto coef_load = [&](int chunk) {
+        const bool on = norm_on && one_img && chunk < nchunks;
+        const float* cp = on ? p.norm + (size_t)img0 * 3 * Ctot + chunk * BK + ld_col : zero;
+        const int st = on ? Ctot : 0;
+        cmu = *reinterpret_cast<const f32x4*>(cp);
+        cga = *reinterpret_cast<const f32x4*>(cp + st);
+        cbe = *reinterpret_cast<const f32x4*>(cp + 2 * st);
+    };
     auto halo_store = [&](int chunk) {
-        const bool do_norm = p.norm != nullptr && chunk < nchunks;
+        const bool do_norm = norm_on && chunk < nchunks;
         const int cq = chunk * BK + ld_col;
 #pragma unroll
         for (int j = 0; j < NS_MAX; ++j) {
@@ -122,10 +135,13 @@ __global__ void __launch_bounds__(128 * WM, 2) conv3x3_halo_kernel(const KParams
                 const int q = tid + j * T;
                 f32x4 v = hreg[j];
                 if (do_norm && h_pix[j] >= 0) {
-                    const float* cp = p.norm + (size_t)(h_pix[j] / p.HW) * 3 * Ctot + cq;
-                    const f32x4 mu = *reinterpret_cast<const f32x4*>(cp);
-                    const f32x4 ga = *reinterpret_cast<const f32x4*>(cp + Ctot);
-                    const f32x4 be = *reinterpret_cast<const f32x4*>(cp + 2 * Ctot);
+                    f32x4 mu = cmu, ga = cga, be = cbe;
+                    if (!one_img) {
+                        const float* cp = p.norm + (size_t)(h_pix[j] / p.HW) * 3 * Ctot + cq;
+                        mu = *reinterpret_cast<const f32x4*>(cp);
+                        ga = *reinterpret_cast<const f32x4*>(cp + Ctot);
+                        be = *reinterpret_cast<const f32x4*>(cp + 2 * Ctot);
+                    }
                     v = (v - mu) * ga + be;
                     if (p.norm_act == DS_ACT_SILU) {
 #pragma unroll
@@ -156,11 +172,12 @@ __global__ void __launch_bounds__(128 * WM, 2) conv3x3_halo_kernel(const KParams
 
     // ---- prologue ----------------------------------------------------------------------------------------------
     halo_load(0);
+    coef_load(0);
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b_addr(0, i));
     halo_store(0);
     b_store(0);
-    if (NCH > 1) halo_load(1);
+    if (NCH > 1) { halo_load(1); coef_load(1); }
     __syncthreads();
 
     const int b_foff = (wc * 64 + (lane & 31)) * LDSK + (lane >> 5) * 4;
@@ -199,7 +216,7 @@ __global__ void __launch_bounds__(128 * WM, 2) conv3x3_halo_kernel(const KParams
         if (chunk + 1 < NCH) {
             // every wave has passed the barrier of the slab's last tap: its halo is dead, publish the next one
             halo_store(chunk + 1);
-            if (chunk + 2 < NCH) halo_load(chunk + 2);
+            if (chunk + 2 < NCH) { halo_load(chunk + 2); coef_load(chunk + 2); }
             __syncthreads();
         }
     }

@@ -1,0 +1,183 @@
+"""GPU unit parity of the individual C-ABI kernels against plain fp32 ATen on the CPU (the third-party arithmetic the
+reference bottoms out in).  Both convolution kernels (LDS-halo and generic gather) are exercised on the same cases,
+including the fused input GroupNorm+SiLU, the dual-source (concat-free) K loop and the appended 1x1 skip columns."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-6))
+
+
+def _nhwc(x):      # [B,C,H,W] -> [B*H*W, C]
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+CONV_CASES = [
+    # B, H, c0, c1, cout, taps, extras(ec0, ec1), norm
+    (3, 16, 64, 0, 64, 9, (0, 0), False),
+    (3, 16, 64, 32, 96, 9, (0, 0), True),
+    (2, 32, 32, 32, 128, 9, (64, 32), True),
+    (5, 8, 64, 64, 160, 9, (64, 0), True),       # 8x8: tiles span two images (per-slot coefficient path)
+    (1, 8, 32, 0, 32, 9, (0, 0), True),          # M = 64 < tile
+    (2, 64, 32, 0, 64, 9, (32, 0), False),       # W = 64
+    (3, 16, 64, 32, 96, 1, (0, 0), False),
+    (7, 1, 128, 0, 40, 1, (0, 0), False),        # Linear: h = w = 1
+    (2, 32, 64, 0, 3, 9, (0, 0), True),          # ragged N (output conv), out_ld = 4
+]
+
+
+@pytest.mark.parametrize('force', [0, 1, 128, 256])
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv2d_nhwc_matches_aten(case, force):
+    from diff_sampler_amd import _lib, ops
+    B, H, c0, c1, cout, taps, (ec0, ec1), use_norm = case
+    lib = _lib.load()
+    if use_norm and force == 1:
+        pytest.skip('fused input normalisation exists only in the halo kernel')
+    if use_norm and not lib.ds_conv3x3_halo_supported(H, H):
+        pytest.skip('geometry not supported by the halo kernel')
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    k = 3 if taps == 9 else 1
+    x = torch.randn(B, c0 + c1, H, H, generator=g)
+    e = torch.randn(B, ec0 + ec1, H, H, generator=g) if ec0 else None
+    w = torch.randn(cout, c0 + c1, k, k, generator=g) / (taps * (c0 + c1)) ** 0.5
+    we = torch.randn(cout, ec0 + ec1, 1, 1, generator=g) / (ec0 + ec1) ** 0.5 if ec0 else None
+    bias = torch.randn(cout, generator=g)
+    cb = torch.randn(B, cout, generator=g)
+    res = torch.randn(B, cout, H, H, generator=g)
+    mu = torch.randn(B, c0 + c1, generator=g) * 0.3
+    ga = 1 + 0.2 * torch.randn(B, c0 + c1, generator=g)
+    be = 0.2 * torch.randn(B, c0 + c1, generator=g)
+    # reference
+    xin = F.silu((x - mu[:, :, None, None]) * ga[:, :, None, None] + be[:, :, None, None]) if use_norm else x
+    ref = F.conv2d(xin, w, padding=k // 2)
+    if ec0:
+        ref = ref + F.conv2d(e, we)
+    ref = (ref + bias[None, :, None, None] + cb[:, :, None, None] + res) * 0.7071
+    ref = F.silu(ref) if cout % 2 == 0 else ref
+    # device
+    dev = 'cuda'
+    xn = _nhwc(x).to(dev)
+    x0 = xn[:, :c0].contiguous()
+    x1 = xn[:, c0:].contiguous() if c1 else None
+    en = _nhwc(e).to(dev) if ec0 else None
+    e0 = en[:, :ec0].contiguous() if ec0 else None
+    e1 = en[:, ec0:].contiguous() if ec1 else None
+    wp = ops.pack_conv_weight(w.to(dev))
+    if ec0:
+        wp = torch.cat([wp, ops.pack_conv_weight(we.to(dev))], 1).contiguous()
+    coefs = torch.stack([mu, ga, be], 1).contiguous().to(dev) if use_norm else None     # [B][3][C]
+    old = cout if cout % 4 == 0 else -(-cout // 4) * 4
+    out = torch.full((B * H * H, old), float('nan'), device=dev)
+    a = _lib.ConvArgs(x0.data_ptr(), x1.data_ptr() if c1 else None, c0, c1, c0, c1, B, H, H, taps, wp.data_ptr(), cout,
+                      bias.to(dev).data_ptr(), cb.to(dev).data_ptr(), cout, B, _nhwc(res).to(dev).data_ptr(), cout, 0.7071,
+                      1 if cout % 2 == 0 else 0, out.data_ptr(), old, coefs.data_ptr() if use_norm else None, 1,
+                      e0.data_ptr() if ec0 else None, e1.data_ptr() if ec1 else None, ec0, ec1, ec0, ec1)
+    keep = [x0, x1, e0, e1, wp, coefs]     # noqa: F841  (raw pointers above)
+    biasd, cbd, resd = bias.to(dev), cb.to(dev), _nhwc(res).to(dev)
+    a.bias, a.cbias, a.res = biasd.data_ptr(), cbd.data_ptr(), resd.data_ptr()
+    import ctypes as C
+    lib.ds_debug_force_generic_conv(force)
+    try:
+        rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
+        torch.cuda.synchronize()
+    finally:
+        lib.ds_debug_force_generic_conv(0)
+    assert rc == 0, lib.ds_error_string(rc)
+    got = out[:, :cout].cpu()
+    assert _rel(got, _nhwc(ref)) < TOL
+
+
+def test_conv_argument_errors():
+    import ctypes as C
+    from diff_sampler_amd import _lib
+    lib = _lib.load()
+    x = torch.zeros(64, 48, device='cuda')
+    w = torch.zeros(128, 48 * 9, device='cuda')
+    o = torch.zeros(64, 32, device='cuda')
+    a = _lib.ConvArgs(x.data_ptr(), None, 48, 0, 48, 0, 1, 8, 8, 9, w.data_ptr(), 32, None, None, 0, 1, None, 0, 1.0, 0, o.data_ptr(), 32)
+    assert lib.ds_conv2d_nhwc(C.byref(a), None) == -3          # c0 % 32 != 0 -> DS_E_SHAPE
+    a.c0, a.ld0, a.taps = 32, 48, 5
+    assert lib.ds_conv2d_nhwc(C.byref(a), None) == -1          # taps must be 1 or 9
+    a.taps, a.ld0 = 9, 47
+    assert lib.ds_conv2d_nhwc(C.byref(a), None) == -2          # ld % 4 != 0 -> DS_E_ALIGN
+
+
+@pytest.mark.parametrize('C_,G,HW', [(64, 16, 16), (96, 24, 8), (192, 32, 16), (384, 32, 8)])
+def test_groupnorm_stats_and_apply(C_, G, HW):
+    from diff_sampler_amd import ops
+    from diff_sampler_amd._lib import DS_ACT_SILU, DS_RESAMPLE_DOWN, DS_RESAMPLE_UP
+    g = torch.Generator().manual_seed(C_)
+    B = 3
+    x = torch.randn(B, C_, HW, HW, generator=g) * 2 + 0.7
+    gamma, beta = 1 + 0.1 * torch.randn(C_, generator=g), 0.1 * torch.randn(C_, generator=g)
+    c0 = 64 if C_ > 64 else C_
+    xn = _nhwc(x).cuda()
+    x0, x1 = xn[:, :c0].contiguous(), (xn[:, c0:].contiguous() if C_ > c0 else None)
+    mean, rstd = torch.empty(B * G, device='cuda'), torch.empty(B * G, device='cuda')
+    ops.gn_stats(x0, c0, c0, B, HW, HW, G, 1e-5, mean, rstd, x1=x1, c1=C_ - c0, ld1=C_ - c0)
+    ref = F.silu(F.group_norm(x, G, gamma, beta, 1e-5))
+    for rs, refr in [(0, ref), (DS_RESAMPLE_DOWN, F.avg_pool2d(ref, 2)), (DS_RESAMPLE_UP, F.interpolate(ref, scale_factor=2, mode='nearest'))]:
+        ho = refr.shape[-1]
+        out = torch.empty(B * ho * ho, C_, device='cuda')
+        ops.norm_act(x0, c0, c0, B, HW, HW, out, C_, x1=x1, c1=C_ - c0, ld1=C_ - c0, groups=G, eps=1e-5, mean=mean, rstd=rstd,
+                     gamma=gamma.cuda(), beta=beta.cuda(), act=DS_ACT_SILU, resample=rs)
+        torch.cuda.synchronize()
+        assert _rel(out.cpu(), _nhwc(refr)) < TOL, rs
+
+
+def test_batched_gemm_and_softmax():
+    from diff_sampler_amd import ops
+    g = torch.Generator().manual_seed(4)
+    Bz, Hd, S, Ch = 3, 2, 64, 64
+    q = torch.randn(Bz, S, Hd * Ch, generator=g)
+    k = torch.randn(Bz, S, Hd * Ch, generator=g)
+    qd, kd = q.cuda().contiguous(), k.cuda().contiguous()
+    sc = torch.empty(Bz * Hd, S, S, device='cuda')
+    ops.gemm_nt_batched(qd, Hd * Ch, kd, Hd * Ch, sc, S, S, S, Ch, batch=Bz, heads=Hd, a_bs=S * Hd * Ch, a_hs=Ch,
+                        b_bs=S * Hd * Ch, b_hs=Ch, c_bs=Hd * S * S, c_hs=S * S, alpha=0.125)
+    ref = torch.einsum('bqhc,bkhc->bhqk', q.reshape(Bz, S, Hd, Ch), k.reshape(Bz, S, Hd, Ch)) * 0.125
+    torch.cuda.synchronize()
+    assert _rel(sc.cpu().reshape(Bz, Hd, S, S), ref) < TOL
+    ops.softmax_rows(sc, sc, Bz * Hd * S, S, S)
+    torch.cuda.synchronize()
+    assert _rel(sc.cpu().reshape(Bz, Hd, S, S), ref.softmax(-1)) < TOL
+
+
+def test_solver_update_bandwidth_kernel_semantics():
+    """x' = cx*xb + cm*m + sum ch*hist with m = d or D, raw NHWC network output and AFS -- against the formulas."""
+    from diff_sampler_amd import ops
+    g = torch.Generator().manual_seed(8)
+    B, Cc, H = 5, 3, 16
+    x = torch.randn(B, Cc, H, H, generator=g) * 3
+    xb = torch.randn(B, Cc, H, H, generator=g)
+    Fraw = torch.randn(B, Cc, H, H, generator=g)
+    h0, h1 = torch.randn(B, Cc, H, H, generator=g), torch.randn(B, Cc, H, H, generator=g)
+    t, sig, sd = 1.7, 2.1, 0.5
+    cskip = sd ** 2 / (sig ** 2 + sd ** 2); cout = sig * sd / (sig ** 2 + sd ** 2) ** 0.5
+    D = cskip * x + cout * Fraw
+    d = (x - D) / t
+    f4 = torch.zeros(B * H * H, 4); f4[:, :Cc] = _nhwc(Fraw)
+    xo, mo = torch.empty(B, Cc, H, H, device='cuda'), torch.empty(B, Cc, H, H, device='cuda')
+    hc = [0.9, -0.4, 0.3, 0.2, 0.0, t, sig, 0.0]
+    a = ops.make_update_args(x.cuda(), xb.cuda(), f4.cuda(), B, Cc, H, H, xo, raw=True, f_ld=4, hist=[h0.cuda(), h1.cuda()], hcoefs=hc,
+                             sigma_data=sd, m_out=mo, store_d=True)
+    ops.solver_update(a); torch.cuda.synchronize()
+    assert _rel(mo.cpu(), d) < TOL
+    assert _rel(xo.cpu(), 0.9 * xb - 0.4 * d + 0.3 * h0 + 0.2 * h1) < TOL
+    a = ops.make_update_args(x.cuda(), x.cuda(), None, B, Cc, H, H, xo, hcoefs=[1.0, 0.5, 0, 0, 0, t, t, 0], afs=True, m_out=mo, store_d=False)
+    ops.solver_update(a); torch.cuda.synchronize()
+    dafs = x / (1 + t * t) ** 0.5
+    assert _rel(mo.cpu(), x - t * dafs) < TOL and _rel(xo.cpu(), x + 0.5 * (x - t * dafs)) < TOL
