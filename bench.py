@@ -11,14 +11,19 @@ random-init (signal-carrying) CIFAR-10 SongUNet.  Ranks shard images, nothing is
 (SURVEY.md section 8e), so scaling is weak: every rank runs ``--batch`` images per step.
 
 Prints ONE JSON line on rank 0 with the driver's contract fields plus
-  roofline      dominant kernel (fp32-MFMA implicit-GEMM conv): algorithmic FLOPs of its launches in one sampler
-                step / their summed duration, measured with HIP events on the launch stream in an instrumented
-                replay of the timed workload; peak = 157.3 TFLOP/s (MI355X fp32 matrix, MI355X_MICROARCH.md)
-  roofline_update   the fused solver-update kernel against HBM 8 TB/s
-  cpu_baseline  the oracle (CPU restatement of the reference, ``oracle/``) timed on this host's cores on a bounded
-                sample of the same workload.
+  roofline         the dominant kernel (largest share of GPU time; the fp32-MFMA LDS-halo 3x3 convolution):
+                   achieved = algorithmic FLOPs of its launches in one sampler step / their summed duration, measured
+                   with HIP events on the launch stream in an instrumented replay of the timed workload;
+                   peak = 157.3 TFLOP/s (MI355X fp32 matrix pipe, MI355X_MICROARCH.md);
+                   traffic = HBM bytes per launch from the PMC pass committed under profiles/ (FETCH_SIZE doubled per
+                   the guide's gfx950 correction + WRITE_SIZE), or null when that file is absent
+  roofline_update  the fused solver-update kernel against HBM 8 TB/s
+  kernels          time share of every kernel class in the instrumented step
+  cpu_baseline     the oracle (CPU restatement of the reference, ``oracle/``) timed on this host's cores on a bounded
+                   sample of the same workload.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -31,6 +36,11 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r1b_bench_pmc_hbm.json')
+KERNEL_NAMES = {0: 'igemm_f32_kernel<0> (generic gather conv / 1x1 / linear)', 128: 'conv3x3_halo_kernel<2> (128-pixel tiles)',
+                256: 'conv3x3_halo_kernel<4> (256-pixel tiles)'}
+PMC_KEYS = {0: 'void igemm::igemm_f32_kernel<0>(igemm::KParams)', 128: 'void igemm::conv3x3_halo_kernel<2>(igemm::KParams)',
+            256: 'void igemm::conv3x3_halo_kernel<4>(igemm::KParams)'}
 
 
 def parse():
@@ -63,18 +73,35 @@ def sampler_call(solvers, solver, net, latents, nfe):
 
 
 def instrumented_pass(net, solvers, solver, latents, nfe):
-    """Replay one sampler call with every launch bracketed by HIP events on the launch stream."""
+    """Replay one sampler call with every launch bracketed by HIP events on the launch stream.
+    Returns {kernel class: [time_ms, launches, algorithmic flops]}."""
     from diff_sampler_amd import _lib, engine, ops
-    import diff_sampler_amd.arch as arch
-    rec = {}          # kernel class -> [time_ms, launches]
+    rec = {}
     plan_run = engine._Plan.run
     upd = ops.solver_update
     thr = ops.dynamic_threshold
+    lib = _lib.load()
 
-    def add(kind, ms):
-        r = rec.setdefault(kind, [0.0, 0])
+    def add(kind, ms, flops=0.0):
+        r = rec.setdefault(kind, [0.0, 0, 0.0])
         r[0] += ms
         r[1] += 1
+        r[2] += flops
+
+    def classify(op):
+        if op.fn is lib.ds_conv2d_nhwc:
+            a = op.keep[0]
+            kid = lib.ds_conv_kernel_id(C.byref(a))
+            fl = 2.0 * a.n * a.h * a.w * a.cout * (a.taps * (a.c0 + a.c1) + a.ec0 + a.ec1)
+            return ('conv', kid), fl
+        if op.fn is lib.ds_gemm_nt_batched:
+            g = op.keep[0]
+            return 'igemm_f32_kernel<1> (attention GEMMs)', 2.0 * g.m * g.n * g.k * g.batch * g.heads
+        if op.fn is lib.ds_gn_stats:
+            return 'gn_stats_kernel', 0.0
+        if op.fn is lib.ds_norm_act:
+            return 'norm_act_kernel', 0.0
+        return 'other', 0.0
 
     def timed_plan_run(self, stream):
         evs = []
@@ -88,17 +115,8 @@ def instrumented_pass(net, solvers, solver, latents, nfe):
             evs.append((op, e0, e1))
         torch.cuda.synchronize()
         for op, e0, e1 in evs:
-            if op.fn is self_lib.ds_conv2d_nhwc:
-                kind = 'igemm_conv'
-            elif op.fn is self_lib.ds_gemm_nt_batched:
-                kind = 'igemm_gemm'
-            elif op.fn is self_lib.ds_gn_stats:
-                kind = 'gn_stats'
-            elif op.fn is self_lib.ds_norm_act:
-                kind = 'norm_act'
-            else:
-                kind = 'other'
-            add(kind, e0.elapsed_time(e1))
+            kind, fl = classify(op)
+            add(kind, e0.elapsed_time(e1), fl)
 
     def timed_call(kind, fn):
         def w(*a, **k):
@@ -108,10 +126,9 @@ def instrumented_pass(net, solvers, solver, latents, nfe):
             return r
         return w
 
-    self_lib = _lib.load()
     engine._Plan.run = timed_plan_run
-    ops.solver_update = timed_call('solver_update', upd)
-    ops.dynamic_threshold = timed_call('dynamic_threshold', thr)
+    ops.solver_update = timed_call('solver_update_kernel', upd)
+    ops.dynamic_threshold = timed_call('dynamic_threshold_kernel', thr)
     try:
         sampler_call(solvers, solver, net, latents, nfe)
         torch.cuda.synchronize()
@@ -122,22 +139,13 @@ def instrumented_pass(net, solvers, solver, latents, nfe):
     return rec
 
 
-def conv_flops_per_eval(spec, B):
-    """Algorithmic FLOPs (2 x MAC) executed by ds_conv2d_nhwc launches in one network evaluation."""
-    import diff_sampler_amd.arch as arch
-    f = 0.0
-    for b in spec.blocks:
-        hw = b.res_out ** 2
-        if b.kind == 'conv':
-            f += 2.0 * hw * 9 * b.cin * b.cout
-            continue
-        f += 2.0 * hw * 9 * (b.cin + b.cout) * b.cout
-        if b.skip_conv:
-            f += 2.0 * hw * b.cin * b.cout
-        if b.heads:
-            f += 2.0 * hw * b.cout * 2 * b.cout + 2.0 * hw * b.cout * b.cout       # qk projection + proj
-    f += 2.0 * spec.img_resolution ** 2 * 9 * spec.blocks[-1].cout * spec.out_channels
-    return f * B
+def pmc_traffic(kid):
+    """HBM bytes per launch of a conv kernel from the committed rocprofv3 PMC summary (profiles/)."""
+    try:
+        k = json.load(open(PMC_FILE))['kernels'][PMC_KEYS[kid]]
+        return 1024.0 * (2.0 * k['FETCH_SIZE_KiB_avg_per_launch'] + k['WRITE_SIZE_KiB_avg_per_launch'])
+    except Exception:
+        return None
 
 
 def cpu_baseline(args, nfe):
@@ -177,7 +185,6 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
-    import diff_sampler_amd.arch as arch
     from diff_sampler_amd import solvers
     from diff_sampler_amd.engine import EDMDenoiser
 
@@ -221,24 +228,32 @@ def main():
         dt = float(tt.item())
     assert torch.isfinite(out).all()
 
-    roof = roof_u = None
+    roof = roof_u = kernels = None
     if rank == 0:
         rec = instrumented_pass(net, solvers, args.solver, latents, args.nfe)
-        ms, launches = rec['igemm_conv']
-        fl = conv_flops_per_eval(spec, B) * args.nfe
+        total_ms = sum(v[0] for v in rec.values())
+        kernels = {(KERNEL_NAMES[k[1]] if isinstance(k, tuple) else k): dict(ms=round(v[0], 2), launches=v[1], share=round(v[0] / total_ms, 4))
+                   for k, v in sorted(rec.items(), key=lambda kv: -kv[1][0])}
+        convs = {k: v for k, v in rec.items() if isinstance(k, tuple)}
+        dom, (ms, launches, fl) = max(convs.items(), key=lambda kv: kv[1][0])
         ach = fl / (ms * 1e-3) / 1e12
-        roof = dict(bound='mfma', kernel='igemm_f32_kernel<conv> (ds_conv2d_nhwc)', achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS,
-                    unit='TFLOP/s', frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None, launches_per_step=launches,
-                    avg_launch_ms=round(ms / launches, 4), share_of_step=round(ms / (dt / args.steps * 1e3), 3))
-        if 'solver_update' in rec:
-            ums, ul = rec['solver_update']
+        traffic = pmc_traffic(dom[1])
+        alg_bytes = None
+        roof = dict(bound='mfma', kernel=KERNEL_NAMES[dom[1]], achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
+                    frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=(round(traffic) if traffic else None),
+                    traffic_unit='HBM bytes per launch (rocprofv3 PMC, profiles/r1b_bench_pmc_hbm.json)',
+                    launches_per_step=launches, avg_launch_ms=round(ms / launches, 4), gflop_per_launch=round(fl / launches / 1e9, 2),
+                    share_of_gpu_time=round(ms / total_ms, 4))
+        if 'solver_update_kernel' in rec:
+            ums, ul, _ = rec['solver_update_kernel']
             per = spec.in_channels * spec.img_resolution ** 2 * 4
             # DPM-Solver++(2M), x0 form: D pass (x, F read; m written) + combine (x, m0, m1 read; x written) = 7 passes/image/step
             passes = {'dpmpp': 7, 'euler': 3, 'ipndm': 7, 'heun': 3.5}[args.solver]
             byts = passes * per * B * args.nfe
             gbs = byts / (ums * 1e-3) / 1e9
             roof_u = dict(bound='hbm', kernel='solver_update_kernel', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s',
-                          frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, launches_per_step=ul, avg_launch_ms=round(ums / ul, 4))
+                          frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, launches_per_step=ul, avg_launch_ms=round(ums / ul, 4),
+                          note='latency-bound at this batch (3 MB per operand); see DESIGN.md section 6 for the large-batch figure')
 
     if rank == 0:
         total_images = B * world * args.steps
@@ -249,8 +264,9 @@ def main():
             'dtype': 'fp32', 'data': 'synthetic N(0,1) latents, random-init (signal-carrying) weights',
             'config': {'workload': 'EDM CIFAR-10 32x32 SongUNet (55.7M params), %s NFE=%d, batch %d/GPU' %
                        ({'dpmpp': 'DPM-Solver++(2M) logSNR', 'euler': 'Euler', 'ipndm': 'iPNDM-4', 'heun': 'Heun'}[args.solver], args.nfe, B),
-                       'images_per_step': B * world, 'sharding': 'independent image batches per rank, no collective', 'launch': 'hipGraph replay' if args.graph else 'eager'},
-            'roofline': roof, 'roofline_update': roof_u, 'cpu_baseline': cpu,
+                       'images_per_step': B * world, 'sharding': 'independent image batches per rank, no collective',
+                       'launch': 'hipGraph replay' if args.graph else 'eager'},
+            'roofline': roof, 'roofline_update': roof_u, 'kernels': kernels, 'cpu_baseline': cpu,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

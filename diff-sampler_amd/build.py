@@ -9,6 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libdsamd.so')
 ARCH = 'gfx950'
+# extra device-compiler flags (experiments: DS_HIPCC_FLAGS="-mllvm -amdgpu-mfma-vgpr-form=0")
+EXTRA_FLAGS = os.environ.get('DS_HIPCC_FLAGS', '').split()
 
 
 def sources():
@@ -32,7 +34,7 @@ def build_lib(force=False, verbose=True):
     objs = []
     for src in sources():
         obj = src[:-4] + '.o'
-        cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-c', src, '-o', obj]
+        cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC'] + EXTRA_FLAGS + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -268,6 +268,19 @@ bool conv3x3_halo_supported(const KParams& p) { return geometry(p, 128).ok; }
 
 void conv3x3_halo_set_tile(int tile) { g_tile_override = tile; }
 
+int conv3x3_halo_choice(const KParams& p) {          // 0 = unsupported, 128 / 256 = M tile the launcher will use
+    const Geo g128 = geometry(p, 128), g256 = geometry(p, 256);
+    if (!g128.ok) return 0;
+    bool use256 = false;
+    if (g256.ok) {
+        const long long blocks256 = (long long)((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
+        use256 = blocks256 >= 512;
+        if (g_tile_override == 256) use256 = true;
+        if (g_tile_override == 128) use256 = false;
+    }
+    return use256 ? 256 : 128;
+}
+
 int launch_conv3x3_halo(KParams& p, hipStream_t stream) {
     const Geo g128 = geometry(p, 128), g256 = geometry(p, 256);
     bool use256 = false;

@@ -243,6 +243,14 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     return launch<0>(p, 1, (hipStream_t)stream);
 }
 
+extern "C" int ds_conv_kernel_id(const ds_conv_args* a) {
+    if (!a) return DS_E_ARG;
+    KParams p{};
+    p.taps = a->taps; p.H = a->h; p.W = a->w; p.HW = a->h * a->w; p.M = a->n * a->h * a->w; p.N = a->cout;
+    if (g_force_generic || a->taps != 9) return 0;
+    return conv3x3_halo_choice(p);
+}
+
 extern "C" int ds_conv3x3_halo_supported(int h, int w) {
     KParams p{};
     p.taps = 9; p.H = h; p.W = w; p.HW = h * w;
