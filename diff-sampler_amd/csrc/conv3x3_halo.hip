@@ -33,11 +33,16 @@ constexpr int NS_MAX = 10;                                    // halo float4 slo
 
 __device__ float g_zero_page_halo[64];   // zero-initialised
 
-template <int WM>
+// GLDS = weight tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write).  The DMA
+// writes lane-linear (wave base + lane*16 B), so the LDS image is unpadded [row][32 floats] and the bank-conflict fix
+// moves to an XOR swizzle of the 16-B chunk index with (row >> 1) & 7, applied to the per-lane SOURCE address when
+// staging and to the fragment read address (same involution on both sides; 16 distinct slots per ds_read_b128 lane group).
+template <int WM, bool GLDS>
 __global__ void __launch_bounds__(128 * WM, 2) conv3x3_halo_kernel(const KParams p) {
     constexpr int T = 128 * WM;            // threads
     constexpr int TBM = 64 * WM;           // output pixels per tile
     constexpr int BROWS = 1024 / T;        // weight float4 per thread per tap (4 or 2)
+    constexpr int BLD = GLDS ? 32 : LDSK;  // floats per weight row in LDS
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Bs = smem;                               // [2][BN][LDSK]
     float* Ah = smem + B_FLOATS;                    // [NP][LDSK]
@@ -86,7 +91,9 @@ __global__ void __launch_bounds__(128 * WM, 2) conv3x3_halo_kernel(const KParams
     for (int i = 0; i < BROWS; ++i) {
         const int n = n0 + ld_row + (T / 8) * i;
         b_ok[i] = n < p.nrows_b;
-        b_off[i] = (size_t)n * p.ldb + ld_col;
+        // GLDS: this lane fills LDS chunk (tid & 7) of its row, which must hold source chunk (tid & 7) ^ swizzle(row);
+        // (T / 8) is a multiple of 16, so the swizzle depends on ld_row only
+        b_off[i] = (size_t)n * p.ldb + (GLDS ? (((tid & 7) ^ ((ld_row >> 1) & 7)) * 4) : ld_col);
     }
 
     f32x4 hreg[NS_MAX];
@@ -158,6 +165,16 @@ __global__ void __launch_bounds__(128 * WM, 2) conv3x3_halo_kernel(const KParams
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) *reinterpret_cast<f32x4*>(bs + (T / 8) * i * LDSK) = rb[i];
     };
+    // LDS-DMA of weight tile kt into buffer buf: one 1-KiB wave instruction covers 8 rows x 128 B
+    auto b_dma = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) {
+            float* dst = Bs + buf * BN * 32 + (wave * 8 + (T / 8) * i) * 32;       // wave-uniform base
+            typedef const __attribute__((address_space(1))) void* gptr_t;
+            typedef __attribute__((address_space(3))) void* lptr_t;
+            __builtin_amdgcn_global_load_lds((gptr_t)(b_addr(kt, i)), (lptr_t)(dst), 16, 0, 0);
+        }
+    };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -173,14 +190,23 @@ __global__ void __launch_bounds__(128 * WM, 2) conv3x3_halo_kernel(const KParams
     // ---- prologue ----------------------------------------------------------------------------------------------
     halo_load(0);
     coef_load(0);
+    if (GLDS) {
+        b_dma(0, 0);
+    } else {
 #pragma unroll
-    for (int i = 0; i < BROWS; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b_addr(0, i));
+        for (int i = 0; i < BROWS; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b_addr(0, i));
+    }
     halo_store(0);
-    b_store(0);
+    if (!GLDS) b_store(0);
     if (NCH > 1) { halo_load(1); coef_load(1); }
     __syncthreads();
 
-    const int b_foff = (wc * 64 + (lane & 31)) * LDSK + (lane >> 5) * 4;
+    // weight fragment offsets: padded rows (register staging) or swizzled 16-B chunks (LDS-DMA)
+    const int b_row = wc * 64 + (lane & 31);
+    const int b_swz = ((lane & 31) >> 1) & 7;
+    auto b_frag = [&](int ks) -> int {
+        return GLDS ? b_row * 32 + (((ks * 2 + (lane >> 5)) ^ b_swz) * 4) : b_row * LDSK + (lane >> 5) * 4 + ks * 8;
+    };
     int kt = 0;
     for (int chunk = 0; chunk < NCH; ++chunk) {
         const int ntaps = chunk < nchunks ? 9 : 1;
@@ -192,16 +218,19 @@ __global__ void __launch_bounds__(128 * WM, 2) conv3x3_halo_kernel(const KParams
             const int nxt = min(kt + 1, KT - 1);            // past the end: re-stage the last tile (branch-free body)
             const float* as0 = Ah + a_foff[0] + toff;
             const float* as1 = Ah + a_foff[1] + toff;
-            const float* bs = Bs + cur * BN * LDSK + b_foff;
+            const float* bs = Bs + cur * BN * BLD;
+            if (GLDS) b_dma(nxt, cur ^ 1);                  // buffer cur^1 was last read in tap kt-1 (barrier passed)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const f32x4 a0 = *reinterpret_cast<const f32x4*>(as0 + ks * 8);
                 const f32x4 a1 = *reinterpret_cast<const f32x4*>(as1 + ks * 8);
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bs + ks * 8);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bs + 32 * LDSK + ks * 8);
-                // the weight-staging loads ride in the shadow of the MFMA groups
-                if (BROWS == 4) rb[ks] = *reinterpret_cast<const f32x4*>(b_addr(nxt, ks));
-                else if (ks < BROWS) rb[ks] = *reinterpret_cast<const f32x4*>(b_addr(nxt, ks));
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bs + b_frag(ks));
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bs + 32 * BLD + b_frag(ks));
+                // register staging: the weight loads ride in the shadow of the MFMA groups
+                if (!GLDS) {
+                    if (BROWS == 4) rb[ks] = *reinterpret_cast<const f32x4*>(b_addr(nxt, ks));
+                    else if (ks < BROWS) rb[ks] = *reinterpret_cast<const f32x4*>(b_addr(nxt, ks));
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[r], b0[r], acc[0][0], 0, 0, 0);
@@ -210,8 +239,8 @@ __global__ void __launch_bounds__(128 * WM, 2) conv3x3_halo_kernel(const KParams
                     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], b1[r], acc[1][1], 0, 0, 0);
                 }
             }
-            b_store(cur ^ 1);
-            __syncthreads();
+            if (!GLDS) b_store(cur ^ 1);
+            __syncthreads();                                // with LDS-DMA in flight the compiler drains vmcnt(0) here
         }
         if (chunk + 1 < NCH) {
             // every wave has passed the barrier of the slab's last tap: its halo is dead, publish the next one
@@ -241,7 +270,9 @@ Geo geometry(const KParams& p, int tbm) {
 
 int g_tile_override = 0;       // 0 = heuristic, 128 / 256 = forced (benchmarks)
 
-template <int WM>
+int g_glds = 1;                // weight staging: 1 = LDS-DMA, 0 = through registers (A/B switch)
+
+template <int WM, bool GLDS>
 int launch_wm(KParams& p, const Geo& g, hipStream_t stream) {
     constexpr int TBM = 64 * WM;
     p.TH = g.TH; p.nimg = g.nimg; p.HP = g.TH + 2; p.WP = p.W + 2; p.NP = g.NP;
@@ -252,12 +283,12 @@ int launch_wm(KParams& p, const Geo& g, hipStream_t stream) {
     if (smem < epi) smem = epi;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, GLDS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv3x3_halo_kernel<WM>, dim3(grid_1d(p.mtiles, p.ntiles)), dim3(128 * WM), smem, stream, p);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<WM, GLDS>), dim3(grid_1d(p.mtiles, p.ntiles)), dim3(128 * WM), smem, stream, p);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }
@@ -267,6 +298,7 @@ int launch_wm(KParams& p, const Geo& g, hipStream_t stream) {
 bool conv3x3_halo_supported(const KParams& p) { return geometry(p, 128).ok; }
 
 void conv3x3_halo_set_tile(int tile) { g_tile_override = tile; }
+void conv3x3_halo_set_glds(int on) { g_glds = on; }
 
 int conv3x3_halo_choice(const KParams& p) {          // 0 = unsupported, 128 / 256 = M tile the launcher will use
     const Geo g128 = geometry(p, 128), g256 = geometry(p, 256);
@@ -291,8 +323,8 @@ int launch_conv3x3_halo(KParams& p, hipStream_t stream) {
         if (g_tile_override == 256) use256 = true;
         if (g_tile_override == 128) use256 = false;
     }
-    if (use256) return launch_wm<4>(p, g256, stream);
-    return launch_wm<2>(p, g128, stream);
+    if (use256) return g_glds ? launch_wm<4, true>(p, g256, stream) : launch_wm<4, false>(p, g256, stream);
+    return g_glds ? launch_wm<2, true>(p, g128, stream) : launch_wm<2, false>(p, g128, stream);
 }
 
 }  // namespace igemm

@@ -134,5 +134,6 @@ bool conv3x3_halo_supported(const KParams& p);
 int launch_conv3x3_halo(KParams& p, hipStream_t stream);
 int conv3x3_halo_choice(const KParams& p);   // 0 / 128 / 256: which halo tile shape the launcher picks
 void conv3x3_halo_set_tile(int tile);     // 0 = heuristic, 128 / 256 = forced M tile (benchmarks)
+void conv3x3_halo_set_glds(int on);       // weight staging by LDS-DMA (default) or through registers
 
 }  // namespace igemm

@@ -38,7 +38,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize('force', [0, 1, 128, 256])
+@pytest.mark.parametrize('force', [0, 1, 2, 128, 256])
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_conv2d_nhwc_matches_aten(case, force):
     from diff_sampler_amd import _lib, ops

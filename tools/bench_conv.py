@@ -28,6 +28,7 @@ ap.add_argument('--only', type=int, nargs='*')
 args = ap.parse_args()
 
 lib = _lib.load()
+lib.ds_debug_force_generic_conv(int(os.environ.get("DS_CONV", "0")))
 fn = getattr(lib, args.entry)
 fn.restype, fn.argtypes = C.c_int, [C.POINTER(ConvArgs), C.c_void_p]
 B = args.batch
