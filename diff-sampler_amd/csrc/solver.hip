@@ -109,6 +109,67 @@ __global__ void __launch_bounds__(256) solver_update_kernel(const ds_update_args
     }
 }
 
+// Streaming variant for the common geometry (CH = 3 or 4 channels, H*W % 4 == 0, raw rows of 4 floats): all loads of
+// a pixel quad -- CH planes of up to five operands plus four network-output rows -- are issued before the first use, so
+// every lane keeps 13-24 independent 16-B loads in flight (the generic kernel above walks the channels one by one).
+template <int CH>
+__global__ void __launch_bounds__(256) solver_update_fast_kernel(const ds_update_args a) {
+    const int HW = a.h * a.w;
+    const int gpi = HW >> 2;
+    const long long total = (long long)a.n * gpi;
+    const bool has_xb = a.xb != a.xe;
+    for (long long gidx = (long long)blockIdx.x * blockDim.x + threadIdx.x; gidx < total; gidx += (long long)gridDim.x * blockDim.x) {
+        const int img = (int)(gidx / gpi);
+        const int p0 = (int)(gidx - (long long)img * gpi) << 2;
+        f32x4 fr[4], xe[CH], xb[CH], fv[CH], h0[CH], h1[CH], h2[CH];
+        if (!a.afs && a.raw) {
+            const f32x4* fp = reinterpret_cast<const f32x4*>(a.f) + ((size_t)img * HW + p0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fr[j] = __builtin_nontemporal_load(fp + j);
+        }
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) {
+            const size_t off = ((size_t)img * CH + ch) * HW + p0;
+            xe[ch] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.xe + off));
+            if (has_xb) xb[ch] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.xb + off));
+            if (!a.afs && !a.raw) fv[ch] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.f + off));
+            if (a.hist[0]) h0[ch] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.hist[0] + off));
+            if (a.hist[1]) h1[ch] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.hist[1] + off));
+            if (a.hist[2]) h2[ch] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.hist[2] + off));
+        }
+        const Coefs k = load_coefs(a, img);
+        float cskip = 0.f, cout_ = 0.f;
+        if (a.raw) { cskip = ds_c_skip(k.sig, a.sigma_data); cout_ = ds_c_out(k.sig, a.sigma_data); }
+        const float afs_div = sqrtf(1.0f + k.t * k.t);
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) {
+            const size_t off = ((size_t)img * CH + ch) * HW + p0;
+            f32x4 m, xo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x = xe[ch][j];
+                float D, d;
+                if (a.afs) {
+                    d = x / afs_div;
+                    D = x - k.t * d;
+                } else {
+                    const float f = a.raw ? fr[j][ch] : fv[ch][j];
+                    D = a.raw ? cskip * x + cout_ * f : f;
+                    d = (x - D) / k.t;
+                }
+                m[j] = a.store_d ? d : D;
+                float acc = k.cx * (has_xb ? xb[ch][j] : x) + k.cm * m[j];
+                if (a.hist[0]) acc += k.ch0 * h0[ch][j];
+                if (a.hist[1]) acc += k.ch1 * h1[ch][j];
+                if (a.hist[2]) acc += k.ch2 * h2[ch][j];
+                xo[j] = acc;
+            }
+            if (a.m_out) __builtin_nontemporal_store(m, reinterpret_cast<f32x4*>(a.m_out + off));
+            if (a.x_out) __builtin_nontemporal_store(xo, reinterpret_cast<f32x4*>(a.x_out + off));
+        }
+    }
+}
+
 __global__ void table_select_kernel(const float* __restrict__ table, int row_floats, int* __restrict__ step, int advance,
                                     float* __restrict__ dst) {
     const int s = *step;
@@ -240,7 +301,10 @@ extern "C" int ds_solver_update(const ds_update_args* a, void* stream) {
     const long long work = (long long)a->n * (vec4 ? HW / 4 : HW);
     long long blocks = (work + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    if (vec4) hipLaunchKernelGGL(solver_update_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    const bool fast = vec4 && (a->c == 3 || a->c == 4) && (!a->raw || a->afs || (a->f_ld == 4 && ds_aligned16(a->f)));
+    if (fast && a->c == 3) hipLaunchKernelGGL(solver_update_fast_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    else if (fast) hipLaunchKernelGGL(solver_update_fast_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    else if (vec4) hipLaunchKernelGGL(solver_update_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL(solver_update_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
     DS_CHECK_LAUNCH();
     return DS_OK;

@@ -1,0 +1,34 @@
+"""HBM roofline of the fused solver-update kernel at large batch (iPNDM order-4 step and Euler step, CIFAR-10 shapes)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diff_sampler_amd import ops  # noqa: E402
+
+C, H = 3, 32
+per = C * H * H * 4
+for B in [256, 4096, 16384, 65536]:
+    dev = 'cuda'
+    x = torch.randn(B, C, H, H, device=dev)
+    f4 = torch.randn(B * H * H, 4, device=dev)
+    hist = [torch.randn(B, C, H, H, device=dev) for _ in range(3)]
+    xo = torch.empty_like(x); mo = torch.empty_like(x)
+    cases = {
+        'euler  (x,F -> x\')        3 passes (F row padded to 4 floats: 3.33)': (ops.make_update_args(x, x, f4, B, C, H, H, xo, raw=True, f_ld=4, hcoefs=[1, -.5, 0, 0, 0, 2., 2., 0]), 3 + 1 / 3),
+        'ipndm4 (x,F,3 hist -> x\',d) 7 passes (7.33)': (ops.make_update_args(x, x, f4, B, C, H, H, xo, raw=True, f_ld=4, hist=hist, hcoefs=[1, -.5, .1, .2, .3, 2., 2., 0], m_out=mo), 7 + 1 / 3),
+    }
+    for name, (a, passes) in cases.items():
+        for _ in range(3):
+            ops.solver_update(a)
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        n = 20
+        e0.record()
+        for _ in range(n):
+            ops.solver_update(a)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        gb = passes * per * B / 1e9
+        print(f'B={B:6d} {name}: {ms*1e3:9.1f} us  {gb/ms*1e3:8.1f} GB/s  ({gb/ms*1e3/8000*100:.1f}% of 8 TB/s)')
