@@ -154,7 +154,20 @@ def run(dataset_name, max_batch_size=64, seeds='0-63', grid=False, outdir=None, 
                      guidance_type=None, guidance_rate=None, return_inters=False).items():
         solver_kwargs.setdefault(k, v)
     solver_kwargs['sigma_min'], solver_kwargs['sigma_max'] = net.sigma_min, net.sigma_max
-    if t_steps is None:
+    if solver_kwargs.get('dp') and t_steps is None:
+        # GITS (gits-main/sample.py:206-224): search the schedule on the device, then sample with teacher_t[dp_list]
+        from . import gits_utils
+        for k, v in dict(metric='dev', coeff=1.15, num_warmup=256, solver_tea=solver_kwargs.get('solver'), num_steps_tea=61).items():
+            if solver_kwargs.get(k) is None:
+                solver_kwargs[k] = v
+        dp_list = gits_utils.get_dp_list(net, device, dataset_name=dataset_name, max_batch_size=max_batch_size, **solver_kwargs)
+        t_steps = solver_utils.get_schedule(solver_kwargs['num_steps_tea'], net.sigma_min, net.sigma_max, device=device,
+                                            schedule_type=solver_kwargs['schedule_type'], schedule_rho=solver_kwargs['schedule_rho'],
+                                            net=net, dp_list=dp_list)
+        solver_kwargs['num_steps'] = t_steps.shape[0]
+        log('GITS dp_list:', dp_list, 't_steps:', [round(float(v), 4) for v in t_steps])
+        solver_kwargs['t_steps'] = t_steps
+    elif t_steps is None:
         t_steps = solver_utils.get_schedule(solver_kwargs['num_steps'], net.sigma_min, net.sigma_max, device=device,
                                             schedule_type=solver_kwargs['schedule_type'], schedule_rho=solver_kwargs['schedule_rho'],
                                             net=net)
@@ -233,6 +246,13 @@ if click is not None:
     @click.option('--grid', help='Whether to make grid', type=bool, default=False)
     @click.option('--subdirs', help='Create subdirectory for every 1000 seeds', type=bool, default=True, is_flag=True)
     @click.option('--random_init', help='Use a random-init network of the named architecture (no checkpoint)', type=bool, default=False)
+    # GITS options (gits-main/sample.py:159-165)
+    @click.option('--dp', help='Whether to search the time schedule with dynamic programming (GITS)', type=bool, default=False)
+    @click.option('--metric', help='Metric of the GITS cost matrix', type=click.Choice(['l1', 'l2', 'dev']), default='dev')
+    @click.option('--coeff', help='GITS coefficient', type=float, default=1.15)
+    @click.option('--num_warmup', help='Number of warm-up trajectories', type=click.IntRange(min=1), default=256)
+    @click.option('--solver_tea', help='Teacher solver', type=click.Choice(list(SOLVER_FNS)), default=None)
+    @click.option('--num_steps_tea', help='Number of teacher time steps', type=click.IntRange(min=2), default=61)
     def main(**kw):
         run(**kw)
 

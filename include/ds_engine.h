@@ -249,6 +249,21 @@ typedef struct ds_amed_coef_args {
 
 int ds_amed_coefs(const ds_amed_coef_args* a, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * GITS schedule search (gits-main/gits_utils.py:108-132 cost matrix, :237-255 cal_deviation).
+ * traj: [n_pts][batch][per] fp32 teacher trajectory (return_inters), eps: [n_pts-1][batch][per] its directions d_i
+ * (return_eps; may be NULL for ds_traj_moments).
+ *
+ * ds_traj_moments: out[(i*batch + b)*6 + k], fp64, k = {P, Q, R, S, T, N} with b0 = traj[0], c = traj[n_pts-1]:
+ *   P = (c - x_i).(c - b0)  Q = d_i.(c - b0)  R = |c - x_i|^2  S = (c - x_i).d_i  T = |d_i|^2  N = |c - b0|^2.
+ *   The 'dev' cost of every Euler jump i -> j follows in closed form (see csrc/gits.hip).
+ * ds_traj_pair_cost: cost[i*n_pts + j] += sum_b | x_i + (t_j - t_i) d_i - x_j |_p for all i < j (p_norm 1 or 2;
+ *   cost must be zeroed by the caller; t_steps is a device array [n_pts]).
+ */
+int ds_traj_moments(const float* traj, const float* eps, int n_pts, int batch, int per, double* out, void* stream);
+int ds_traj_pair_cost(const float* traj, const float* eps, const float* t_steps, int n_pts, int batch, int per, int p_norm,
+                      double* cost, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

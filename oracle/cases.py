@@ -70,3 +70,23 @@ def amed_predictor_params(seed, scale_dir, scale_time):
     return {k: (torch.randn(s, generator=g) * (0.3 if k.endswith('weight') else 0.1)) for k, s in shapes}
 
 
+
+
+# GITS schedule search (gits-main/gits_utils.py): tag, kwargs of get_dp_list
+GITS_CASES = [
+    ('dev_ipndm', dict(num_steps=5, num_steps_tea=13, metric='dev', coeff=1.15, afs=False, solver='ipndm', solver_tea='ipndm', max_order=3,
+                       schedule_type='polynomial', schedule_rho=7, num_warmup=6, max_batch_size=4)),
+    ('l2_euler_afs', dict(num_steps=4, num_steps_tea=10, metric='l2', coeff=1.0, afs=True, solver='euler', solver_tea='heun', max_order=None,
+                          schedule_type='logsnr', schedule_rho=7, num_warmup=3, max_batch_size=3)),
+    ('l1_dpmpp', dict(num_steps=4, num_steps_tea=9, metric='l1', coeff=0.9, afs=False, solver='dpmpp', solver_tea='dpmpp', max_order=2,
+                      schedule_type='time_uniform', schedule_rho=2, num_warmup=2, max_batch_size=2)),
+]
+GITS_COMMON = dict(dataset_name='cifar10', sigma_min=0.002, sigma_max=80., model_source='edm', prompt=None, guidance_type=None,
+                   guidance_rate=None, predict_x0=True, lower_order_final=True, deis_mode='tab', denoise_to_zero=False)
+
+
+def gits_warmup_latents(seed, rounds, batch, shape):
+    """The latents the reference draws (unseeded torch.randn on the default generator, gits_utils.py:85) after
+    torch.manual_seed(seed): one [batch, *shape] tensor per accumulation round."""
+    torch.manual_seed(seed)
+    return [torch.randn([batch] + list(shape)) for _ in range(rounds)]

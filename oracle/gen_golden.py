@@ -30,8 +30,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = '/root/reference'
 OUT = os.path.join(ROOT, 'tests', 'golden')
 sys.path.insert(0, ROOT)
-from oracle.cases import (GITS_TSTEPS, SAMPLER_CASES, AMED_CASES, make_inputs as _inputs,  # noqa: E402
-                          amed_predictor_params)
+from oracle.cases import (GITS_TSTEPS, SAMPLER_CASES, AMED_CASES, GITS_CASES, GITS_COMMON, make_inputs as _inputs,  # noqa: E402
+                          amed_predictor_params, gits_warmup_latents)
 
 def _ref_net(name, seed):
     import diff_sampler_amd.arch as arch
@@ -171,7 +171,34 @@ def part_amed():
         np.savez_compressed(os.path.join(OUT, f'sampler_{netname}.npz'), **d)
 
 
-PARTS = dict(net=part_net, sched=part_sched, samplers=part_samplers, amed=part_amed)
+def part_gits():
+    """gits-main/gits_utils.py: cal_deviation, dp and the full get_dp_list on a tiny net (single-rank gloo group)."""
+    sys.path.insert(0, os.path.join(REF, 'gits-main'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29571', RANK='0', WORLD_SIZE='1')
+    torch.distributed.init_process_group('gloo', rank=0, world_size=1)
+    import gits_utils
+    net, kw = _ref_net('tiny_song', 51)
+    d = dict(seed=51, config='tiny_song')
+    g = torch.Generator().manual_seed(9)
+    traj = torch.randn(7, 3, 3, 16, 16, generator=g).cumsum(0)
+    d['dev_traj'] = traj.numpy()
+    d['dev_out'] = gits_utils.cal_deviation(traj, 3, 16, bs=3).numpy()
+    cm = torch.rand(12, 12, generator=g).numpy().astype(np.float64) + np.triu(np.ones((12, 12)), 1) * 0.1
+    d['dp_cost'] = cm
+    for ns, coeff in [(4, 1.0), (6, 1.15), (8, 0.85)]:
+        d[f'dp_{ns}_{coeff}'] = np.array(gits_utils.dp(cm, ns, 12, coeff))
+    for tag, gk in GITS_CASES:
+        kwargs = dict(GITS_COMMON); kwargs.update(gk)
+        kwargs['solver_kwargs_seed'] = 1000 + len(tag)
+        torch.manual_seed(kwargs['solver_kwargs_seed'])
+        dp_list = gits_utils.get_dp_list(net, torch.device('cpu'), **kwargs)
+        d[f'{tag}_dp_list'] = np.array(dp_list)
+        print('gits', tag, dp_list)
+    np.savez_compressed(os.path.join(OUT, 'gits.npz'), **d)
+    torch.distributed.destroy_process_group()
+
+
+PARTS = dict(net=part_net, sched=part_sched, samplers=part_samplers, amed=part_amed, gits=part_gits)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

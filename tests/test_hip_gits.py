@@ -1,0 +1,43 @@
+"""GPU: GITS schedule search (cost matrix from trajectory moments, DP, AFS slot search) against the real reference's
+outputs on the same seeded warm-up latents (tests/golden/gits.npz, made by oracle/gen_golden.py --part gits)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cases  # noqa: E402
+
+G = os.path.join(ROOT, 'tests', 'golden')
+
+
+def test_cal_deviation_matches_reference():
+    from diff_sampler_amd import gits_utils
+    z = np.load(os.path.join(G, 'gits.npz'))
+    dev = gits_utils.cal_deviation(torch.from_numpy(z['dev_traj']).cuda(), 3, 16, bs=3)
+    assert np.allclose(dev.cpu().numpy(), z['dev_out'], rtol=2e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('tag', [c[0] for c in cases.GITS_CASES])
+def test_get_dp_list_matches_reference(tag):
+    from diff_sampler_amd import gits_utils
+    from diff_sampler_amd.engine import EDMDenoiser
+    z = np.load(os.path.join(G, 'gits.npz'))
+    net = EDMDenoiser.from_config('tiny_song', seed=int(z['seed']))
+    gk = dict(cases.GITS_CASES)[tag]
+    kwargs = dict(cases.GITS_COMMON); kwargs.update(gk)
+    rounds = kwargs['num_warmup'] // (kwargs['max_batch_size'] + 1) + 1
+    lat = cases.gits_warmup_latents(1000 + len(tag), rounds, kwargs['max_batch_size'], (3, 16, 16))
+    dp_list = gits_utils.get_dp_list(net, torch.device('cuda'), warmup_latents=lat, **kwargs)
+    assert list(dp_list) == list(z[f'{tag}_dp_list']), (tag, dp_list, z[f'{tag}_dp_list'])
+    # the searched schedule is consumed exactly like the reference does (gits-main/solver_utils.py:52-53)
+    from diff_sampler_amd import solver_utils
+    ts = solver_utils.get_schedule(kwargs['num_steps_tea'], 0.002, 80., device='cuda', schedule_type=kwargs['schedule_type'],
+                                   schedule_rho=kwargs['schedule_rho'], dp_list=dp_list)
+    assert ts.shape[0] == len(dp_list) and float(ts[0]) > float(ts[-1])

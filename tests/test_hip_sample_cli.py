@@ -47,3 +47,10 @@ def test_sample_run_t_steps_literal_and_deis(tmp_path):
     out, n = sample.run('tiny_song', max_batch_size=4, seeds='0-3', outdir=str(tmp_path / 'c'), solver='deis', max_order=3,
                         t_steps='[80,10.9836,3.8811,1.584,0.5666,0.1698,0.002]', random_init=True)
     assert n == 4 and len(_read(out)) == 4
+
+
+def test_sample_run_with_gits_schedule_search(tmp_path):
+    from diff_sampler_amd import sample
+    out, n = sample.run('tiny_song', max_batch_size=4, seeds='0-3', outdir=str(tmp_path / 'g'), solver='ipndm', max_order=3, num_steps=5,
+                        dp=True, metric='dev', coeff=1.15, num_warmup=4, solver_tea='ipndm', num_steps_tea=11, random_init=True)
+    assert n == 4 and len(_read(out)) == 4

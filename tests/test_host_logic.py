@@ -152,3 +152,10 @@ def test_get_schedule_errors_and_types():
     t = U.get_schedule(6, 0.002, 80.)
     assert t.dtype == torch.float32 and t.shape == (6,) and float(t[0]) == pytest.approx(79.99998474, rel=1e-7)
     assert torch.all(t[:-1] > t[1:])
+
+
+def test_gits_dynamic_programme_matches_reference_golden():
+    from diff_sampler_amd import gits_utils
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'gits.npz'))
+    for ns, coeff in [(4, 1.0), (6, 1.15), (8, 0.85)]:
+        assert gits_utils.dp(z['dp_cost'], ns, 12, coeff) == list(z[f'dp_{ns}_{coeff}'])
