@@ -24,7 +24,8 @@ class ConvArgs(C.Structure):
                 ('bias', vp), ('cbias', vp), ('cbias_ld', C.c_int), ('cbias_rows', C.c_int), ('res', vp),
                 ('res_ld', C.c_int), ('out_scale', C.c_float), ('act', C.c_int), ('out', vp), ('out_ld', C.c_int),
                 ('norm_coefs', vp), ('norm_act', C.c_int),
-                ('e0', vp), ('e1', vp), ('ec0', C.c_int), ('ec1', C.c_int), ('eld0', C.c_int), ('eld1', C.c_int)]
+                ('e0', vp), ('e1', vp), ('ec0', C.c_int), ('ec1', C.c_int), ('eld0', C.c_int), ('eld1', C.c_int),
+                ('stride', C.c_int)]
 
 
 class GemmArgs(C.Structure):
@@ -41,6 +42,13 @@ class NormArgs(C.Structure):
                 ('mean', vp), ('rstd', vp), ('gamma', vp), ('beta', vp), ('scale', vp), ('shift', vp),
                 ('ss_ld', C.c_int), ('ss_rows', C.c_int), ('act', C.c_int), ('resample', C.c_int), ('out', vp),
                 ('out_ld', C.c_int), ('coefs', vp)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [('q', vp), ('k', vp), ('v', vp), ('out', vp), ('ldq', C.c_int), ('ldk', C.c_int), ('ldv', C.c_int),
+                ('ldo', C.c_int), ('q_bs', C.c_longlong), ('k_bs', C.c_longlong), ('v_bs', C.c_longlong),
+                ('o_bs', C.c_longlong), ('batch', C.c_int), ('heads', C.c_int), ('sq', C.c_int), ('skv', C.c_int),
+                ('d', C.c_int), ('scale', C.c_float)]
 
 
 class UpdateArgs(C.Structure):
@@ -73,6 +81,11 @@ _SIGNATURES = {
     'ds_gn_stats': (C.c_int, [C.POINTER(NormArgs), vp]),
     'ds_norm_act': (C.c_int, [C.POINTER(NormArgs), vp]),
     'ds_softmax_rows': (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp]),
+    'ds_attention': (C.c_int, [C.POINTER(AttnArgs), vp]),
+    'ds_attention_supported': (C.c_int, [C.c_int]),
+    'ds_layernorm_rows': (C.c_int, [vp, C.c_int, vp, vp, C.c_float, vp, C.c_int, C.c_longlong, C.c_int, vp]),
+    'ds_geglu': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_longlong, C.c_int, vp]),
+    'ds_cfg_denoise': (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     'ds_noise_embed': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp]),
     'ds_stem_im2col': (C.c_int, [vp, vp, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     'ds_solver_update': (C.c_int, [C.POINTER(UpdateArgs), vp]),

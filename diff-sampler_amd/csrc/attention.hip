@@ -1,0 +1,204 @@
+// Fused softmax(Q K^T * scale) V on the gfx950 fp32 matrix pipe (online-softmax / "flash" formulation).
+//
+// Replaces, per attention layer, the reference's  einsum -> softmax -> einsum  chain (networks_edm.py:98-110 AttentionOp,
+// :171-176 UNetBlock; ldm/modules/attention.py:168-194 CrossAttention) and the four launches + S x S score tensor of the
+// unfused path (Q K^T GEMM, row softmax, V^T GEMM, P V GEMM): the scores never leave the CU.
+//
+// Work split: block = 128 queries of one (image, head), 4 waves x 32 queries; K/V are streamed in tiles of 32 keys
+// through LDS (register-prefetched one tile ahead).  Everything is computed TRANSPOSED so that a query is a lane:
+//     S^T[key, q] = sum_d K[key, d] Q[q, d]              A operand = K tile (LDS, ds_read_b128), B = Q (registers)
+//     O^T[d,   q] += sum_key V[key, d] P^T[key, q]       A operand = V tile (LDS, ds_read_b32),  B = P^T (registers)
+// In the 32x32 MFMA C/D layout the column is lane & 31, so lane (q, hb) holds 16 of the 32 scores of ITS query: the
+// row maximum / sum are 16 register operations plus one cross-half shuffle, the O^T rescale is a per-lane scalar, and
+// register r of P^T is directly the B operand of the P V MFMA whose two contracted keys are
+// key(r, hb) = (r & 3) + 8 (r >> 2) + 4 hb  -- no data movement between the two GEMMs.
+// exp is evaluated as exp2 with scale * log2(e) folded into Q at load time.
+#include "ds_common.h"
+
+namespace {
+
+template <int D>
+__global__ void __launch_bounds__(256) flash_attn_kernel(const ds_attn_args a) {
+    constexpr int DB = (D + 31) / 32;        // 32-row blocks of O^T
+    constexpr int KLD = D + 4;               // (D + 4) / 4 odd: conflict-free ds_read_b128 of 32 distinct rows
+    constexpr int VLD = DB * 32 + 8;         // rows 4 apart land 32 banks apart
+    constexpr int NQ4 = D / 8;
+    constexpr int D4 = D / 4;
+    constexpr int NLD = (8 * D + 255) / 256;
+    constexpr bool PREFETCH = D <= 96;       // larger heads: the O^T / Q registers leave no room for a staged tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;
+    float* Vs = smem + 32 * KLD;
+    float* Es = smem + 32 * KLD + 32 * VLD + 32;   // epilogue transposition patches, 32 x 33 floats per wave
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hb = lane >> 5, l31 = lane & 31;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const bool active = q0 < a.sq;
+    const float* qp = a.q + (size_t)b * a.q_bs + h * D;
+    const float* kp = a.k + (size_t)b * a.k_bs + h * D;
+    const float* vp = a.v + (size_t)b * a.v_bs + h * D;
+
+    const float sc = a.scale * 1.4426950408889634f;
+    f32x4 qf[NQ4];
+    {
+        const int qrow = min(q0 + l31, a.sq - 1);
+        const float* qr = qp + (size_t)qrow * a.ldq + 4 * hb;
+#pragma unroll
+        for (int ks = 0; ks < NQ4; ++ks) qf[ks] = *reinterpret_cast<const f32x4*>(qr + 8 * ks) * sc;
+    }
+    f32x16 ot[DB];
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
+    float m = -1e30f, l = 0.f;
+
+    f32x4 kr[NLD], vr[NLD];
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int idx = tid + 256 * j;
+            if (NLD * 256 == 8 * D || idx < 8 * D) {
+                const int row = idx / D4, c4 = idx - row * D4;
+                const int key = min(t * 32 + row, a.skv - 1);
+                kr[j] = *reinterpret_cast<const f32x4*>(kp + (size_t)key * a.ldk + c4 * 4);
+                vr[j] = *reinterpret_cast<const f32x4*>(vp + (size_t)key * a.ldv + c4 * 4);
+            }
+        }
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int idx = tid + 256 * j;
+            if (NLD * 256 == 8 * D || idx < 8 * D) {
+                const int row = idx / D4, c4 = idx - row * D4;
+                *reinterpret_cast<f32x4*>(Ks + row * KLD + c4 * 4) = kr[j];
+                *reinterpret_cast<f32x4*>(Vs + row * VLD + c4 * 4) = vr[j];
+            }
+        }
+    };
+
+    const int ntiles = (a.skv + 31) / 32;
+    if (PREFETCH) gload(0);
+    const float* kfrag = Ks + l31 * KLD + 4 * hb;
+    for (int t = 0; t < ntiles; ++t) {
+        if (!PREFETCH) gload(t);
+        __syncthreads();                     // every wave is done with the previous tile
+        sstore();
+        __syncthreads();
+        if (PREFETCH && t + 1 < ntiles) gload(t + 1);    // in flight during the MFMAs below
+        if (!active) continue;
+
+        f32x16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NQ4; ++ks) {
+            const f32x4 kv = *reinterpret_cast<const f32x4*>(kfrag + 8 * ks);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[r], qf[ks][r], st, 0, 0, 0);
+        }
+        const int kbase = t * 32 + 4 * hb;
+        if (t == ntiles - 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kbase + (r & 3) + 8 * (r >> 2) >= a.skv) st[r] = -1e30f;
+        }
+        float mx = st[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mn = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = __builtin_amdgcn_exp2f(st[r] - mn); rs += st[r]; }
+        l = l * alpha + rs;
+#pragma unroll
+        for (int i = 0; i < DB; ++i) ot[i] *= alpha;
+#pragma unroll
+        for (int i = 0; i < DB; ++i) {
+            const float* vcol = Vs + 4 * hb * VLD + i * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float vv = vcol[((r & 3) + 8 * (r >> 2)) * VLD];
+                ot[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, st[r], ot[i], 0, 0, 0);
+            }
+        }
+    }
+    if (!active) return;
+
+    const float inv = 1.0f / (l + __shfl_xor(l, 32));
+    float* patch = Es + wave * (32 * 33);
+    float* op = a.out + (size_t)b * a.o_bs + h * D;
+#pragma unroll
+    for (int i = 0; i < DB; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) patch[l31 * 33 + (r & 3) + 8 * (r >> 2) + 4 * hb] = ot[i][r] * inv;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int c4 = (lane & 7) * 4;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int q = pass * 8 + (lane >> 3);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = patch[q * 33 + c4 + j];
+            if (q0 + q < a.sq && i * 32 + c4 < D)
+                *reinterpret_cast<f32x4*>(op + (size_t)(q0 + q) * a.ldo + i * 32 + c4) = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int D>
+int launch(const ds_attn_args* a, hipStream_t stream) {
+    constexpr int DB = (D + 31) / 32;
+    constexpr int bytes = (32 * (D + 4) + 32 * (DB * 32 + 8) + 32 + 4 * 32 * 33) * (int)sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_kernel<D>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid((a->sq + 127) / 128, a->heads, a->batch);
+    hipLaunchKernelGGL(flash_attn_kernel<D>, grid, dim3(256), bytes, stream, *a);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+}  // namespace
+
+extern "C" int ds_attention_supported(int d) {
+    switch (d) {
+        case 8: case 16: case 32: case 40: case 64: case 80: case 96: case 128: case 160: case 256: return 1;
+        default: return 0;
+    }
+}
+
+extern "C" int ds_attention(const ds_attn_args* a, void* stream) {
+    (void)hipGetLastError();
+    if (!a || !a->q || !a->k || !a->v || !a->out) return DS_E_ARG;
+    if (a->batch <= 0 || a->heads <= 0 || a->sq <= 0 || a->skv <= 0 || a->batch > 65535 || a->heads > 65535) return DS_E_ARG;
+    if ((a->ldq & 3) || (a->ldk & 3) || (a->ldv & 3) || (a->ldo & 3) || (a->q_bs & 3) || (a->k_bs & 3) || (a->v_bs & 3) || (a->o_bs & 3))
+        return DS_E_ALIGN;
+    if (!ds_aligned16(a->q) || !ds_aligned16(a->k) || !ds_aligned16(a->v) || !ds_aligned16(a->out)) return DS_E_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    switch (a->d) {
+        case 8: return launch<8>(a, s);
+        case 16: return launch<16>(a, s);
+        case 32: return launch<32>(a, s);
+        case 40: return launch<40>(a, s);
+        case 64: return launch<64>(a, s);
+        case 80: return launch<80>(a, s);
+        case 96: return launch<96>(a, s);
+        case 128: return launch<128>(a, s);
+        case 160: return launch<160>(a, s);
+        case 256: return launch<256>(a, s);
+        default: return DS_E_SHAPE;
+    }
+}

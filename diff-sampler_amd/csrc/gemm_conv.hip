@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(const KParams p) {
             const int rem = m - img * p.HW;
             a_oh[i] = rem / p.W;
             a_ow[i] = rem - a_oh[i] * p.W;
-            a_off[i] = (size_t)img * p.HW;
+            a_off[i] = (size_t)img * p.IH * p.IW;
         } else {
             a_oh[i] = a_ow[i] = 0;
             a_off[i] = (size_t)m * p.lda0 + ld_col;
@@ -95,9 +95,9 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(const KParams p) {
             const float* s1 = extra ? p.e1 : p.a1;
             const float* src = first ? s0 + c + ld_col : s1 + (c - cc0) + ld_col;
             const int ld = first ? (extra ? p.elda0 : p.lda0) : (extra ? p.elda1 : p.lda1);
-            const int ih = a_oh[i] + dy, iw = a_ow[i] + dx;
-            const bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            return ok ? src + (a_off[i] + (size_t)(ih * p.W + iw)) * ld : zero;
+            const int ih = a_oh[i] * p.stride + dy, iw = a_ow[i] * p.stride + dx;
+            const bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+            return ok ? src + (a_off[i] + (size_t)(ih * p.IW + iw)) * ld : zero;
         } else {
             return a_ok[i] ? a_base + a_off[i] + kt * BK : zero;
         }
@@ -223,6 +223,9 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     KParams p{};
     p.a0 = a->x0; p.a1 = a->x1; p.c0 = a->c0; p.c1 = a->c1; p.lda0 = a->ld0; p.lda1 = a->ld1;
     p.H = a->h; p.W = a->w; p.HW = a->h * a->w; p.taps = a->taps;
+    const int stride = a->stride ? a->stride : 1;
+    if (stride != 1 && (stride != 2 || a->taps != 9 || a->norm_coefs || a->ec0)) return DS_E_ARG;
+    p.stride = stride; p.IH = a->h * stride; p.IW = a->w * stride;
     if (a->ec0 < 0 || a->ec1 < 0 || a->ec0 % 32 || a->ec1 % 32 || (a->ec1 && !a->ec0)) return DS_E_SHAPE;
     if (a->ec0) {
         if (a->taps != 9 || !a->e0 || (a->ec1 && !a->e1)) return DS_E_ARG;
@@ -239,7 +242,7 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     p.res = a->res; p.res_ld = a->res_ld;
     p.scale = a->out_scale; p.act = a->act; p.heads = 1;
     p.vec_ok = vec_epilogue_ok(p) ? 1 : 0;
-    if (!g_force_generic && conv3x3_halo_supported(p)) return launch_conv3x3_halo(p, (hipStream_t)stream);
+    if (!g_force_generic && stride == 1 && conv3x3_halo_supported(p)) return launch_conv3x3_halo(p, (hipStream_t)stream);
     if (p.norm) return DS_E_SHAPE;           // fused input normalisation exists only in the halo kernel
     return launch<0>(p, 1, (hipStream_t)stream);
 }
@@ -248,7 +251,7 @@ extern "C" int ds_conv_kernel_id(const ds_conv_args* a) {
     if (!a) return DS_E_ARG;
     KParams p{};
     p.taps = a->taps; p.H = a->h; p.W = a->w; p.HW = a->h * a->w; p.M = a->n * a->h * a->w; p.N = a->cout;
-    if (g_force_generic || a->taps != 9) return 0;
+    if (g_force_generic || a->taps != 9 || a->stride > 1) return 0;
     return conv3x3_halo_choice(p);
 }
 
@@ -271,6 +274,7 @@ extern "C" int ds_gemm_nt_batched(const ds_gemm_args* a, void* stream) {
     p.b = a->b; p.ldb = a->ldb; p.b_bs = a->b_bstride; p.b_hs = a->b_hstride; p.nrows_b = a->n;
     p.out = a->c; p.ldo = a->ldc; p.o_bs = a->c_bstride; p.o_hs = a->c_hstride;
     p.M = a->m; p.N = a->n; p.K = a->k; p.HW = 1; p.H = p.W = 1; p.taps = 1; p.c0 = a->k; p.c1 = 0;
+    p.stride = 1; p.IH = p.IW = 1;
     p.colbias = a->colbias; p.rowbias = a->rowbias; p.cbias = nullptr; p.res = nullptr;
     p.scale = a->alpha; p.act = a->act; p.heads = a->heads;
     p.vec_ok = vec_epilogue_ok(p) ? 1 : 0;

@@ -13,6 +13,7 @@ static_assert(4 * 64 * EPI_LD * (int)sizeof(float) <= SMEM_BYTES, "epilogue stag
 struct KParams {
     // A side (conv gather)
     const float* a0; const float* a1; int c0, c1, lda0, lda1; int H, W, HW, taps;
+    int stride, IH, IW;            // generic kernel only: output stride and INPUT size (= H, W when stride == 1)
     // A side (gemm) uses a0/lda0 plus batch strides
     long long a_bs, a_hs;
     // B side

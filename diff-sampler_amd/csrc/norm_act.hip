@@ -170,11 +170,11 @@ __global__ void noise_embed_kernel(const float* __restrict__ sigma, int bs, cons
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= bs * half) return;
     const int b = idx / half, i = idx - b * half;
-    const float cn = logf(sigma[b]) / 4.0f;       // c_noise (networks_edm.py:491)
+    const float cn = (swap & 2) ? sigma[b] : logf(sigma[b]) / 4.0f;       // c_noise (networks_edm.py:491) or given
     const float ang = cn * freqs[i];
     const float cs = cosf(ang), sn = sinf(ang);
     float* o = out + (size_t)b * out_ld;
-    if (swap) { o[i] = sn; o[half + i] = cs; } else { o[i] = cs; o[half + i] = sn; }
+    if (swap & 1) { o[i] = sn; o[half + i] = cs; } else { o[i] = cs; o[half + i] = sn; }
 }
 
 // rows = pixels; k = tap*c + ch, zero-padded to kpad.
@@ -210,6 +210,70 @@ __global__ void channel_mean_kernel(const float* __restrict__ x, int ld, int c, 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) out[row] = s / (float)c;
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// LayerNorm over the channel dimension of token rows: one wave per row, the row lives in registers (<= 8 float4 per
+// lane), two-pass mean / variance like ATen's row-wise moments.
+__global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, float* __restrict__ y, int ldy,
+                                                             long long rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int n4 = cols >> 2;
+    const float* xr = x + row * ldx;
+    f32x4 v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < n4) { v[i] = *reinterpret_cast<const f32x4*>(xr + idx * 4); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < n4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)cols + eps);
+    float* yr = y + row * ldy;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < n4) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + idx * 4);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + idx * 4);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+            *reinterpret_cast<f32x4*>(yr + idx * 4) = o;
+        }
+    }
+}
+
+// y[r, c] = x[r, c] * gelu(x[r, inner + c]), exact GELU 0.5 g (1 + erf(g / sqrt 2)).
+__global__ void __launch_bounds__(256) geglu_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, long long rows,
+                                                    int inner4) {
+    const long long total = rows * inner4;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long r = idx / inner4;
+        const int c4 = (int)(idx - r * inner4) * 4;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + r * ldx + c4);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(x + r * ldx + (size_t)inner4 * 4 + c4);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = a[j] * (0.5f * g[j] * (1.0f + erff(g[j] * 0.70710678118654752440f)));
+        *reinterpret_cast<f32x4*>(y + r * ldy + c4) = o;
+    }
 }
 
 int norm_geometry(const ds_norm_args* a, int* CQ, int* PL) {
@@ -306,6 +370,32 @@ extern "C" int ds_channel_mean(const float* x, int ld, int c, long long rows, fl
     (void)hipGetLastError();   // drop stale errors of unrelated runtime calls
     if (!x || !out || rows <= 0 || c <= 0) return DS_E_ARG;
     hipLaunchKernelGGL(channel_mean_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ld, c, rows, out);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+extern "C" int ds_layernorm_rows(const float* x, int ldx, const float* gamma, const float* beta, float eps, float* y, int ldy,
+                                 long long rows, int cols, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !gamma || !beta || !y || rows <= 0 || cols <= 0) return DS_E_ARG;
+    if ((cols & 3) || cols > 2048) return DS_E_SHAPE;
+    if ((ldx & 3) || (ldy & 3) || !ds_aligned16(x) || !ds_aligned16(y) || !ds_aligned16(gamma) || !ds_aligned16(beta)) return DS_E_ALIGN;
+    const long long blocks = (rows + 3) / 4;
+    if (blocks > 0x7fffffffLL) return DS_E_SHAPE;
+    hipLaunchKernelGGL(layernorm_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, eps, y,
+                       ldy, rows, cols);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+extern "C" int ds_geglu(const float* x, int ldx, float* y, int ldy, long long rows, int inner, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !y || rows <= 0 || inner <= 0) return DS_E_ARG;
+    if (inner & 3) return DS_E_SHAPE;
+    if ((ldx & 3) || (ldy & 3) || !ds_aligned16(x) || !ds_aligned16(y)) return DS_E_ALIGN;
+    long long blocks = (rows * (inner / 4) + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(geglu_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, inner / 4);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }

@@ -285,6 +285,27 @@ __global__ void __launch_bounds__(512) dynamic_threshold_kernel(const float* __r
     }
 }
 
+// CFGPrecond epilogue: D = x - sigma * F, F = Fu + g (Fc - Fu) for a doubled evaluation.  Thread = one pixel (all channels):
+// the NHWC row of F is one 16-B load when f_ld == 4.
+__global__ void __launch_bounds__(256) cfg_denoise_kernel(const float* __restrict__ x, const float* __restrict__ f, int f_ld,
+                                                          const float* __restrict__ sigma, int sigma_rows, float g, int doubled, int n,
+                                                          int c, int hw, float* __restrict__ out) {
+    const long long total = (long long)n * hw;
+    for (long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (long long)gridDim.x * blockDim.x) {
+        const int img = (int)(pix / hw);
+        const int p = (int)(pix - (long long)img * hw);
+        const float sg = sigma[sigma_rows == 1 ? 0 : img];
+        const float* fu = f + pix * f_ld;
+        const float* fc = f + (pix + total) * f_ld;
+        for (int ch = 0; ch < c; ++ch) {
+            float fx = fu[ch];
+            if (doubled) fx = fx + g * (fc[ch] - fx);
+            const size_t o = ((size_t)img * c + ch) * hw + p;
+            out[o] = x[o] - sg * fx;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int ds_solver_update(const ds_update_args* a, void* stream) {
@@ -331,6 +352,18 @@ extern "C" int ds_dynamic_threshold(const float* x0, float* out, int n, int per,
         attr_set = true;
     }
     hipLaunchKernelGGL(dynamic_threshold_kernel, dim3(n), dim3(512), smem, (hipStream_t)stream, x0, out, per, p);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+extern "C" int ds_cfg_denoise(const float* x, const float* f, int f_ld, const float* sigma, int sigma_rows, float guidance, int doubled,
+                              int n, int c, int h, int w, float* out, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !f || !sigma || !out || n <= 0 || c <= 0 || h <= 0 || w <= 0 || f_ld < c || (sigma_rows != 1 && sigma_rows != n)) return DS_E_ARG;
+    long long blocks = ((long long)n * h * w + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(cfg_denoise_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, f, f_ld, sigma, sigma_rows, guidance,
+                       doubled, n, c, h * w, out);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }

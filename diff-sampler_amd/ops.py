@@ -57,9 +57,10 @@ def pack_linear_weight(w: torch.Tensor, row_pad: int = 128, k_pad: int = 32) -> 
 
 
 def conv2d_nhwc(x0, c0, ld0, n, h, w, wgt, cout, out, out_ld, *, taps=9, x1=None, c1=0, ld1=0, bias=None, cbias=None,
-                cbias_ld=0, cbias_rows=1, res=None, res_ld=0, out_scale=1.0, act=DS_ACT_NONE):
+                cbias_ld=0, cbias_rows=1, res=None, res_ld=0, out_scale=1.0, act=DS_ACT_NONE, stride=1):
     a = ConvArgs(_p(x0), _p(x1), c0, c1, ld0, ld1, n, h, w, taps, _p(wgt), cout, _p(bias), _p(cbias), cbias_ld,
                  cbias_rows, _p(res), res_ld, out_scale, act, _p(out), out_ld)
+    a.stride = stride
     _lib.check(_lib.load().ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr()), 'ds_conv2d_nhwc')
 
 
@@ -149,3 +150,22 @@ def copy_rows(src, src_ld, dst, dst_ld, rows, cols):
 
 def fill(dst, value, count=None):
     _lib.check(_lib.load().ds_fill(_p(dst), float(value), dst.numel() if count is None else count, _lib.stream_ptr()), 'ds_fill')
+
+
+def attention(q, k, v, out, *, batch, heads, sq, skv, d, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, scale):
+    a = _lib.AttnArgs(_p(q), _p(k), _p(v), _p(out), ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, batch, heads, sq, skv, d, scale)
+    _lib.check(_lib.load().ds_attention(C.byref(a), _lib.stream_ptr()), 'ds_attention')
+
+
+def layernorm_rows(x, ldx, gamma, beta, eps, y, ldy, rows, cols):
+    _lib.check(_lib.load().ds_layernorm_rows(_p(x), ldx, _p(gamma), _p(beta), eps, _p(y), ldy, rows, cols, _lib.stream_ptr()),
+               'ds_layernorm_rows')
+
+
+def geglu(x, ldx, y, ldy, rows, inner):
+    _lib.check(_lib.load().ds_geglu(_p(x), ldx, _p(y), ldy, rows, inner, _lib.stream_ptr()), 'ds_geglu')
+
+
+def cfg_denoise(x, f, f_ld, sigma, sigma_rows, guidance, doubled, n, c, h, w, out):
+    _lib.check(_lib.load().ds_cfg_denoise(_p(x), _p(f), f_ld, _p(sigma), sigma_rows, float(guidance), int(doubled), n, c, h, w,
+                                          _p(out), _lib.stream_ptr()), 'ds_cfg_denoise')

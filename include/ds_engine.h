@@ -76,6 +76,10 @@ typedef struct ds_conv_args {
      * 9*(c0+c1) columns the weight rows carry ec0+ec1 more columns that multiply [e0 | e1] at the output pixel.
      * ec0 == 0 = none.  Same constraints as c0/c1 (multiples of 32, ld % 4 == 0). */
     const float* e0; const float* e1; int ec0, ec1; int eld0, eld1;
+    /* Output stride of a 3x3 convolution: 0 or 1 = dense; 2 = the LDM `Downsample` convolution (stride 2, pad 1,
+     * ldm/modules/diffusionmodules/openaimodel.py:146-148): h, w are then the OUTPUT size and the input is 2h x 2w.
+     * stride 2 excludes norm_coefs and the e0/e1 extras. */
+    int stride;
 } ds_conv_args;
 
 int ds_conv2d_nhwc(const ds_conv_args* a, void* stream);
@@ -136,9 +140,37 @@ int ds_norm_act(const ds_norm_args* a, void* stream);
 int ds_softmax_rows(const float* x, float* y, long long rows, int cols, int ld, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Fused attention  out[b, i, h*d : (h+1)*d] = sum_j softmax_j(scale * q[b,i,h,:] . k[b,j,h,:]) v[b,j,h,:]
+ * (networks_edm.py:98-110 + :171-176; ldm/modules/attention.py:168-194).  q/k/v/out are token-major matrices
+ * [rows][ld] whose head h occupies columns h*d ... (h+1)*d - 1 (so NHWC activations and packed q|k|v projections are
+ * consumed in place); image b starts at b * *_bs floats.  skv may be any length (cross-attention: 77); sq any.
+ * d must satisfy ds_attention_supported(d).  One launch, online softmax, scores never written to HBM.
+ */
+typedef struct ds_attn_args {
+    const float* q; const float* k; const float* v; float* out;
+    int ldq, ldk, ldv, ldo;
+    long long q_bs, k_bs, v_bs, o_bs;
+    int batch, heads, sq, skv, d;
+    float scale;
+} ds_attn_args;
+
+int ds_attention(const ds_attn_args* a, void* stream);
+int ds_attention_supported(int d);
+
+/* LayerNorm over the last dimension (ldm/modules/attention.py:206-208): y[r, :] = (x[r, :] - mean) / sqrt(var + eps)
+ * * gamma + beta, cols % 4 == 0, cols <= 2048. */
+int ds_layernorm_rows(const float* x, int ldx, const float* gamma, const float* beta, float eps, float* y, int ldy,
+                      long long rows, int cols, void* stream);
+
+/* GEGLU gate (ldm/modules/attention.py:45-52): y[r, c] = x[r, c] * gelu(x[r, inner + c]) with the exact (erf) GELU. */
+int ds_geglu(const float* x, int ldx, float* y, int ldy, long long rows, int inner, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Noise embedding front end (networks_edm.py:185-198, :314-315, :488-491).
  * sigma: [bs] device.  out[b, :] = PositionalEmbedding(ln(sigma_b)/4) with the precomputed freqs table
  * [nch/2]; swap=1 gives [sin | cos] (SongUNet), swap=0 [cos | sin] (DhariwalUNet).
+ * swap bit 1 (value 2): `sigma` already holds the embedding argument (c_noise) -- the LDM `timestep_embedding`
+ * (ldm/modules/diffusionmodules/util.py:151-171) fed by CFGPrecond's c_noise = M * sigma_inv(sigma) - 1.
  */
 int ds_noise_embed(const float* sigma, int bs, const float* freqs, int nch, int swap, float* out, int out_ld, void* stream);
 
@@ -189,6 +221,13 @@ int ds_table_select(const float* table, int row_floats, int* step, int advance, 
 /* x0 <- clamp(x0, -s, s) / s with s = max(quantile_{0.995}(|x0|) per sample, 1): solver_utils.py:77-86, exact
  * torch.quantile semantics (linear interpolation between the two order statistics around p*(n-1)). */
 int ds_dynamic_threshold(const float* x0, float* out, int n, int per, float p, void* stream);
+
+/* CFGPrecond epilogue (networks_edm.py:668-690): D = x - sigma * F with, when `doubled`, the classifier-free
+ * combination F = F_uncond + guidance * (F_cond - F_uncond) of the two halves of a 2n-image evaluation
+ * (rows [0, n*h*w) = unconditional, [n*h*w, 2n*h*w) = conditional).  x / out NCHW [n][c][h][w]; f NHWC rows of f_ld
+ * floats; sigma [sigma_rows] (1 = shared). */
+int ds_cfg_denoise(const float* x, const float* f, int f_ld, const float* sigma, int sigma_rows, float guidance, int doubled,
+                   int n, int c, int h, int w, float* out, void* stream);
 
 /* y = a * x (latents * t_steps[0], solvers.py:68). */
 int ds_scale(const float* x, float a, float* y, long long count, void* stream);

@@ -52,10 +52,10 @@ def _resample(x, up, down):
     # resample_filter=[1,1]: f = [[1,1],[1,1]]/4 (networks_edm.py:56-57).
     c = x.shape[1]
     if up:      # conv_transpose2d with 4*f, stride 2 (networks_edm.py:75)
-        f = torch.ones(c, 1, 2, 2, dtype=x.dtype)
+        f = torch.ones(c, 1, 2, 2, dtype=x.dtype, device=x.device)
         x = F.conv_transpose2d(x, f, groups=c, stride=2, padding=0)
     if down:    # conv2d with f, stride 2 (networks_edm.py:77)
-        f = torch.full((c, 1, 2, 2), 0.25, dtype=x.dtype)
+        f = torch.full((c, 1, 2, 2), 0.25, dtype=x.dtype, device=x.device)
         x = F.conv2d(x, f, groups=c, stride=2, padding=0)
     return x
 
@@ -73,7 +73,7 @@ def _conv(p, prefix, x, up=False, down=False):
 
 def _pos_emb(x, num_channels, endpoint, max_positions=10000):
     half = num_channels // 2
-    freqs = torch.arange(0, half, dtype=torch.float32)
+    freqs = torch.arange(0, half, dtype=torch.float32, device=x.device)
     freqs = freqs / (half - (1 if endpoint else 0))
     freqs = (1 / max_positions) ** freqs
     x = x.ger(freqs.to(x.dtype))
@@ -182,7 +182,7 @@ def edm_denoise(p, cfg, x, sigma, class_labels=None, taps=None):
     if label_dim == 0:
         class_labels = None
     elif class_labels is None:
-        class_labels = torch.zeros([1, label_dim])
+        class_labels = torch.zeros([1, label_dim], device=x.device)
     else:
         class_labels = class_labels.to(torch.float32).reshape(-1, label_dim)
     sd = cfg.get('sigma_data', 0.5)

@@ -181,3 +181,87 @@ def test_solver_update_bandwidth_kernel_semantics():
     ops.solver_update(a); torch.cuda.synchronize()
     dafs = x / (1 + t * t) ** 0.5
     assert _rel(mo.cpu(), x - t * dafs) < TOL and _rel(xo.cpu(), x + 0.5 * (x - t * dafs)) < TOL
+
+
+@pytest.mark.parametrize('d,heads,sq,skv', [(40, 8, 256, 256), (40, 8, 1024, 77), (64, 3, 64, 64), (80, 2, 160, 77),
+                                            (160, 2, 64, 64), (256, 1, 256, 256), (8, 4, 96, 33), (32, 2, 128, 1000),
+                                            (16, 1, 40, 5), (96, 1, 32, 64), (128, 2, 200, 130)])
+def test_fused_attention_matches_softmax_qk_v(d, heads, sq, skv):
+    """ds_attention against softmax(q k^T * scale) v in fp64; q/k/v are read in place from packed projections (column
+    offsets h*d inside wider rows), cross-attention lengths included."""
+    from diff_sampler_amd import ops, _lib
+    assert _lib.load().ds_attention_supported(d)
+    g = torch.Generator().manual_seed(d * 1000 + sq)
+    Bz, C_ = 2, heads * d
+    qkv = torch.randn(Bz, sq, 3 * C_ + 4, generator=g)           # q | (unused k) | junk, ld not a multiple of C
+    kv = torch.randn(Bz, skv, 2 * C_, generator=g) * 1.5
+    q = qkv[:, :, :C_]
+    k, v = kv[:, :, :C_], kv[:, :, C_:]
+    scale = d ** -0.5
+    qd, kvd = qkv.cuda().contiguous(), kv.cuda().contiguous()
+    out = torch.full((Bz, sq, C_), float('nan'), device='cuda')
+    ops.attention(qd, kvd, kvd[:, :, C_:], out, batch=Bz, heads=heads, sq=sq, skv=skv, d=d, ldq=3 * C_ + 4, ldk=2 * C_, ldv=2 * C_,
+                  ldo=C_, q_bs=sq * (3 * C_ + 4), k_bs=skv * 2 * C_, v_bs=skv * 2 * C_, o_bs=sq * C_, scale=scale)
+    torch.cuda.synchronize()
+    qh = q.reshape(Bz, sq, heads, d).double()
+    kh = k.reshape(Bz, skv, heads, d).double()
+    vh = v.reshape(Bz, skv, heads, d).double()
+    w = (torch.einsum('bqhd,bkhd->bhqk', qh, kh) * scale).softmax(-1)
+    ref = torch.einsum('bhqk,bkhd->bqhd', w, vh).reshape(Bz, sq, C_).float()
+    assert _rel(out.cpu(), ref) < TOL
+
+
+def test_layernorm_geglu_cfg_and_timestep_embedding():
+    from diff_sampler_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for rows, cols in [(77, 320), (130, 1280), (5, 64)]:
+        x = torch.randn(rows, cols + 8, generator=g) * 3 + 1
+        ga, be = torch.randn(cols, generator=g), torch.randn(cols, generator=g)
+        y = torch.empty(rows, cols, device='cuda')
+        ops.layernorm_rows(x.cuda(), cols + 8, ga.cuda(), be.cuda(), 1e-5, y, cols, rows, cols)
+        torch.cuda.synchronize()
+        assert _rel(y.cpu(), F.layer_norm(x[:, :cols], (cols,), ga, be, 1e-5)) < TOL
+    x = torch.randn(50, 2 * 1280, generator=g) * 2
+    y = torch.empty(50, 1280, device='cuda')
+    ops.geglu(x.cuda(), 2560, y, 1280, 50, 1280)
+    torch.cuda.synchronize()
+    assert _rel(y.cpu(), x[:, :1280] * F.gelu(x[:, 1280:])) < TOL
+    # CFG epilogue
+    n, c, h, w = 3, 4, 8, 8
+    xi = torch.randn(n, c, h, w, generator=g)
+    f = torch.randn(2 * n * h * w, 4, generator=g)
+    sig = torch.tensor([3.0, 0.5, 11.0])
+    out = torch.empty(n, c, h, w, device='cuda')
+    ops.cfg_denoise(xi.cuda(), f.cuda(), 4, sig.cuda(), n, 7.5, True, n, c, h, w, out)
+    fu = f[:n * h * w].reshape(n, h, w, c).permute(0, 3, 1, 2)
+    fc = f[n * h * w:].reshape(n, h, w, c).permute(0, 3, 1, 2)
+    ref = xi - sig.reshape(-1, 1, 1, 1) * (fu + 7.5 * (fc - fu))
+    torch.cuda.synchronize()
+    assert _rel(out.cpu(), ref) < TOL
+    ops.cfg_denoise(xi.cuda(), f.cuda(), 4, sig[:1].cuda(), 1, 1.0, False, n, c, h, w, out)
+    torch.cuda.synchronize()
+    assert _rel(out.cpu(), xi - 3.0 * fu) < TOL
+    # timestep embedding with the argument given directly (flag 2), [cos | sin]
+    tt = torch.tensor([999.0, 0.25, 500.5])
+    half = 160
+    freqs = torch.exp(-torch.log(torch.tensor(10000.0)) * torch.arange(half, dtype=torch.float32) / half)
+    emb = torch.empty(3, 320, device='cuda')
+    ops.noise_embed(tt.cuda(), 3, freqs.cuda(), 320, 2, emb, 320)
+    torch.cuda.synchronize()
+    args = tt[:, None] * freqs[None]
+    assert float((emb.cpu() - torch.cat([args.cos(), args.sin()], -1)).abs().max()) < 2e-4   # sin/cos of arguments up to 1e3
+
+
+@pytest.mark.parametrize('B,Ho,cin,cout', [(2, 16, 64, 96), (3, 8, 32, 32), (1, 32, 320, 320)])
+def test_stride2_conv_matches_aten(B, Ho, cin, cout):
+    from diff_sampler_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + Ho)
+    x = torch.randn(B, cin, 2 * Ho, 2 * Ho, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    bias = torch.randn(cout, generator=g)
+    out = torch.empty(B * Ho * Ho, cout, device='cuda')
+    ops.conv2d_nhwc(_nhwc(x).cuda(), cin, cin, B, Ho, Ho, ops.pack_conv_weight(wt).cuda(), cout, out, cout, taps=9, bias=bias.cuda(),
+                    stride=2)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x, wt, bias, stride=2, padding=1)
+    assert _rel(out.cpu(), _nhwc(ref)) < TOL
