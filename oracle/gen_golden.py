@@ -17,6 +17,9 @@ Parts
   samplers  every sampler of diff-solvers-main/solvers.py on a tiny net, with trajectories; config-1
             (Euler, NFE=10, B=8, CIFAR-10 net) final images
   amed      amed-solver-main/solvers_amed.py (AMED-Solver + plugins) with a random-init AMED_predictor
+  gits      gits-main/gits_utils.py get_dp_list (cost matrix + dynamic programme) on a tiny net
+  ldm       reference CFGPrecond + ldm UNetModel (tiny configs and full SD-1.5 size): denoiser outputs with
+            classifier-free guidance, sigma / sigma_inv / discrete schedule probes, sampler trajectories
 """
 import argparse
 import os
@@ -198,7 +201,92 @@ def part_gits():
     torch.distributed.destroy_process_group()
 
 
-PARTS = dict(net=part_net, sched=part_sched, samplers=part_samplers, amed=part_amed, gits=part_gits)
+def _ref_cfg_net(name, seed, guidance_rate=7.5):
+    """The reference CFGPrecond (networks_edm.py:630-762) around the reference UNetModel (openaimodel.py:413-742), with
+    weights from ldm_arch.init_ldm_params.  LatentDiffusion itself needs pytorch_lightning/CLIP/VAE and is replaced by a
+    shim exposing exactly what CFGPrecond uses: ``alphas_cumprod`` and ``apply_model`` (= DiffusionWrapper 'crossattn',
+    ddpm.py:1409-1411)."""
+    import types
+    if 'omegaconf' not in sys.modules:
+        try:
+            import omegaconf  # noqa: F401
+        except ImportError:
+            m, lc = types.ModuleType('omegaconf'), types.ModuleType('omegaconf.listconfig')
+            lc.ListConfig = type('ListConfig', (list,), {})
+            m.listconfig = lc
+            sys.modules['omegaconf'], sys.modules['omegaconf.listconfig'] = m, lc
+    import diff_sampler_amd.ldm_arch as la
+    from models.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from models.networks_edm import CFGPrecond
+    kw = dict(la.NAMED_LDM_CONFIGS[name])
+    spec = la.ldm_unet_spec(**kw)
+    unet = UNetModel(image_size=32, in_channels=kw['in_channels'], out_channels=kw['out_channels'], model_channels=kw['model_channels'],
+                     attention_resolutions=list(kw['attention_resolutions']), num_res_blocks=kw['num_res_blocks'],
+                     channel_mult=list(kw['channel_mult']), num_heads=kw['num_heads'], use_spatial_transformer=True,
+                     transformer_depth=1, context_dim=kw['context_dim'], use_checkpoint=False, legacy=False).eval()
+    unet.load_state_dict(la.init_ldm_params(spec, seed=seed), strict=True)
+
+    class Shim(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.unet = unet
+            self.register_buffer('alphas_cumprod', la.alphas_cumprod(spec))
+
+        def apply_model(self, x, t, cond):
+            return self.unet(x, t, context=cond)
+
+    net = CFGPrecond(Shim(), img_resolution=kw['img_resolution'], img_channels=kw['in_channels'], guidance_rate=guidance_rate,
+                     guidance_type='classifier-free', label_dim=True).eval()
+    return net, unet, kw, spec
+
+
+def part_ldm():
+    sys.path.insert(0, os.path.join(REF, 'diff-solvers-main'))
+    import solvers
+    import solver_utils
+    for name, B, seed in [('tiny_ldm', 2, 21), ('tiny_ldm_1res', 3, 22), ('sd15', 1, 23)]:
+        net, unet, kw, spec = _ref_cfg_net(name, seed)
+        g = torch.Generator().manual_seed(seed + 100)
+        R, Cc, ctx = kw['img_resolution'], kw['in_channels'], kw['context_dim']
+        sig = torch.tensor([11.0, 0.7, 2.3][:B])
+        x = torch.randn(B, Cc, R, R, generator=g) * sig.reshape(-1, 1, 1, 1)
+        cond = torch.randn(B, 77, ctx, generator=g)
+        uncond = torch.randn(B, 77, ctx, generator=g)
+        d = dict(config=name, seed=seed, x=x.numpy(), sigma=sig.numpy(), cond=cond.numpy(), uncond=uncond.numpy(),
+                 sigma_min=net.sigma_min, sigma_max=net.sigma_max)
+        with torch.no_grad():
+            d['out_vec'] = net(x, sig, condition=cond, unconditional_condition=uncond).numpy()
+            if name != 'sd15':
+                d['out_scalar'] = net(x, torch.tensor(1.9), condition=cond, unconditional_condition=uncond).numpy()
+                d['out_nocfg'] = net(x, torch.tensor(1.9), condition=cond, unconditional_condition=None).numpy()
+                tt = torch.tensor([3.0, 998.0, 421.7][:B])
+                d['unet_t'] = tt.numpy()
+                d['unet_out'] = unet(x, tt, context=cond).numpy()
+            probe = torch.tensor([0.03, 0.1, 0.5, 1.0, 2.5, 7.0, 14.6], dtype=torch.float32)
+            d['probe_sigma'] = probe.numpy()
+            d['probe_sigma_inv'] = net.sigma_inv(probe).numpy()
+            tpr = torch.tensor([0.001, 0.0105, 0.2, 0.5, 0.77, 1.0], dtype=torch.float32)
+            d['probe_t'] = tpr.numpy()
+            d['probe_sigma_of_t'] = net.sigma(tpr).numpy()
+            d['sched_discrete_6'] = solver_utils.get_schedule(6, net.sigma_min, net.sigma_max, device='cpu', schedule_type='discrete',
+                                                              schedule_rho=1, net=net).numpy()
+            if name != 'sd15':
+                lat = torch.randn(B, Cc, R, R, generator=g)
+                d['latents'] = lat.numpy()
+                for tag, fn, kws in [
+                    ('dpmpp2m_eps', solvers.dpm_pp_sampler, dict(max_order=2, predict_x0=False, lower_order_final=True)),
+                    ('dpmpp2m_x0', solvers.dpm_pp_sampler, dict(max_order=2, predict_x0=True, lower_order_final=True)),
+                    ('euler', solvers.euler_sampler, {}),
+                    ('ipndm3', solvers.ipndm_sampler, dict(max_order=3)),
+                ]:
+                    tr = fn(net, lat, condition=cond, unconditional_condition=uncond, num_steps=6, sigma_min=net.sigma_min,
+                            sigma_max=net.sigma_max, schedule_type='discrete', schedule_rho=1, return_inters=True, **kws)
+                    d[f'traj_{tag}'] = tr.numpy()
+        np.savez_compressed(os.path.join(OUT, f'ldm_{name}.npz'), **d)
+        print('ldm', name, float(np.abs(d['out_vec']).max()), net.sigma_min, net.sigma_max)
+
+
+PARTS = dict(net=part_net, sched=part_sched, samplers=part_samplers, amed=part_amed, gits=part_gits, ldm=part_ldm)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

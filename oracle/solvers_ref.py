@@ -247,7 +247,7 @@ def _push(hist, d, cap):
 
 def sample(solver, net, latents, t_steps, class_labels=None, afs=False, denoise_to_zero=False,
            max_order=None, r=0.5, coeff_list=None, predict_x0=True, lower_order_final=True, num_steps=None,
-           predictor=None, want_inters=False, want_eps=False):
+           predictor=None, want_inters=False, want_eps=False, condition=None, unconditional_condition=None):
     """Run one reference sampler.  ``net(x, sigma, class_labels=...)`` -> denoised.
 
     solver: euler | heun | dpm_2 | ipndm | ipndm_v | deis | dpm_pp, or amed | amed_euler | amed_ipndm |
@@ -255,7 +255,10 @@ def sample(solver, net, latents, t_steps, class_labels=None, afs=False, denoise_
             (r, scale_dir, scale_time) and ``net.last_bottleneck`` holding the U-Net bottleneck.
     Returns x (or (inters[, eps]) when requested) exactly like the reference functions.
     """
-    D = lambda x, t: net(x, t, class_labels=class_labels)
+    if hasattr(net, 'guidance_type'):      # get_denoised dispatch (solvers.py:9-14)
+        D = lambda x, t: net(x, t, condition=condition, unconditional_condition=unconditional_condition)
+    else:
+        D = lambda x, t: net(x, t, class_labels=class_labels)
     afs_d = lambda x, t: x / ((1 + t ** 2).sqrt())
     n = len(t_steps)
     x = latents * t_steps[0]
