@@ -368,6 +368,7 @@ class EDMDenoiser:
     ``net(x, sigma, class_labels=None)`` -> denoised NCHW fp32, like the reference.  The fused solvers bypass
     the final ``c_skip x + c_out F`` pass and read the raw output through ``raw()`` instead.
     """
+    edm_raw_output = True      # solvers._Run: ds_solver_update applies the EDM preconditioning to the raw output itself
 
     def __init__(self, spec: arch.UNetSpec, params: Dict[str, torch.Tensor], device='cuda'):
         self.spec = spec

@@ -1,0 +1,348 @@
+"""Latent-diffusion denoiser on the HIP engine: drop-in for the reference ``CFGPrecond`` around the ldm ``UNetModel``
+(diff-solvers-main/models/networks_edm.py:630-762; ldm/modules/diffusionmodules/openaimodel.py:413-742;
+ldm/modules/attention.py:152-260) -- BASELINE config 5 (Stable Diffusion v1.5 latent U-Net, classifier-free guidance).
+
+One evaluation = one flat plan of libdsamd launches over NHWC fp32 workspaces:
+
+    ResBlock            GN stats -> 3x3 conv with GroupNorm+SiLU fused in its loader (+bias +time-embedding row)
+                        -> GN stats -> 3x3 conv (fused norm) with the 1x1 skip_connection appended along K (+residual)
+    SpatialTransformer  GN -> 1x1 proj_in -> [LN -> packed q|k|v linear -> fused attention -> to_out (+res)]
+                        -> [LN -> q linear, context k|v linear -> fused cross-attention -> to_out (+res)]
+                        -> [LN -> GEGLU linear -> gate -> linear (+res)] -> 1x1 proj_out (+res)
+    Downsample          3x3 stride-2 conv;   Upsample: nearest x2 -> 3x3 conv
+    CFG                 the conditional and unconditional halves run as ONE 2B-image evaluation (networks_edm.py:679-683);
+                        ``ds_cfg_denoise`` forms F_u + g (F_c - F_u) and D = x - sigma F in one pass.
+
+NHWC makes ``rearrange('b c h w -> b (h w) c')`` free: the transformer consumes the convolution outputs in place, and the
+decoder's ``torch.cat([h, hs.pop()])`` is never materialised (dual-source convolutions).  Everything is fp32 (the
+reference runs this U-Net under autocast; fp32 is the stricter contract -- DESIGN.md section 2).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib, ldm_arch, ops
+from ._lib import DS_ACT_NONE, DS_ACT_SILU, DS_RESAMPLE_UP
+from .ops import pack_conv_weight, pack_linear_weight, pack_stem_weight
+from .plan import Builder, Plan, ptr
+
+
+class LDMUNetEngine:
+    def __init__(self, spec: ldm_arch.LDMUNetSpec, params: Dict[str, torch.Tensor], device='cuda'):
+        self.spec = spec
+        self.device = torch.device(device)
+        self.lib = _lib.load()
+        self._plans: Dict[tuple, Plan] = {}
+        self._pack(params)
+
+    # ------------------------------------------------------------------------------------------ weights
+    def _pack(self, params):
+        spec, dev = self.spec, self.device
+        g = lambda k: params[k].detach().to(device=dev, dtype=torch.float32).contiguous()
+        w: Dict[str, torch.Tensor] = {}
+        half = spec.model_channels // 2
+        w['freqs'] = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(dev)   # util.py:162-164
+        w['te0.w'], w['te0.b'] = pack_linear_weight(g('time_embed.0.weight')), g('time_embed.0.bias')
+        w['te2.w'], w['te2.b'] = pack_linear_weight(g('time_embed.2.weight')), g('time_embed.2.bias')
+        aff_w, aff_b, off = [], [], 0
+        self.aff_off: Dict[str, int] = {}
+        for l in spec.res_layers():                  # every ResBlock's emb_layers Linear, concatenated into one GEMM
+            aff_w.append(g(f'{l.key}.emb_layers.1.weight')); aff_b.append(g(f'{l.key}.emb_layers.1.bias'))
+            self.aff_off[l.key] = off
+            off += l.cout
+        self.aff_total = off
+        w['aff.w'], w['aff.b'] = pack_linear_weight(torch.cat(aff_w, 0)), torch.cat(aff_b, 0).contiguous()
+        for b in spec.blocks:
+            for l in b.layers:
+                p = l.key
+                if l.kind == 'stem':
+                    w[f'{p}.w'], w[f'{p}.b'] = pack_stem_weight(g(f'{p}.weight')), g(f'{p}.bias')
+                elif l.kind == 'res':
+                    for n_, src in (('n0', 'in_layers.0'), ('n1', 'out_layers.0')):
+                        w[f'{p}.{n_}.g'], w[f'{p}.{n_}.b'] = g(f'{p}.{src}.weight'), g(f'{p}.{src}.bias')
+                    w[f'{p}.c0.w'], w[f'{p}.c0.b'] = pack_conv_weight(g(f'{p}.in_layers.2.weight')), g(f'{p}.in_layers.2.bias')
+                    c1 = pack_conv_weight(g(f'{p}.out_layers.3.weight'))
+                    b1 = g(f'{p}.out_layers.3.bias')
+                    if l.skip_conv:      # 1x1 skip_connection fused into the second conv: extra K columns, biases summed
+                        c1 = torch.cat([c1, pack_conv_weight(g(f'{p}.skip_connection.weight'))], dim=1).contiguous()
+                        b1 = (b1 + g(f'{p}.skip_connection.bias')).contiguous()
+                    w[f'{p}.c1.w'], w[f'{p}.c1.b'] = c1, b1
+                elif l.kind == 'st':
+                    t = f'{p}.transformer_blocks.0'
+                    w[f'{p}.n.g'], w[f'{p}.n.b'] = g(f'{p}.norm.weight'), g(f'{p}.norm.bias')
+                    w[f'{p}.pi.w'], w[f'{p}.pi.b'] = pack_conv_weight(g(f'{p}.proj_in.weight')), g(f'{p}.proj_in.bias')
+                    w[f'{p}.po.w'], w[f'{p}.po.b'] = pack_conv_weight(g(f'{p}.proj_out.weight')), g(f'{p}.proj_out.bias')
+                    w[f'{p}.qkv1.w'] = pack_linear_weight(torch.cat([g(f'{t}.attn1.to_{x}.weight') for x in 'qkv'], 0))
+                    w[f'{p}.q2.w'] = pack_linear_weight(g(f'{t}.attn2.to_q.weight'))
+                    w[f'{p}.kv2.w'] = pack_linear_weight(torch.cat([g(f'{t}.attn2.to_{x}.weight') for x in 'kv'], 0))
+                    for a in ('attn1', 'attn2'):
+                        w[f'{p}.{a}.o.w'], w[f'{p}.{a}.o.b'] = pack_linear_weight(g(f'{t}.{a}.to_out.0.weight')), g(f'{t}.{a}.to_out.0.bias')
+                    w[f'{p}.ff0.w'], w[f'{p}.ff0.b'] = pack_linear_weight(g(f'{t}.ff.net.0.proj.weight')), g(f'{t}.ff.net.0.proj.bias')
+                    w[f'{p}.ff2.w'], w[f'{p}.ff2.b'] = pack_linear_weight(g(f'{t}.ff.net.2.weight')), g(f'{t}.ff.net.2.bias')
+                    for n_ in ('norm1', 'norm2', 'norm3'):
+                        w[f'{p}.{n_}.g'], w[f'{p}.{n_}.b'] = g(f'{t}.{n_}.weight'), g(f'{t}.{n_}.bias')
+                elif l.kind == 'down':
+                    w[f'{p}.w'], w[f'{p}.b'] = pack_conv_weight(g(f'{p}.op.weight')), g(f'{p}.op.bias')
+                elif l.kind == 'up':
+                    w[f'{p}.w'], w[f'{p}.b'] = pack_conv_weight(g(f'{p}.conv.weight')), g(f'{p}.conv.bias')
+        w['out.g'], w['out.b'] = g('out.0.weight'), g('out.0.bias')
+        w['outc.w'], w['outc.b'] = pack_conv_weight(g('out.2.weight')), g('out.2.bias')
+        self.w = w
+
+    # ------------------------------------------------------------------------------------------ plan
+    def plan(self, N: int, emb_rows: int, ctx_len: int) -> Plan:
+        """N = images in the U-Net batch (2B under classifier-free guidance); emb_rows = 1 (shared sigma) or N."""
+        key = (N, emb_rows, ctx_len)
+        if key in self._plans:
+            return self._plans[key]
+        spec, w, lib = self.spec, self.w, self.lib
+        bd = Builder(self.device)
+        P, new = bd.P, bd.new
+        bufs = P.bufs
+        R, Cin, MC, E = spec.img_resolution, spec.in_channels, spec.model_channels, spec.time_embed_dim
+        if not lib.ds_attention_supported(MC // spec.num_heads):
+            raise NotImplementedError(f'attention head size {MC // spec.num_heads} has no kernel instantiation')
+        kpad = -(-9 * Cin // 32) * 32
+        bufs['x'] = new(N, Cin, R, R)
+        bufs['sigma'] = new(emb_rows)
+        bufs['c_noise'] = new(emb_rows)
+        bufs['context'] = new(N * ctx_len, spec.context_dim)
+        bufs['out'] = new(N * R * R, 4)
+        cmax = max(max(l.cin, l.cout) for b in spec.blocks for l in b.layers)
+        ncoef = new(N * 3 * cmax)
+
+        # ---- time embedding (openaimodel.py:726-727) and every ResBlock's emb_layers in one GEMM ---------------------------
+        pos, e0, emb, aff = new(emb_rows, MC), new(emb_rows, E), new(emb_rows, E), new(emb_rows, self.aff_total)
+        bd.add(lib.ds_noise_embed, (ptr(bufs['c_noise']), emb_rows, ptr(w['freqs']), MC, 2, ptr(pos), MC), 'timestep_embedding')
+        bd.linear(pos, MC, emb_rows, w['te0.w'], E, e0, 'time_embed.0', bias=w['te0.b'], act=DS_ACT_SILU)
+        bd.linear(e0, E, emb_rows, w['te2.w'], E, emb, 'time_embed.2', bias=w['te2.b'], act=DS_ACT_SILU)   # SiLU of emb_layers[0]
+        bd.linear(emb, E, emb_rows, w['aff.w'], self.aff_total, aff, 'emb_layers_all', bias=w['aff.b'])
+
+        def gn_conv(x0, c0, x1, c1, side, gk, bk, eps, wgt, bias, cout, out, out_ld, name, **kw):
+            """GroupNorm(32) + SiLU + 3x3 conv over the concatenation [x0 | x1]; the normalisation rides in the conv's loader
+            when the LDS-halo kernel takes the shape, otherwise it is a separate pass."""
+            cin = c0 + c1
+            if lib.ds_conv3x3_halo_supported(side, side):
+                bd.norm('stats', x0, c0, c0, N, side, side, name + '.gn.stats', x1=x1, c1=c1, ld1=c1, groups=32, eps=eps, gamma=gk,
+                        beta=bk, coefs=ncoef)
+                bd.conv(x0, c0, c0, N, side, side, wgt, cout, out, out_ld, 9, name, x1=x1, c1=c1, ld1=c1, bias=bias, norm_coefs=ncoef,
+                        norm_act=DS_ACT_SILU, **kw)
+            else:
+                tmp = new(N * side * side, cin)
+                bd.norm('stats', x0, c0, c0, N, side, side, name + '.gn.stats', x1=x1, c1=c1, ld1=c1, groups=32, eps=eps)
+                bd.norm('apply', x0, c0, c0, N, side, side, name + '.gn', x1=x1, c1=c1, ld1=c1, groups=32, eps=eps, gamma=gk, beta=bk,
+                        act=DS_ACT_SILU, out=tmp, out_ld=cin)
+                bd.conv(tmp, cin, cin, N, side, side, wgt, cout, out, out_ld, 9, name, bias=bias, **kw)
+
+        def res_layer(l, x0, c0, x1, c1):
+            p, res, cout = l.key, l.res_out, l.cout
+            M = N * res * res
+            h1, out = new(M, cout), new(M, cout)
+            ao = self.aff_off[p]
+            gn_conv(x0, c0, x1, c1, res, w[f'{p}.n0.g'], w[f'{p}.n0.b'], 1e-5, w[f'{p}.c0.w'], w[f'{p}.c0.b'], cout, h1, cout,
+                    p + '.in_layers', cbias=aff[:, ao:], cbias_ld=self.aff_total, cbias_rows=emb_rows)
+            if l.skip_conv:
+                skip = dict(e0=x0, ec0=c0, e1=x1, ec1=c1)
+            else:
+                assert x1 is None and c0 == cout
+                skip = dict(res=x0, res_ld=cout)
+            gn_conv(h1, cout, None, 0, res, w[f'{p}.n1.g'], w[f'{p}.n1.b'], 1e-5, w[f'{p}.c1.w'], w[f'{p}.c1.b'], cout, out, cout,
+                    p + '.out_layers', **skip)
+            return out, cout
+
+        def st_layer(l, x_in, c):
+            p, res, hd = l.key, l.res_out, l.heads
+            S = res * res
+            M = N * S
+            d = c // hd
+            L = ctx_len
+            n2, t0, ln, ao = new(M, c), new(M, c), new(M, c), new(M, c)
+            bd.norm('stats', x_in, c, c, N, res, res, p + '.norm.stats', groups=32, eps=1e-6)
+            bd.norm('apply', x_in, c, c, N, res, res, p + '.norm', groups=32, eps=1e-6, gamma=w[f'{p}.n.g'], beta=w[f'{p}.n.b'],
+                    out=n2, out_ld=c)
+            bd.conv(n2, c, c, N, res, res, w[f'{p}.pi.w'], c, t0, c, 1, p + '.proj_in', bias=w[f'{p}.pi.b'])
+            # self-attention
+            qkv, t1 = new(M, 3 * c), new(M, c)
+            bd.layernorm(t0, c, w[f'{p}.norm1.g'], w[f'{p}.norm1.b'], 1e-5, ln, c, M, c, p + '.norm1')
+            bd.linear(ln, c, M, w[f'{p}.qkv1.w'], 3 * c, qkv, p + '.attn1.qkv')
+            bd.attention(qkv, qkv[:, c:], qkv[:, 2 * c:], ao, p + '.attn1', batch=N, heads=hd, sq=S, skv=S, d=d, ldq=3 * c, ldk=3 * c,
+                         ldv=3 * c, ldo=c, q_bs=S * 3 * c, k_bs=S * 3 * c, v_bs=S * 3 * c, o_bs=S * c, scale=d ** -0.5)
+            bd.linear(ao, c, M, w[f'{p}.attn1.o.w'], c, t1, p + '.attn1.to_out', bias=w[f'{p}.attn1.o.b'], res=t0, res_ld=c)
+            # cross-attention over the context tokens
+            q2, kv2, t2 = new(M, c), new(N * L, 2 * c), new(M, c)
+            bd.layernorm(t1, c, w[f'{p}.norm2.g'], w[f'{p}.norm2.b'], 1e-5, ln, c, M, c, p + '.norm2')
+            bd.linear(ln, c, M, w[f'{p}.q2.w'], c, q2, p + '.attn2.q')
+            bd.linear(bufs['context'], spec.context_dim, N * L, w[f'{p}.kv2.w'], 2 * c, kv2, p + '.attn2.kv')
+            bd.attention(q2, kv2, kv2[:, c:], ao, p + '.attn2', batch=N, heads=hd, sq=S, skv=L, d=d, ldq=c, ldk=2 * c, ldv=2 * c, ldo=c,
+                         q_bs=S * c, k_bs=L * 2 * c, v_bs=L * 2 * c, o_bs=S * c, scale=d ** -0.5)
+            bd.linear(ao, c, M, w[f'{p}.attn2.o.w'], c, t2, p + '.attn2.to_out', bias=w[f'{p}.attn2.o.b'], res=t1, res_ld=c)
+            # GEGLU feed-forward
+            ff, gg, t3 = new(M, 8 * c), new(M, 4 * c), new(M, c)
+            bd.layernorm(t2, c, w[f'{p}.norm3.g'], w[f'{p}.norm3.b'], 1e-5, ln, c, M, c, p + '.norm3')
+            bd.linear(ln, c, M, w[f'{p}.ff0.w'], 8 * c, ff, p + '.ff.proj', bias=w[f'{p}.ff0.b'])
+            bd.geglu(ff, 8 * c, gg, 4 * c, M, 4 * c, p + '.ff.geglu')
+            bd.linear(gg, 4 * c, M, w[f'{p}.ff2.w'], c, t3, p + '.ff.out', bias=w[f'{p}.ff2.b'], res=t2, res_ld=c)
+            out = new(M, c)
+            bd.conv(t3, c, c, N, res, res, w[f'{p}.po.w'], c, out, c, 1, p + '.proj_out', bias=w[f'{p}.po.b'], res=x_in, res_ld=c)
+            return out, c
+
+        cur = None
+        skips = []
+        for b in spec.blocks:
+            x1, c1 = (None, 0)
+            if b.pops_skip:
+                x1, c1 = skips.pop()
+                assert c1 == b.skip_cin
+            for l in b.layers:
+                p = l.key
+                if l.kind == 'stem':
+                    col = new(N * R * R, kpad)
+                    bd.add(lib.ds_stem_im2col, (ptr(bufs['x']), ptr(bufs['sigma']), emb_rows, 1.0, N, Cin, R, R, ptr(col), kpad),
+                           'stem_im2col')      # c_in = 1/sqrt(sigma^2 + 1): EDM's c_in with sigma_data = 1
+                    out = new(N * R * R, l.cout)
+                    bd.conv(col, kpad, kpad, N, R, R, w[f'{p}.w'], l.cout, out, l.cout, 1, p, bias=w[f'{p}.b'])
+                    cur = (out, l.cout)
+                elif l.kind == 'res':
+                    cur = res_layer(l, cur[0], cur[1], x1, c1)
+                    x1, c1 = None, 0
+                elif l.kind == 'st':
+                    cur = st_layer(l, cur[0], cur[1])
+                elif l.kind == 'down':
+                    out = new(N * l.res_out ** 2, l.cout)
+                    bd.conv(cur[0], l.cin, l.cin, N, l.res_out, l.res_out, w[f'{p}.w'], l.cout, out, l.cout, 9, p + '.op',
+                            bias=w[f'{p}.b'], stride=2)
+                    cur = (out, l.cout)
+                elif l.kind == 'up':
+                    up = new(N * l.res_out ** 2, l.cin)
+                    bd.norm('apply', cur[0], l.cin, l.cin, N, l.res_in, l.res_in, p + '.nearest', use_stats=False,
+                            resample=DS_RESAMPLE_UP, out=up, out_ld=l.cin)
+                    out = new(N * l.res_out ** 2, l.cout)
+                    bd.conv(up, l.cin, l.cin, N, l.res_out, l.res_out, w[f'{p}.w'], l.cout, out, l.cout, 9, p + '.conv', bias=w[f'{p}.b'])
+                    cur = (out, l.cout)
+                bufs[p] = cur[0]
+            if b.pushes_skip:
+                skips.append(cur)
+        assert not skips
+        gn_conv(cur[0], cur[1], None, 0, R, w['out.g'], w['out.b'], 1e-5, w['outc.w'], w['outc.b'], spec.out_channels, bufs['out'], 4,
+                'out')
+        self._plans[key] = P
+        return P
+
+    def flops(self, n_images, ctx_len=77):
+        return ldm_arch.ldm_flops_per_image(self.spec, ctx_len) * n_images
+
+
+def _interp(x, xp, yp):
+    """Piecewise-linear through (xp ascending, yp), linearly extended beyond both ends (CFGPrecond.interpolate_fn,
+    networks_edm.py:716-759)."""
+    K = xp.shape[0]
+    i = torch.searchsorted(xp, x.contiguous()).clamp(1, K - 1) - 1
+    return yp[i] + (x - xp[i]) * (yp[i + 1] - yp[i]) / (xp[i + 1] - xp[i])
+
+
+class CFGDenoiser:
+    """Drop-in for the reference ``CFGPrecond`` object (networks_edm.py:630-762): ``net(x, sigma, condition=...,
+    unconditional_condition=...)`` -> denoised latents NCHW fp32, plus the attributes and methods the samplers and
+    ``get_schedule('discrete')`` read (``guidance_type, guidance_rate, img_resolution, img_channels, label_dim, sigma_min,
+    sigma_max, sigma(), sigma_inv(), round_sigma()``)."""
+
+    def __init__(self, spec: ldm_arch.LDMUNetSpec, params: Dict[str, torch.Tensor], device='cuda', guidance_rate=None,
+                 guidance_type=None):
+        self.spec = spec
+        self.engine = LDMUNetEngine(spec, params, device)
+        self.device = self.engine.device
+        self.guidance_rate = spec.guidance_rate if guidance_rate is None else guidance_rate
+        self.guidance_type = spec.guidance_type if guidance_type is None else guidance_type
+        self.img_resolution, self.img_channels, self.label_dim = spec.img_resolution, spec.in_channels, True
+        log_alphas = 0.5 * torch.log(ldm_arch.alphas_cumprod(spec))         # host tables (networks_edm.py:654-658)
+        self.M = len(log_alphas)
+        self.t_array = torch.linspace(0., 1., self.M + 1)[1:]
+        self.log_alpha_array = log_alphas
+        self.sigma_min = float(self.sigma(spec.epsilon_t))
+        self.sigma_max = float(self.sigma(1))
+        self.use_fp16 = False
+
+    @classmethod
+    def from_config(cls, name_or_kwargs, seed=0, device='cuda', **kw):
+        cfg = ldm_arch.NAMED_LDM_CONFIGS[name_or_kwargs] if isinstance(name_or_kwargs, str) else name_or_kwargs
+        spec = ldm_arch.ldm_unet_spec(**cfg)
+        return cls(spec, ldm_arch.init_ldm_params(spec, seed=seed), device, **kw)
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    # -- noise schedule maps, evaluated on the host in fp32 like the reference's formulas (networks_edm.py:692-714) ---------
+    def sigma(self, t):
+        dev = t.device if isinstance(t, torch.Tensor) else None
+        t = torch.as_tensor(t, dtype=torch.float32).detach().cpu().reshape(-1)
+        lmc = _interp(t, self.t_array, self.log_alpha_array)
+        out = torch.sqrt(1. - torch.exp(2. * lmc)) / torch.exp(lmc)
+        return out.to(dev) if dev is not None else out
+
+    def sigma_inv(self, sigma):
+        dev = sigma.device if isinstance(sigma, torch.Tensor) else None
+        sigma = torch.as_tensor(sigma, dtype=torch.float32).detach().cpu().reshape(-1)
+        log_alpha = -0.5 * torch.logaddexp(torch.zeros((1,)), -2. * (-(sigma.log())))
+        out = _interp(log_alpha, torch.flip(self.log_alpha_array, [0]), torch.flip(self.t_array, [0]))
+        return out.to(dev) if dev is not None else out
+
+    def round_sigma(self, sigma):
+        return torch.as_tensor(sigma)
+
+    # -- evaluation ----------------------------------------------------------------------------------------------------------
+    def raw(self, x, sigma, condition=None, unconditional_condition=None):
+        """Runs the plan; returns (F rows NHWC [N*H*W, 4], plan, doubled)."""
+        lib = self.engine.lib
+        st = _lib.stream_ptr()
+        B = x.shape[0]
+        doubled = (self.guidance_type == 'classifier-free' and self.guidance_rate != 1. and unconditional_condition is not None)
+        if self.guidance_type != 'uncond' and condition is None:
+            raise ValueError('CFGDenoiser needs `condition` (text-encoder states [B, L, context_dim])')
+        N = 2 * B if doubled else B
+        host_scalar = isinstance(sigma, (int, float)) or (isinstance(sigma, torch.Tensor) and sigma.numel() == 1)
+        emb_rows = 1 if host_scalar else N
+        cond = condition if condition is not None else torch.zeros(B, 1, self.spec.context_dim, device=self.device)
+        L = cond.shape[1]
+        plan = self.engine.plan(N, emb_rows, L)
+        bufs = plan.bufs
+        x = x.to(torch.float32).contiguous()
+        per = x[0].numel()
+        for half in range(2 if doubled else 1):
+            _lib.check(lib.ds_copy_rows(ptr(x), per, ptr(bufs['x'][half * B:]), per, B, per, st), 'copy x')
+        if host_scalar:
+            s = float(sigma)
+            cn = float(self.M * self.sigma_inv(torch.tensor(s, dtype=torch.float32)) - 1.)
+            _lib.check(lib.ds_fill(ptr(bufs['sigma']), s, 1, st), 'fill sigma')
+            _lib.check(lib.ds_fill(ptr(bufs['c_noise']), cn, 1, st), 'fill c_noise')
+        else:
+            sg = torch.as_tensor(sigma, dtype=torch.float32, device=self.device).reshape(-1)
+            cn = (self.M * self.sigma_inv(sg) - 1.).to(torch.float32)
+            if doubled:
+                sg, cn = torch.cat([sg, sg]), torch.cat([cn, cn])
+            bufs['sigma'].copy_(sg)
+            bufs['c_noise'].copy_(cn)
+        cd = self.spec.context_dim
+        parts = [unconditional_condition, cond] if doubled else [cond]
+        for i, c_ in enumerate(parts):
+            c_ = c_.to(device=self.device, dtype=torch.float32)
+            if c_.shape[0] == 1 and B > 1:
+                c_ = c_.expand(B, -1, -1)
+            c_ = c_.contiguous()
+            assert c_.shape == (B, L, cd), (c_.shape, (B, L, cd))
+            _lib.check(lib.ds_copy_rows(ptr(c_), cd, ptr(bufs['context'][i * B * L:]), cd, B * L, cd, st), 'copy context')
+        plan.run(st)
+        return bufs['out'], plan, doubled
+
+    def __call__(self, x, sigma, condition=None, unconditional_condition=None, force_fp32=False, **kwargs):
+        B, Cc, H, W = x.shape
+        f, plan, doubled = self.raw(x, sigma, condition, unconditional_condition)
+        out = torch.empty(B, Cc, H, W, dtype=torch.float32, device=self.device)
+        rows = plan.bufs['sigma'].numel()
+        ops.cfg_denoise(plan.bufs['x'], f, 4, plan.bufs['sigma'], 1 if rows == 1 else B, self.guidance_rate, doubled, B, Cc, H, W, out)
+        return out

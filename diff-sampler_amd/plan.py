@@ -1,0 +1,96 @@
+"""Launch plans: a flat list of (C entry point, prebuilt argument struct) over engine-owned workspaces.
+
+A plan is compiled once per (network, batch size); running it is a tight ctypes loop, and because no pointer changes
+between runs it can be captured into a hipGraph (``graph.py``).  ``Builder`` is the small DSL the engines use to emit
+launches; it only marshals arguments -- every operation is a libdsamd kernel.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List
+
+import torch
+
+from . import _lib
+from ._lib import AttnArgs, ConvArgs, GemmArgs, NormArgs, DS_ACT_NONE, DS_RESAMPLE_NONE
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Op:
+    """One launch: C entry point + argument tuple (struct by reference or scalars)."""
+    __slots__ = ('fn', 'args', 'name', 'keep')
+
+    def __init__(self, fn, args, name, keep=()):
+        self.fn, self.args, self.name, self.keep = fn, args, name, keep
+
+
+class Plan:
+    def __init__(self):
+        self.ops: List[Op] = []
+        self.bufs: Dict[str, torch.Tensor] = {}
+        self.keep: List[torch.Tensor] = []      # every workspace tensor the launch arguments point into
+
+    def run(self, stream):
+        for op in self.ops:
+            rc = op.fn(*op.args, stream)
+            if rc:
+                _lib.check(rc, op.name)
+
+
+class Builder:
+    def __init__(self, device):
+        self.P = Plan()
+        self.dev = device
+        self.lib = _lib.load()
+        self.mean = self.rstd = None
+
+    def new(self, *shape, zero=False):
+        # The argument structs hold raw pointers: the plan must own every tensor they point into, otherwise the
+        # caching allocator would hand the memory to the next torch.empty() while the plan still uses it.
+        t = (torch.zeros if zero else torch.empty)(*shape, dtype=torch.float32, device=self.dev)
+        self.P.keep.append(t)
+        return t
+
+    def add(self, fn, args, name, keep=()):
+        self.P.ops.append(Op(fn, args, name, keep))
+
+    def conv(self, x0, c0, ld0, n, h, w, wgt, cout, out, out_ld, taps, name, x1=None, c1=0, ld1=0, bias=None, cbias=None,
+             cbias_ld=0, cbias_rows=1, res=None, res_ld=0, scale=1.0, act=DS_ACT_NONE, norm_coefs=None, norm_act=DS_ACT_NONE,
+             e0=None, ec0=0, e1=None, ec1=0, stride=1):
+        a = ConvArgs(ptr(x0), ptr(x1), c0, c1, ld0, ld1, n, h, w, taps, ptr(wgt), cout, ptr(bias), ptr(cbias), cbias_ld,
+                     cbias_rows, ptr(res), res_ld, scale, act, ptr(out), out_ld, ptr(norm_coefs), norm_act, ptr(e0), ptr(e1),
+                     ec0, ec1, ec0, ec1, stride)
+        self.add(self.lib.ds_conv2d_nhwc, (C.byref(a),), name, keep=(a,))
+
+    def linear(self, x, k, rows, wgt, cout, out, name, ldx=None, out_ld=None, **kw):
+        """out[rows, cout] = x[rows, k] W^T (+bias +res ...): a 1x1 'convolution' over rows."""
+        self.conv(x, k, ldx or k, rows, 1, 1, wgt, cout, out, out_ld or cout, 1, name, **kw)
+
+    def norm(self, kind, x0, c0, ld0, n, h, w, name, x1=None, c1=0, ld1=0, groups=1, eps=1e-5, use_stats=True, gamma=None,
+             beta=None, scale=None, shift=None, ss_ld=0, ss_rows=1, act=DS_ACT_NONE, resample=DS_RESAMPLE_NONE, out=None,
+             out_ld=0, coefs=None):
+        if use_stats and (self.mean is None or self.mean.numel() < n * 64):
+            self.mean, self.rstd = self.new(n * 64), self.new(n * 64)
+        a = NormArgs(ptr(x0), ptr(x1), c0, c1, ld0, ld1, n, h, w, groups, eps, ptr(self.mean) if use_stats else None,
+                     ptr(self.rstd) if use_stats else None, ptr(gamma), ptr(beta), ptr(scale), ptr(shift), ss_ld, ss_rows, act,
+                     resample, ptr(out), out_ld, ptr(coefs))
+        self.add(self.lib.ds_gn_stats if kind == 'stats' else self.lib.ds_norm_act, (C.byref(a),), name, keep=(a,))
+
+    def gemm(self, a_, lda, b_, ldb, c_, ldc, m, n, k, name, batch=1, heads=1, a_bs=0, a_hs=0, b_bs=0, b_hs=0, c_bs=0, c_hs=0,
+             alpha=1.0, rowbias=None, colbias=None):
+        g = GemmArgs(ptr(a_), lda, a_bs, a_hs, ptr(b_), ldb, b_bs, b_hs, ptr(c_), ldc, c_bs, c_hs, m, n, k, batch, heads, alpha,
+                     ptr(rowbias), ptr(colbias), DS_ACT_NONE)
+        self.add(self.lib.ds_gemm_nt_batched, (C.byref(g),), name, keep=(g,))
+
+    def attention(self, q, k, v, out, name, *, batch, heads, sq, skv, d, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, scale):
+        a = AttnArgs(ptr(q), ptr(k), ptr(v), ptr(out), ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, batch, heads, sq, skv, d, scale)
+        self.add(self.lib.ds_attention, (C.byref(a),), name, keep=(a,))
+
+    def layernorm(self, x, ldx, gamma, beta, eps, y, ldy, rows, cols, name):
+        self.add(self.lib.ds_layernorm_rows, (ptr(x), ldx, ptr(gamma), ptr(beta), eps, ptr(y), ldy, rows, cols), name)
+
+    def geglu(self, x, ldx, y, ldy, rows, inner, name):
+        self.add(self.lib.ds_geglu, (ptr(x), ldx, ptr(y), ldy, rows, inner), name)

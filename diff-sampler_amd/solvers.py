@@ -43,7 +43,7 @@ class _Run:
             raise RuntimeError('diff-sampler_amd runs on the MI355X only: latents must be a CUDA/HIP tensor '
                                '(there is no CPU fallback; use the reference for CPU runs)')
         self.net = net
-        self.fused = hasattr(net, 'raw') and hasattr(net, 'engine')
+        self.fused = bool(getattr(net, 'edm_raw_output', False))   # engine.EDMDenoiser: raw F consumed by the update kernel
         self.latents = latents.to(torch.float32).contiguous()
         self.B, self.C, self.H, self.W = self.latents.shape
         self.cl, self.cond, self.ucond = class_labels, condition, unconditional_condition
