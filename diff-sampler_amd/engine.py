@@ -5,7 +5,7 @@ What it replaces: ``EDMPrecond.forward`` -> ``SongUNet/DhariwalUNet.forward`` ->
 network evaluation of the reference, by ~10 hand-written launches per block:
 
     GN stats -> normalise+SiLU(+resample) -> 3x3 implicit GEMM (+bias +emb) -> GN stats -> normalise+SiLU
-      -> 3x3 implicit GEMM (+bias +skip +scale)   [+ 1x1 skip projection, + attention: 1x1 qk, V^T, QK^T, softmax, PV, proj]
+      -> 3x3 implicit GEMM (+bias +skip +scale)   [+ attention: GN, packed 1x1 q|k|v, fused softmax(QK^T)V kernel, 1x1 proj]
 
 Activations are NHWC fp32 and live in engine-owned workspaces (allocated once per batch size through torch, which
 is only the allocator here); the decoder's ``torch.cat`` is never materialised (both sources are read in place).
@@ -24,7 +24,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _lib, arch
-from ._lib import (ConvArgs, GemmArgs, NormArgs, DS_ACT_NONE, DS_ACT_SILU, DS_RESAMPLE_NONE, DS_RESAMPLE_DOWN,
+from ._lib import (AttnArgs, ConvArgs, GemmArgs, NormArgs, DS_ACT_NONE, DS_ACT_SILU, DS_RESAMPLE_NONE, DS_RESAMPLE_DOWN,
                    DS_RESAMPLE_UP)
 from .ops import pack_conv_weight, pack_linear_weight, pack_stem_weight
 
@@ -117,10 +117,9 @@ class UNetEngine:
                 # reference layout of the 3C output channels: index = (head*ch + c)*3 + {q,k,v}  (networks_edm.py:174)
                 wq = g(f'{p}.qkv.weight').reshape(h, ch, 3, c)
                 bq = g(f'{p}.qkv.bias').reshape(h, ch, 3)
-                w[f'{b.name}.qk.w'] = pack_linear_weight(torch.cat([wq[:, :, 0].reshape(c, c), wq[:, :, 1].reshape(c, c)], 0))
-                w[f'{b.name}.qk.b'] = torch.cat([bq[:, :, 0].reshape(c), bq[:, :, 1].reshape(c)], 0).contiguous()
-                w[f'{b.name}.v.w'] = wq[:, :, 2].reshape(c, c).contiguous()
-                w[f'{b.name}.v.b'] = bq[:, :, 2].reshape(c).contiguous()
+                # q | k | v column blocks, each head-major (head*ch + c): the fused attention kernel reads them in place
+                w[f'{b.name}.qkv.w'] = pack_linear_weight(torch.cat([wq[:, :, i].reshape(c, c) for i in range(3)], 0))
+                w[f'{b.name}.qkv.b'] = torch.cat([bq[:, :, i].reshape(c) for i in range(3)], 0).contiguous()
                 w[f'{b.name}.proj.w'] = pack_conv_weight(g(f'{p}.proj.weight')); w[f'{b.name}.proj.b'] = g(f'{p}.proj.bias')
         w['out.g'] = g(f'{m}.{spec.out_norm}.weight'); w['out.b'] = g(f'{m}.{spec.out_norm}.bias')
         w['outc.w'] = pack_conv_weight(g(f'{m}.{spec.out_conv}.weight')); w['outc.b'] = g(f'{m}.{spec.out_conv}.bias')
@@ -177,8 +176,7 @@ class UNetEngine:
         mean = new(B * 64); rstd = new(B * 64)
         ncoef = new(B * 3 * max(max(b.cin, b.cout) for b in spec.blocks))      # {mu, A, B} planes of the fused GroupNorm
         if max_attn:
-            n2 = new(B * max_attn // 2); qk = new(B * max_attn); vt = new(B * max_attn // 2)
-            ao = new(B * max_attn // 2); sc = new(B * max_sc)
+            n2 = new(B * max_attn // 2); qk = new(B * max_attn // 2 * 3); ao = new(B * max_attn // 2)
         bufs.update(act=act, hbuf=hbuf, sres=sres, sproj=sproj)
 
         def add(fn, args, name, keep=()):
@@ -315,18 +313,11 @@ class UNetEngine:
                 norm('stats', out, cout, cout, n, Ho, Ho, nm + '.norm2.stats', groups=G_out, eps=b.eps)
                 norm('apply', out, cout, cout, n, Ho, Ho, nm + '.norm2', groups=G_out, eps=b.eps, gamma=w[f'{nm}.norm2.g'],
                      beta=w[f'{nm}.norm2.b'], out=n2, out_ld=cout)
-                conv(n2, cout, cout, n, Ho, Ho, w[f'{nm}.qk.w'], 2 * cout, qk, 2 * cout, 1, nm + '.qk', bias=w[f'{nm}.qk.b'])
-                # V^T[b] = Wv . n2[b]^T + bv  -> [B][C][S]
-                gemm(w[f'{nm}.v.w'], cout, n2, cout, vt, S, cout, S, cout, nm + '.vT', batch=B, b_bs=S * cout, c_bs=cout * S,
-                     rowbias=w[f'{nm}.v.b'])
-                # scores[b,h] = Q K^T / sqrt(ch)
-                gemm(qk, 2 * cout, qk[cout:], 2 * cout, sc, S, S, S, ch, nm + '.qkT', batch=B, heads=hd,
-                     a_bs=S * 2 * cout, a_hs=ch, b_bs=S * 2 * cout, b_hs=ch, c_bs=hd * S * S, c_hs=S * S,
-                     alpha=1.0 / math.sqrt(ch))
-                add(lib.ds_softmax_rows, (_ptr(sc), _ptr(sc), B * hd * S, S, S), nm + '.softmax')
-                # O[b, :, h] = P[b,h] V[b,h]   (B operand = V^T rows of head h)
-                gemm(sc, S, vt, S, ao, cout, S, ch, S, nm + '.pv', batch=B, heads=hd, a_bs=hd * S * S, a_hs=S * S,
-                     b_bs=cout * S, b_hs=ch * S, c_bs=S * cout, c_hs=ch)
+                conv(n2, cout, cout, n, Ho, Ho, w[f'{nm}.qkv.w'], 3 * cout, qk, 3 * cout, 1, nm + '.qkv', bias=w[f'{nm}.qkv.b'])
+                # softmax(Q K^T / sqrt(ch)) V per (image, head), scores kept on chip (networks_edm.py:171-176)
+                at = AttnArgs(_ptr(qk), _ptr(qk[cout:]), _ptr(qk[2 * cout:]), _ptr(ao), 3 * cout, 3 * cout, 3 * cout, cout,
+                              S * 3 * cout, S * 3 * cout, S * 3 * cout, S * cout, B, hd, S, S, ch, 1.0 / math.sqrt(ch))
+                add(lib.ds_attention, (C.byref(at),), nm + '.attention', keep=(at,))
                 if b.pushes_skip:
                     out2 = new(M, cout)
                 else:
@@ -357,7 +348,7 @@ class UNetEngine:
         self._plans[key] = P
         return P
 
-    # attention qk slice helper relies on 2-D views
+
     def flops(self, B):
         return arch.flops_per_image(self.spec) * B
 

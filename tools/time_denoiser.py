@@ -18,6 +18,39 @@ ap.add_argument('--iters', type=int, default=5)
 ap.add_argument('--breakdown', action='store_true')
 args = ap.parse_args()
 
+import diff_sampler_amd.ldm_arch as ldm_arch  # noqa: E402
+if args.config in ldm_arch.NAMED_LDM_CONFIGS:
+    from diff_sampler_amd.ldm_engine import CFGDenoiser  # noqa: E402
+    net = CFGDenoiser.from_config(args.config, seed=0, guidance_rate=7.5)
+    spec = net.spec
+    for B in args.batch:
+        x = torch.randn(B, spec.in_channels, spec.img_resolution, spec.img_resolution, device='cuda')
+        c = torch.randn(B, 77, spec.context_dim, device='cuda'); uc = torch.randn(B, 77, spec.context_dim, device='cuda')
+        net.raw(x, 1.5, c, uc)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(args.iters):
+            out, plan, _ = net.raw(x, 1.5, c, uc)
+        torch.cuda.synchronize()
+        dt = (time.time() - t0) / args.iters
+        fl = net.engine.flops(2 * B)
+        print(f'{args.config} B={B} (CFG: {2*B} U-Net images): {dt*1e3:.2f} ms/eval  {fl/dt/1e12:.1f} TFLOP/s  {B/dt:.1f} img-evals/s  ({len(plan.ops)} launches)', flush=True)
+        if args.breakdown:
+            st = _lib.stream_ptr()
+            tot = {}
+            for op in plan.ops:
+                torch.cuda.synchronize()
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                op.fn(*op.args, st)
+                e1.record(); torch.cuda.synchronize()
+                parts = op.name.split('.')
+                kind = parts[-1] if parts[-1] not in ('stats',) else '.'.join(parts[-2:])
+                if 'attn1' in op.name and kind == 'attn1': kind = 'attn1(self)'
+                tot[kind] = tot.get(kind, 0.0) + e0.elapsed_time(e1)
+            for k, v in sorted(tot.items(), key=lambda kv: -kv[1]):
+                print(f'   {k:20s} {v:8.2f} ms')
+    sys.exit(0)
 net = EDMDenoiser.from_config(args.config, seed=0)
 spec = net.spec
 for B in args.batch:
