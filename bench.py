@@ -59,7 +59,13 @@ def parse():
     return ap.parse_args()
 
 
-def sampler_call(solvers, solver, net, latents, nfe):
+def sampler_call(solvers, solver, net, latents, nfe, ldm=None):
+    if ldm is not None:
+        # BASELINE config 5: DPM-Solver++(2M) noise prediction, discrete rho=1 schedule; every step is one CFG-doubled
+        # evaluation = 2 NFE (sample.py:218), so NFE=10 is num_steps=6
+        return solvers.dpm_pp_sampler(net, latents, condition=ldm[0], unconditional_condition=ldm[1], num_steps=nfe // 2 + 1,
+                                      sigma_min=net.sigma_min, sigma_max=net.sigma_max, schedule_type='discrete', schedule_rho=1,
+                                      max_order=2, predict_x0=False, lower_order_final=True)
     if solver == 'dpmpp':
         return solvers.dpm_pp_sampler(net, latents, num_steps=nfe + 1, sigma_min=0.002, sigma_max=80., schedule_type='logsnr',
                                       schedule_rho=7, max_order=2, predict_x0=True, lower_order_final=True)
@@ -72,7 +78,7 @@ def sampler_call(solvers, solver, net, latents, nfe):
     raise ValueError(solver)
 
 
-def instrumented_pass(net, solvers, solver, latents, nfe):
+def instrumented_pass(net, solvers, solver, latents, nfe, ldm=None):
     """Replay one sampler call with every launch bracketed by HIP events on the launch stream.
     Returns {kernel class: [time_ms, launches, algorithmic flops]}."""
     from diff_sampler_amd import _lib, engine, ops
@@ -96,7 +102,10 @@ def instrumented_pass(net, solvers, solver, latents, nfe):
             return ('conv', kid), fl
         if op.fn is lib.ds_gemm_nt_batched:
             g = op.keep[0]
-            return 'igemm_f32_kernel<1> (attention GEMMs)', 2.0 * g.m * g.n * g.k * g.batch * g.heads
+            return 'igemm_f32_kernel<1> (batched GEMM)', 2.0 * g.m * g.n * g.k * g.batch * g.heads
+        if op.fn is lib.ds_attention:
+            t = op.keep[0]
+            return 'flash_attn_kernel (fused attention)', 4.0 * t.batch * t.heads * t.sq * t.skv * t.d
         if op.fn is lib.ds_gn_stats:
             return 'gn_stats_kernel', 0.0
         if op.fn is lib.ds_norm_act:
@@ -126,16 +135,19 @@ def instrumented_pass(net, solvers, solver, latents, nfe):
             return r
         return w
 
+    cfg = ops.cfg_denoise
     engine._Plan.run = timed_plan_run
     ops.solver_update = timed_call('solver_update_kernel', upd)
     ops.dynamic_threshold = timed_call('dynamic_threshold_kernel', thr)
+    ops.cfg_denoise = timed_call('cfg_denoise_kernel', cfg)
     try:
-        sampler_call(solvers, solver, net, latents, nfe)
+        sampler_call(solvers, solver, net, latents, nfe, ldm)
         torch.cuda.synchronize()
     finally:
         engine._Plan.run = plan_run
         ops.solver_update = upd
         ops.dynamic_threshold = thr
+        ops.cfg_denoise = cfg
     return rec
 
 
@@ -146,6 +158,29 @@ def pmc_traffic(kid):
         return 1024.0 * (2.0 * k['FETCH_SIZE_KiB_avg_per_launch'] + k['WRITE_SIZE_KiB_avg_per_launch'])
     except Exception:
         return None
+
+
+def cpu_baseline_ldm(args, nfe):
+    """Oracle CFG denoiser + DPM-Solver++(2M) on the host cores, bounded sample (1 latent, CFG-doubled)."""
+    from oracle import solvers_ref
+    from oracle.ldm_net import OracleCFG
+    import diff_sampler_amd.ldm_arch as la
+    kw = dict(la.NAMED_LDM_CONFIGS[args.config])
+    spec = la.ldm_unet_spec(**kw)
+    net = OracleCFG(la.init_ldm_params(spec, seed=0), kw, la.alphas_cumprod(spec), guidance_rate=7.5)
+    g = torch.Generator().manual_seed(0)
+    lat = torch.randn(1, kw['in_channels'], kw['img_resolution'], kw['img_resolution'], generator=g)
+    c, uc = torch.randn(1, 77, kw['context_dim'], generator=g), torch.randn(1, 77, kw['context_dim'], generator=g)
+    t_min, t_max = net.sigma_inv(torch.tensor(net.sigma_min)), net.sigma_inv(torch.tensor(net.sigma_max))
+    n = nfe // 2 + 1
+    ts = net.sigma(t_max + torch.arange(n) / (n - 1) * (t_min - t_max))
+    with torch.no_grad():
+        t0 = time.time()
+        solvers_ref.sample('dpm_pp', net, lat, ts, condition=c, unconditional_condition=uc, max_order=2, predict_x0=False,
+                           lower_order_final=True, num_steps=n)
+        dt = time.time() - t0
+    return dict(value=round(1 / dt, 4), unit='images/sec', cores=torch.get_num_threads(), kind='port',
+                sample=f'1 sampler call x batch 1 (2 U-Net images per evaluation), NFE={nfe}, same net/solver ({dt:.1f} s of CPU work)')
 
 
 def cpu_baseline(args, nfe):
@@ -188,18 +223,28 @@ def main():
     from diff_sampler_amd import solvers
     from diff_sampler_amd.engine import EDMDenoiser
 
-    net = EDMDenoiser.from_config(args.config, seed=0, device=dev)
-    spec = net.spec
+    import diff_sampler_amd.ldm_arch as ldm_arch
     B = args.batch
     g = torch.Generator(device='cpu').manual_seed(1234 + rank)
+    ldm = None
+    if args.config in ldm_arch.NAMED_LDM_CONFIGS:
+        from diff_sampler_amd.ldm_engine import CFGDenoiser
+        net = CFGDenoiser.from_config(args.config, seed=0, device=dev, guidance_rate=7.5)
+        spec = net.spec
+        ldm = (torch.randn(B, 77, spec.context_dim, generator=g).to(dev), torch.randn(B, 77, spec.context_dim, generator=g).to(dev))
+        args.solver = 'dpmpp'
+    else:
+        net = EDMDenoiser.from_config(args.config, seed=0, device=dev)
+        spec = net.spec
     latents = torch.randn(B, spec.in_channels, spec.img_resolution, spec.img_resolution, generator=g).to(dev)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, args.nfe)
+        cpu = cpu_baseline_ldm(args, args.nfe) if ldm is not None else cpu_baseline(args, args.nfe)
 
-    run_step = lambda: sampler_call(solvers, args.solver, net, latents, args.nfe)
+    run_step = lambda: sampler_call(solvers, args.solver, net, latents, args.nfe, ldm)
     if args.graph:
+        assert ldm is None, '--graph covers the EDM nets'
         from diff_sampler_amd.graph import GraphedSampler
 
         class _Rec:        # records the sampler function and kwargs sampler_call() would use
@@ -230,21 +275,21 @@ def main():
 
     roof = roof_u = kernels = None
     if rank == 0:
-        rec = instrumented_pass(net, solvers, args.solver, latents, args.nfe)
+        rec = instrumented_pass(net, solvers, args.solver, latents, args.nfe, ldm)
         total_ms = sum(v[0] for v in rec.values())
         kernels = {(KERNEL_NAMES[k[1]] if isinstance(k, tuple) else k): dict(ms=round(v[0], 2), launches=v[1], share=round(v[0] / total_ms, 4))
                    for k, v in sorted(rec.items(), key=lambda kv: -kv[1][0])}
         convs = {k: v for k, v in rec.items() if isinstance(k, tuple)}
         dom, (ms, launches, fl) = max(convs.items(), key=lambda kv: kv[1][0])
         ach = fl / (ms * 1e-3) / 1e12
-        traffic = pmc_traffic(dom[1])
+        traffic = pmc_traffic(dom[1]) if (args.config == 'cifar10' and B == 256) else None   # the PMC pass is of the default workload
         alg_bytes = None
         roof = dict(bound='mfma', kernel=KERNEL_NAMES[dom[1]], achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
                     frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=(round(traffic) if traffic else None),
                     traffic_unit='HBM bytes per launch (rocprofv3 PMC, profiles/r1b_bench_pmc_hbm.json)',
                     launches_per_step=launches, avg_launch_ms=round(ms / launches, 4), gflop_per_launch=round(fl / launches / 1e9, 2),
                     share_of_gpu_time=round(ms / total_ms, 4))
-        if 'solver_update_kernel' in rec:
+        if 'solver_update_kernel' in rec and ldm is None:
             ums, ul, _ = rec['solver_update_kernel']
             per = spec.in_channels * spec.img_resolution ** 2 * 4
             # DPM-Solver++(2M), x0 form: D pass (x, F read; m written) + combine (x, m0, m1 read; x written) = 7 passes/image/step
@@ -256,14 +301,18 @@ def main():
                           note='latency-bound at this batch (3 MB per operand); see DESIGN.md section 6 for the large-batch figure')
 
     if rank == 0:
+        workload_name = {'cifar10': 'EDM CIFAR-10 32x32 SongUNet (55.7M params)', 'ffhq': 'EDM FFHQ-64 SongUNet (61.8M params)',
+                         'afhqv2': 'EDM AFHQv2-64 SongUNet', 'imagenet64': 'EDM ImageNet-64 DhariwalUNet (295.9M params)',
+                         'sd15': 'Stable Diffusion v1.5 64x64x4 latent U-Net (859.5M params)'}.get(args.config, args.config)
         total_images = B * world * args.steps
         line = {
-            'metric': 'images/sec (whole node) at NFE=%d, EDM CIFAR-10' % args.nfe,
+            'metric': 'images/sec (whole node) at NFE=%d, %s' % (args.nfe, 'EDM CIFAR-10' if args.config == 'cifar10' else workload_name.split(' (')[0]),
             'value': round(total_images / dt, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'fp32', 'data': 'synthetic N(0,1) latents, random-init (signal-carrying) weights',
-            'config': {'workload': 'EDM CIFAR-10 32x32 SongUNet (55.7M params), %s NFE=%d, batch %d/GPU' %
-                       ({'dpmpp': 'DPM-Solver++(2M) logSNR', 'euler': 'Euler', 'ipndm': 'iPNDM-4', 'heun': 'Heun'}[args.solver], args.nfe, B),
+            'config': {'workload': '%s, %s NFE=%d, batch %d/GPU' %
+                       (workload_name, 'DPM-Solver++(2M) eps-prediction, discrete rho=1, CFG 7.5 (2 U-Net images per latent)' if ldm is not None else
+                        {'dpmpp': 'DPM-Solver++(2M) logSNR', 'euler': 'Euler', 'ipndm': 'iPNDM-4', 'heun': 'Heun'}[args.solver], args.nfe, B),
                        'images_per_step': B * world, 'sharding': 'independent image batches per rank, no collective',
                        'launch': 'hipGraph replay' if args.graph else 'eager'},
             'roofline': roof, 'roofline_update': roof_u, 'kernels': kernels, 'cpu_baseline': cpu,

@@ -29,29 +29,7 @@ from ._lib import (AttnArgs, ConvArgs, GemmArgs, NormArgs, DS_ACT_NONE, DS_ACT_S
 from .ops import pack_conv_weight, pack_linear_weight, pack_stem_weight
 
 
-def _ptr(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
-
-
-class _Op:
-    """One launch: C entry point + argument tuple (struct by reference or scalars)."""
-    __slots__ = ('fn', 'args', 'name', 'keep')
-
-    def __init__(self, fn, args, name, keep=()):
-        self.fn, self.args, self.name, self.keep = fn, args, name, keep
-
-
-class _Plan:
-    def __init__(self):
-        self.ops: List[_Op] = []
-        self.bufs: Dict[str, torch.Tensor] = {}
-        self.keep: List[torch.Tensor] = []      # every workspace tensor the launch arguments point into
-
-    def run(self, stream):
-        for op in self.ops:
-            rc = op.fn(*op.args, stream)
-            if rc:
-                _lib.check(rc, op.name)
+from .plan import Op as _Op, Plan as _Plan, ptr as _ptr  # noqa: E402
 
 
 class UNetEngine:
