@@ -184,21 +184,26 @@ __global__ void __launch_bounds__(128 * WM, 2) conv3x3_halo_kernel(const KParams
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int NCH = nchunks + nextra;                // slabs: 3x3 ones (9 taps each) then 1x1 ones (centre tap only)
-    const int KT = nchunks * 9 + nextra;
+    const int NCH_all = nchunks + nextra;            // slabs: 3x3 ones (9 taps each) then 1x1 ones (centre tap only)
+    // split-K: this block contracts slabs [c_begin, NCH) only (splits == 1: everything)
+    const int c_begin = (int)((long long)blockIdx.y * NCH_all / p.splits);
+    const int NCH = (int)((long long)(blockIdx.y + 1) * NCH_all / p.splits);
+    auto kt_of = [&](int chunk) { return chunk < nchunks ? chunk * 9 : nchunks * 9 + (chunk - nchunks); };
+    const int kt0 = kt_of(c_begin);
+    const int KT = kt_of(NCH);
 
     // ---- prologue ----------------------------------------------------------------------------------------------
-    halo_load(0);
-    coef_load(0);
+    halo_load(c_begin);
+    coef_load(c_begin);
     if (GLDS) {
-        b_dma(0, 0);
+        b_dma(kt0, kt0 & 1);
     } else {
 #pragma unroll
-        for (int i = 0; i < BROWS; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b_addr(0, i));
+        for (int i = 0; i < BROWS; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b_addr(kt0, i));
     }
-    halo_store(0);
-    if (!GLDS) b_store(0);
-    if (NCH > 1) { halo_load(1); coef_load(1); }
+    halo_store(c_begin);
+    if (!GLDS) b_store(kt0 & 1);
+    if (c_begin + 1 < NCH) { halo_load(c_begin + 1); coef_load(c_begin + 1); }
     __syncthreads();
 
     // weight fragment offsets: padded rows (register staging) or swizzled 16-B chunks (LDS-DMA)
@@ -207,8 +212,8 @@ __global__ void __launch_bounds__(128 * WM, 2) conv3x3_halo_kernel(const KParams
     auto b_frag = [&](int ks) -> int {
         return GLDS ? b_row * 32 + (((ks * 2 + (lane >> 5)) ^ b_swz) * 4) : b_row * LDSK + (lane >> 5) * 4 + ks * 8;
     };
-    int kt = 0;
-    for (int chunk = 0; chunk < NCH; ++chunk) {
+    int kt = kt0;
+    for (int chunk = c_begin; chunk < NCH; ++chunk) {
         const int ntaps = chunk < nchunks ? 9 : 1;
         for (int t9 = 0; t9 < ntaps; ++t9, ++kt) {
             const int tap = ntaps == 9 ? t9 : 4;
@@ -251,6 +256,12 @@ __global__ void __launch_bounds__(128 * WM, 2) conv3x3_halo_kernel(const KParams
     }
 
     // epilogue staging overlays the LDS allocation (the launcher sizes it for 4 x 64 or 8 x 32 staging rows per wave)
+    if (p.splits > 1) {
+        const KParams q = split_params(p, blockIdx.y);
+        if (WM == 2) epilogue<0, false>(q, acc, smem + wave * 64 * EPI_LD, lane, m0 + wr * 64, n0 + wc * 64, q.out);
+        else epilogue<0, true>(q, acc, smem + wave * 32 * EPI_LD, lane, m0 + wr * 64, n0 + wc * 64, q.out);
+        return;
+    }
     if (WM == 2) epilogue<0, false>(p, acc, smem + wave * 64 * EPI_LD, lane, m0 + wr * 64, n0 + wc * 64, p.out);
     else epilogue<0, true>(p, acc, smem + wave * 32 * EPI_LD, lane, m0 + wr * 64, n0 + wc * 64, p.out);
 }
@@ -288,8 +299,11 @@ int launch_wm(KParams& p, const Geo& g, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_halo_kernel<WM, GLDS>), dim3(grid_1d(p.mtiles, p.ntiles)), dim3(128 * WM), smem, stream, p);
+    const int units = (p.c0 + p.c1 + p.ec0 + p.ec1) / BK;
+    p.splits = choose_splits((long long)p.mtiles * p.ntiles, units, p.part ? p.part_cap : 0, (long long)p.M * p.N);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<WM, GLDS>), dim3(grid_1d(p.mtiles, p.ntiles), p.splits), dim3(128 * WM), smem, stream, p);
     DS_CHECK_LAUNCH();
+    if (p.splits > 1) return launch_splitk_reduce(p, stream);
     return DS_OK;
 }
 

@@ -121,17 +121,20 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(const KParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int KT = p.K / BK;
+    // split-K (conv mode only): this block contracts K tiles [kt0, KT)
+    const int KT_all = p.K / BK;
+    const int kt0 = (MODE == 0) ? (int)((long long)blockIdx.y * KT_all / p.splits) : 0;
+    const int KT = (MODE == 0) ? (int)((long long)(blockIdx.y + 1) * KT_all / p.splits) : KT_all;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        ra[i] = *reinterpret_cast<const f32x4*>(a_addr(0, i));
-        rb[i] = *reinterpret_cast<const f32x4*>(b_addr(0, i));
+        ra[i] = *reinterpret_cast<const f32x4*>(a_addr(kt0, i));
+        rb[i] = *reinterpret_cast<const f32x4*>(b_addr(kt0, i));
     }
-    store_tiles(0);
+    store_tiles(kt0 & 1);
     __syncthreads();
 
     const int frag_off = (lane & 31) * LDSK + (lane >> 5) * 4;
-    for (int kt = 0; kt < KT; ++kt) {
+    for (int kt = kt0; kt < KT; ++kt) {
         const int cur = kt & 1;
         const int nxt = min(kt + 1, KT - 1);      // the last iteration re-stages its own tile (harmless, keeps the body branch-free)
         const float* as = As + cur * BM * LDSK + wr * 64 * LDSK + frag_off;
@@ -162,7 +165,37 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(const KParams p) {
         __syncthreads();
     }
 
+    if (MODE == 0 && p.splits > 1) {
+        const KParams q = split_params(p, blockIdx.y);
+        epilogue<MODE>(q, acc, smem + wave * 64 * EPI_LD, lane, m0 + wr * 64, n0 + wc * 64, q.out);
+        return;
+    }
     epilogue<MODE>(p, acc, smem + wave * 64 * EPI_LD, lane, m0 + wr * 64, n0 + wc * 64, o_base);
+}
+
+// Sum of the split-K partial tiles + the fused epilogue: out = act((sum + colbias + cbias[img] + res) * scale).
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const KParams p) {
+    const int n4 = (p.N + 3) >> 2;
+    const long long total = (long long)p.M * n4;
+    const size_t plane = (size_t)p.M * p.N;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(idx / n4);
+        const int col = (int)(idx - (long long)row * n4) * 4;
+        const int img = p.cbias_bcast ? 0 : row / p.HW;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = col + j;
+            if (c >= p.N) break;
+            float v = 0.f;
+            for (int s = 0; s < p.splits; ++s) v += p.part[s * plane + (size_t)row * p.N + c];
+            if (p.colbias) v += p.colbias[c];
+            if (p.cbias) v += p.cbias[(size_t)img * p.cbias_ld + c];
+            if (p.res) v += p.res[(size_t)row * p.res_ld + c];
+            v *= p.scale;
+            if (p.act == DS_ACT_SILU) v = ds_silu(v);
+            p.out[(size_t)row * p.ldo + c] = v;
+        }
+    }
 }
 
 template <int MODE>
@@ -177,10 +210,16 @@ int launch(KParams& p, int batch, hipStream_t stream) {
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = (p.N + BN - 1) / BN;
     dim3 grid;
-    if (MODE == 0) grid = dim3(grid_1d(p.mtiles, p.ntiles), 1, 1);
-    else grid = dim3(p.mtiles, p.ntiles, batch);
+    if (MODE == 0) {
+        p.splits = choose_splits((long long)p.mtiles * p.ntiles, p.K / BK, p.part ? p.part_cap : 0, (long long)p.M * p.N);
+        grid = dim3(grid_1d(p.mtiles, p.ntiles), p.splits, 1);
+    } else {
+        p.splits = 1;
+        grid = dim3(p.mtiles, p.ntiles, batch);
+    }
     hipLaunchKernelGGL(igemm_f32_kernel<MODE>, grid, dim3(256), SMEM_BYTES, stream, p);
     DS_CHECK_LAUNCH();
+    if (p.splits > 1) return launch_splitk_reduce(p, stream);
     return DS_OK;
 }
 
@@ -196,6 +235,15 @@ bool vec_epilogue_ok(const KParams& p) {
 int g_force_generic = 0;
 
 }  // namespace
+
+int launch_splitk_reduce(const KParams& p, hipStream_t stream) {
+    long long blocks = ((long long)p.M * ((p.N + 3) / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
 }  // namespace igemm
 
 using namespace igemm;
@@ -242,6 +290,10 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     p.res = a->res; p.res_ld = a->res_ld;
     p.scale = a->out_scale; p.act = a->act; p.heads = 1;
     p.vec_ok = vec_epilogue_ok(p) ? 1 : 0;
+    p.splits = 1; p.part = nullptr; p.part_cap = 0; p.vec_part = 0;
+    if (a->workspace && a->workspace_floats > 0 && ds_aligned16(a->workspace)) {
+        p.part = a->workspace; p.part_cap = a->workspace_floats; p.vec_part = (p.N & 3) ? 0 : 1;
+    }
     if (!g_force_generic && stride == 1 && conv3x3_halo_supported(p)) return launch_conv3x3_halo(p, (hipStream_t)stream);
     if (p.norm) return DS_E_SHAPE;           // fused input normalisation exists only in the halo kernel
     return launch<0>(p, 1, (hipStream_t)stream);
@@ -278,5 +330,6 @@ extern "C" int ds_gemm_nt_batched(const ds_gemm_args* a, void* stream) {
     p.colbias = a->colbias; p.rowbias = a->rowbias; p.cbias = nullptr; p.res = nullptr;
     p.scale = a->alpha; p.act = a->act; p.heads = a->heads;
     p.vec_ok = vec_epilogue_ok(p) ? 1 : 0;
+    p.splits = 1; p.part = nullptr; p.part_cap = 0; p.vec_part = 0;
     return launch<1>(p, a->batch * a->heads, (hipStream_t)stream);
 }

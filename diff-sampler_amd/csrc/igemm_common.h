@@ -33,6 +33,9 @@ struct KParams {
     const float* res; int res_ld;
     float scale; int act; int heads;
     int vec_ok;                                                    // float4 epilogue allowed (alignment, ld % 4)
+    // split-K (small-M layers): blockIdx.y = split; each split contracts a contiguous range of K slabs / tiles and writes
+    // its raw partial tile to part[split][M][N]; splitk_reduce_kernel sums them and applies the epilogue
+    int splits; float* part; int vec_part; long long part_cap;     // part_cap: workspace capacity in floats (host side only)
 };
 
 // Fused epilogue of one wave's 64x64 accumulator tile (2x2 MFMA 32x32 tiles).
@@ -129,6 +132,26 @@ __device__ __forceinline__ bool decode_tile(int b, int mtiles, int ntiles, int& 
 }
 
 inline unsigned grid_1d(int mtiles, int ntiles) { return (unsigned)(((mtiles + 7) / 8) * 8 * ntiles); }
+
+// Parameters of one split's partial-tile store: plain [M][N] matrix, no fused epilogue terms.
+__device__ __forceinline__ KParams split_params(const KParams& p, int split) {
+    KParams q = p;
+    q.out = p.part + (size_t)split * p.M * p.N; q.ldo = p.N;
+    q.colbias = nullptr; q.rowbias = nullptr; q.cbias = nullptr; q.res = nullptr; q.scale = 1.f; q.act = DS_ACT_NONE;
+    q.vec_ok = p.vec_part;
+    return q;
+}
+
+// How many K splits a layer with `blocks` output tiles and `units` K slabs gets (1 = no split-K).
+inline int choose_splits(long long blocks, int units, long long part_capacity_floats, long long mn) {
+    if (blocks >= 256 || units < 4 || mn <= 0) return 1;
+    long long s = (640 + blocks - 1) / blocks;
+    if (s > units / 2) s = units / 2;
+    if (s > 64) s = 64;
+    if (s * mn > part_capacity_floats) s = part_capacity_floats / mn;
+    return s < 2 ? 1 : (int)s;
+}
+int launch_splitk_reduce(const KParams& p, hipStream_t stream);   // gemm_conv.hip
 
 // conv3x3_halo.hip
 bool conv3x3_halo_supported(const KParams& p);

@@ -29,7 +29,7 @@ from ._lib import (AttnArgs, ConvArgs, GemmArgs, NormArgs, DS_ACT_NONE, DS_ACT_S
 from .ops import pack_conv_weight, pack_linear_weight, pack_stem_weight
 
 
-from .plan import Op as _Op, Plan as _Plan, ptr as _ptr  # noqa: E402
+from .plan import Op as _Op, Plan as _Plan, ptr as _ptr, SPLITK_WORKSPACE_FLOATS  # noqa: E402
 
 
 class UNetEngine:
@@ -156,6 +156,7 @@ class UNetEngine:
         if max_attn:
             n2 = new(B * max_attn // 2); qk = new(B * max_attn // 2 * 3); ao = new(B * max_attn // 2)
         bufs.update(act=act, hbuf=hbuf, sres=sres, sproj=sproj)
+        splitk_ws = new(SPLITK_WORKSPACE_FLOATS)      # scratch of the split-K path (under-filled layers at small batch)
 
         def add(fn, args, name, keep=()):
             P.ops.append(_Op(fn, args, name, keep))
@@ -166,6 +167,7 @@ class UNetEngine:
             a = ConvArgs(_ptr(x0), _ptr(x1), c0, c1, ld0, ld1, n, h, wd, taps, _ptr(wgt), cout, _ptr(bias), _ptr(cbias),
                          cbias_ld, cbias_rows, _ptr(res), res_ld, scale, act_, _ptr(out), out_ld, _ptr(norm_coefs), norm_act,
                          _ptr(e0), _ptr(e1), ec0, ec1, ec0, ec1)
+            a.workspace, a.workspace_floats = _ptr(splitk_ws), splitk_ws.numel()
             add(lib.ds_conv2d_nhwc, (C.byref(a),), name, keep=(a,))
 
         def norm(kind, x0, c0, ld0, n, h, wd, name, x1=None, c1=0, ld1=0, groups=1, eps=1e-5, use_stats=True, gamma=None,

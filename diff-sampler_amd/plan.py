@@ -15,6 +15,9 @@ from . import _lib
 from ._lib import AttnArgs, ConvArgs, GemmArgs, NormArgs, DS_ACT_NONE, DS_RESAMPLE_NONE
 
 
+SPLITK_WORKSPACE_FLOATS = 32 << 20      # 128 MiB per plan
+
+
 def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -46,6 +49,7 @@ class Builder:
         self.dev = device
         self.lib = _lib.load()
         self.mean = self.rstd = None
+        self.ws = None                      # split-K scratch shared by every convolution of the plan (launches are serial)
 
     def new(self, *shape, zero=False):
         # The argument structs hold raw pointers: the plan must own every tensor they point into, otherwise the
@@ -63,6 +67,9 @@ class Builder:
         a = ConvArgs(ptr(x0), ptr(x1), c0, c1, ld0, ld1, n, h, w, taps, ptr(wgt), cout, ptr(bias), ptr(cbias), cbias_ld,
                      cbias_rows, ptr(res), res_ld, scale, act, ptr(out), out_ld, ptr(norm_coefs), norm_act, ptr(e0), ptr(e1),
                      ec0, ec1, ec0, ec1, stride)
+        if self.ws is None:
+            self.ws = self.new(SPLITK_WORKSPACE_FLOATS)
+        a.workspace, a.workspace_floats = ptr(self.ws), self.ws.numel()
         self.add(self.lib.ds_conv2d_nhwc, (C.byref(a),), name, keep=(a,))
 
     def linear(self, x, k, rows, wgt, cout, out, name, ldx=None, out_ld=None, **kw):

@@ -80,6 +80,11 @@ typedef struct ds_conv_args {
      * ldm/modules/diffusionmodules/openaimodel.py:146-148): h, w are then the OUTPUT size and the input is 2h x 2w.
      * stride 2 excludes norm_coefs and the e0/e1 extras. */
     int stride;
+    /* Optional split-K scratch (floats): layers whose output has too few tiles to fill the 256 CUs (small batch, 8x8 /
+     * 16x16 stages) split the K loop over up to 64 workgroups per tile, each writing a raw partial tile here; a second
+     * launch sums them in a fixed order (deterministic) and applies the epilogue.  NULL / 0 = never split.  The launcher
+     * uses at most min(workspace_floats, 64 * M * cout) floats; contents are scratch. */
+    float* workspace; long long workspace_floats;
 } ds_conv_args;
 
 int ds_conv2d_nhwc(const ds_conv_args* a, void* stream);

@@ -35,12 +35,17 @@ CONV_CASES = [
     (3, 16, 64, 32, 96, 1, (0, 0), False),
     (7, 1, 128, 0, 40, 1, (0, 0), False),        # Linear: h = w = 1
     (2, 32, 64, 0, 3, 9, (0, 0), True),          # ragged N (output conv), out_ld = 4
+    (1, 8, 256, 256, 320, 9, (256, 256), True),  # small M, long K: split-K when a workspace is given (SD-1.5 8x8 stage)
+    (2, 16, 256, 0, 64, 1, (0, 0), False),       # 1x1 with 8 K tiles
+    (3, 4, 128, 0, 96, 9, (0, 0), False),        # 4x4: generic 3x3 fallback, 36 K tiles
+    (2, 8, 160, 0, 7, 9, (0, 0), True),          # split-K with a ragged N
 ]
 
 
+@pytest.mark.parametrize('ws', [False, True])
 @pytest.mark.parametrize('force', [0, 1, 2, 128, 256])
 @pytest.mark.parametrize('case', CONV_CASES)
-def test_conv2d_nhwc_matches_aten(case, force):
+def test_conv2d_nhwc_matches_aten(case, force, ws):
     from diff_sampler_amd import _lib, ops
     B, H, c0, c1, cout, taps, (ec0, ec1), use_norm = case
     lib = _lib.load()
@@ -86,6 +91,9 @@ def test_conv2d_nhwc_matches_aten(case, force):
                       1 if cout % 2 == 0 else 0, out.data_ptr(), old, coefs.data_ptr() if use_norm else None, 1,
                       e0.data_ptr() if ec0 else None, e1.data_ptr() if ec1 else None, ec0, ec1, ec0, ec1)
     keep = [x0, x1, e0, e1, wp, coefs]     # noqa: F841  (raw pointers above)
+    if ws:                                 # split-K scratch: the launcher splits the K loop of under-filled layers
+        scratch = torch.full((8 << 20,), float('nan'), device=dev)
+        a.workspace, a.workspace_floats = scratch.data_ptr(), scratch.numel()
     biasd, cbd, resd = bias.to(dev), cb.to(dev), _nhwc(res).to(dev)
     a.bias, a.cbias, a.res = biasd.data_ptr(), cbd.data_ptr(), resd.data_ptr()
     import ctypes as C
