@@ -16,6 +16,7 @@ vp = C.c_void_p
 
 DS_ACT_NONE, DS_ACT_SILU = 0, 1
 DS_RESAMPLE_NONE, DS_RESAMPLE_DOWN, DS_RESAMPLE_UP = 0, 1, 2
+DS_GN_MAX_CHUNKS = 32
 
 
 class ConvArgs(C.Structure):
@@ -41,7 +42,7 @@ class NormArgs(C.Structure):
                 ('n', C.c_int), ('h', C.c_int), ('w', C.c_int), ('groups', C.c_int), ('eps', C.c_float),
                 ('mean', vp), ('rstd', vp), ('gamma', vp), ('beta', vp), ('scale', vp), ('shift', vp),
                 ('ss_ld', C.c_int), ('ss_rows', C.c_int), ('act', C.c_int), ('resample', C.c_int), ('out', vp),
-                ('out_ld', C.c_int), ('coefs', vp)]
+                ('out_ld', C.c_int), ('coefs', vp), ('partial', vp), ('counters', vp)]
 
 
 class AttnArgs(C.Structure):

@@ -8,11 +8,14 @@ namespace {
 // --------------------------------------------------------------------------------------------------------------
 // GroupNorm statistics.  One block per image; thread t owns channel quad (t % CQ) and walks pixels t / CQ, t / CQ + PL, ...
 // Sums are kept in fp64 (one pass, no cancellation problem in E[x^2] - E[x]^2), reduced through LDS atomics per group.
+__device__ __forceinline__ void gn_finalize(const ds_norm_args& a, double* s_sum, double* s_sq);
+
 __global__ void __launch_bounds__(1024) gn_stats_kernel(const ds_norm_args a, int CQ, int PL) {
     __shared__ double s_sum[64];
     __shared__ double s_sq[64];
     const int tid = threadIdx.x;
     const int n = blockIdx.x;
+    const int P = gridDim.y;                 // pixel chunks per image (> 1: small batches, needs a.partial / a.counters)
     if (tid < 64) { s_sum[tid] = 0.0; s_sq[tid] = 0.0; }
     __syncthreads();
     const int C = a.c0 + a.c1;
@@ -25,7 +28,7 @@ __global__ void __launch_bounds__(1024) gn_stats_kernel(const ds_norm_args a, in
         if (c < a.c0) { src = a.x0 + c; ld = a.ld0; } else { src = a.x1 + (c - a.c0); ld = a.ld1; }
         src += (size_t)n * HW * ld;
         double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-        for (int p = pl; p < HW; p += PL) {
+        for (int p = blockIdx.y * PL + pl; p < HW; p += PL * P) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)p * ld);
 #pragma unroll
             for (int j = 0; j < 4; ++j) { s[j] += (double)v[j]; q[j] += (double)v[j] * (double)v[j]; }
@@ -45,6 +48,21 @@ __global__ void __launch_bounds__(1024) gn_stats_kernel(const ds_norm_args a, in
         atomicAdd(&s_sum[g_prev], ss); atomicAdd(&s_sq[g_prev], qq);
     }
     __syncthreads();
+    if (P > 1) {
+        // small batches: publish this chunk's partial sums; gn_finalize_kernel (next launch) adds them in chunk order
+        double* part = a.partial + ((size_t)n * P + blockIdx.y) * 128;
+        if (tid < a.groups) { part[tid] = s_sum[tid]; part[64 + tid] = s_sq[tid]; }
+        return;
+    }
+    gn_finalize(a, s_sum, s_sq);
+}
+
+__device__ __forceinline__ void gn_finalize(const ds_norm_args& a, double* s_sum, double* s_sq) {
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x;
+    const int C = a.c0 + a.c1;
+    const int cpg = C / a.groups;
+    const int HW = a.h * a.w;
     if (tid < a.groups) {
         const double cnt = (double)cpg * (double)HW;
         const double mean = s_sum[tid] / cnt;
@@ -73,6 +91,20 @@ __global__ void __launch_bounds__(1024) gn_stats_kernel(const ds_norm_args a, in
             cp[c] = m; cp[C + c] = r * gm * sc1; cp[2 * C + c] = bt * sc1 + sh;
         }
     }
+}
+
+__global__ void __launch_bounds__(256) gn_finalize_kernel(const ds_norm_args a, int P) {
+    __shared__ double s_sum[64];
+    __shared__ double s_sq[64];
+    const int tid = threadIdx.x, n = blockIdx.x;
+    if (tid < a.groups) {
+        double ss = 0.0, qq = 0.0;
+        const double* pp = a.partial + (size_t)n * P * 128;
+        for (int k = 0; k < P; ++k) { ss += pp[k * 128 + tid]; qq += pp[k * 128 + 64 + tid]; }
+        s_sum[tid] = ss; s_sq[tid] = qq;
+    }
+    __syncthreads();
+    gn_finalize(a, s_sum, s_sq);
 }
 
 // --------------------------------------------------------------------------------------------------------------
@@ -300,7 +332,17 @@ extern "C" int ds_gn_stats(const ds_norm_args* a, void* stream) {
     int threads = CQ * PL;
     threads = ((threads + 63) / 64) * 64;
     if (threads < 64) threads = 64;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(a->n), dim3(threads), 0, (hipStream_t)stream, *a, CQ, PL);
+    // small batches: split every image over P pixel chunks so that the launch still covers the chip
+    int P = 1;
+    if (a->partial && a->n < 256) {
+        P = (512 + a->n - 1) / a->n;
+        const int maxp = (a->h * a->w) / (PL * 4);          // at least 4 pixel iterations per thread
+        if (P > maxp) P = maxp;
+        if (P > DS_GN_MAX_CHUNKS) P = DS_GN_MAX_CHUNKS;
+        if (P < 1) P = 1;
+    }
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(a->n, P), dim3(threads), 0, (hipStream_t)stream, *a, CQ, PL);
+    if (P > 1) hipLaunchKernelGGL(gn_finalize_kernel, dim3(a->n), dim3(256), 0, (hipStream_t)stream, *a, P);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }

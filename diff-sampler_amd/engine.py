@@ -156,6 +156,9 @@ class UNetEngine:
         if max_attn:
             n2 = new(B * max_attn // 2); qk = new(B * max_attn // 2 * 3); ao = new(B * max_attn // 2)
         bufs.update(act=act, hbuf=hbuf, sres=sres, sproj=sproj)
+        gn_partial = torch.empty(B * _lib.DS_GN_MAX_CHUNKS * 128, dtype=torch.float64, device=dev)   # multi-workgroup GroupNorm
+        gn_counters = torch.zeros(B, dtype=torch.int32, device=dev)                                  # statistics at small batch
+        P.keep += [gn_partial, gn_counters]
         splitk_ws = new(SPLITK_WORKSPACE_FLOATS)      # scratch of the split-K path (under-filled layers at small batch)
 
         def add(fn, args, name, keep=()):
@@ -176,6 +179,8 @@ class UNetEngine:
             a = NormArgs(_ptr(x0), _ptr(x1), c0, c1, ld0, ld1, n, h, wd, groups, eps,
                          _ptr(mean) if use_stats else None, _ptr(rstd) if use_stats else None, _ptr(gamma), _ptr(beta),
                          _ptr(scale), _ptr(shift), ss_ld, ss_rows, act_, resample, _ptr(out), out_ld, _ptr(coefs))
+            if kind == 'stats' and n < 256:
+                a.partial, a.counters = _ptr(gn_partial), _ptr(gn_counters)
             add(lib.ds_gn_stats if kind == 'stats' else lib.ds_norm_act, (C.byref(a),), name, keep=(a,))
 
         def gemm(a_, lda, b_, ldb, c_, ldc, m_, n_, k_, name, batch=1, heads=1, a_bs=0, a_hs=0, b_bs=0, b_hs=0, c_bs=0, c_hs=0,

@@ -78,8 +78,10 @@ def _norm_args(x0, c0, ld0, n, h, w, *, x1=None, c1=0, ld1=0, groups=1, eps=1e-5
                     _p(scale), _p(shift), ss_ld, ss_rows, act, resample, _p(out), out_ld)
 
 
-def gn_stats(x0, c0, ld0, n, h, w, groups, eps, mean, rstd, *, x1=None, c1=0, ld1=0):
+def gn_stats(x0, c0, ld0, n, h, w, groups, eps, mean, rstd, *, x1=None, c1=0, ld1=0, partial=None, counters=None):
     a = _norm_args(x0, c0, ld0, n, h, w, x1=x1, c1=c1, ld1=ld1, groups=groups, eps=eps, mean=mean, rstd=rstd)
+    if partial is not None:     # multi-workgroup statistics (small batches): fp64 scratch + zeroed int32 counters
+        a.partial, a.counters = C.c_void_p(partial.data_ptr()), C.c_void_p(counters.data_ptr())
     _lib.check(_lib.load().ds_gn_stats(C.byref(a), _lib.stream_ptr()), 'ds_gn_stats')
 
 

@@ -49,6 +49,7 @@ class Builder:
         self.dev = device
         self.lib = _lib.load()
         self.mean = self.rstd = None
+        self.gn_partial = self.gn_counters = None
         self.ws = None                      # split-K scratch shared by every convolution of the plan (launches are serial)
 
     def new(self, *shape, zero=False):
@@ -84,6 +85,12 @@ class Builder:
         a = NormArgs(ptr(x0), ptr(x1), c0, c1, ld0, ld1, n, h, w, groups, eps, ptr(self.mean) if use_stats else None,
                      ptr(self.rstd) if use_stats else None, ptr(gamma), ptr(beta), ptr(scale), ptr(shift), ss_ld, ss_rows, act,
                      resample, ptr(out), out_ld, ptr(coefs))
+        if kind == 'stats' and n < 256:
+            if self.gn_partial is None or self.gn_counters.numel() < n:
+                self.gn_partial = torch.empty(n * _lib.DS_GN_MAX_CHUNKS * 128, dtype=torch.float64, device=self.dev)
+                self.gn_counters = torch.zeros(n, dtype=torch.int32, device=self.dev)
+                self.P.keep += [self.gn_partial, self.gn_counters]
+            a.partial, a.counters = ptr(self.gn_partial), ptr(self.gn_counters)
         self.add(self.lib.ds_gn_stats if kind == 'stats' else self.lib.ds_norm_act, (C.byref(a),), name, keep=(a,))
 
     def gemm(self, a_, lda, b_, ldb, c_, ldc, m, n, k, name, batch=1, heads=1, a_bs=0, a_hs=0, b_bs=0, b_hs=0, c_bs=0, c_hs=0,

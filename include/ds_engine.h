@@ -136,8 +136,14 @@ typedef struct ds_norm_args {
     float* coefs;                          /* ds_gn_stats only, optional: [n][3][c0+c1] planes {mu, A, B} with
                                               A = rstd*gamma*(1+scale), B = beta*(1+scale)+shift, for ds_conv2d_nhwc's
                                               fused input normalisation */
+    /* ds_gn_stats only, optional scratch for small batches (n < 256): the statistics of one image are then gathered by
+     * up to DS_GN_MAX_CHUNKS workgroups and a second small launch adds their partial sums in a fixed order.
+     * partial: [n][DS_GN_MAX_CHUNKS][128] doubles (scratch).  counters: reserved, may be NULL.  partial == NULL = one
+     * workgroup per image. */
+    double* partial; int* counters;
 } ds_norm_args;
 
+#define DS_GN_MAX_CHUNKS 32
 int ds_gn_stats(const ds_norm_args* a, void* stream);
 int ds_norm_act(const ds_norm_args* a, void* stream);
 

@@ -123,7 +123,7 @@ def test_conv_argument_errors():
     assert lib.ds_conv2d_nhwc(C.byref(a), None) == -2          # ld % 4 != 0 -> DS_E_ALIGN
 
 
-@pytest.mark.parametrize('C_,G,HW', [(64, 16, 16), (96, 24, 8), (192, 32, 16), (384, 32, 8)])
+@pytest.mark.parametrize('C_,G,HW', [(64, 16, 16), (96, 24, 8), (192, 32, 16), (384, 32, 8), (320, 32, 64), (32, 8, 32)])
 def test_groupnorm_stats_and_apply(C_, G, HW):
     from diff_sampler_amd import ops
     from diff_sampler_amd._lib import DS_ACT_SILU, DS_RESAMPLE_DOWN, DS_RESAMPLE_UP
@@ -136,6 +136,15 @@ def test_groupnorm_stats_and_apply(C_, G, HW):
     x0, x1 = xn[:, :c0].contiguous(), (xn[:, c0:].contiguous() if C_ > c0 else None)
     mean, rstd = torch.empty(B * G, device='cuda'), torch.empty(B * G, device='cuda')
     ops.gn_stats(x0, c0, c0, B, HW, HW, G, 1e-5, mean, rstd, x1=x1, c1=C_ - c0, ld1=C_ - c0)
+    # same statistics gathered by several workgroups per image (small-batch path), twice to exercise the counter reset
+    from diff_sampler_amd._lib import DS_GN_MAX_CHUNKS
+    part = torch.full((B * DS_GN_MAX_CHUNKS * 128,), float('nan'), dtype=torch.float64, device='cuda')
+    cnt = torch.zeros(B, dtype=torch.int32, device='cuda')
+    for _ in range(2):
+        mean2, rstd2 = torch.full_like(mean, float('nan')), torch.full_like(rstd, float('nan'))
+        ops.gn_stats(x0, c0, c0, B, HW, HW, G, 1e-5, mean2, rstd2, x1=x1, c1=C_ - c0, ld1=C_ - c0, partial=part, counters=cnt)
+        torch.cuda.synchronize()
+        assert torch.allclose(mean2, mean, rtol=1e-6, atol=1e-7) and torch.allclose(rstd2, rstd, rtol=1e-6, atol=1e-7)
     ref = F.silu(F.group_norm(x, G, gamma, beta, 1e-5))
     for rs, refr in [(0, ref), (DS_RESAMPLE_DOWN, F.avg_pool2d(ref, 2)), (DS_RESAMPLE_UP, F.interpolate(ref, scale_factor=2, mode='nearest'))]:
         ho = refr.shape[-1]
