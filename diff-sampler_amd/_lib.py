@@ -76,6 +76,7 @@ _SIGNATURES = {
     'ds_error_string': (C.c_char_p, [C.c_int]),
     'ds_conv2d_nhwc': (C.c_int, [C.POINTER(ConvArgs), vp]),
     'ds_debug_force_generic_conv': (C.c_int, [C.c_int]),
+    'ds_debug_force_splits': (C.c_int, [C.c_int]),
     'ds_conv_kernel_id': (C.c_int, [C.POINTER(ConvArgs)]),
     'ds_conv3x3_halo_supported': (C.c_int, [C.c_int, C.c_int]),
     'ds_gemm_nt_batched': (C.c_int, [C.POINTER(GemmArgs), vp]),

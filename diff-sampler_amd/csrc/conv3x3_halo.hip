@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(128 * WM, 2) conv3x3_halo_kernel(const KParams
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     int mt, nt;
-    if (!decode_tile(blockIdx.x, p.mtiles, p.ntiles, mt, nt)) return;
+    if (!decode_tile(blockIdx.x, p.mtiles, p.ntiles, mt, nt, blockIdx.y)) return;
     const int m0 = mt * TBM, n0 = nt * BN;
     const int ld_row = tid >> 3, ld_col = (tid & 7) * 4;
     const float* zero = g_zero_page_halo;
@@ -299,8 +299,6 @@ int launch_wm(KParams& p, const Geo& g, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const int units = (p.c0 + p.c1 + p.ec0 + p.ec1) / BK;
-    p.splits = choose_splits((long long)p.mtiles * p.ntiles, units, p.part ? p.part_cap : 0, (long long)p.M * p.N);
     hipLaunchKernelGGL((conv3x3_halo_kernel<WM, GLDS>), dim3(grid_1d(p.mtiles, p.ntiles), p.splits), dim3(128 * WM), smem, stream, p);
     DS_CHECK_LAUNCH();
     if (p.splits > 1) return launch_splitk_reduce(p, stream);
@@ -314,31 +312,37 @@ bool conv3x3_halo_supported(const KParams& p) { return geometry(p, 128).ok; }
 void conv3x3_halo_set_tile(int tile) { g_tile_override = tile; }
 void conv3x3_halo_set_glds(int on) { g_glds = on; }
 
-int conv3x3_halo_choice(const KParams& p) {          // 0 = unsupported, 128 / 256 = M tile the launcher will use
+// Tile shape and split-K factor of a layer: the cheaper of the two tile shapes under the cost model (igemm_common.h); the
+// 256-pixel tile gets a 3 % bonus where both fill the chip (weights shared by twice the pixels).
+struct HaloPlan { int tile, splits; };
+
+HaloPlan plan_halo(const KParams& p) {
     const Geo g128 = geometry(p, 128), g256 = geometry(p, 256);
-    if (!g128.ok) return 0;
-    bool use256 = false;
-    if (g256.ok) {
-        const long long blocks256 = (long long)((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
-        use256 = blocks256 >= 512;
-        if (g_tile_override == 256) use256 = true;
-        if (g_tile_override == 128) use256 = false;
+    HaloPlan hp{0, 1};
+    if (!g128.ok) return hp;
+    const int nt = (p.N + BN - 1) / BN;
+    const int units = (p.c0 + p.c1 + p.ec0 + p.ec1) / BK;
+    const long long mn = (long long)p.M * p.N, cap = p.part ? p.part_cap : 0;
+    double c128 = 0.0, c256 = 0.0;
+    const int s128 = choose_splits((long long)((p.M + 127) / 128) * nt, false, units, 9, cap, mn, &c128);
+    hp.tile = 128; hp.splits = s128;
+    const long long blocks256 = (long long)((p.M + 255) / 256) * nt;
+    // the 8-wave shape only where its tiles alone cover the 256 CUs twice (below that the model is optimistic about it)
+    if (g256.ok && g_tile_override != 128 && (blocks256 >= 512 || g_tile_override == 256)) {
+        const int s256 = choose_splits(blocks256, true, units, 9, cap, mn, &c256);
+        if (g_tile_override == 256 || 0.97 * c256 < c128) { hp.tile = 256; hp.splits = s256; }
     }
-    return use256 ? 256 : 128;
+    return hp;
 }
 
+int conv3x3_halo_choice(const KParams& p) { return plan_halo(p).tile; }   // 0 = unsupported, 128 / 256 = M tile
+
 int launch_conv3x3_halo(KParams& p, hipStream_t stream) {
-    const Geo g128 = geometry(p, 128), g256 = geometry(p, 256);
-    bool use256 = false;
-    if (g256.ok) {
-        // one 8-wave workgroup per CU: worth it when the 256-pixel tiles alone cover the 256 CUs at least twice
-        const long long blocks256 = (long long)((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
-        use256 = blocks256 >= 512;
-        if (g_tile_override == 256) use256 = true;
-        if (g_tile_override == 128) use256 = false;
-    }
-    if (use256) return g_glds ? launch_wm<4, true>(p, g256, stream) : launch_wm<4, false>(p, g256, stream);
-    return g_glds ? launch_wm<2, true>(p, g128, stream) : launch_wm<2, false>(p, g128, stream);
+    const HaloPlan hp = plan_halo(p);
+    p.splits = hp.splits;
+    if (hp.tile == 256) { const Geo g = geometry(p, 256); return g_glds ? launch_wm<4, true>(p, g, stream) : launch_wm<4, false>(p, g, stream); }
+    const Geo g = geometry(p, 128);
+    return g_glds ? launch_wm<2, true>(p, g, stream) : launch_wm<2, false>(p, g, stream);
 }
 
 }  // namespace igemm

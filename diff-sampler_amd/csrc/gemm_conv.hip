@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(const KParams p) {
     const int wr = wave >> 1, wc = wave & 1;
     int mt, nt;
     if (MODE == 0) {
-        if (!decode_tile(blockIdx.x, p.mtiles, p.ntiles, mt, nt)) return;
+        if (!decode_tile(blockIdx.x, p.mtiles, p.ntiles, mt, nt, blockIdx.y)) return;
     } else {
         mt = blockIdx.x; nt = blockIdx.y;
     }
@@ -211,7 +211,7 @@ int launch(KParams& p, int batch, hipStream_t stream) {
     p.ntiles = (p.N + BN - 1) / BN;
     dim3 grid;
     if (MODE == 0) {
-        p.splits = choose_splits((long long)p.mtiles * p.ntiles, p.K / BK, p.part ? p.part_cap : 0, (long long)p.M * p.N);
+        p.splits = choose_splits((long long)p.mtiles * p.ntiles, false, p.K / BK, 1, p.part ? p.part_cap : 0, (long long)p.M * p.N);
         grid = dim3(grid_1d(p.mtiles, p.ntiles), p.splits, 1);
     } else {
         p.splits = 1;
@@ -236,6 +236,8 @@ int g_force_generic = 0;
 
 }  // namespace
 
+int g_force_splits = 0;
+
 int launch_splitk_reduce(const KParams& p, hipStream_t stream) {
     long long blocks = ((long long)p.M * ((p.N + 3) / 4) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -254,6 +256,11 @@ extern "C" int ds_debug_force_generic_conv(int v) {
     g_force_generic = (v == 1);
     conv3x3_halo_set_tile((v == 128 || v == 256) ? v : 0);
     conv3x3_halo_set_glds(v == 2 ? 0 : 1);           // v = 2: halo kernel with register-staged weights
+    return DS_OK;
+}
+
+extern "C" int ds_debug_force_splits(int s) {
+    g_force_splits = s > 0 ? s : 0;
     return DS_OK;
 }
 
@@ -303,6 +310,8 @@ extern "C" int ds_conv_kernel_id(const ds_conv_args* a) {
     if (!a) return DS_E_ARG;
     KParams p{};
     p.taps = a->taps; p.H = a->h; p.W = a->w; p.HW = a->h * a->w; p.M = a->n * a->h * a->w; p.N = a->cout;
+    p.c0 = a->c0; p.c1 = a->c1; p.ec0 = a->ec0; p.ec1 = a->ec1;
+    if (a->workspace && a->workspace_floats > 0) { p.part = a->workspace; p.part_cap = a->workspace_floats; }
     if (g_force_generic || a->taps != 9 || a->stride > 1) return 0;
     return conv3x3_halo_choice(p);
 }

@@ -122,16 +122,32 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
 
 // XCD-aware decode of a 1-D workgroup id into (m tile, n tile): the dispatcher places workgroup b on XCD b % 8, so
 // within each group of 8*NT ids the NT column tiles that share an A slab get the SAME b % 8 (same L2) and are
-// dispatched back to back.  Placement only affects speed, never results.
-__device__ __forceinline__ bool decode_tile(int b, int mtiles, int ntiles, int& mt, int& nt) {
+// dispatched back to back.  With fewer than 8 row tiles (small batch: the weights are the traffic) the roles swap: the
+// row tiles that share a WEIGHT tile get the same XCD and the column tiles spread over all 8 XCDs -- otherwise a layer
+// with one row tile would run on a single XCD.  Placement only affects speed, never results.
+__device__ __host__ __forceinline__ bool tile_order_swapped(int mtiles, int ntiles) { return mtiles < 8 && ntiles > mtiles; }
+
+// `rot` (the split-K index) rotates which tile of a group of 8 lands on which XCD, so that a partly filled last group
+// does not load the same XCDs in every split.
+__device__ __forceinline__ bool decode_tile(int b, int mtiles, int ntiles, int& mt, int& nt, int rot = 0) {
+    if (tile_order_swapped(mtiles, ntiles)) {
+        const int per = 8 * mtiles;
+        const int g = b / per, r = b - g * per;
+        nt = g * 8 + ((r + rot) & 7);
+        mt = r >> 3;
+        return nt < ntiles;
+    }
     const int per = 8 * ntiles;
     const int g = b / per, r = b - g * per;
-    mt = g * 8 + (r & 7);
+    mt = g * 8 + ((r + rot) & 7);
     nt = r >> 3;
     return mt < mtiles;
 }
 
-inline unsigned grid_1d(int mtiles, int ntiles) { return (unsigned)(((mtiles + 7) / 8) * 8 * ntiles); }
+inline unsigned grid_1d(int mtiles, int ntiles) {
+    if (tile_order_swapped(mtiles, ntiles)) return (unsigned)(((ntiles + 7) / 8) * 8 * mtiles);
+    return (unsigned)(((mtiles + 7) / 8) * 8 * ntiles);
+}
 
 // Parameters of one split's partial-tile store: plain [M][N] matrix, no fused epilogue terms.
 __device__ __forceinline__ KParams split_params(const KParams& p, int split) {
@@ -142,14 +158,45 @@ __device__ __forceinline__ KParams split_params(const KParams& p, int split) {
     return q;
 }
 
-// How many K splits a layer with `blocks` output tiles and `units` K slabs gets (1 = no split-K).
-inline int choose_splits(long long blocks, int units, long long part_capacity_floats, long long mn) {
-    if (blocks >= 256 || units < 4 || mn <= 0) return 1;
-    long long s = (640 + blocks - 1) / blocks;
-    if (s > units / 2) s = units / 2;
-    if (s > 64) s = 64;
-    if (s * mn > part_capacity_floats) s = part_capacity_floats / mn;
-    return s < 2 ? 1 : (int)s;
+// Split-K / tile-shape cost model (microseconds), calibrated on MI355X with tools/sweep_splits.py.
+//   A 128x128 workgroup contracts one 32-deep K tile in ~2.1 us when it has a CU to itself and two co-resident ones take
+//   ~3.4 us for one tile each (the CU's fp32-MFMA rate); a 256x128 workgroup (8 waves, one per CU) takes 3.3 us.
+//   `blocks` equal workgroups spread over 256 CUs => the busiest CU runs n = ceil(blocks / 256) of them back to back.
+//   Splitting K by S multiplies the workgroups and divides their length; it costs a reduce launch (~8 us) plus writing and
+//   re-reading S partial tiles (~2 TB/s effective).
+inline double cu_time_us(long long n, bool big_tile) {
+    return big_tile ? 3.3 * (double)n : 3.4 * (double)(n / 2) + 2.1 * (double)(n & 1);
+}
+inline double layer_cost_us(long long blocks, bool big_tile, int ktiles, int s, long long mn) {
+    const long long n = (blocks * s + 255) / 256;
+    double t = (double)((ktiles + s - 1) / s) * cu_time_us(n, big_tile);
+    if (s > 1) t += 8.0 + (double)s * (double)mn * 8.0 / 2.0e6;
+    return t;
+}
+extern int g_force_splits;      // benchmarks: > 0 overrides the heuristic (ds_debug_force_splits)
+// Best split count for a layer of `blocks` tiles whose K loop has `units` splittable units of `tiles_per_unit` K tiles.
+inline int choose_splits(long long blocks, bool big_tile, int units, int tiles_per_unit, long long part_capacity_floats,
+                         long long mn, double* cost_out = nullptr) {
+    const int ktiles = units * tiles_per_unit;
+    double best_c = layer_cost_us(blocks, big_tile, ktiles, 1, mn);
+    int best = 1;
+    long long smax = units / 2;
+    if (smax > 16) smax = 16;
+    if (mn > 0 && smax * mn > part_capacity_floats) smax = part_capacity_floats / mn;
+    if (units >= 4 && mn > 0) {
+        if (g_force_splits > 0) {
+            best = (int)(g_force_splits < smax ? g_force_splits : smax);
+            if (best < 1) best = 1;
+            best_c = layer_cost_us(blocks, big_tile, ((units + best - 1) / best) * tiles_per_unit * best, best, mn);
+        } else {
+            for (long long s = 2; s <= smax; ++s) {
+                const double c = layer_cost_us(blocks, big_tile, ((units + s - 1) / s) * tiles_per_unit * (int)s, (int)s, mn);
+                if (c < 0.97 * best_c) { best_c = c; best = (int)s; }
+            }
+        }
+    }
+    if (cost_out) *cost_out = best_c;
+    return best;
 }
 int launch_splitk_reduce(const KParams& p, hipStream_t stream);   // gemm_conv.hip
 

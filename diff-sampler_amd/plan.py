@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import AttnArgs, ConvArgs, GemmArgs, NormArgs, DS_ACT_NONE, DS_RESAMPLE_NONE
 
 
-SPLITK_WORKSPACE_FLOATS = 32 << 20      # 128 MiB per plan
+SPLITK_WORKSPACE_FLOATS = 64 << 20      # 256 MiB per plan
 
 
 def ptr(t):

@@ -100,6 +100,10 @@ int ds_conv3x3_halo_supported(int h, int w);
  * LDS-halo kernel (both are exact fp32; used for A/B measurements and as a cross-check in the tests). */
 int ds_debug_force_generic_conv(int v);
 
+/* Benchmark switch: s > 0 forces the split-K factor of every convolution that has a workspace (clamped to what the layer
+ * allows); 0 restores the heuristic. */
+int ds_debug_force_splits(int s);
+
 /* Batched C[z] = act(alpha * A[z] * B[z]^T + rowbias + colbias) on the same MFMA core ("NT": both operands have k
  * contiguous).  Used for attention: S = Q K^T / sqrt(C) and O = P V (networks_edm.py:108, :176) and the transposed
  * V projection.  z = zb * heads + zh;  X_z = X + zb*x_bstride + zh*x_hstride. Constraints: k % 32 == 0. */
