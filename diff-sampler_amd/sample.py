@@ -79,13 +79,27 @@ SOLVER_FNS = dict(euler='euler_sampler', heun='heun_sampler', dpm='dpm_2_sampler
 
 
 # ------------------------------------------------------------------------------------------------------------------
-def create_model(dataset_name=None, model_path=None, random_init=False, device=None, seed=0):
-    """EDM networks only (cifar10 / ffhq / afhqv2 / imagenet64; sample.py:80-85).  Returns (net, 'edm')."""
+def create_model(dataset_name=None, model_path=None, random_init=False, device=None, seed=0, guidance_type=None, guidance_rate=None):
+    """EDM networks (cifar10 / ffhq / afhqv2 / imagenet64; sample.py:80-85) -> (net, 'edm'); Stable Diffusion v1.x latent
+    U-Net under classifier-free guidance (ms_coco; sample.py:111-116) -> (net, 'ldm')."""
     from . import arch
     from .engine import EDMDenoiser
+    if dataset_name == 'ms_coco':
+        from . import ldm_arch
+        from .ldm_engine import CFGDenoiser
+        assert guidance_type == 'cfg', 'ms_coco samples with classifier-free guidance (sample.py:112)'
+        spec = ldm_arch.ldm_unet_spec(**ldm_arch.NAMED_LDM_CONFIGS['sd15'])
+        if random_init or model_path is None:
+            params = ldm_arch.init_ldm_params(spec, seed=seed)
+        else:                                   # SD checkpoint: the U-Net lives under 'model.diffusion_model.' (ddpm.py:1399)
+            sd = torch.load(model_path, map_location='cpu')
+            sd = sd.get('state_dict', sd)
+            pre = 'model.diffusion_model.'
+            params = {k[len(pre):]: v.float() for k, v in sd.items() if k.startswith(pre)}
+        return CFGDenoiser(spec, params, device, guidance_rate=(7.5 if guidance_rate is None else guidance_rate)), 'ldm'
     if dataset_name not in arch.NAMED_CONFIGS:
         raise ValueError(f'dataset {dataset_name!r}: only the EDM networks are in scope of the HIP engine '
-                         f'({sorted(k for k in arch.NAMED_CONFIGS if not k.startswith("tiny"))}); CM/ADM/LDM models run on the reference')
+                         f'({sorted(k for k in arch.NAMED_CONFIGS if not k.startswith("tiny"))} and ms_coco); CM / ADM-classifier-guided / LSUN-LDM models run on the reference')
     if random_init or model_path is None:
         net = EDMDenoiser.from_config(dataset_name, seed=seed, device=device)
     else:
@@ -144,7 +158,14 @@ def run(dataset_name, max_batch_size=64, seeds='0-63', grid=False, outdir=None, 
 
     if dist is not None and rank != 0:
         dist.barrier()                                              # rank 0 goes first (sample.py:183-193)
-    net, solver_kwargs['model_source'] = create_model(dataset_name, model_path, random_init, device)
+    net, solver_kwargs['model_source'] = create_model(dataset_name, model_path, random_init, device,
+                                                      guidance_type=solver_kwargs.get('guidance_type'),
+                                                      guidance_rate=solver_kwargs.get('guidance_rate'))
+    ldm = solver_kwargs['model_source'] == 'ldm'
+    cond_table = None
+    if ldm and solver_kwargs.get('condition_path'):
+        # text-encoder states computed elsewhere (CLIP is not on the sampling path): {'c': [N, L, 768] indexed by seed, 'uc': [1, L, 768]}
+        cond_table = torch.load(solver_kwargs['condition_path'], map_location='cpu')
     if dist is not None and rank == 0:
         dist.barrier()
 
@@ -200,13 +221,32 @@ def run(dataset_name, max_batch_size=64, seeds='0-63', grid=False, outdir=None, 
         rnd = StackedRandomGenerator(device, batch_seeds)
         latents = rnd.randn([B, net.img_channels, net.img_resolution, net.img_resolution], device=device)
         class_labels = None
-        if net.label_dim:
+        if net.label_dim and not ldm:
             class_labels = torch.eye(net.label_dim, device=device)[rnd.randint(net.label_dim, size=[B], device=device)]
         with torch.no_grad():
-            images = sampler_fn(net, latents, class_labels=class_labels, **solver_kwargs)
+            if ldm:
+                if cond_table is not None:
+                    c = cond_table['c'][torch.as_tensor(batch_seeds) % cond_table['c'].shape[0]].to(device)
+                    uc = cond_table['uc'].to(device).expand(B, -1, -1)
+                else:       # no text encoder here: seeded N(0,1) states of the CLIP shape (BASELINE config 5)
+                    c = rnd.randn([B, 77, net.spec.context_dim], device=device)
+                    uc = torch.randn(1, 77, net.spec.context_dim, generator=torch.Generator().manual_seed(0)).to(device).expand(B, -1, -1)
+                if solver_kwargs['guidance_rate'] == 1.0:
+                    uc = None
+                images = sampler_fn(net, latents, condition=c, unconditional_condition=uc, **solver_kwargs)
+            else:
+                images = sampler_fn(net, latents, class_labels=class_labels, **solver_kwargs)
         if solver_kwargs.get('return_inters'):
             images = images[-1]
-        if grid:
+        if ldm:
+            # latents [B, 4, 64, 64]: decoding them is the VAE's job (net.model.decode_first_stage, sample.py:303), not on this path
+            import numpy as np
+            for seed, z in zip(batch_seeds, images.cpu().numpy()):
+                seed = int(seed)
+                d = os.path.join(outdir, f'{seed - seed % 1000:06d}') if subdirs else outdir
+                os.makedirs(d, exist_ok=True)
+                np.save(os.path.join(d, f'{seed:06d}.npy'), z)
+        elif grid:
             save_grid(images, outdir)
         else:
             save_images(images, batch_seeds, outdir, subdirs)
@@ -245,6 +285,7 @@ if click is not None:
     @click.option('--outdir', help='Where to save the output images', metavar='DIR', type=str)
     @click.option('--grid', help='Whether to make grid', type=bool, default=False)
     @click.option('--subdirs', help='Create subdirectory for every 1000 seeds', type=bool, default=True, is_flag=True)
+    @click.option('--condition_path', help='ms_coco: torch file with precomputed text-encoder states {c: [N,L,768], uc: [1,L,768]}', type=str, default=None)
     @click.option('--random_init', help='Use a random-init network of the named architecture (no checkpoint)', type=bool, default=False)
     # GITS options (gits-main/sample.py:159-165)
     @click.option('--dp', help='Whether to search the time schedule with dynamic programming (GITS)', type=bool, default=False)

@@ -54,3 +54,16 @@ def test_sample_run_with_gits_schedule_search(tmp_path):
     out, n = sample.run('tiny_song', max_batch_size=4, seeds='0-3', outdir=str(tmp_path / 'g'), solver='ipndm', max_order=3, num_steps=5,
                         dp=True, metric='dev', coeff=1.15, num_warmup=4, solver_tea='ipndm', num_steps_tea=11, random_init=True)
     assert n == 4 and len(_read(out)) == 4
+
+
+def test_sample_run_ms_coco_latent_diffusion(tmp_path):
+    """BASELINE config 5 through the CLI body: SD-1.5 latent U-Net (random init), classifier-free guidance, DPM-Solver++(2M)
+    noise prediction on the discrete schedule; writes one latent per seed (the VAE decode is not on this path)."""
+    import numpy as np
+    from diff_sampler_amd import sample
+    out, n = sample.run('ms_coco', max_batch_size=2, seeds='0-1', outdir=str(tmp_path / 'sd'), solver='dpmpp', max_order=2,
+                        num_steps=3, predict_x0=False, lower_order_final=True, schedule_type='discrete', schedule_rho=1,
+                        guidance_type='cfg', guidance_rate=7.5, random_init=True)
+    assert n == 2
+    z = np.load(os.path.join(out, '000000', '000001.npy'))
+    assert z.shape == (4, 64, 64) and np.isfinite(z).all()
