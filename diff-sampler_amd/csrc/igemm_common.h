@@ -200,6 +200,10 @@ inline int choose_splits(long long blocks, bool big_tile, int units, int tiles_p
 }
 int launch_splitk_reduce(const KParams& p, hipStream_t stream);   // gemm_conv.hip
 
+// gemm256.hip
+bool gemm256_applicable(const KParams& p);
+int launch_gemm256(KParams& p, hipStream_t stream);
+
 // conv3x3_halo.hip
 bool conv3x3_halo_supported(const KParams& p);
 int launch_conv3x3_halo(KParams& p, hipStream_t stream);

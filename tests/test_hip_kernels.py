@@ -39,6 +39,8 @@ CONV_CASES = [
     (2, 16, 256, 0, 64, 1, (0, 0), False),       # 1x1 with 8 K tiles
     (3, 4, 128, 0, 96, 9, (0, 0), False),        # 4x4: generic 3x3 fallback, 36 K tiles
     (2, 8, 160, 0, 7, 9, (0, 0), True),          # split-K with a ragged N
+    (16, 32, 640, 0, 1024, 1, (0, 0), False),    # 1x1 with K >= 640 and >= 256 tiles of 256x256: large-tile kernel (gemm256)
+    (17, 32, 320, 320, 1000, 1, (0, 0), False),  # same, dual source, ragged M and N
 ]
 
 
