@@ -17,7 +17,8 @@ Prints ONE JSON line on rank 0 with the driver's contract fields plus
                    peak = 157.3 TFLOP/s (MI355X fp32 matrix pipe, MI355X_MICROARCH.md);
                    traffic = HBM bytes per launch from the PMC pass committed under profiles/ (FETCH_SIZE doubled per
                    the guide's gfx950 correction + WRITE_SIZE), or null when that file is absent
-  roofline_update  the fused solver-update kernel against HBM 8 TB/s
+  roofline_update  the fused solver-update kernel against HBM 8 TB/s at the benchmark's batch (latency-bound there), and
+  roofline_update_large_batch  the same kernel measured in-process at 16 384 images per launch, where it is bandwidth-bound
   kernels          time share of every kernel class in the instrumented step
   cpu_baseline     the oracle (CPU restatement of the reference, ``oracle/``) timed on this host's cores on a bounded
                    sample of the same workload.
@@ -149,6 +150,34 @@ def instrumented_pass(net, solvers, solver, latents, nfe, ldm=None):
         ops.dynamic_threshold = thr
         ops.cfg_denoise = cfg
     return rec
+
+
+def update_roofline_large_batch(dev, batch=16384):
+    """The fused solver-update kernel where it is bandwidth-bound: one iPNDM order-4 step (x, F, 3 history tensors read;
+    x' and d written = 7 passes of 12 288 B per CIFAR-10 image) on `batch` images, HIP-event timed."""
+    from diff_sampler_amd import ops
+    C_, H = 3, 32
+    x = torch.randn(batch, C_, H, H, device=dev)
+    fr = torch.randn(batch, C_, H, H, device=dev)           # raw network output, channel-planar as the engine's output conv writes it
+    hist = [torch.randn(batch, C_, H, H, device=dev) for _ in range(3)]
+    xo, mo = torch.empty_like(x), torch.empty_like(x)
+    a = ops.make_update_args(x, x, fr, batch, C_, H, H, xo, raw=True, f_ld=0, hist=hist, hcoefs=[1, -.5, .1, .2, .3, 2., 2., 0], m_out=mo)
+    for _ in range(3):
+        ops.solver_update(a)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    n = 20
+    e0.record()
+    for _ in range(n):
+        ops.solver_update(a)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    byts = 7 * C_ * H * H * 4 * batch
+    gbs = byts / (ms * 1e-3) / 1e9
+    return dict(bound='hbm', kernel='solver_update_fast_kernel (iPNDM order-4 step)', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s',
+                frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, images_per_launch=batch, avg_launch_ms=round(ms, 4),
+                algorithmic_bytes_per_launch=byts,
+                note='micro-benchmark inside bench.py at the batch where the update is bandwidth-bound (every operand is touched once)')
 
 
 def pmc_traffic(kid):
@@ -300,6 +329,9 @@ def main():
                           frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, launches_per_step=ul, avg_launch_ms=round(ums / ul, 4),
                           note='latency-bound at this batch (3 MB per operand); see DESIGN.md section 6 for the large-batch figure')
 
+    roof_ul = None
+    if rank == 0 and ldm is None:
+        roof_ul = update_roofline_large_batch(dev)
     if rank == 0:
         workload_name = {'cifar10': 'EDM CIFAR-10 32x32 SongUNet (55.7M params)', 'ffhq': 'EDM FFHQ-64 SongUNet (61.8M params)',
                          'afhqv2': 'EDM AFHQv2-64 SongUNet', 'imagenet64': 'EDM ImageNet-64 DhariwalUNet (295.9M params)',
@@ -315,7 +347,7 @@ def main():
                         {'dpmpp': 'DPM-Solver++(2M) logSNR', 'euler': 'Euler', 'ipndm': 'iPNDM-4', 'heun': 'Heun'}[args.solver], args.nfe, B),
                        'images_per_step': B * world, 'sharding': 'independent image batches per rank, no collective',
                        'launch': 'hipGraph replay' if args.graph else 'eager'},
-            'roofline': roof, 'roofline_update': roof_u, 'kernels': kernels, 'cpu_baseline': cpu,
+            'roofline': roof, 'roofline_update': roof_u, 'roofline_update_large_batch': roof_ul, 'kernels': kernels, 'cpu_baseline': cpu,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -26,7 +26,8 @@ class ConvArgs(C.Structure):
                 ('res_ld', C.c_int), ('out_scale', C.c_float), ('act', C.c_int), ('out', vp), ('out_ld', C.c_int),
                 ('norm_coefs', vp), ('norm_act', C.c_int),
                 ('e0', vp), ('e1', vp), ('ec0', C.c_int), ('ec1', C.c_int), ('eld0', C.c_int), ('eld1', C.c_int),
-                ('stride', C.c_int), ('workspace', vp), ('workspace_floats', C.c_longlong)]
+                ('stride', C.c_int), ('workspace', vp), ('workspace_floats', C.c_longlong),
+                ('out_nchw', C.c_int)]
 
 
 class GemmArgs(C.Structure):

@@ -193,7 +193,8 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const KParams p) {
             if (p.res) v += p.res[(size_t)row * p.res_ld + c];
             v *= p.scale;
             if (p.act == DS_ACT_SILU) v = ds_silu(v);
-            p.out[(size_t)row * p.ldo + c] = v;
+            if (p.out_planar) { const int im = row / p.HW; p.out[((size_t)im * p.N + c) * p.HW + (row - im * p.HW)] = v; }
+            else p.out[(size_t)row * p.ldo + c] = v;
         }
     }
 }
@@ -297,6 +298,11 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     p.res = a->res; p.res_ld = a->res_ld;
     p.scale = a->out_scale; p.act = a->act; p.heads = 1;
     p.vec_ok = vec_epilogue_ok(p) ? 1 : 0;
+    p.out_planar = 0;
+    if (a->out_nchw) {
+        if (a->cout >= 64) return DS_E_ARG;
+        p.out_planar = 1; p.vec_ok = 0;
+    }
     p.splits = 1; p.part = nullptr; p.part_cap = 0; p.vec_part = 0;
     if (a->workspace && a->workspace_floats > 0 && ds_aligned16(a->workspace)) {
         p.part = a->workspace; p.part_cap = a->workspace_floats; p.vec_part = (p.N & 3) ? 0 : 1;
@@ -341,7 +347,7 @@ extern "C" int ds_gemm_nt_batched(const ds_gemm_args* a, void* stream) {
     p.stride = 1; p.IH = p.IW = 1;
     p.colbias = a->colbias; p.rowbias = a->rowbias; p.cbias = nullptr; p.res = nullptr;
     p.scale = a->alpha; p.act = a->act; p.heads = a->heads;
-    p.vec_ok = vec_epilogue_ok(p) ? 1 : 0;
+    p.vec_ok = vec_epilogue_ok(p) ? 1 : 0; p.out_planar = 0;
     p.splits = 1; p.part = nullptr; p.part_cap = 0; p.vec_part = 0;
     return launch<1>(p, a->batch * a->heads, (hipStream_t)stream);
 }

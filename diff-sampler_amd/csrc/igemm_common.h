@@ -33,6 +33,7 @@ struct KParams {
     const float* res; int res_ld;
     float scale; int act; int heads;
     int vec_ok;                                                    // float4 epilogue allowed (alignment, ld % 4)
+    int out_planar;                                                // scalar epilogue writes out[(img * N + col) * HW + pixel]
     // split-K (small-M layers): blockIdx.y = split; each split contracts a contiguous range of K slabs / tiles and writes
     // its raw partial tile to part[split][M][N]; splitk_reduce_kernel sums them and applies the epilogue
     int splits; float* part; int vec_part; long long part_cap;     // part_cap: workspace capacity in floats (host side only)
@@ -114,7 +115,8 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
                 if (p.res) v += p.res[(size_t)row * p.res_ld + col];
                 if (MODE == 0) v *= p.scale;
                 if (p.act == DS_ACT_SILU) v = ds_silu(v);
-                o_base[(size_t)row * p.ldo + col] = v;
+                if (p.out_planar) { const int im = row / p.HW; o_base[((size_t)im * p.N + col) * p.HW + (row - im * p.HW)] = v; }
+                else o_base[(size_t)row * p.ldo + col] = v;
             }
         }
     }
@@ -154,7 +156,7 @@ __device__ __forceinline__ KParams split_params(const KParams& p, int split) {
     KParams q = p;
     q.out = p.part + (size_t)split * p.M * p.N; q.ldo = p.N;
     q.colbias = nullptr; q.rowbias = nullptr; q.cbias = nullptr; q.res = nullptr; q.scale = 1.f; q.act = DS_ACT_NONE;
-    q.vec_ok = p.vec_part;
+    q.vec_ok = p.vec_part; q.out_planar = 0;
     return q;
 }
 

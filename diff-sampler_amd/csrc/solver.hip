@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(256) solver_update_kernel(const ds_update_args
                 for (int j = 0; j < VEC; ++j) xb[j] = xe[j];
             }
             if (!a.afs) {
-                if (a.raw) {
+                if (a.raw && a.f_ld > 0) {
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) f[j] = a.f[((size_t)img * HW + p0 + j) * a.f_ld + ch];
                 } else if (VEC == 4) {
@@ -122,7 +122,8 @@ __global__ void __launch_bounds__(256) solver_update_fast_kernel(const ds_update
         const int img = (int)(gidx / gpi);
         const int p0 = (int)(gidx - (long long)img * gpi) << 2;
         f32x4 fr[4], xe[CH], xb[CH], fv[CH], h0[CH], h1[CH], h2[CH];
-        if (!a.afs && a.raw) {
+        const bool rows = a.raw && a.f_ld > 0;       // F as NHWC rows of 4 floats; otherwise F / D as NCHW planes
+        if (!a.afs && rows) {
             const f32x4* fp = reinterpret_cast<const f32x4*>(a.f) + ((size_t)img * HW + p0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) fr[j] = __builtin_nontemporal_load(fp + j);
@@ -132,7 +133,7 @@ __global__ void __launch_bounds__(256) solver_update_fast_kernel(const ds_update
             const size_t off = ((size_t)img * CH + ch) * HW + p0;
             xe[ch] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.xe + off));
             if (has_xb) xb[ch] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.xb + off));
-            if (!a.afs && !a.raw) fv[ch] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.f + off));
+            if (!a.afs && !rows) fv[ch] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.f + off));
             if (a.hist[0]) h0[ch] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.hist[0] + off));
             if (a.hist[1]) h1[ch] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.hist[1] + off));
             if (a.hist[2]) h2[ch] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.hist[2] + off));
@@ -153,7 +154,7 @@ __global__ void __launch_bounds__(256) solver_update_fast_kernel(const ds_update
                     d = x / afs_div;
                     D = x - k.t * d;
                 } else {
-                    const float f = a.raw ? fr[j][ch] : fv[ch][j];
+                    const float f = rows ? fr[j][ch] : fv[ch][j];
                     D = a.raw ? cskip * x + cout_ * f : f;
                     d = (x - D) / k.t;
                 }
@@ -313,16 +314,17 @@ extern "C" int ds_solver_update(const ds_update_args* a, void* stream) {
     if (!a || !a->xe || !a->xb) return DS_E_ARG;
     if (!a->afs && !a->f) return DS_E_ARG;
     if (!a->x_out && !a->m_out) return DS_E_ARG;
+    if (a->raw && !a->afs && a->f_ld != 0 && a->f_ld < a->c) return DS_E_ARG;
     if (a->n <= 0 || a->c <= 0 || a->h <= 0 || a->w <= 0) return DS_E_ARG;
     if (a->coefs && a->coef_rows != 1 && a->coef_rows != a->n) return DS_E_ARG;
     const int HW = a->h * a->w;
-    bool vec4 = (HW % 4 == 0) && ds_aligned16(a->xe) && ds_aligned16(a->xb) && (a->raw || !a->f || ds_aligned16(a->f)) &&
+    bool vec4 = (HW % 4 == 0) && ds_aligned16(a->xe) && ds_aligned16(a->xb) && ((a->raw && a->f_ld > 0) || !a->f || ds_aligned16(a->f)) &&
                 (!a->x_out || ds_aligned16(a->x_out)) && (!a->m_out || ds_aligned16(a->m_out));
     for (int i = 0; i < 3; ++i) if (a->hist[i] && !ds_aligned16(a->hist[i])) vec4 = false;
     const long long work = (long long)a->n * (vec4 ? HW / 4 : HW);
     long long blocks = (work + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    const bool fast = vec4 && (a->c == 3 || a->c == 4) && (!a->raw || a->afs || (a->f_ld == 4 && ds_aligned16(a->f)));
+    const bool fast = vec4 && (a->c == 3 || a->c == 4) && (!a->raw || a->afs || a->f_ld == 0 || (a->f_ld == 4 && ds_aligned16(a->f)));
     if (fast && a->c == 3) hipLaunchKernelGGL(solver_update_fast_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
     else if (fast) hipLaunchKernelGGL(solver_update_fast_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
     else if (vec4) hipLaunchKernelGGL(solver_update_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);

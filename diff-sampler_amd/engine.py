@@ -127,7 +127,7 @@ class UNetEngine:
         bufs['x'] = new(B, spec.in_channels, R, R)           # NCHW, un-scaled (c_in is applied by the stem)
         bufs['sigma'] = new(B)                                # per-sample sigma (row 0 only when Bs == 1 and scalar)
         bufs['sigma_rows'] = torch.zeros(1, dtype=torch.int32, device=dev)
-        bufs['out'] = new(B * R * R, 4)                       # raw network output F, NHWC rows padded to 4 floats
+        bufs['out'] = new(B, spec.out_channels, R, R)         # raw network output F, channel-planar (NCHW) like the user tensors
         if spec.label_dim:
             lpad = -(-spec.label_dim // 32) * 32
             bufs['labels'] = torch.zeros(Bs, lpad, dtype=torch.float32, device=dev)
@@ -166,11 +166,12 @@ class UNetEngine:
 
         def conv(x0, c0, ld0, n, h, wd, wgt, cout, out, out_ld, taps, name, x1=None, c1=0, ld1=0, bias=None, cbias=None,
                  cbias_ld=0, cbias_rows=1, res=None, res_ld=0, scale=1.0, act_=DS_ACT_NONE, norm_coefs=None, norm_act=DS_ACT_NONE,
-                 e0=None, ec0=0, e1=None, ec1=0):
+                 e0=None, ec0=0, e1=None, ec1=0, out_nchw=0):
             a = ConvArgs(_ptr(x0), _ptr(x1), c0, c1, ld0, ld1, n, h, wd, taps, _ptr(wgt), cout, _ptr(bias), _ptr(cbias),
                          cbias_ld, cbias_rows, _ptr(res), res_ld, scale, act_, _ptr(out), out_ld, _ptr(norm_coefs), norm_act,
                          _ptr(e0), _ptr(e1), ec0, ec1, ec0, ec1)
             a.workspace, a.workspace_floats = _ptr(splitk_ws), splitk_ws.numel()
+            a.out_nchw = out_nchw
             add(lib.ds_conv2d_nhwc, (C.byref(a),), name, keep=(a,))
 
         def norm(kind, x0, c0, ld0, n, h, wd, name, x1=None, c1=0, ld1=0, groups=1, eps=1e-5, use_stats=True, gamma=None,
@@ -324,12 +325,12 @@ class UNetEngine:
             norm('stats', xo, co, co, B, R, R, 'out.norm.stats', groups=arch.num_groups(co), eps=spec.out_eps, gamma=w['out.g'],
                  beta=w['out.b'], coefs=ncoef)
             conv(xo, co, co, B, R, R, w['outc.w'], spec.out_channels, bufs['out'], 4, 9, 'out.conv', bias=w['outc.b'],
-                 norm_coefs=ncoef, norm_act=DS_ACT_SILU)
+                 norm_coefs=ncoef, norm_act=DS_ACT_SILU, out_nchw=1)
         else:
             norm('stats', xo, co, co, B, R, R, 'out.norm.stats', groups=arch.num_groups(co), eps=spec.out_eps)
             norm('apply', xo, co, co, B, R, R, 'out.norm', groups=arch.num_groups(co), eps=spec.out_eps, gamma=w['out.g'],
                  beta=w['out.b'], act_=DS_ACT_SILU, out=act, out_ld=co)
-            conv(act, co, co, B, R, R, w['outc.w'], spec.out_channels, bufs['out'], 4, 9, 'out.conv', bias=w['outc.b'])
+            conv(act, co, co, B, R, R, w['outc.w'], spec.out_channels, bufs['out'], 4, 9, 'out.conv', bias=w['outc.b'], out_nchw=1)
         self._plans[key] = P
         return P
 
@@ -413,7 +414,7 @@ class EDMDenoiser:
         return plan, emb_rows
 
     def raw(self, x, sigma, class_labels=None):
-        """F(c_in x; c_noise) as an NHWC [B*H*W, 4] tensor (channels 0..C-1 valid).  Engine-owned, overwritten by the
+        """F(c_in x; c_noise), the raw network output, as an NCHW [B, C, H, W] tensor.  Engine-owned, overwritten by the
         next evaluation at the same batch size."""
         plan, _ = self._prepare(x, sigma, class_labels)
         plan.run(_lib.stream_ptr())
@@ -427,7 +428,7 @@ class EDMDenoiser:
         plan.run(_lib.stream_ptr())
         out = torch.empty_like(x)
         # D = c_skip x + c_out F, evaluated by the update kernel with cx = 0, cm = 1, store_d = 0 (m = D)
-        args = ops.make_update_args(plan.bufs['x'], plan.bufs['x'], plan.bufs['out'], B, Cc, H, W, None, raw=True, f_ld=4,
+        args = ops.make_update_args(plan.bufs['x'], plan.bufs['x'], plan.bufs['out'], B, Cc, H, W, None, raw=True, f_ld=0,
                                     coefs=self._sigma_coefs(plan, emb_rows), coef_rows=(B if emb_rows > 1 else 1),
                                     sigma_data=self.sigma_data, m_out=out, store_d=False)
         ops.solver_update(args)

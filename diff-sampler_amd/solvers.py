@@ -94,7 +94,7 @@ class _Run:
         f = self._f if f is None else f
         raw = self._raw if raw is None else raw
         a = ops.make_update_args(xe, xb, None if afs else f, self.B, self.C, self.H, self.W, x_out, raw=(raw and not afs),
-                                 f_ld=4, hist=list(hist), hcoefs=hc, afs=afs, sigma_data=self.sigma_data, m_out=m_out,
+                                 f_ld=0, hist=list(hist), hcoefs=hc, afs=afs, sigma_data=self.sigma_data, m_out=m_out,
                                  store_d=store_d, coefs=coefs, coef_rows=(self.B if coefs is not None else 1))
         ops.solver_update(a)
 

@@ -85,6 +85,10 @@ typedef struct ds_conv_args {
      * launch sums them in a fixed order (deterministic) and applies the epilogue.  NULL / 0 = never split.  The launcher
      * uses at most min(workspace_floats, 64 * M * cout) floats; contents are scratch. */
     float* workspace; long long workspace_floats;
+    /* 1: write the output channel-planar, out[(img * cout + co) * h * w + pixel] (NCHW), instead of NHWC rows; used for the
+     * 3-channel network output F so that the solver update reads 12 B per pixel, not a row padded to 16 B.  Only for
+     * cout < 64 (the scalar epilogue); out_ld is ignored. */
+    int out_nchw;
 } ds_conv_args;
 
 int ds_conv2d_nhwc(const ds_conv_args* a, void* stream);
@@ -214,7 +218,8 @@ int ds_stem_im2col(const float* x, const float* sigma, int sigma_rows, float sig
  */
 typedef struct ds_update_args {
     const float* xe; const float* xb;      /* NCHW                                                               */
-    const float* f;                        /* raw: NHWC [n*h*w][f_ld] network output; else NCHW denoised          */
+    const float* f;                        /* raw: network output F -- NHWC [n*h*w][f_ld] rows, or channel-planar NCHW
+                                              when f_ld == 0 (ds_conv_args.out_nchw); else NCHW denoised D      */
     int raw; int f_ld;
     const float* hist[3];                  /* NCHW history tensors or NULL                                       */
     const float* coefs; int coef_rows;     /* device [coef_rows][8]; NULL -> use hcoefs (host scalars by value)  */

@@ -196,6 +196,13 @@ def test_solver_update_bandwidth_kernel_semantics():
     ops.solver_update(a); torch.cuda.synchronize()
     assert _rel(mo.cpu(), d) < TOL
     assert _rel(xo.cpu(), 0.9 * xb - 0.4 * d + 0.3 * h0 + 0.2 * h1) < TOL
+    # the same step with the raw network output given channel-planar (f_ld = 0: what the engine's output conv writes)
+    xo.fill_(float('nan')); mo.fill_(float('nan'))
+    a = ops.make_update_args(x.cuda(), xb.cuda(), Fraw.cuda().contiguous(), B, Cc, H, H, xo, raw=True, f_ld=0, hist=[h0.cuda(), h1.cuda()],
+                             hcoefs=hc, sigma_data=sd, m_out=mo, store_d=True)
+    ops.solver_update(a); torch.cuda.synchronize()
+    assert _rel(mo.cpu(), d) < TOL
+    assert _rel(xo.cpu(), 0.9 * xb - 0.4 * d + 0.3 * h0 + 0.2 * h1) < TOL
     a = ops.make_update_args(x.cuda(), x.cuda(), None, B, Cc, H, H, xo, hcoefs=[1.0, 0.5, 0, 0, 0, t, t, 0], afs=True, m_out=mo, store_d=False)
     ops.solver_update(a); torch.cuda.synchronize()
     dafs = x / (1 + t * t) ** 0.5
@@ -284,3 +291,26 @@ def test_stride2_conv_matches_aten(B, Ho, cin, cout):
     torch.cuda.synchronize()
     ref = F.conv2d(x, wt, bias, stride=2, padding=1)
     assert _rel(out.cpu(), _nhwc(ref)) < TOL
+
+
+@pytest.mark.parametrize('B,H,cin,cout,ws', [(3, 16, 64, 3, False), (2, 8, 256, 3, True), (2, 32, 32, 5, False)])
+def test_conv_planar_output(B, H, cin, cout, ws):
+    """out_nchw: the few-channel output conv writes NCHW planes directly (with and without the split-K reduce)."""
+    import ctypes as C
+    from diff_sampler_amd import _lib, ops
+    g = torch.Generator().manual_seed(B * 7 + H)
+    x = torch.randn(B, cin, H, H, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    bias = torch.randn(cout, generator=g)
+    xn, wp, bd = _nhwc(x).cuda(), ops.pack_conv_weight(wt).cuda(), bias.cuda()
+    out = torch.full((B, cout, H, H), float('nan'), device='cuda')
+    a = _lib.ConvArgs(xn.data_ptr(), None, cin, 0, cin, 0, B, H, H, 9, wp.data_ptr(), cout, bd.data_ptr(), None, 0, 1, None, 0, 1.0, 0,
+                      out.data_ptr(), 4)
+    a.out_nchw = 1
+    if ws:
+        scratch = torch.empty(4 << 20, device='cuda')
+        a.workspace, a.workspace_floats = scratch.data_ptr(), scratch.numel()
+    lib = _lib.load()
+    assert lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert _rel(out.cpu(), F.conv2d(x, wt, bias, padding=1)) < TOL

@@ -12,12 +12,12 @@ per = C * H * H * 4
 for B in [256, 4096, 16384, 65536]:
     dev = 'cuda'
     x = torch.randn(B, C, H, H, device=dev)
-    f4 = torch.randn(B * H * H, 4, device=dev)
+    f4 = torch.randn(B, C, H, H, device=dev)        # raw network output, channel-planar (f_ld = 0)
     hist = [torch.randn(B, C, H, H, device=dev) for _ in range(3)]
     xo = torch.empty_like(x); mo = torch.empty_like(x)
     cases = {
-        'euler  (x,F -> x\')        3 passes (F row padded to 4 floats: 3.33)': (ops.make_update_args(x, x, f4, B, C, H, H, xo, raw=True, f_ld=4, hcoefs=[1, -.5, 0, 0, 0, 2., 2., 0]), 3 + 1 / 3),
-        'ipndm4 (x,F,3 hist -> x\',d) 7 passes (7.33)': (ops.make_update_args(x, x, f4, B, C, H, H, xo, raw=True, f_ld=4, hist=hist, hcoefs=[1, -.5, .1, .2, .3, 2., 2., 0], m_out=mo), 7 + 1 / 3),
+        'euler  (x,F -> x\')        3 passes': (ops.make_update_args(x, x, f4, B, C, H, H, xo, raw=True, f_ld=0, hcoefs=[1, -.5, 0, 0, 0, 2., 2., 0]), 3),
+        'ipndm4 (x,F,3 hist -> x\',d) 7 passes': (ops.make_update_args(x, x, f4, B, C, H, H, xo, raw=True, f_ld=0, hist=hist, hcoefs=[1, -.5, .1, .2, .3, 2., 2., 0], m_out=mo), 7),
     }
     for name, (a, passes) in cases.items():
         for _ in range(3):
