@@ -27,9 +27,7 @@
 namespace igemm {
 namespace {
 
-constexpr int B_FLOATS = 2 * BN * LDSK;                       // double-buffered weight tile
-constexpr int B_BYTES = B_FLOATS * (int)sizeof(float);
-constexpr int NS_MAX = 10;                                    // halo float4 slots per thread (upper bound, both shapes)
+constexpr int ns_max(int wn) { return wn == 2 ? 10 : 18; }    // halo float4 slots per thread (upper bound per shape)
 
 __device__ float g_zero_page_halo[64];   // zero-initialised
 
@@ -37,21 +35,27 @@ __device__ float g_zero_page_halo[64];   // zero-initialised
 // writes lane-linear (wave base + lane*16 B), so the LDS image is unpadded [row][32 floats] and the bank-conflict fix
 // moves to an XOR swizzle of the 16-B chunk index with (row >> 1) & 7, applied to the per-lane SOURCE address when
 // staging and to the fragment read address (same involution on both sides; 16 distinct slots per ds_read_b128 lane group).
-template <int WM, bool GLDS>
-__global__ void __launch_bounds__(128 * WM, 2) conv3x3_halo_kernel(const KParams p) {
-    constexpr int T = 128 * WM;            // threads
+// WN = wave columns: 2 = 128 output channels per tile (the normal shape), 1 = 64 (launched only for the ragged last
+// column tile of layers whose channel count is not a multiple of 128 -- 192, 320, 576 ... -- and for the few-channel
+// output conv, instead of multiplying a half-empty 128-wide tile; it starts at column p.n_begin).
+template <int WM, bool GLDS, int WN>
+__global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KParams p) {
+    constexpr int T = 64 * WM * WN;        // threads
     constexpr int TBM = 64 * WM;           // output pixels per tile
-    constexpr int BROWS = 1024 / T;        // weight float4 per thread per tap (4 or 2)
+    constexpr int BNT = 64 * WN;           // output channels per tile
+    constexpr int BROWS = BNT * 8 / T;     // weight float4 per thread per tap (4 or 2)
     constexpr int BLD = GLDS ? 32 : LDSK;  // floats per weight row in LDS
+    constexpr int NS_MAX = ns_max(WN);
+    constexpr int B_FLOATS = 2 * BNT * LDSK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Bs = smem;                               // [2][BN][LDSK]
+    float* Bs = smem;                               // [2][BNT][LDSK]
     float* Ah = smem + B_FLOATS;                    // [NP][LDSK]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = (WN == 2) ? wave >> 1 : wave, wc = (WN == 2) ? wave & 1 : 0;
     int mt, nt;
     if (!decode_tile(blockIdx.x, p.mtiles, p.ntiles, mt, nt, blockIdx.y)) return;
-    const int m0 = mt * TBM, n0 = nt * BN;
+    const int m0 = mt * TBM, n0 = p.n_begin + nt * BNT;
     const int ld_row = tid >> 3, ld_col = (tid & 7) * 4;
     const float* zero = g_zero_page_halo;
 
@@ -161,7 +165,7 @@ __global__ void __launch_bounds__(128 * WM, 2) conv3x3_halo_kernel(const KParams
     };
     auto b_addr = [&](int kt, int i) -> const float* { return b_ok[i] ? p.b + b_off[i] + kt * BK : zero; };
     auto b_store = [&](int buf) {
-        float* bs = Bs + buf * BN * LDSK + ld_row * LDSK + ld_col;
+        float* bs = Bs + buf * BNT * LDSK + ld_row * LDSK + ld_col;
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) *reinterpret_cast<f32x4*>(bs + (T / 8) * i * LDSK) = rb[i];
     };
@@ -169,7 +173,7 @@ __global__ void __launch_bounds__(128 * WM, 2) conv3x3_halo_kernel(const KParams
     auto b_dma = [&](int kt, int buf) {
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) {
-            float* dst = Bs + buf * BN * 32 + (wave * 8 + (T / 8) * i) * 32;       // wave-uniform base
+            float* dst = Bs + buf * BNT * 32 + (wave * 8 + (T / 8) * i) * 32;      // wave-uniform base
             typedef const __attribute__((address_space(1))) void* gptr_t;
             typedef __attribute__((address_space(3))) void* lptr_t;
             __builtin_amdgcn_global_load_lds((gptr_t)(b_addr(kt, i)), (lptr_t)(dst), 16, 0, 0);
@@ -223,7 +227,7 @@ __global__ void __launch_bounds__(128 * WM, 2) conv3x3_halo_kernel(const KParams
             const int nxt = min(kt + 1, KT - 1);            // past the end: re-stage the last tile (branch-free body)
             const float* as0 = Ah + a_foff[0] + toff;
             const float* as1 = Ah + a_foff[1] + toff;
-            const float* bs = Bs + cur * BN * BLD;
+            const float* bs = Bs + cur * BNT * BLD;
             if (GLDS) b_dma(nxt, cur ^ 1);                  // buffer cur^1 was last read in tap kt-1 (barrier passed)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -256,51 +260,71 @@ __global__ void __launch_bounds__(128 * WM, 2) conv3x3_halo_kernel(const KParams
     }
 
     // epilogue staging overlays the LDS allocation (the launcher sizes it for 4 x 64 or 8 x 32 staging rows per wave)
+    constexpr bool HALF = (WM * WN == 8);            // 8 waves: 32-row staging halves; up to 4 waves: 64 rows each
     if (p.splits > 1) {
         const KParams q = split_params(p, blockIdx.y);
-        if (WM == 2) epilogue<0, false>(q, acc, smem + wave * 64 * EPI_LD, lane, m0 + wr * 64, n0 + wc * 64, q.out);
-        else epilogue<0, true>(q, acc, smem + wave * 32 * EPI_LD, lane, m0 + wr * 64, n0 + wc * 64, q.out);
+        epilogue<0, HALF>(q, acc, smem + wave * (HALF ? 32 : 64) * EPI_LD, lane, m0 + wr * 64, n0 + wc * 64, q.out);
         return;
     }
-    if (WM == 2) epilogue<0, false>(p, acc, smem + wave * 64 * EPI_LD, lane, m0 + wr * 64, n0 + wc * 64, p.out);
-    else epilogue<0, true>(p, acc, smem + wave * 32 * EPI_LD, lane, m0 + wr * 64, n0 + wc * 64, p.out);
+    epilogue<0, HALF>(p, acc, smem + wave * (HALF ? 32 : 64) * EPI_LD, lane, m0 + wr * 64, n0 + wc * 64, p.out);
 }
 
 struct Geo { int TH, nimg, NP; bool ok; };
 
-Geo geometry(const KParams& p, int tbm) {
+Geo geometry(const KParams& p, int tbm, int wn = 2) {
     Geo g{0, 0, 0, false};
     if (p.taps != 9 || p.W < 4 || p.W > 64) return g;
     if (p.HW >= tbm) { if (tbm % p.W || p.HW % tbm) return g; g.TH = tbm / p.W; g.nimg = 1; }
     else { if (tbm % p.HW) return g; g.TH = p.H; g.nimg = tbm / p.HW; }
     g.NP = g.nimg * (g.TH + 2) * (p.W + 2);
-    const int threads = tbm * 2;                      // 128 * WM
-    g.ok = (g.NP * 8 + threads - 1) / threads <= NS_MAX;
+    const int threads = tbm * wn;                     // 64 * WM * WN
+    g.ok = (g.NP * 8 + threads - 1) / threads <= ns_max(wn);
     return g;
 }
 
 int g_tile_override = 0;       // 0 = heuristic, 128 / 256 = forced (benchmarks)
 
 int g_glds = 1;                // weight staging: 1 = LDS-DMA, 0 = through registers (A/B switch)
+int g_tail64 = 1;              // 64-column tiles for a ragged last column tile (A/B switch)
 
-template <int WM, bool GLDS>
-int launch_wm(KParams& p, const Geo& g, hipStream_t stream) {
+template <int WM, bool GLDS, int WN>
+int launch_one(KParams p, const Geo& g, int n_begin, int ntiles, hipStream_t stream) {
     constexpr int TBM = 64 * WM;
+    constexpr int B_BYTES = 2 * 64 * WN * LDSK * (int)sizeof(float);
     p.TH = g.TH; p.nimg = g.nimg; p.HP = g.TH + 2; p.WP = p.W + 2; p.NP = g.NP;
     p.mtiles = (p.M + TBM - 1) / TBM;
-    p.ntiles = (p.N + BN - 1) / BN;
+    p.ntiles = ntiles;
+    p.n_begin = n_begin;
     int smem = B_BYTES + p.NP * LDSK * (int)sizeof(float);
     const int epi = 4 * 64 * EPI_LD * (int)sizeof(float);       // = 8 x 32 x EPI_LD for the 8-wave shape
     if (smem < epi) smem = epi;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, GLDS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, GLDS, WN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_halo_kernel<WM, GLDS>), dim3(grid_1d(p.mtiles, p.ntiles), p.splits), dim3(128 * WM), smem, stream, p);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<WM, GLDS, WN>), dim3(grid_1d(p.mtiles, p.ntiles), p.splits), dim3(64 * WM * WN), smem, stream, p);
     DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+// One layer = the full 128-column tiles (WN = 2) plus, when the channel count leaves 1..64 columns over, one launch of
+// 64-column tiles for them (WN = 1); the split-K partial planes are shared and reduced once.
+template <int WM, bool GLDS>
+int launch_wm(KParams& p, hipStream_t stream) {
+    const int full = p.N / BN, rem = p.N - full * BN;
+    const bool tail64 = rem > 0 && rem <= 64 && geometry(p, 64 * WM, 1).ok && g_tail64;
+    const int wide = tail64 ? full : (p.N + BN - 1) / BN;
+    if (wide > 0) {
+        int rc = launch_one<WM, GLDS, 2>(p, geometry(p, 64 * WM, 2), 0, wide, stream);
+        if (rc) return rc;
+    }
+    if (tail64) {
+        int rc = launch_one<WM, GLDS, 1>(p, geometry(p, 64 * WM, 1), full * BN, 1, stream);
+        if (rc) return rc;
+    }
     if (p.splits > 1) return launch_splitk_reduce(p, stream);
     return DS_OK;
 }
@@ -311,6 +335,7 @@ bool conv3x3_halo_supported(const KParams& p) { return geometry(p, 128).ok; }
 
 void conv3x3_halo_set_tile(int tile) { g_tile_override = tile; }
 void conv3x3_halo_set_glds(int on) { g_glds = on; }
+void conv3x3_halo_set_tail64(int on) { g_tail64 = on; }
 
 // Tile shape and split-K factor of a layer: the cheaper of the two tile shapes under the cost model (igemm_common.h); the
 // 256-pixel tile gets a 3 % bonus where both fill the chip (weights shared by twice the pixels).
@@ -340,9 +365,8 @@ int conv3x3_halo_choice(const KParams& p) { return plan_halo(p).tile; }   // 0 =
 int launch_conv3x3_halo(KParams& p, hipStream_t stream) {
     const HaloPlan hp = plan_halo(p);
     p.splits = hp.splits;
-    if (hp.tile == 256) { const Geo g = geometry(p, 256); return g_glds ? launch_wm<4, true>(p, g, stream) : launch_wm<4, false>(p, g, stream); }
-    const Geo g = geometry(p, 128);
-    return g_glds ? launch_wm<2, true>(p, g, stream) : launch_wm<2, false>(p, g, stream);
+    if (hp.tile == 256) return g_glds ? launch_wm<4, true>(p, stream) : launch_wm<4, false>(p, stream);
+    return g_glds ? launch_wm<2, true>(p, stream) : launch_wm<2, false>(p, stream);
 }
 
 }  // namespace igemm

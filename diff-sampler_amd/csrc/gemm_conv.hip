@@ -257,6 +257,7 @@ extern "C" int ds_debug_force_generic_conv(int v) {
     g_force_generic = (v == 1);
     conv3x3_halo_set_tile((v == 128 || v == 256) ? v : 0);
     conv3x3_halo_set_glds(v == 2 ? 0 : 1);           // v = 2: halo kernel with register-staged weights
+    conv3x3_halo_set_tail64(v == 4 ? 0 : 1);         // v = 4: no 64-column tail tiles (A/B measurements)
     return DS_OK;
 }
 

@@ -20,6 +20,7 @@ struct KParams {
     const float* b; int ldb; long long b_bs, b_hs; int nrows_b;   // rows of B that may be read
     int M, N, K;
     int mtiles, ntiles;
+    int n_begin;                   // first output column of this launch (halo kernel: the 64-column tail launch)
     // halo kernel geometry: a 128-pixel M tile = nimg image slots x TH rows x W columns
     int TH, nimg, HP, WP, NP;      // HP = TH + 2, WP = W + 2, NP = nimg * HP * WP halo pixels
     // fused input normalisation of the 3x3 sources: planes [n][3][c0+c1] = {mu, A, B}; in = act((x - mu) * A + B)
@@ -212,5 +213,6 @@ int launch_conv3x3_halo(KParams& p, hipStream_t stream);
 int conv3x3_halo_choice(const KParams& p);   // 0 / 128 / 256: which halo tile shape the launcher picks
 void conv3x3_halo_set_tile(int tile);     // 0 = heuristic, 128 / 256 = forced M tile (benchmarks)
 void conv3x3_halo_set_glds(int on);       // weight staging by LDS-DMA (default) or through registers
+void conv3x3_halo_set_tail64(int on);     // 64-column tiles for the ragged last column tile (default on)
 
 }  // namespace igemm
