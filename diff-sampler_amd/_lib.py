@@ -27,7 +27,7 @@ class ConvArgs(C.Structure):
                 ('norm_coefs', vp), ('norm_act', C.c_int),
                 ('e0', vp), ('e1', vp), ('ec0', C.c_int), ('ec1', C.c_int), ('eld0', C.c_int), ('eld1', C.c_int),
                 ('stride', C.c_int), ('workspace', vp), ('workspace_floats', C.c_longlong),
-                ('out_nchw', C.c_int)]
+                ('out_nchw', C.c_int), ('stats_out', vp)]
 
 
 class GemmArgs(C.Structure):
@@ -51,6 +51,12 @@ class AttnArgs(C.Structure):
                 ('ldo', C.c_int), ('q_bs', C.c_longlong), ('k_bs', C.c_longlong), ('v_bs', C.c_longlong),
                 ('o_bs', C.c_longlong), ('batch', C.c_int), ('heads', C.c_int), ('sq', C.c_int), ('skv', C.c_int),
                 ('d', C.c_int), ('scale', C.c_float)]
+
+
+class GnFinalizeArgs(C.Structure):
+    _fields_ = [('stats0', vp), ('stats1', vp), ('c0', C.c_int), ('c1', C.c_int), ('n', C.c_int), ('hw', C.c_int),
+                ('groups', C.c_int), ('eps', C.c_float), ('gamma', vp), ('beta', vp), ('scale', vp), ('shift', vp),
+                ('ss_ld', C.c_int), ('ss_rows', C.c_int), ('mean', vp), ('rstd', vp), ('coefs', vp)]
 
 
 class UpdateArgs(C.Structure):
@@ -83,6 +89,7 @@ _SIGNATURES = {
     'ds_gemm_nt_batched': (C.c_int, [C.POINTER(GemmArgs), vp]),
     'ds_gn_stats': (C.c_int, [C.POINTER(NormArgs), vp]),
     'ds_norm_act': (C.c_int, [C.POINTER(NormArgs), vp]),
+    'ds_gn_finalize': (C.c_int, [C.POINTER(GnFinalizeArgs), vp]),
     'ds_softmax_rows': (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp]),
     'ds_attention': (C.c_int, [C.POINTER(AttnArgs), vp]),
     'ds_attention_supported': (C.c_int, [C.c_int]),

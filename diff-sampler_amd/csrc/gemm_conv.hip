@@ -239,11 +239,37 @@ int g_force_generic = 0;
 
 int g_force_splits = 0;
 
+namespace {
+// Column statistics of a finished output tensor in the epilogue's partial format (split-K layers: their epilogue runs in
+// splitk_reduce_kernel, element-wise).  grid = (row blocks of 64, column chunks of 64); thread = (column, 16-row group).
+__global__ void __launch_bounds__(256) colstats_kernel(const KParams p) {
+    __shared__ float sh[2][4][64];
+    const int rb = blockIdx.x, cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.y * 64 + cl;
+    float s = 0.f, q = 0.f;
+    if (col < p.N) {
+        const int r0 = rb * 64 + rg * 16, r1 = min(r0 + 16, p.M);
+#pragma unroll 4
+        for (int r = r0; r < r1; ++r) { const float v = p.out[(size_t)r * p.ldo + col]; s += v; q += v * v; }
+    }
+    sh[0][rg][cl] = s; sh[1][rg][cl] = q;
+    __syncthreads();
+    if (rg == 0 && col < p.N) {
+        p.stats[((size_t)rb * 2) * p.N + col] = (sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]);
+        p.stats[((size_t)rb * 2 + 1) * p.N + col] = (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]);
+    }
+}
+}  // namespace
+
 int launch_splitk_reduce(const KParams& p, hipStream_t stream) {
     long long blocks = ((long long)p.M * ((p.N + 3) / 4) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
     DS_CHECK_LAUNCH();
+    if (p.stats) {
+        hipLaunchKernelGGL(colstats_kernel, dim3((p.M + 63) / 64, (p.N + 63) / 64), dim3(256), 0, stream, p);
+        DS_CHECK_LAUNCH();
+    }
     return DS_OK;
 }
 
@@ -299,6 +325,11 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     p.res = a->res; p.res_ld = a->res_ld;
     p.scale = a->out_scale; p.act = a->act; p.heads = 1;
     p.vec_ok = vec_epilogue_ok(p) ? 1 : 0;
+    p.stats = nullptr;
+    if (a->stats_out) {
+        if ((a->cout & 63) || !p.vec_ok || a->out_nchw || !ds_aligned16(a->stats_out)) return DS_E_ARG;
+        p.stats = a->stats_out;
+    }
     p.out_planar = 0;
     if (a->out_nchw) {
         if (a->cout >= 64) return DS_E_ARG;
@@ -348,7 +379,7 @@ extern "C" int ds_gemm_nt_batched(const ds_gemm_args* a, void* stream) {
     p.stride = 1; p.IH = p.IW = 1;
     p.colbias = a->colbias; p.rowbias = a->rowbias; p.cbias = nullptr; p.res = nullptr;
     p.scale = a->alpha; p.act = a->act; p.heads = a->heads;
-    p.vec_ok = vec_epilogue_ok(p) ? 1 : 0; p.out_planar = 0;
+    p.vec_ok = vec_epilogue_ok(p) ? 1 : 0; p.out_planar = 0; p.stats = nullptr;
     p.splits = 1; p.part = nullptr; p.part_cap = 0; p.vec_part = 0;
     return launch<1>(p, a->batch * a->heads, (hipStream_t)stream);
 }

@@ -35,6 +35,9 @@ struct KParams {
     float scale; int act; int heads;
     int vec_ok;                                                    // float4 epilogue allowed (alignment, ld % 4)
     int out_planar;                                                // scalar epilogue writes out[(img * N + col) * HW + pixel]
+    // optional per-(64-row block, column) sums of the OUTPUT for the consumer's GroupNorm: stats[(rb * 2 + {0: sum, 1: sum of
+    // squares}) * N + col], rb = row / 64 (vector epilogue only: N % 64 == 0)
+    float* stats;
     // split-K (small-M layers): blockIdx.y = split; each split contracts a contiguous range of K slabs / tiles and writes
     // its raw partial tile to part[split][M][N]; splitk_reduce_kernel sums them and applies the epilogue
     int splits; float* part; int vec_part; long long part_cap;     // part_cap: workspace capacity in floats (host side only)
@@ -58,6 +61,7 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
         const int col = wn0 + c4;
         f32x4 cb = {0.f, 0.f, 0.f, 0.f};
         if (p.colbias) cb = *reinterpret_cast<const f32x4*>(p.colbias + col);
+        f32x4 st_s = {0.f, 0.f, 0.f, 0.f}, st_q = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int half = 0; half < (HALF ? 2 : 1); ++half) {
 #pragma unroll
@@ -89,6 +93,20 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
                     for (int q = 0; q < 4; ++q) v[q] = ds_silu(v[q]);
                 }
                 *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col) = v;
+                st_s += v; st_q += v * v;
+            }
+        }
+        if (p.stats && wm0 < p.M) {
+            // column sums of this wave's 64 rows: the 4 lane groups (lane >> 4) hold disjoint rows of the same 4 columns
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                st_s[q] += __shfl_xor(st_s[q], 16); st_s[q] += __shfl_xor(st_s[q], 32);
+                st_q[q] += __shfl_xor(st_q[q], 16); st_q[q] += __shfl_xor(st_q[q], 32);
+            }
+            if (lane < 16) {
+                float* sp = p.stats + (size_t)(wm0 >> 6) * 2 * p.N + col;
+                *reinterpret_cast<f32x4*>(sp) = st_s;
+                *reinterpret_cast<f32x4*>(sp + p.N) = st_q;
             }
         }
         return;
@@ -157,7 +175,7 @@ __device__ __forceinline__ KParams split_params(const KParams& p, int split) {
     KParams q = p;
     q.out = p.part + (size_t)split * p.M * p.N; q.ldo = p.N;
     q.colbias = nullptr; q.rowbias = nullptr; q.cbias = nullptr; q.res = nullptr; q.scale = 1.f; q.act = DS_ACT_NONE;
-    q.vec_ok = p.vec_part; q.out_planar = 0;
+    q.vec_ok = p.vec_part; q.out_planar = 0; q.stats = nullptr;
     return q;
 }
 
@@ -201,7 +219,7 @@ inline int choose_splits(long long blocks, bool big_tile, int units, int tiles_p
     if (cost_out) *cost_out = best_c;
     return best;
 }
-int launch_splitk_reduce(const KParams& p, hipStream_t stream);   // gemm_conv.hip
+int launch_splitk_reduce(const KParams& p, hipStream_t stream);   // gemm_conv.hip (also fills p.stats when requested)
 
 // gemm256.hip
 bool gemm256_applicable(const KParams& p);

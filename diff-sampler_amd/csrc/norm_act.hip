@@ -308,6 +308,34 @@ __global__ void __launch_bounds__(256) geglu_kernel(const float* __restrict__ x,
     }
 }
 
+// GroupNorm statistics from the convolutions' epilogue partial sums: one block per image; thread = channel (strided);
+// per-channel sums over the image's HW / 64 row blocks in fp64, merged into the groups through LDS atomics, then the same
+// finalisation as gn_stats_kernel.
+__global__ void __launch_bounds__(256) gn_from_partials_kernel(const ds_gn_finalize_args f) {
+    __shared__ double s_sum[64];
+    __shared__ double s_sq[64];
+    const int tid = threadIdx.x, n = blockIdx.x;
+    if (tid < 64) { s_sum[tid] = 0.0; s_sq[tid] = 0.0; }
+    __syncthreads();
+    const int C = f.c0 + f.c1;
+    const int cpg = C / f.groups;
+    const int nrb = f.hw >> 6;
+    for (int c = tid; c < C; c += blockDim.x) {
+        const bool first = c < f.c0;
+        const float* sp = first ? f.stats0 : f.stats1;
+        const int cs = first ? f.c0 : f.c1, cc = first ? c : c - f.c0;
+        const float* base = sp + ((size_t)n * nrb * 2) * cs + cc;
+        double s = 0.0, q = 0.0;
+        for (int rb = 0; rb < nrb; ++rb) { s += (double)base[(size_t)rb * 2 * cs]; q += (double)base[((size_t)rb * 2 + 1) * cs]; }
+        atomicAdd(&s_sum[c / cpg], s); atomicAdd(&s_sq[c / cpg], q);
+    }
+    __syncthreads();
+    ds_norm_args a{};
+    a.c0 = f.c0; a.c1 = f.c1; a.h = f.hw; a.w = 1; a.groups = f.groups; a.eps = f.eps; a.mean = f.mean; a.rstd = f.rstd;
+    a.gamma = f.gamma; a.beta = f.beta; a.scale = f.scale; a.shift = f.shift; a.ss_ld = f.ss_ld; a.ss_rows = f.ss_rows; a.coefs = f.coefs;
+    gn_finalize(a, s_sum, s_sq);
+}
+
 int norm_geometry(const ds_norm_args* a, int* CQ, int* PL) {
     const int C = a->c0 + a->c1;
     if (C <= 0 || (C & 3) || (a->c0 & 3)) return DS_E_SHAPE;
@@ -438,6 +466,17 @@ extern "C" int ds_geglu(const float* x, int ldx, float* y, int ldy, long long ro
     long long blocks = (rows * (inner / 4) + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(geglu_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, inner / 4);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+extern "C" int ds_gn_finalize(const ds_gn_finalize_args* a, void* stream) {
+    (void)hipGetLastError();
+    if (!a || !a->stats0 || !a->mean || !a->rstd || a->c0 <= 0 || a->c1 < 0 || (a->c1 && !a->stats1)) return DS_E_ARG;
+    if (a->n <= 0 || a->hw <= 0 || (a->hw & 63)) return DS_E_SHAPE;
+    if (a->groups <= 0 || a->groups > 64 || (a->c0 + a->c1) % a->groups) return DS_E_SHAPE;
+    if ((a->scale == nullptr) != (a->shift == nullptr)) return DS_E_ARG;
+    hipLaunchKernelGGL(gn_from_partials_kernel, dim3(a->n), dim3(256), 0, (hipStream_t)stream, *a);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }

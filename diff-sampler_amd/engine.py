@@ -24,7 +24,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _lib, arch
-from ._lib import (AttnArgs, ConvArgs, GemmArgs, NormArgs, DS_ACT_NONE, DS_ACT_SILU, DS_RESAMPLE_NONE, DS_RESAMPLE_DOWN,
+from ._lib import (AttnArgs, ConvArgs, GemmArgs, GnFinalizeArgs, NormArgs, DS_ACT_NONE, DS_ACT_SILU, DS_RESAMPLE_NONE, DS_RESAMPLE_DOWN,
                    DS_RESAMPLE_UP)
 from .ops import pack_conv_weight, pack_linear_weight, pack_stem_weight
 
@@ -159,6 +159,7 @@ class UNetEngine:
         gn_partial = torch.empty(B * _lib.DS_GN_MAX_CHUNKS * 128, dtype=torch.float64, device=dev)   # multi-workgroup GroupNorm
         gn_counters = torch.zeros(B, dtype=torch.int32, device=dev)                                  # statistics at small batch
         P.keep += [gn_partial, gn_counters]
+        stats_of: Dict[int, tuple] = {}               # data_ptr of an activation -> (epilogue column-sum buffer, channels)
         splitk_ws = new(SPLITK_WORKSPACE_FLOATS)      # scratch of the split-K path (under-filled layers at small batch)
 
         def add(fn, args, name, keep=()):
@@ -166,12 +167,18 @@ class UNetEngine:
 
         def conv(x0, c0, ld0, n, h, wd, wgt, cout, out, out_ld, taps, name, x1=None, c1=0, ld1=0, bias=None, cbias=None,
                  cbias_ld=0, cbias_rows=1, res=None, res_ld=0, scale=1.0, act_=DS_ACT_NONE, norm_coefs=None, norm_act=DS_ACT_NONE,
-                 e0=None, ec0=0, e1=None, ec1=0, out_nchw=0):
+                 e0=None, ec0=0, e1=None, ec1=0, out_nchw=0, stats=False):
             a = ConvArgs(_ptr(x0), _ptr(x1), c0, c1, ld0, ld1, n, h, wd, taps, _ptr(wgt), cout, _ptr(bias), _ptr(cbias),
                          cbias_ld, cbias_rows, _ptr(res), res_ld, scale, act_, _ptr(out), out_ld, _ptr(norm_coefs), norm_act,
                          _ptr(e0), _ptr(e1), ec0, ec1, ec0, ec1)
             a.workspace, a.workspace_floats = _ptr(splitk_ws), splitk_ws.numel()
             a.out_nchw = out_nchw
+            stats_of.pop(out.data_ptr(), None)
+            if stats and cout % 64 == 0 and out_ld == cout:
+                # the epilogue leaves the output's per-(64-row block, channel) sums for the consumer's GroupNorm
+                sb = new(-(-(n * h * wd) // 64) * 2 * cout)
+                a.stats_out = _ptr(sb)
+                stats_of[out.data_ptr()] = (sb, cout)
             add(lib.ds_conv2d_nhwc, (C.byref(a),), name, keep=(a,))
 
         def norm(kind, x0, c0, ld0, n, h, wd, name, x1=None, c1=0, ld1=0, groups=1, eps=1e-5, use_stats=True, gamma=None,
@@ -180,6 +187,15 @@ class UNetEngine:
             a = NormArgs(_ptr(x0), _ptr(x1), c0, c1, ld0, ld1, n, h, wd, groups, eps,
                          _ptr(mean) if use_stats else None, _ptr(rstd) if use_stats else None, _ptr(gamma), _ptr(beta),
                          _ptr(scale), _ptr(shift), ss_ld, ss_rows, act_, resample, _ptr(out), out_ld, _ptr(coefs))
+            if kind == 'stats':
+                s0 = stats_of.get(x0.data_ptr())
+                s1 = stats_of.get(x1.data_ptr()) if x1 is not None else None
+                if s0 is not None and s0[1] == c0 == ld0 and (x1 is None or (s1 is not None and s1[1] == c1 == ld1)) and (h * wd) % 64 == 0:
+                    # statistics already produced by the convolutions that wrote these tensors: only finalise them
+                    f = GnFinalizeArgs(_ptr(s0[0]), _ptr(s1[0]) if s1 else None, c0, c1, n, h * wd, groups, eps, _ptr(gamma), _ptr(beta),
+                                       _ptr(scale), _ptr(shift), ss_ld, ss_rows, _ptr(mean), _ptr(rstd), _ptr(coefs))
+                    add(lib.ds_gn_finalize, (C.byref(f),), name + '.finalize', keep=(f,))
+                    return
             if kind == 'stats' and n < 256:
                 a.partial, a.counters = _ptr(gn_partial), _ptr(gn_counters)
             add(lib.ds_gn_stats if kind == 'stats' else lib.ds_norm_act, (C.byref(a),), name, keep=(a,))
@@ -226,7 +242,7 @@ class UNetEngine:
                 add(lib.ds_stem_im2col, (_ptr(bufs['x']), _ptr(bufs['sigma']), Bs, spec.sigma_data, B, spec.in_channels, R, R,
                                          _ptr(act), kpad), 'stem_im2col')
                 out = new(M, b.cout)
-                conv(act, kpad, kpad, B, R, R, w[f'{b.name}.w'], b.cout, out, b.cout, 1, b.name, bias=w[f'{b.name}.b'])
+                conv(act, kpad, kpad, B, R, R, w[f'{b.name}.w'], b.cout, out, b.cout, 1, b.name, bias=w[f'{b.name}.b'], stats=True)
                 x_cur = (out, b.cout)
                 skips.append(x_cur)
                 bufs[b.name] = out
@@ -249,12 +265,12 @@ class UNetEngine:
                 norm('stats', x0, c0, c0, n, Hin, Hin, nm + '.norm0.stats', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps,
                      gamma=w[f'{nm}.norm0.g'], beta=w[f'{nm}.norm0.b'], coefs=ncoef)
                 conv(x0, c0, c0, n, Ho, Ho, w[f'{nm}.conv0.w'], cout, hbuf, cout, 9, nm + '.conv0', x1=x1, c1=c1, ld1=c1,
-                     bias=w[f'{nm}.conv0.b'], norm_coefs=ncoef, norm_act=DS_ACT_SILU, **cb)
+                     bias=w[f'{nm}.conv0.b'], norm_coefs=ncoef, norm_act=DS_ACT_SILU, stats=True, **cb)
             else:
                 norm('stats', x0, c0, c0, n, Hin, Hin, nm + '.norm0.stats', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps)
                 norm('apply', x0, c0, c0, n, Hin, Hin, nm + '.norm0', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps,
                      gamma=w[f'{nm}.norm0.g'], beta=w[f'{nm}.norm0.b'], act_=DS_ACT_SILU, resample=rs, out=act, out_ld=cin)
-                conv(act, cin, cin, n, Ho, Ho, w[f'{nm}.conv0.w'], cout, hbuf, cout, 9, nm + '.conv0', bias=w[f'{nm}.conv0.b'], **cb)
+                conv(act, cin, cin, n, Ho, Ho, w[f'{nm}.conv0.w'], cout, hbuf, cout, 9, nm + '.conv0', bias=w[f'{nm}.conv0.b'], stats=True, **cb)
             # norm1 (+adaptive scale/shift) + silu
             ss = dict(scale=aff[:, aoff:], shift=aff[:, aoff + cout:], ss_ld=self.aff_total, ss_rows=Bs) if b.adaptive_scale else {}
             if fuse:
@@ -290,7 +306,7 @@ class UNetEngine:
             if b.heads:
                 mid = out
                 out2 = None
-            conv(c1_in, cout, cout, n, Ho, Ho, c1_w, cout, out, cout, 9, nm + '.conv1', bias=c1_b, scale=b.skip_scale,
+            conv(c1_in, cout, cout, n, Ho, Ho, c1_w, cout, out, cout, 9, nm + '.conv1', bias=c1_b, scale=b.skip_scale, stats=True,
                  **c1_norm, **c1_skip)
             if b.heads:
                 S = Ho * Ho
@@ -312,7 +328,7 @@ class UNetEngine:
                     out2 = dec_pp[dec_i]
                     dec_i ^= 1
                 conv(ao, cout, cout, n, Ho, Ho, w[f'{nm}.proj.w'], cout, out2, cout, 1, nm + '.proj', bias=w[f'{nm}.proj.b'],
-                     res=out, res_ld=cout, scale=b.skip_scale)
+                     res=out, res_ld=cout, scale=b.skip_scale, stats=True)
                 out = out2
             x_cur = (out, cout)
             bufs[nm] = out

@@ -129,13 +129,13 @@ class LDMUNetEngine:
                 bd.norm('stats', x0, c0, c0, N, side, side, name + '.gn.stats', x1=x1, c1=c1, ld1=c1, groups=32, eps=eps, gamma=gk,
                         beta=bk, coefs=ncoef)
                 bd.conv(x0, c0, c0, N, side, side, wgt, cout, out, out_ld, 9, name, x1=x1, c1=c1, ld1=c1, bias=bias, norm_coefs=ncoef,
-                        norm_act=DS_ACT_SILU, **kw)
+                        norm_act=DS_ACT_SILU, stats=True, **kw)
             else:
                 tmp = new(N * side * side, cin)
                 bd.norm('stats', x0, c0, c0, N, side, side, name + '.gn.stats', x1=x1, c1=c1, ld1=c1, groups=32, eps=eps)
                 bd.norm('apply', x0, c0, c0, N, side, side, name + '.gn', x1=x1, c1=c1, ld1=c1, groups=32, eps=eps, gamma=gk, beta=bk,
                         act=DS_ACT_SILU, out=tmp, out_ld=cin)
-                bd.conv(tmp, cin, cin, N, side, side, wgt, cout, out, out_ld, 9, name, bias=bias, **kw)
+                bd.conv(tmp, cin, cin, N, side, side, wgt, cout, out, out_ld, 9, name, bias=bias, stats=True, **kw)
 
         def res_layer(l, x0, c0, x1, c1):
             p, res, cout = l.key, l.res_out, l.cout
@@ -186,7 +186,8 @@ class LDMUNetEngine:
             bd.geglu(ff, 8 * c, gg, 4 * c, M, 4 * c, p + '.ff.geglu')
             bd.linear(gg, 4 * c, M, w[f'{p}.ff2.w'], c, t3, p + '.ff.out', bias=w[f'{p}.ff2.b'], res=t2, res_ld=c)
             out = new(M, c)
-            bd.conv(t3, c, c, N, res, res, w[f'{p}.po.w'], c, out, c, 1, p + '.proj_out', bias=w[f'{p}.po.b'], res=x_in, res_ld=c)
+            bd.conv(t3, c, c, N, res, res, w[f'{p}.po.w'], c, out, c, 1, p + '.proj_out', bias=w[f'{p}.po.b'], res=x_in, res_ld=c,
+                    stats=True)
             return out, c
 
         cur = None
@@ -203,7 +204,7 @@ class LDMUNetEngine:
                     bd.add(lib.ds_stem_im2col, (ptr(bufs['x']), ptr(bufs['sigma']), emb_rows, 1.0, N, Cin, R, R, ptr(col), kpad),
                            'stem_im2col')      # c_in = 1/sqrt(sigma^2 + 1): EDM's c_in with sigma_data = 1
                     out = new(N * R * R, l.cout)
-                    bd.conv(col, kpad, kpad, N, R, R, w[f'{p}.w'], l.cout, out, l.cout, 1, p, bias=w[f'{p}.b'])
+                    bd.conv(col, kpad, kpad, N, R, R, w[f'{p}.w'], l.cout, out, l.cout, 1, p, bias=w[f'{p}.b'], stats=True)
                     cur = (out, l.cout)
                 elif l.kind == 'res':
                     cur = res_layer(l, cur[0], cur[1], x1, c1)
@@ -213,14 +214,15 @@ class LDMUNetEngine:
                 elif l.kind == 'down':
                     out = new(N * l.res_out ** 2, l.cout)
                     bd.conv(cur[0], l.cin, l.cin, N, l.res_out, l.res_out, w[f'{p}.w'], l.cout, out, l.cout, 9, p + '.op',
-                            bias=w[f'{p}.b'], stride=2)
+                            bias=w[f'{p}.b'], stride=2, stats=True)
                     cur = (out, l.cout)
                 elif l.kind == 'up':
                     up = new(N * l.res_out ** 2, l.cin)
                     bd.norm('apply', cur[0], l.cin, l.cin, N, l.res_in, l.res_in, p + '.nearest', use_stats=False,
                             resample=DS_RESAMPLE_UP, out=up, out_ld=l.cin)
                     out = new(N * l.res_out ** 2, l.cout)
-                    bd.conv(up, l.cin, l.cin, N, l.res_out, l.res_out, w[f'{p}.w'], l.cout, out, l.cout, 9, p + '.conv', bias=w[f'{p}.b'])
+                    bd.conv(up, l.cin, l.cin, N, l.res_out, l.res_out, w[f'{p}.w'], l.cout, out, l.cout, 9, p + '.conv', bias=w[f'{p}.b'],
+                            stats=True)
                     cur = (out, l.cout)
                 bufs[p] = cur[0]
             if b.pushes_skip:

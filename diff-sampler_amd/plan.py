@@ -12,7 +12,7 @@ from typing import Dict, List
 import torch
 
 from . import _lib
-from ._lib import AttnArgs, ConvArgs, GemmArgs, NormArgs, DS_ACT_NONE, DS_RESAMPLE_NONE
+from ._lib import AttnArgs, ConvArgs, GemmArgs, GnFinalizeArgs, NormArgs, DS_ACT_NONE, DS_RESAMPLE_NONE
 
 
 SPLITK_WORKSPACE_FLOATS = 64 << 20      # 256 MiB per plan
@@ -50,6 +50,7 @@ class Builder:
         self.lib = _lib.load()
         self.mean = self.rstd = None
         self.gn_partial = self.gn_counters = None
+        self.stats_of: Dict[int, tuple] = {}   # data_ptr of an activation tensor -> (epilogue column-sum buffer, channels)
         self.ws = None                      # split-K scratch shared by every convolution of the plan (launches are serial)
 
     def new(self, *shape, zero=False):
@@ -64,13 +65,20 @@ class Builder:
 
     def conv(self, x0, c0, ld0, n, h, w, wgt, cout, out, out_ld, taps, name, x1=None, c1=0, ld1=0, bias=None, cbias=None,
              cbias_ld=0, cbias_rows=1, res=None, res_ld=0, scale=1.0, act=DS_ACT_NONE, norm_coefs=None, norm_act=DS_ACT_NONE,
-             e0=None, ec0=0, e1=None, ec1=0, stride=1):
+             e0=None, ec0=0, e1=None, ec1=0, stride=1, stats=False):
+        """stats=True: the epilogue also leaves the output's per-(64-row block, channel) sums for the consumer's GroupNorm
+        (honoured when cout % 64 == 0; otherwise the consumer falls back to a ds_gn_stats pass)."""
         a = ConvArgs(ptr(x0), ptr(x1), c0, c1, ld0, ld1, n, h, w, taps, ptr(wgt), cout, ptr(bias), ptr(cbias), cbias_ld,
                      cbias_rows, ptr(res), res_ld, scale, act, ptr(out), out_ld, ptr(norm_coefs), norm_act, ptr(e0), ptr(e1),
                      ec0, ec1, ec0, ec1, stride)
         if self.ws is None:
             self.ws = self.new(SPLITK_WORKSPACE_FLOATS)
         a.workspace, a.workspace_floats = ptr(self.ws), self.ws.numel()
+        self.stats_of.pop(out.data_ptr(), None)
+        if stats and cout % 64 == 0 and out_ld == cout:
+            sb = self.new(-(-(n * h * w) // 64) * 2 * cout)
+            a.stats_out = ptr(sb)
+            self.stats_of[out.data_ptr()] = (sb, cout)
         self.add(self.lib.ds_conv2d_nhwc, (C.byref(a),), name, keep=(a,))
 
     def linear(self, x, k, rows, wgt, cout, out, name, ldx=None, out_ld=None, **kw):
@@ -82,6 +90,15 @@ class Builder:
              out_ld=0, coefs=None):
         if use_stats and (self.mean is None or self.mean.numel() < n * 64):
             self.mean, self.rstd = self.new(n * 64), self.new(n * 64)
+        if kind == 'stats':
+            # statistics already left behind by the producing convolutions' epilogues?  Then only finalise them.
+            s0 = self.stats_of.get(x0.data_ptr())
+            s1 = self.stats_of.get(x1.data_ptr()) if x1 is not None else None
+            if s0 is not None and s0[1] == c0 == ld0 and (x1 is None or (s1 is not None and s1[1] == c1 == ld1)) and (h * w) % 64 == 0:
+                f = GnFinalizeArgs(ptr(s0[0]), ptr(s1[0]) if s1 else None, c0, c1, n, h * w, groups, eps, ptr(gamma), ptr(beta),
+                                   ptr(scale), ptr(shift), ss_ld, ss_rows, ptr(self.mean), ptr(self.rstd), ptr(coefs))
+                self.add(self.lib.ds_gn_finalize, (C.byref(f),), name + '.finalize', keep=(f,))
+                return
         a = NormArgs(ptr(x0), ptr(x1), c0, c1, ld0, ld1, n, h, w, groups, eps, ptr(self.mean) if use_stats else None,
                      ptr(self.rstd) if use_stats else None, ptr(gamma), ptr(beta), ptr(scale), ptr(shift), ss_ld, ss_rows, act,
                      resample, ptr(out), out_ld, ptr(coefs))

@@ -89,6 +89,11 @@ typedef struct ds_conv_args {
      * 3-channel network output F so that the solver update reads 12 B per pixel, not a row padded to 16 B.  Only for
      * cout < 64 (the scalar epilogue); out_ld is ignored. */
     int out_nchw;
+    /* Optional: column statistics of the OUTPUT for the consumer's GroupNorm, produced by the epilogue while the tile is
+     * still in registers (replaces a ds_gn_stats pass over the tensor): stats_out[(rb * 2 + k) * cout + co] = sum (k = 0) /
+     * sum of squares (k = 1) of out[rb * 64 .. rb * 64 + 63][co]; ceil(n*h*w / 64) * 2 * cout floats, consumed by
+     * ds_gn_finalize.  Requires cout % 64 == 0 and the aligned (float4) epilogue; NULL = not needed. */
+    float* stats_out;
 } ds_conv_args;
 
 int ds_conv2d_nhwc(const ds_conv_args* a, void* stream);
@@ -154,6 +159,19 @@ typedef struct ds_norm_args {
 
 #define DS_GN_MAX_CHUNKS 32
 int ds_gn_stats(const ds_norm_args* a, void* stream);
+
+/* GroupNorm statistics from the per-(64-row block, channel) sums the producing convolutions left behind
+ * (ds_conv_args.stats_out) instead of a pass over the activations: same outputs as ds_gn_stats (mean / rstd per (image,
+ * group) and, optionally, the {mu, A, B} coefficient planes) for the channel concatenation [source 0 | source 1].
+ * Requires h * w % 64 == 0 (an image is a whole number of 64-row blocks). */
+typedef struct ds_gn_finalize_args {
+    const float* stats0; const float* stats1;   /* partial sums of the two sources (stats1 NULL when c1 == 0)          */
+    int c0, c1;
+    int n, hw, groups; float eps;
+    const float* gamma; const float* beta; const float* scale; const float* shift; int ss_ld; int ss_rows;
+    float* mean; float* rstd; float* coefs;     /* as in ds_norm_args                                                   */
+} ds_gn_finalize_args;
+int ds_gn_finalize(const ds_gn_finalize_args* a, void* stream);
 int ds_norm_act(const ds_norm_args* a, void* stream);
 
 /* Row softmax, in place or out of place: y[r, :] = softmax(x[r, :cols]) (networks_edm.py:108). */

@@ -314,3 +314,45 @@ def test_conv_planar_output(B, H, cin, cout, ws):
     assert lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr()) == 0
     torch.cuda.synchronize()
     assert _rel(out.cpu(), F.conv2d(x, wt, bias, padding=1)) < TOL
+
+
+@pytest.mark.parametrize('B,H,cin,cout,taps,ws', [(3, 16, 64, 128, 9, False), (2, 8, 256, 320, 9, True), (2, 32, 32, 192, 9, False),
+                                                   (16, 32, 640, 1024, 1, False), (4, 8, 64, 64, 1, False), (2, 64, 32, 64, 9, False)])
+def test_conv_epilogue_statistics_feed_groupnorm(B, H, cin, cout, taps, ws):
+    """stats_out + ds_gn_finalize reproduce ds_gn_stats / F.group_norm statistics of the convolution's output (128- and
+    64-column halo tiles, the split-K reduce path, the generic and the large-tile 1x1 kernels)."""
+    import ctypes as C
+    from diff_sampler_amd import _lib, ops
+    g = torch.Generator().manual_seed(B * 11 + H + cout)
+    k = 3 if taps == 9 else 1
+    x = torch.randn(B, cin, H, H, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (taps * cin) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    xn, wp, bd = _nhwc(x).cuda(), ops.pack_conv_weight(wt).cuda(), bias.cuda()
+    M = B * H * H
+    out = torch.empty(M, cout, device='cuda')
+    stats = torch.full((-(-M // 64) * 2 * cout,), float('nan'), device='cuda')
+    a = _lib.ConvArgs(xn.data_ptr(), None, cin, 0, cin, 0, B, H, H, taps, wp.data_ptr(), cout, bd.data_ptr(), None, 0, 1, None, 0, 1.0, 0,
+                      out.data_ptr(), cout)
+    a.stats_out = stats.data_ptr()
+    if ws:
+        scratch = torch.empty(8 << 20, device='cuda')
+        a.workspace, a.workspace_floats = scratch.data_ptr(), scratch.numel()
+    lib = _lib.load()
+    assert lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr()) == 0
+    G_ = 32
+    mean, rstd = torch.empty(B * G_, device='cuda'), torch.empty(B * G_, device='cuda')
+    coefs = torch.empty(B * 3 * cout, device='cuda')
+    gamma, beta = (1 + 0.1 * torch.randn(cout, generator=g)).cuda(), (0.1 * torch.randn(cout, generator=g)).cuda()
+    f = _lib.GnFinalizeArgs(stats.data_ptr(), None, cout, 0, B, H * H, G_, 1e-5, gamma.data_ptr(), beta.data_ptr(), None, None, 0, 1,
+                            mean.data_ptr(), rstd.data_ptr(), coefs.data_ptr())
+    assert lib.ds_gn_finalize(C.byref(f), _lib.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    ref = F.conv2d(x, wt, bias, padding=k // 2)
+    assert _rel(out.cpu(), _nhwc(ref)) < TOL
+    r = ref.reshape(B, G_, -1).double()
+    assert torch.allclose(mean.cpu(), r.mean(-1).float().reshape(-1), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(rstd.cpu(), (1.0 / (r.var(-1, unbiased=False) + 1e-5).sqrt()).float().reshape(-1), rtol=1e-4, atol=1e-5)
+    cf = coefs.cpu().reshape(B, 3, cout)
+    cpg = cout // G_
+    assert torch.allclose(cf[:, 1], (rstd.cpu().reshape(B, G_).repeat_interleave(cpg, 1) * gamma.cpu()), rtol=1e-5)
