@@ -19,9 +19,13 @@ namespace {
 
 template <int D>
 __global__ void __launch_bounds__(256) flash_attn_kernel(const ds_attn_args a) {
-    constexpr int DB = (D + 31) / 32;        // 32-row blocks of O^T
+    // A head size that leaves 8 channels beyond the last full 32-row block of O^T (d = 40: SD-1.5's 64x64 stage) would spend
+    // a whole MFMA block (16 MFMAs per key tile) on 8 useful rows; those VREM channels are accumulated by the vector ALU
+    // instead (16 keys x 8 channels = 128 FMAs per lane and tile, V read as LDS broadcasts), in the shadow of the MFMAs.
+    constexpr int VREM = (D > 32 && (D % 32) == 8) ? 8 : 0;
+    constexpr int DB = VREM ? D / 32 : (D + 31) / 32;        // 32-row blocks of O^T on the matrix pipe
     constexpr int KLD = D + 4;               // (D + 4) / 4 odd: conflict-free ds_read_b128 of 32 distinct rows
-    constexpr int VLD = DB * 32 + 8;         // rows 4 apart land 32 banks apart
+    constexpr int VLD = DB * 32 + 8;         // rows 4 apart land 32 banks apart (and room for the VREM channels)
     constexpr int NQ4 = D / 8;
     constexpr int D4 = D / 4;
     constexpr int NLD = (8 * D + 255) / 256;
@@ -54,6 +58,9 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(const ds_attn_args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
     float m = -1e30f, l = 0.f;
+    float oe[VREM ? VREM : 1];
+#pragma unroll
+    for (int j = 0; j < (VREM ? VREM : 1); ++j) oe[j] = 0.f;
 
     f32x4 kr[NLD], vr[NLD];
     auto gload = [&](int t) {
@@ -119,6 +126,18 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(const ds_attn_args a) {
         l = l * alpha + rs;
 #pragma unroll
         for (int i = 0; i < DB; ++i) ot[i] *= alpha;
+        if (VREM) {
+            const float* vrow = Vs + 4 * hb * VLD + DB * 32;
+#pragma unroll
+            for (int j = 0; j < VREM; ++j) oe[j] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(vrow + ((r & 3) + 8 * (r >> 2)) * VLD);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(vrow + ((r & 3) + 8 * (r >> 2)) * VLD + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { oe[j] += st[r] * v0[j]; oe[4 + j] += st[r] * v1[j]; }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < DB; ++i) {
             const float* vcol = Vs + 4 * hb * VLD + i * 32 + l31;
@@ -152,11 +171,25 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(const ds_attn_args a) {
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if (VREM) {
+        // the two lane halves hold the sums over their own keys: combine, normalise, 32 B per query row
+        f32x4 e0, e1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            e0[j] = (oe[j] + __shfl_xor(oe[j], 32)) * inv;
+            e1[j] = (oe[4 + j] + __shfl_xor(oe[4 + j], 32)) * inv;
+        }
+        if (hb == 0 && q0 + l31 < a.sq) {
+            float* dst = op + (size_t)(q0 + l31) * a.ldo + DB * 32;
+            *reinterpret_cast<f32x4*>(dst) = e0;
+            *reinterpret_cast<f32x4*>(dst + 4) = e1;
+        }
+    }
 }
 
 template <int D>
 int launch(const ds_attn_args* a, hipStream_t stream) {
-    constexpr int DB = (D + 31) / 32;
+    constexpr int DB = (D > 32 && (D % 32) == 8) ? D / 32 : (D + 31) / 32;
     constexpr int bytes = (32 * (D + 4) + 32 * (DB * 32 + 8) + 32 + 4 * 32 * 33) * (int)sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {

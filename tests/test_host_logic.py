@@ -159,3 +159,25 @@ def test_gits_dynamic_programme_matches_reference_golden():
     z = np.load(os.path.join(ROOT, 'tests', 'golden', 'gits.npz'))
     for ns, coeff in [(4, 1.0), (6, 1.15), (8, 0.85)]:
         assert gits_utils.dp(z['dp_cost'], ns, 12, coeff) == list(z[f'dp_{ns}_{coeff}'])
+
+
+def test_ldm_spec_matches_stable_diffusion_v15_inventory():
+    """The SD-1.5 layer list: parameter count and FLOPs of SURVEY.md section 8d (859.5 M parameters, 803.27 GFLOP per forward),
+    block counts of openaimodel.py's construction loop, and the CFG schedule end points."""
+    import numpy as np
+    import diff_sampler_amd.ldm_arch as la
+    spec = la.ldm_unet_spec(**la.NAMED_LDM_CONFIGS['sd15'])
+    n_params = sum(int(np.prod(shape)) for _, shape, _ in la.ldm_param_table(spec))
+    assert n_params == 859_520_964
+    assert abs(la.ldm_flops_per_image(spec) / 1e9 - 803.27) < 0.01
+    names = [b.name for b in spec.blocks]
+    assert names.count('middle_block') == 1
+    assert sum(n.startswith('input_blocks') for n in names) == 12 and sum(n.startswith('output_blocks') for n in names) == 12
+    kinds = [l.kind for b in spec.blocks for l in b.layers]
+    assert kinds.count('st') == 16 and kinds.count('res') == 22 and kinds.count('down') == 3 and kinds.count('up') == 3
+    keys = [k for k, _, _ in la.ldm_param_table(spec)]
+    assert len(keys) == len(set(keys)) == 686
+    ac = la.alphas_cumprod(spec)
+    assert ac.shape == (1000,) and abs(float(((1 - ac[-1]) / ac[-1]).sqrt()) - 14.6146) < 1e-3
+    with pytest.raises(NotImplementedError):
+        la.ldm_unet_spec(use_spatial_transformer=False)
