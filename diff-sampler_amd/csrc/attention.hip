@@ -4,7 +4,7 @@
 // :171-176 UNetBlock; ldm/modules/attention.py:168-194 CrossAttention) and the four launches + S x S score tensor of the
 // unfused path (Q K^T GEMM, row softmax, V^T GEMM, P V GEMM): the scores never leave the CU.
 //
-// Work split: block = 128 queries of one (image, head), 4 waves x 32 queries; K/V are streamed in tiles of 32 keys
+// Work split: block = 128 queries of one (image, head), 4 waves x 32 queries; K/V are streamed in tiles of 32 or 64 keys
 // through LDS (register-prefetched one tile ahead).  Everything is computed TRANSPOSED so that a query is a lane:
 //     S^T[key, q] = sum_d K[key, d] Q[q, d]              A operand = K tile (LDS, ds_read_b128), B = Q (registers)
 //     O^T[d,   q] += sum_key V[key, d] P^T[key, q]       A operand = V tile (LDS, ds_read_b32),  B = P^T (registers)
@@ -28,12 +28,17 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(const ds_attn_args a) {
     constexpr int VLD = DB * 32 + 8;         // rows 4 apart land 32 banks apart (and room for the VREM channels)
     constexpr int NQ4 = D / 8;
     constexpr int D4 = D / 4;
-    constexpr int NLD = (8 * D + 255) / 256;
     constexpr bool PREFETCH = D <= 96;       // larger heads: the O^T / Q registers leave no room for a staged tile
+    // 32-key blocks per K/V tile: 64-key tiles halve the barriers and the per-tile softmax bookkeeping (max / rescale) where
+    // the registers still allow two waves per SIMD (d = 64: 7.07 -> 6.85 ms on ImageNet-64; d = 40 with 64-key tiles needs
+    // 288 registers, drops to one wave per SIMD and loses 13 %)
+    constexpr int KB = (D <= 64 && VREM == 0) ? 2 : 1;
+    constexpr int KT = 32 * KB;
+    constexpr int NLD = (KT / 4 * D + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;
-    float* Vs = smem + 32 * KLD;
-    float* Es = smem + 32 * KLD + 32 * VLD + 32;   // epilogue transposition patches, 32 x 33 floats per wave
+    float* Vs = smem + KT * KLD;
+    float* Es = smem + KT * KLD + KT * VLD + 32;   // epilogue transposition patches, 32 x 33 floats per wave
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hb = lane >> 5, l31 = lane & 31;
@@ -67,9 +72,9 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(const ds_attn_args a) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             const int idx = tid + 256 * j;
-            if (NLD * 256 == 8 * D || idx < 8 * D) {
+            if (NLD * 256 == KT / 4 * D || idx < KT / 4 * D) {
                 const int row = idx / D4, c4 = idx - row * D4;
-                const int key = min(t * 32 + row, a.skv - 1);
+                const int key = min(t * KT + row, a.skv - 1);
                 kr[j] = *reinterpret_cast<const f32x4*>(kp + (size_t)key * a.ldk + c4 * 4);
                 vr[j] = *reinterpret_cast<const f32x4*>(vp + (size_t)key * a.ldv + c4 * 4);
             }
@@ -79,7 +84,7 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(const ds_attn_args a) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             const int idx = tid + 256 * j;
-            if (NLD * 256 == 8 * D || idx < 8 * D) {
+            if (NLD * 256 == KT / 4 * D || idx < KT / 4 * D) {
                 const int row = idx / D4, c4 = idx - row * D4;
                 *reinterpret_cast<f32x4*>(Ks + row * KLD + c4 * 4) = kr[j];
                 *reinterpret_cast<f32x4*>(Vs + row * VLD + c4 * 4) = vr[j];
@@ -87,7 +92,7 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(const ds_attn_args a) {
         }
     };
 
-    const int ntiles = (a.skv + 31) / 32;
+    const int ntiles = (a.skv + KT - 1) / KT;
     if (PREFETCH) gload(0);
     const float* kfrag = Ks + l31 * KLD + 4 * hb;
     for (int t = 0; t < ntiles; ++t) {
@@ -98,53 +103,67 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(const ds_attn_args a) {
         if (PREFETCH && t + 1 < ntiles) gload(t + 1);    // in flight during the MFMAs below
         if (!active) continue;
 
-        f32x16 st;
+        f32x16 st[KB];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+        for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
-        for (int ks = 0; ks < NQ4; ++ks) {
-            const f32x4 kv = *reinterpret_cast<const f32x4*>(kfrag + 8 * ks);
+            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[r], qf[ks][r], st, 0, 0, 0);
+            for (int ks = 0; ks < NQ4; ++ks) {
+                const f32x4 kv = *reinterpret_cast<const f32x4*>(kfrag + kb * 32 * KLD + 8 * ks);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[r], qf[ks][r], st[kb], 0, 0, 0);
+            }
         }
-        const int kbase = t * 32 + 4 * hb;
         if (t == ntiles - 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (kbase + (r & 3) + 8 * (r >> 2) >= a.skv) st[r] = -1e30f;
-        }
-        float mx = st[0];
+            for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
+                for (int r = 0; r < 16; ++r)
+                    if (t * KT + kb * 32 + 4 * hb + (r & 3) + 8 * (r >> 2) >= a.skv) st[kb][r] = -1e30f;
+        }
+        float mx = st[0][0];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float mn = fmaxf(m, mx);
         const float alpha = __builtin_amdgcn_exp2f(m - mn);
         m = mn;
         float rs = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { st[r] = __builtin_amdgcn_exp2f(st[r] - mn); rs += st[r]; }
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[kb][r] = __builtin_amdgcn_exp2f(st[kb][r] - mn); rs += st[kb][r]; }
         l = l * alpha + rs;
 #pragma unroll
         for (int i = 0; i < DB; ++i) ot[i] *= alpha;
         if (VREM) {
-            const float* vrow = Vs + 4 * hb * VLD + DB * 32;
 #pragma unroll
             for (int j = 0; j < VREM; ++j) oe[j] *= alpha;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(vrow + ((r & 3) + 8 * (r >> 2)) * VLD);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(vrow + ((r & 3) + 8 * (r >> 2)) * VLD + 4);
+            for (int kb = 0; kb < KB; ++kb) {
+                const float* vrow = Vs + (kb * 32 + 4 * hb) * VLD + DB * 32;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { oe[j] += st[r] * v0[j]; oe[4 + j] += st[r] * v1[j]; }
+                for (int r = 0; r < 16; ++r) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(vrow + ((r & 3) + 8 * (r >> 2)) * VLD);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(vrow + ((r & 3) + 8 * (r >> 2)) * VLD + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { oe[j] += st[kb][r] * v0[j]; oe[4 + j] += st[kb][r] * v1[j]; }
+                }
             }
         }
 #pragma unroll
         for (int i = 0; i < DB; ++i) {
-            const float* vcol = Vs + 4 * hb * VLD + i * 32 + l31;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float vv = vcol[((r & 3) + 8 * (r >> 2)) * VLD];
-                ot[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, st[r], ot[i], 0, 0, 0);
+            for (int kb = 0; kb < KB; ++kb) {
+                const float* vcol = Vs + (kb * 32 + 4 * hb) * VLD + i * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float vv = vcol[((r & 3) + 8 * (r >> 2)) * VLD];
+                    ot[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, st[kb][r], ot[i], 0, 0, 0);
+                }
             }
         }
     }
@@ -190,7 +209,8 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(const ds_attn_args a) {
 template <int D>
 int launch(const ds_attn_args* a, hipStream_t stream) {
     constexpr int DB = (D > 32 && (D % 32) == 8) ? D / 32 : (D + 31) / 32;
-    constexpr int bytes = (32 * (D + 4) + 32 * (DB * 32 + 8) + 32 + 4 * 32 * 33) * (int)sizeof(float);
+    constexpr int KT = (D <= 64 && !(D > 32 && (D % 32) == 8)) ? 64 : 32;
+    constexpr int bytes = (KT * (D + 4) + KT * (DB * 32 + 8) + 32 + 4 * 32 * 33) * (int)sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_kernel<D>),
