@@ -245,9 +245,98 @@ def _push(hist, d, cap):
         hist.append(d)
 
 
+def _unipc_update(x, models, times, t, order, variant, predict_x0, evaluate, corrector):
+    """One UniPC step from ``times[-1]`` to ``t`` (solver_utils.py:174-287): B(h)-weighted predictor over the buffered
+    model outputs, then -- unless ``corrector`` is off -- one network evaluation at the predicted point and the corrector.
+    Returns (x_t, model output at t or None).  ``evaluate(x_t, t)`` -> thresholded x0 (data prediction) or D(x_t; t)."""
+    assert order <= len(models)
+    t_last = times[-1].reshape(1,)
+    t = t.reshape(1,)
+    lam_last, lam_t = -1 * t_last.log(), -1 * t.log()
+    m0 = models[-1]
+    h = lam_t - lam_last
+    rks, diffs = [], []
+    for i in range(1, order):
+        lam_i = -1 * times[-(i + 1)].reshape(1,).log()
+        rk = (lam_i - lam_last) / h
+        rks.append(rk)
+        diffs.append((models[-(i + 1)] - m0) / rk)
+    rks.append(1.)
+    rks = torch.tensor(rks)
+    hh = -h if predict_x0 else h
+    h_phi_1 = torch.expm1(hh)
+    h_phi_k = h_phi_1 / hh - 1
+    B_h = hh if variant == 'bh1' else torch.expm1(hh)
+    if variant not in ('bh1', 'bh2'):
+        raise NotImplementedError()
+    rows, rhs, fact = [], [], 1
+    for i in range(1, order + 1):
+        rows.append(torch.pow(rks, i - 1))
+        rhs.append(h_phi_k * fact / B_h)
+        fact *= (i + 1)
+        h_phi_k = h_phi_k / hh - 1 / fact
+    R, b = torch.stack(rows), torch.cat(rhs)
+    D1s = torch.stack(diffs, dim=1) if diffs else None
+    rhos_p = None
+    if D1s is not None:
+        rhos_p = torch.tensor([0.5]) if order == 2 else torch.linalg.solve(R[:-1, :-1], b[:-1])
+    rhos_c = None
+    if corrector:
+        rhos_c = torch.tensor([0.5]) if order == 1 else torch.linalg.solve(R, b)
+    scale = 1 if predict_x0 else t                      # the noise-prediction form carries a factor t on every correction
+    base = (t / t_last * x - h_phi_1 * m0) if predict_x0 else (x - t * h_phi_1 * m0)
+    pred = torch.einsum('k,bkchw->bchw', rhos_p, D1s) if D1s is not None else 0
+    x_t = base - scale * B_h * pred
+    model_t = None
+    if corrector:
+        out = evaluate(x_t, t)
+        model_t = out if predict_x0 else (x_t - out) / t
+        corr = torch.einsum('k,bkchw->bchw', rhos_c[:-1], D1s) if D1s is not None else 0
+        x_t = base - scale * B_h * (corr + rhos_c[-1] * (model_t - m0))
+    return x_t, model_t
+
+
+def _sample_unipc(D, latents, t_steps, afs, denoise_to_zero, max_order, predict_x0, lower_order_final, variant, num_steps,
+                  want_inters):
+    """unipc_sampler (solvers.py:718-821): one evaluation up front, then one per step inside the corrector (none in the
+    last step); the model / time buffers grow to ``max_order`` entries and then shift."""
+    assert 0 < max_order < 4
+    x = latents * t_steps[0]
+    inters = [x.unsqueeze(0)]
+    if afs:
+        d = x / ((1 + t_steps[0] ** 2).sqrt())
+        den = x - t_steps[0] * d
+    else:
+        den = D(x, t_steps[0])
+        d = (x - den) / t_steps[0]
+    models = [threshold(den) if predict_x0 else d]
+    times = [t_steps[0]]
+    evaluate = (lambda xt, t: threshold(D(xt, t))) if predict_x0 else D
+    for i in range(len(t_steps) - 1):
+        tn = t_steps[i + 1]
+        if i + 1 < max_order:
+            x, m = _unipc_update(x, models, times, tn, i + 1, variant, predict_x0, evaluate, True)
+            models.append(m)
+            times.append(tn)
+        else:
+            order = min(max_order, num_steps - i - 1) if lower_order_final else max_order
+            x, m = _unipc_update(x, models, times, tn, order, variant, predict_x0, evaluate, i != num_steps - 2)
+            models[:max_order - 1], times[:max_order - 1] = models[1:max_order], times[1:max_order]
+            times[-1] = tn
+            if i < num_steps - 2:
+                models[-1] = m
+        if want_inters:
+            inters.append(x.unsqueeze(0))
+    if denoise_to_zero:
+        x = D(x, t_steps[-1])
+        if want_inters:
+            inters.append(x.unsqueeze(0))
+    return torch.cat(inters, dim=0) if want_inters else x
+
+
 def sample(solver, net, latents, t_steps, class_labels=None, afs=False, denoise_to_zero=False,
            max_order=None, r=0.5, coeff_list=None, predict_x0=True, lower_order_final=True, num_steps=None,
-           predictor=None, want_inters=False, want_eps=False, condition=None, unconditional_condition=None):
+           predictor=None, want_inters=False, want_eps=False, condition=None, unconditional_condition=None, variant='bh2'):
     """Run one reference sampler.  ``net(x, sigma, class_labels=...)`` -> denoised.
 
     solver: euler | heun | dpm_2 | ipndm | ipndm_v | deis | dpm_pp, or amed | amed_euler | amed_ipndm |
@@ -259,6 +348,9 @@ def sample(solver, net, latents, t_steps, class_labels=None, afs=False, denoise_
         D = lambda x, t: net(x, t, condition=condition, unconditional_condition=unconditional_condition)
     else:
         D = lambda x, t: net(x, t, class_labels=class_labels)
+    if solver == 'unipc':
+        return _sample_unipc(D, latents, t_steps, afs, denoise_to_zero, max_order, predict_x0, lower_order_final,
+                             variant, num_steps, want_inters)
     afs_d = lambda x, t: x / ((1 + t ** 2).sqrt())
     n = len(t_steps)
     x = latents * t_steps[0]
@@ -412,5 +504,5 @@ def sample(solver, net, latents, t_steps, class_labels=None, afs=False, denoise_
     return x
 
 
-SOLVERS = ('euler', 'heun', 'dpm_2', 'ipndm', 'ipndm_v', 'deis', 'dpm_pp',
+SOLVERS = ('euler', 'heun', 'dpm_2', 'ipndm', 'ipndm_v', 'deis', 'dpm_pp', 'unipc',
            'amed', 'amed_euler', 'amed_ipndm', 'amed_dpm_2', 'amed_dpm_pp')
