@@ -110,19 +110,52 @@ def create_model(dataset_name=None, model_path=None, random_init=False, device=N
     return net, 'edm'
 
 
-def save_images(images: torch.Tensor, batch_seeds, outdir, subdirs=True):
-    """uint8 NHWC conversion on the GPU (sample.py:311), then one PNG per seed (sample.py:312-316)."""
-    import PIL.Image
+class PngSink:
+    """Background PNG writer: the reference encodes every image with PIL in the sampling thread (sample.py:312-316), so the
+    GPU idles while a batch is written.  Here the uint8 batch is handed to a small thread pool (PIL releases the GIL while
+    compressing) and the next batch samples meanwhile; ``drain()`` waits for everything and re-raises the first failure."""
+
+    def __init__(self, workers=4):
+        from concurrent.futures import ThreadPoolExecutor
+        self.pool = ThreadPoolExecutor(max_workers=workers)
+        self.pending = []
+
+    @staticmethod
+    def _write(arr, seeds, outdir, subdirs):
+        import PIL.Image
+        for seed, img in zip(seeds, arr):
+            seed = int(seed)
+            d = os.path.join(outdir, f'{seed - seed % 1000:06d}') if subdirs else outdir
+            os.makedirs(d, exist_ok=True)
+            PIL.Image.fromarray(img, 'RGB' if img.shape[-1] == 3 else None).save(os.path.join(d, f'{seed:06d}.png'))
+
+    def submit(self, arr, seeds, outdir, subdirs=True, chunk=64):
+        seeds = [int(s) for s in seeds]
+        for i in range(0, len(seeds), chunk):
+            self.pending.append(self.pool.submit(self._write, arr[i:i + chunk], seeds[i:i + chunk], outdir, subdirs))
+
+    def drain(self):
+        pending, self.pending = self.pending, []
+        for f in pending:
+            f.result()
+
+    def close(self):
+        self.drain()
+        self.pool.shutdown()
+
+
+def save_images(images: torch.Tensor, batch_seeds, outdir, subdirs=True, sink: 'PngSink' = None):
+    """uint8 NHWC conversion on the GPU (sample.py:311), then one PNG per seed (sample.py:312-316) -- written by ``sink`` in
+    the background when one is given."""
     from . import ops
     B, C, H, W = images.shape
     u8 = torch.empty(B, H, W, C, dtype=torch.uint8, device=images.device)
     ops.quantize_u8_nhwc(images.contiguous(), u8, B, C, H, W)
     arr = u8.cpu().numpy()
-    for seed, img in zip(batch_seeds, arr):
-        seed = int(seed)
-        d = os.path.join(outdir, f'{seed - seed % 1000:06d}') if subdirs else outdir
-        os.makedirs(d, exist_ok=True)
-        PIL.Image.fromarray(img, 'RGB').save(os.path.join(d, f'{seed:06d}.png'))
+    if sink is not None:
+        sink.submit(arr, batch_seeds, outdir, subdirs)
+    else:
+        PngSink._write(arr, [int(s) for s in batch_seeds], outdir, subdirs)
 
 
 def save_grid(images: torch.Tensor, outdir):
@@ -212,6 +245,7 @@ def run(dataset_name, max_batch_size=64, seeds='0-63', grid=False, outdir=None, 
     log(f'Generating {len(seeds)} images to "{outdir}"...')
 
     n_done = 0
+    sink = PngSink()
     for batch_seeds in rank_batches:
         if dist is not None:
             dist.barrier()                                          # per-batch barrier, as the reference (sample.py:268)
@@ -249,8 +283,9 @@ def run(dataset_name, max_batch_size=64, seeds='0-63', grid=False, outdir=None, 
         elif grid:
             save_grid(images, outdir)
         else:
-            save_images(images, batch_seeds, outdir, subdirs)
+            save_images(images, batch_seeds, outdir, subdirs, sink=sink)
         n_done += B
+    sink.close()                                                    # every PNG is on disk before the final barrier
     if dist is not None:
         dist.barrier()
     log('Done.')

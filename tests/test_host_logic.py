@@ -181,3 +181,25 @@ def test_ldm_spec_matches_stable_diffusion_v15_inventory():
     assert ac.shape == (1000,) and abs(float(((1 - ac[-1]) / ac[-1]).sqrt()) - 14.6146) < 1e-3
     with pytest.raises(NotImplementedError):
         la.ldm_unet_spec(use_spatial_transformer=False)
+
+
+def test_png_sink_writes_reference_tree(tmp_path):
+    """Background PNG sink: the reference's output tree <outdir>/<seed - seed % 1000:06d>/<seed:06d>.png (sample.py:313-316),
+    pixel-exact, and failures surface on drain()."""
+    import numpy as np
+    import PIL.Image
+    from diff_sampler_amd.sample import PngSink
+    rng = np.random.default_rng(0)
+    arr = rng.integers(0, 256, size=(70, 8, 8, 3), dtype=np.uint8)
+    seeds = list(range(990, 1060))
+    sink = PngSink(workers=3)
+    sink.submit(arr, seeds, str(tmp_path), subdirs=True, chunk=16)
+    sink.close()
+    for i, s in enumerate(seeds):
+        p = tmp_path / f'{s - s % 1000:06d}' / f'{s:06d}.png'
+        assert np.array_equal(np.asarray(PIL.Image.open(p)), arr[i])
+    (tmp_path / 'file_not_dir').write_text('x')
+    bad = PngSink(workers=1)
+    bad.submit(arr[:1], [1], str(tmp_path / 'file_not_dir' / 'y'), subdirs=False)      # makedirs under a regular file
+    with pytest.raises(OSError):
+        bad.close()
