@@ -250,6 +250,7 @@ class CFGDenoiser:
     unconditional_condition=...)`` -> denoised latents NCHW fp32, plus the attributes and methods the samplers and
     ``get_schedule('discrete')`` read (``guidance_type, guidance_rate, img_resolution, img_channels, label_dim, sigma_min,
     sigma_max, sigma(), sigma_inv(), round_sigma()``)."""
+    host_sigma_ok = True       # solvers._Run: pass sigma as a Python float (c_noise is host math; nothing to copy or sync)
 
     def __init__(self, spec: ldm_arch.LDMUNetSpec, params: Dict[str, torch.Tensor], device='cuda', guidance_rate=None,
                  guidance_type=None):

@@ -69,7 +69,9 @@ class _Run:
             self._f, self._plan = self.net.raw(x, sigma, self.cl)
             self._raw = True
         else:
-            t = torch.tensor(sigma, dtype=torch.float32, device=x.device)
+            # a denoiser that takes sigma as a host float (ldm_engine.CFGDenoiser) gets it as such: no H2D copy, no sync,
+            # capturable into a hipGraph; any other callable gets the reference's 0-dim device tensor
+            t = sigma if getattr(self.net, 'host_sigma_ok', False) else torch.tensor(sigma, dtype=torch.float32, device=x.device)
             self._f = get_denoised(self.net, x, t, class_labels=self.cl, condition=self.cond,
                                    unconditional_condition=self.ucond).to(torch.float32).contiguous()
             self._raw = False

@@ -32,3 +32,23 @@ def test_graphed_sampler_equals_eager(case):
         graphed = g(lat, lab)
         torch.cuda.synchronize()
         assert torch.equal(eager, graphed), (case, trial)
+
+
+def test_graphed_cfg_sampler_equals_eager():
+    """The config-5 solver on the latent-diffusion denoiser (CFG-doubled evaluations) captured into one hipGraph."""
+    from diff_sampler_amd import solvers
+    from diff_sampler_amd.graph import GraphedSampler
+    from diff_sampler_amd.ldm_engine import CFGDenoiser
+    dev = torch.device('cuda')
+    net = CFGDenoiser.from_config('tiny_ldm_1res', seed=9, guidance_rate=7.5)
+    kw = dict(num_steps=4, sigma_min=net.sigma_min, sigma_max=net.sigma_max, schedule_type='discrete', schedule_rho=1, max_order=2,
+              predict_x0=False, lower_order_final=True)
+    g = GraphedSampler(solvers.dpm_pp_sampler, net, (2, 4, 16, 16), condition_shape=(2, 77, 64), uncond_shape=(2, 77, 64), **kw)
+    gen = torch.Generator().manual_seed(0)
+    for trial in range(2):
+        lat = torch.randn(2, 4, 16, 16, generator=gen).to(dev)
+        c, uc = torch.randn(2, 77, 64, generator=gen).to(dev), torch.randn(2, 77, 64, generator=gen).to(dev)
+        eager = solvers.dpm_pp_sampler(net, lat, condition=c, unconditional_condition=uc, **kw)
+        graphed = g(lat, condition=c, unconditional_condition=uc)
+        torch.cuda.synchronize()
+        assert torch.equal(eager, graphed), trial
