@@ -308,32 +308,59 @@ __global__ void __launch_bounds__(256) geglu_kernel(const float* __restrict__ x,
     }
 }
 
-// GroupNorm statistics from the convolutions' epilogue partial sums: one block per image; thread = channel (strided);
-// per-channel sums over the image's HW / 64 row blocks in fp64, merged into the groups through LDS atomics, then the same
-// finalisation as gn_stats_kernel.
-__global__ void __launch_bounds__(256) gn_from_partials_kernel(const ds_gn_finalize_args f) {
+// GroupNorm statistics from the convolutions' epilogue partial sums.  Groups are independent, so the grid is
+// (image, chunk of GPB groups): a block sums its channels' per-row-block partials in fp64 (thread = channel lane x row-block
+// lane), merges them into its groups through LDS atomics and finalises exactly like gn_stats_kernel (mean / rstd and the
+// {mu, A, B} planes of its channels).  GPB is chosen by the launcher so that small batches still get >= 64 blocks.
+__global__ void __launch_bounds__(256) gn_from_partials_kernel(const ds_gn_finalize_args f, int GPB) {
     __shared__ double s_sum[64];
     __shared__ double s_sq[64];
     const int tid = threadIdx.x, n = blockIdx.x;
+    const int g0 = blockIdx.y * GPB, g1 = min(g0 + GPB, f.groups);
     if (tid < 64) { s_sum[tid] = 0.0; s_sq[tid] = 0.0; }
     __syncthreads();
     const int C = f.c0 + f.c1;
     const int cpg = C / f.groups;
     const int nrb = f.hw >> 6;
-    for (int c = tid; c < C; c += blockDim.x) {
+    const int cb0 = g0 * cpg, cb1 = g1 * cpg;
+    const int cl = tid & 63, rl = tid >> 6;
+    for (int c = cb0 + cl; c < cb1; c += 64) {
         const bool first = c < f.c0;
         const float* sp = first ? f.stats0 : f.stats1;
         const int cs = first ? f.c0 : f.c1, cc = first ? c : c - f.c0;
         const float* base = sp + ((size_t)n * nrb * 2) * cs + cc;
         double s = 0.0, q = 0.0;
-        for (int rb = 0; rb < nrb; ++rb) { s += (double)base[(size_t)rb * 2 * cs]; q += (double)base[((size_t)rb * 2 + 1) * cs]; }
-        atomicAdd(&s_sum[c / cpg], s); atomicAdd(&s_sq[c / cpg], q);
+        for (int rb = rl; rb < nrb; rb += 4) { s += (double)base[(size_t)rb * 2 * cs]; q += (double)base[((size_t)rb * 2 + 1) * cs]; }
+        atomicAdd(&s_sum[c / cpg - g0], s); atomicAdd(&s_sq[c / cpg - g0], q);
     }
     __syncthreads();
-    ds_norm_args a{};
-    a.c0 = f.c0; a.c1 = f.c1; a.h = f.hw; a.w = 1; a.groups = f.groups; a.eps = f.eps; a.mean = f.mean; a.rstd = f.rstd;
-    a.gamma = f.gamma; a.beta = f.beta; a.scale = f.scale; a.shift = f.shift; a.ss_ld = f.ss_ld; a.ss_rows = f.ss_rows; a.coefs = f.coefs;
-    gn_finalize(a, s_sum, s_sq);
+    if (tid < g1 - g0) {
+        const double cnt = (double)cpg * (double)f.hw;
+        const double mean = s_sum[tid] / cnt;
+        double var = s_sq[tid] / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)f.eps);
+        f.mean[(size_t)n * f.groups + g0 + tid] = (float)mean;
+        f.rstd[(size_t)n * f.groups + g0 + tid] = (float)rstd;
+        s_sum[tid] = mean; s_sq[tid] = rstd;
+    }
+    if (f.coefs) {
+        __syncthreads();
+        float* cp = f.coefs + (size_t)n * 3 * C;
+        for (int c = cb0 + tid; c < cb1; c += blockDim.x) {
+            const int g = c / cpg - g0;
+            const float m = (float)s_sum[g], r = (float)s_sq[g];
+            const float gm = f.gamma ? f.gamma[c] : 1.f;
+            const float bt = f.beta ? f.beta[c] : 0.f;
+            float sc1 = 1.f, sh = 0.f;
+            if (f.scale) {
+                const size_t row = (f.ss_rows == 1) ? 0 : (size_t)n;
+                sc1 = f.scale[row * f.ss_ld + c] + 1.f;
+                sh = f.shift[row * f.ss_ld + c];
+            }
+            cp[c] = m; cp[C + c] = r * gm * sc1; cp[2 * C + c] = bt * sc1 + sh;
+        }
+    }
 }
 
 int norm_geometry(const ds_norm_args* a, int* CQ, int* PL) {
@@ -476,7 +503,10 @@ extern "C" int ds_gn_finalize(const ds_gn_finalize_args* a, void* stream) {
     if (a->n <= 0 || a->hw <= 0 || (a->hw & 63)) return DS_E_SHAPE;
     if (a->groups <= 0 || a->groups > 64 || (a->c0 + a->c1) % a->groups) return DS_E_SHAPE;
     if ((a->scale == nullptr) != (a->shift == nullptr)) return DS_E_ARG;
-    hipLaunchKernelGGL(gn_from_partials_kernel, dim3(a->n), dim3(256), 0, (hipStream_t)stream, *a);
+    int gpb = (int)(((long long)a->n * a->groups + 511) / 512);          // groups per block: ~512 blocks at large batch,
+    if (gpb < 1) gpb = 1;                                                 // one group per block at small batch
+    if (gpb > a->groups) gpb = a->groups;
+    hipLaunchKernelGGL(gn_from_partials_kernel, dim3(a->n, (a->groups + gpb - 1) / gpb), dim3(256), 0, (hipStream_t)stream, *a, gpb);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }
