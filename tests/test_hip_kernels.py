@@ -356,3 +356,27 @@ def test_conv_epilogue_statistics_feed_groupnorm(B, H, cin, cout, taps, ws):
     cf = coefs.cpu().reshape(B, 3, cout)
     cpg = cout // G_
     assert torch.allclose(cf[:, 1], (rstd.cpu().reshape(B, G_).repeat_interleave(cpg, 1) * gamma.cpu()), rtol=1e-5)
+
+
+@pytest.mark.parametrize('B,H,W,cin,cout', [(2, 8, 16, 64, 128), (3, 16, 8, 32, 64), (1, 32, 64, 32, 128), (2, 4, 32, 64, 64)])
+def test_conv_non_square_images(B, H, W, cin, cout):
+    """The ABI takes h and w separately: non-square NHWC images through the halo / generic kernels, stride 1 and 2, with the
+    epilogue statistics."""
+    import ctypes as C
+    from diff_sampler_amd import _lib, ops
+    g = torch.Generator().manual_seed(H * 100 + W)
+    x = torch.randn(B, cin, H, W, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    bias = torch.randn(cout, generator=g)
+    xn, wp, bd = x.permute(0, 2, 3, 1).reshape(-1, cin).contiguous().cuda(), ops.pack_conv_weight(wt).cuda(), bias.cuda()
+    lib = _lib.load()
+    for stride in (1, 2):
+        Ho, Wo = H // stride, W // stride
+        out = torch.full((B * Ho * Wo, cout), float('nan'), device='cuda')
+        a = _lib.ConvArgs(xn.data_ptr(), None, cin, 0, cin, 0, B, Ho, Wo, 9, wp.data_ptr(), cout, bd.data_ptr(), None, 0, 1, None, 0, 1.0, 0,
+                          out.data_ptr(), cout)
+        a.stride = stride
+        assert lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr()) == 0
+        torch.cuda.synchronize()
+        ref = F.conv2d(x, wt, bias, stride=stride, padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+        assert _rel(out.cpu(), ref) < TOL, stride
