@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libdsamd.so')
 c_float_p = C.POINTER(C.c_float)
 vp = C.c_void_p
 
-DS_ACT_NONE, DS_ACT_SILU = 0, 1
+DS_ACT_NONE, DS_ACT_SILU, DS_ACT_GEGLU = 0, 1, 2
 DS_RESAMPLE_NONE, DS_RESAMPLE_DOWN, DS_RESAMPLE_UP = 0, 1, 2
 DS_GN_MAX_CHUNKS = 32
 

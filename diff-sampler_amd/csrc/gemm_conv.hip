@@ -336,6 +336,10 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
         p.out_planar = 1; p.vec_ok = 0;
     }
     p.splits = 1; p.part = nullptr; p.part_cap = 0; p.vec_part = 0;
+    if (a->act == DS_ACT_GEGLU) {
+        // gate fused into the epilogue: needs the staged float4 path on whole 64-column wave tiles, and no split-K
+        if (a->taps != 1 || (a->cout & 63) || !p.vec_ok || a->res || a->cbias || a->out_nchw || a->stats_out) return DS_E_ARG;
+    } else
     if (a->workspace && a->workspace_floats > 0 && ds_aligned16(a->workspace)) {
         p.part = a->workspace; p.part_cap = a->workspace_floats; p.vec_part = (p.N & 3) ? 0 : 1;
     }

@@ -62,6 +62,9 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
         f32x4 cb = {0.f, 0.f, 0.f, 0.f};
         if (p.colbias) cb = *reinterpret_cast<const f32x4*>(p.colbias + col);
         f32x4 st_s = {0.f, 0.f, 0.f, 0.f}, st_q = {0.f, 0.f, 0.f, 0.f};
+        const bool geglu = (MODE == 0) && p.act == DS_ACT_GEGLU;      // columns [0,32) of the wave tile: values, [32,64): their gates
+        f32x4 cbg = {0.f, 0.f, 0.f, 0.f};
+        if (geglu && p.colbias && c4 < 32) cbg = *reinterpret_cast<const f32x4*>(p.colbias + col + 32);
 #pragma unroll
         for (int half = 0; half < (HALF ? 2 : 1); ++half) {
 #pragma unroll
@@ -88,6 +91,15 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
                 }
                 if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.res_ld + col);
                 if (MODE == 0) v *= p.scale;
+                if (geglu) {
+                    if (c4 < 32) {
+                        const f32x4 gt = *reinterpret_cast<const f32x4*>(stage + rr * EPI_LD + c4 + 32) + cbg;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] *= 0.5f * gt[q] * (1.0f + erff(gt[q] * 0.70710678118654752440f));
+                        *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + (wn0 >> 1) + c4) = v;
+                    }
+                    continue;
+                }
                 if (p.act == DS_ACT_SILU) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = ds_silu(v[q]);

@@ -8,7 +8,7 @@ One evaluation = one flat plan of libdsamd launches over NHWC fp32 workspaces:
                         -> GN stats -> 3x3 conv (fused norm) with the 1x1 skip_connection appended along K (+residual)
     SpatialTransformer  GN -> 1x1 proj_in -> [LN -> packed q|k|v linear -> fused attention -> to_out (+res)]
                         -> [LN -> q linear, context k|v linear -> fused cross-attention -> to_out (+res)]
-                        -> [LN -> GEGLU linear -> gate -> linear (+res)] -> 1x1 proj_out (+res)
+                        -> [LN -> GEGLU linear with the gate in its epilogue -> linear (+res)] -> 1x1 proj_out (+res)
     Downsample          3x3 stride-2 conv;   Upsample: nearest x2 -> 3x3 conv
     CFG                 the conditional and unconditional halves run as ONE 2B-image evaluation (networks_edm.py:679-683);
                         ``ds_cfg_denoise`` forms F_u + g (F_c - F_u) and D = x - sigma F in one pass.
@@ -25,7 +25,7 @@ from typing import Dict, Optional
 import torch
 
 from . import _lib, ldm_arch, ops
-from ._lib import DS_ACT_NONE, DS_ACT_SILU, DS_RESAMPLE_UP
+from ._lib import DS_ACT_GEGLU, DS_ACT_NONE, DS_ACT_SILU, DS_RESAMPLE_UP
 from .ops import pack_conv_weight, pack_linear_weight, pack_stem_weight
 from .plan import Builder, Plan, ptr
 
@@ -80,7 +80,15 @@ class LDMUNetEngine:
                     w[f'{p}.kv2.w'] = pack_linear_weight(torch.cat([g(f'{t}.attn2.to_{x}.weight') for x in 'kv'], 0))
                     for a in ('attn1', 'attn2'):
                         w[f'{p}.{a}.o.w'], w[f'{p}.{a}.o.b'] = pack_linear_weight(g(f'{t}.{a}.to_out.0.weight')), g(f'{t}.{a}.to_out.0.bias')
-                    w[f'{p}.ff0.w'], w[f'{p}.ff0.b'] = pack_linear_weight(g(f'{t}.ff.net.0.proj.weight')), g(f'{t}.ff.net.0.proj.bias')
+                    # GEGLU projection with the gate fused into its epilogue: rows reordered so that every 64-row block of
+                    # the packed weight = 32 value rows followed by their 32 gate rows (DS_ACT_GEGLU)
+                    inner = 4 * l.cin
+                    perm = torch.arange(2 * inner, device=dev).reshape(-1, 2, 32)
+                    perm = (perm[:, 0] // 64 * 32 + perm[:, 0] % 32).reshape(-1, 1, 32).repeat(1, 2, 1)
+                    perm[:, 1] += inner
+                    perm = perm.reshape(-1)
+                    w[f'{p}.ff0.w'] = pack_linear_weight(g(f'{t}.ff.net.0.proj.weight')[perm])
+                    w[f'{p}.ff0.b'] = g(f'{t}.ff.net.0.proj.bias')[perm].contiguous()
                     w[f'{p}.ff2.w'], w[f'{p}.ff2.b'] = pack_linear_weight(g(f'{t}.ff.net.2.weight')), g(f'{t}.ff.net.2.bias')
                     for n_ in ('norm1', 'norm2', 'norm3'):
                         w[f'{p}.{n_}.g'], w[f'{p}.{n_}.b'] = g(f'{t}.{n_}.weight'), g(f'{t}.{n_}.bias')
@@ -180,10 +188,9 @@ class LDMUNetEngine:
                          q_bs=S * c, k_bs=L * 2 * c, v_bs=L * 2 * c, o_bs=S * c, scale=d ** -0.5)
             bd.linear(ao, c, M, w[f'{p}.attn2.o.w'], c, t2, p + '.attn2.to_out', bias=w[f'{p}.attn2.o.b'], res=t1, res_ld=c)
             # GEGLU feed-forward
-            ff, gg, t3 = new(M, 8 * c), new(M, 4 * c), new(M, c)
+            gg, t3 = new(M, 4 * c), new(M, c)
             bd.layernorm(t2, c, w[f'{p}.norm3.g'], w[f'{p}.norm3.b'], 1e-5, ln, c, M, c, p + '.norm3')
-            bd.linear(ln, c, M, w[f'{p}.ff0.w'], 8 * c, ff, p + '.ff.proj', bias=w[f'{p}.ff0.b'])
-            bd.geglu(ff, 8 * c, gg, 4 * c, M, 4 * c, p + '.ff.geglu')
+            bd.linear(ln, c, M, w[f'{p}.ff0.w'], 8 * c, gg, p + '.ff.proj_geglu', out_ld=4 * c, bias=w[f'{p}.ff0.b'], act=DS_ACT_GEGLU)
             bd.linear(gg, 4 * c, M, w[f'{p}.ff2.w'], c, t3, p + '.ff.out', bias=w[f'{p}.ff2.b'], res=t2, res_ld=c)
             out = new(M, c)
             bd.conv(t3, c, c, N, res, res, w[f'{p}.po.w'], c, out, c, 1, p + '.proj_out', bias=w[f'{p}.po.b'], res=x_in, res_ld=c,

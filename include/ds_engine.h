@@ -32,6 +32,9 @@ extern "C" {
 
 #define DS_ACT_NONE 0
 #define DS_ACT_SILU 1
+#define DS_ACT_GEGLU 2  /* ds_conv2d_nhwc, taps == 1 only: the GEGLU gate of ldm/modules/attention.py:45-52 fused into the
+                          projection's epilogue.  The weight rows must be packed so that every 64-row block holds 32 value
+                          rows followed by their 32 gate rows; out gets cout / 2 columns: value * gelu(gate). */
 
 #define DS_RESAMPLE_NONE 0
 #define DS_RESAMPLE_DOWN 1  /* 2x2 box filter, stride 2  (networks_edm.py:77 with resample_filter [1,1]) */

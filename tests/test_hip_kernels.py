@@ -380,3 +380,26 @@ def test_conv_non_square_images(B, H, W, cin, cout):
         torch.cuda.synchronize()
         ref = F.conv2d(x, wt, bias, stride=stride, padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
         assert _rel(out.cpu(), ref) < TOL, stride
+
+
+@pytest.mark.parametrize('rows,k,inner', [(300, 64, 128), (16384, 640, 1280), (77, 320, 1280)])
+def test_geglu_fused_into_projection(rows, k, inner):
+    """DS_ACT_GEGLU: x W^T + b with the gate applied in the epilogue (generic and large-tile kernels) == value * gelu(gate)."""
+    import ctypes as C
+    from diff_sampler_amd import _lib, ops
+    g = torch.Generator().manual_seed(rows + k)
+    x = torch.randn(rows, k, generator=g)
+    wt = torch.randn(2 * inner, k, generator=g) / k ** 0.5
+    bias = torch.randn(2 * inner, generator=g) * 0.3
+    perm = torch.arange(2 * inner).reshape(-1, 2, 32)
+    perm = (perm[:, 0] // 64 * 32 + perm[:, 0] % 32).reshape(-1, 1, 32).repeat(1, 2, 1)
+    perm[:, 1] += inner
+    perm = perm.reshape(-1)
+    xd, wp, bd = x.cuda(), ops.pack_linear_weight(wt[perm].cuda()), bias[perm].contiguous().cuda()
+    out = torch.full((rows, inner), float('nan'), device='cuda')
+    a = _lib.ConvArgs(xd.data_ptr(), None, k, 0, k, 0, rows, 1, 1, 1, wp.data_ptr(), 2 * inner, bd.data_ptr(), None, 0, 1, None, 0, 1.0,
+                      _lib.DS_ACT_GEGLU, out.data_ptr(), inner)
+    assert _lib.load().ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    y = F.linear(x, wt, bias)
+    assert _rel(out.cpu(), y[:, :inner] * F.gelu(y[:, inner:])) < TOL
