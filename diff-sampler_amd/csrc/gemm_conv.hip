@@ -238,6 +238,7 @@ int g_force_generic = 0;
 }  // namespace
 
 int g_force_splits = 0;
+int g_use_dma8 = 1;
 
 namespace {
 // Column statistics of a finished output tensor in the epilogue's partial format (split-K layers: their epilogue runs in
@@ -283,7 +284,8 @@ extern "C" int ds_debug_force_generic_conv(int v) {
     g_force_generic = (v == 1);
     conv3x3_halo_set_tile((v == 128 || v == 256) ? v : 0);
     conv3x3_halo_set_glds(v == 2 ? 0 : 1);           // v = 2: halo kernel with register-staged weights
-    conv3x3_halo_set_tail64(v == 4 ? 0 : 1);         // v = 4: no 64-column tail tiles (A/B measurements)
+    conv3x3_halo_set_tail64(v == 4 ? 0 : 1);
+    g_use_dma8 = (v == 6) ? 0 : 1;                   // v = 6: no 8-wave DMA kernel for 1x1 / Linear layers (A/B measurements)         // v = 4: no 64-column tail tiles (A/B measurements)
     return DS_OK;
 }
 
@@ -346,6 +348,7 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     if (!g_force_generic && stride == 1 && conv3x3_halo_supported(p)) return launch_conv3x3_halo(p, (hipStream_t)stream);
     if (p.norm) return DS_E_SHAPE;           // fused input normalisation exists only in the halo kernel
     if (!g_force_generic && gemm256_applicable(p)) return launch_gemm256(p, (hipStream_t)stream);
+    if (!g_force_generic && g_use_dma8 && gemm_dma8_applicable(p)) return launch_gemm_dma8(p, (hipStream_t)stream);
     return launch<0>(p, 1, (hipStream_t)stream);
 }
 
@@ -357,7 +360,7 @@ extern "C" int ds_conv_kernel_id(const ds_conv_args* a) {
     if (a->workspace && a->workspace_floats > 0) { p.part = a->workspace; p.part_cap = a->workspace_floats; }
     p.stride = a->stride ? a->stride : 1; p.K = a->taps * (a->c0 + a->c1) + a->ec0 + a->ec1; p.norm = a->norm_coefs;
     if (g_force_generic) return 0;
-    if (a->taps != 9 || a->stride > 1) return gemm256_applicable(p) ? 2560 : 0;
+    if (a->taps != 9 || a->stride > 1) return gemm256_applicable(p) ? 2560 : ((g_use_dma8 && gemm_dma8_applicable(p)) ? 2561 : 0);
     return conv3x3_halo_choice(p);
 }
 

@@ -233,6 +233,11 @@ inline int choose_splits(long long blocks, bool big_tile, int units, int tiles_p
 }
 int launch_splitk_reduce(const KParams& p, hipStream_t stream);   // gemm_conv.hip (also fills p.stats when requested)
 
+// gemm_dma8.hip
+bool gemm_dma8_applicable(const KParams& p);
+int launch_gemm_dma8(KParams& p, hipStream_t stream);
+extern int g_use_dma8;
+
 // gemm256.hip
 bool gemm256_applicable(const KParams& p);
 int launch_gemm256(KParams& p, hipStream_t stream);

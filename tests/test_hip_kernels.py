@@ -41,6 +41,8 @@ CONV_CASES = [
     (2, 8, 160, 0, 7, 9, (0, 0), True),          # split-K with a ragged N
     (16, 32, 640, 0, 1024, 1, (0, 0), False),    # 1x1 with K >= 640 and >= 256 tiles of 256x256: large-tile kernel (gemm256)
     (17, 32, 320, 320, 1000, 1, (0, 0), False),  # same, dual source, ragged M and N
+    (16, 32, 64, 0, 1024, 1, (0, 0), False),     # short K, 512 tiles of 256x128: 8-wave LDS-DMA kernel (gemm_dma8)
+    (17, 32, 32, 32, 1000, 1, (0, 0), False),    # same (544 tiles), dual source, ragged M and N
 ]
 
 
