@@ -39,11 +39,9 @@ PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 PMC_FILE = os.path.join(ROOT, 'profiles', 'r1e_bench_pmc_hbm.json')
 KERNEL_NAMES = {0: 'igemm_f32_kernel<0> (generic gather conv / 1x1 / linear)', 128: 'conv3x3_halo_kernel<2> (128-pixel tiles)',
-                256: 'conv3x3_halo_kernel<4> (256-pixel tiles)', 2560: 'gemm256_kernel (256x256 tiles, 1x1 / linear)',
-                2561: 'gemm_dma8_kernel (256x128 tiles, LDS-DMA, 1x1 / linear)'}
+                256: 'conv3x3_halo_kernel<4> (256-pixel tiles)', 2561: 'gemm_dma8_kernel (256x128 tiles, LDS-DMA, 1x1 / linear)'}
 PMC_KEYS = {0: 'void igemm::igemm_f32_kernel<0>(igemm::KParams)', 128: 'void igemm::conv3x3_halo_kernel<2, true, 2>(igemm::KParams)',
-            256: 'void igemm::conv3x3_halo_kernel<4, true, 2>(igemm::KParams)', 2560: 'igemm::gemm256_kernel(igemm::KParams)',
-            2561: 'igemm::gemm_dma8_kernel(igemm::KParams)'}
+            256: 'void igemm::conv3x3_halo_kernel<4, true, 2>(igemm::KParams)', 2561: 'igemm::gemm_dma8_kernel(igemm::KParams)'}
 
 
 def parse():

@@ -347,7 +347,6 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     }
     if (!g_force_generic && stride == 1 && conv3x3_halo_supported(p)) return launch_conv3x3_halo(p, (hipStream_t)stream);
     if (p.norm) return DS_E_SHAPE;           // fused input normalisation exists only in the halo kernel
-    if (!g_force_generic && gemm256_applicable(p)) return launch_gemm256(p, (hipStream_t)stream);
     if (!g_force_generic && g_use_dma8 && gemm_dma8_applicable(p)) return launch_gemm_dma8(p, (hipStream_t)stream);
     return launch<0>(p, 1, (hipStream_t)stream);
 }
@@ -360,7 +359,7 @@ extern "C" int ds_conv_kernel_id(const ds_conv_args* a) {
     if (a->workspace && a->workspace_floats > 0) { p.part = a->workspace; p.part_cap = a->workspace_floats; }
     p.stride = a->stride ? a->stride : 1; p.K = a->taps * (a->c0 + a->c1) + a->ec0 + a->ec1; p.norm = a->norm_coefs;
     if (g_force_generic) return 0;
-    if (a->taps != 9 || a->stride > 1) return gemm256_applicable(p) ? 2560 : ((g_use_dma8 && gemm_dma8_applicable(p)) ? 2561 : 0);
+    if (a->taps != 9 || a->stride > 1) return (g_use_dma8 && gemm_dma8_applicable(p)) ? 2561 : 0;
     return conv3x3_halo_choice(p);
 }
 

@@ -1,10 +1,15 @@
-// 256x128-tile NT GEMM with both operands staged by LDS-DMA: the 1x1 / Linear kernel for many-row layers with short K
-// (SD-1.5's 320-wide projections), between the generic gather kernel (128x128, register-staged, 2 workgroups per CU) and
-// gemm256.hip (256x256, one wave per SIMD, needs a long K loop).  Eight waves in a 4x2 grid, 64x64 outputs each (2x2
-// v_mfma_f32_32x32x2_f32 tiles), exactly the wave layout of the 8-wave convolution; a tile step moves 48 KB for 2 MFLOP
-// (generic kernel: 32 KB per MFLOP) with no VGPR round trip and no ds_write.  LDS image and swizzle as in gemm256.hip.
-// Measured against the generic kernel (tools/bench_linear.py, bit-identical results): +4 ... +12 % on the 320- / 384- /
-// 640-deep projections of SD-1.5, ADM and CIFAR-10 (e.g. qkv 64x64: 82 -> 91 TFLOP/s).
+// 256x128-tile NT GEMM with both operands staged by LDS-DMA: the 1x1 / Linear kernel for many-row layers (every projection
+// of SD-1.5's SpatialTransformer at batch >= 8, the qkv / proj 1x1s of the EDM nets at batch >= 64).  Eight waves in a 4x2
+// grid, 64x64 outputs each (2x2 v_mfma_f32_32x32x2_f32 tiles), exactly the wave layout of the 8-wave convolution; a tile
+// step moves 48 KB for 2 MFLOP (generic gather kernel: 32 KB per MFLOP) by global_load_lds_dwordx4 -- no VGPR round trip,
+// no ds_write -- into the unpadded [row][32 floats] LDS image with the 16-byte chunk index XOR-swizzled by (row >> 1) & 7
+// (same involution on the DMA source address and on the fragment read), like the weight tiles of conv3x3_halo.hip.
+// A 256x256-tile variant with ONE wave per SIMD (128x128 accumulators per wave, 4 MFLOP per 64 KB) was built first and
+// rejected: 7.8 us per K tile in steady state (6.8 us = MFMA peak) but ~50 us of prologue / epilogue per tile that nothing
+// overlaps (one workgroup per CU, all CUs in phase, epilogues at HBM speed): 116 TFLOP/s at K = 1280, 100 at K = 640, 80 at
+// K = 320 -- this kernel does 125 / 115 / 91.
+// Measured against the generic kernel (tools/bench_linear.py, bit-identical results): +8 ... +18 % (qkv 64x64 K = 320: 82 ->
+// 91 TFLOP/s; ff.proj 16x16 K = 1280: 106 -> 125).
 #include "igemm_common.h"
 
 namespace igemm {

@@ -238,10 +238,6 @@ bool gemm_dma8_applicable(const KParams& p);
 int launch_gemm_dma8(KParams& p, hipStream_t stream);
 extern int g_use_dma8;
 
-// gemm256.hip
-bool gemm256_applicable(const KParams& p);
-int launch_gemm256(KParams& p, hipStream_t stream);
-
 // conv3x3_halo.hip
 bool conv3x3_halo_supported(const KParams& p);
 int launch_conv3x3_halo(KParams& p, hipStream_t stream);

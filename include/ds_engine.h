@@ -102,9 +102,8 @@ typedef struct ds_conv_args {
 int ds_conv2d_nhwc(const ds_conv_args* a, void* stream);
 
 /* Which kernel ds_conv2d_nhwc dispatches this call to: 0 = generic gather kernel (igemm_f32_kernel<0>), 128 / 256 =
- * LDS-halo kernel with that M tile (conv3x3_halo_kernel<2> / <4>), 2560 = large-tile 1x1 / Linear kernel
- * (gemm256_kernel), 2561 = 8-wave LDS-DMA 1x1 / Linear kernel (gemm_dma8_kernel).  Used by bench.py to attribute time
- * per kernel. */
+ * LDS-halo kernel with that M tile (conv3x3_halo_kernel<2> / <4>), 2561 = 8-wave LDS-DMA 1x1 / Linear kernel
+ * (gemm_dma8_kernel).  Used by bench.py to attribute time per kernel. */
 int ds_conv_kernel_id(const ds_conv_args* a);
 
 /* 1 if a 3x3 convolution on h x w images runs on the LDS-halo kernel (needed for norm_coefs), else 0. */

@@ -39,7 +39,7 @@ CONV_CASES = [
     (2, 16, 256, 0, 64, 1, (0, 0), False),       # 1x1 with 8 K tiles
     (3, 4, 128, 0, 96, 9, (0, 0), False),        # 4x4: generic 3x3 fallback, 36 K tiles
     (2, 8, 160, 0, 7, 9, (0, 0), True),          # split-K with a ragged N
-    (16, 32, 640, 0, 1024, 1, (0, 0), False),    # 1x1 with K >= 640 and >= 256 tiles of 256x256: large-tile kernel (gemm256)
+    (16, 32, 640, 0, 1024, 1, (0, 0), False),    # 1x1 with a long K loop and many rows (gemm_dma8)
     (17, 32, 320, 320, 1000, 1, (0, 0), False),  # same, dual source, ragged M and N
     (16, 32, 64, 0, 1024, 1, (0, 0), False),     # short K, 512 tiles of 256x128: 8-wave LDS-DMA kernel (gemm_dma8)
     (17, 32, 32, 32, 1000, 1, (0, 0), False),    # same (544 tiles), dual source, ragged M and N
@@ -322,7 +322,7 @@ def test_conv_planar_output(B, H, cin, cout, ws):
                                                    (16, 32, 640, 1024, 1, False), (4, 8, 64, 64, 1, False), (2, 64, 32, 64, 9, False)])
 def test_conv_epilogue_statistics_feed_groupnorm(B, H, cin, cout, taps, ws):
     """stats_out + ds_gn_finalize reproduce ds_gn_stats / F.group_norm statistics of the convolution's output (128- and
-    64-column halo tiles, the split-K reduce path, the generic and the large-tile 1x1 kernels)."""
+    64-column halo tiles, the split-K reduce path, the generic and the 8-wave LDS-DMA 1x1 kernels)."""
     import ctypes as C
     from diff_sampler_amd import _lib, ops
     g = torch.Generator().manual_seed(B * 11 + H + cout)
@@ -386,7 +386,7 @@ def test_conv_non_square_images(B, H, W, cin, cout):
 
 @pytest.mark.parametrize('rows,k,inner', [(300, 64, 128), (16384, 640, 1280), (77, 320, 1280)])
 def test_geglu_fused_into_projection(rows, k, inner):
-    """DS_ACT_GEGLU: x W^T + b with the gate applied in the epilogue (generic and large-tile kernels) == value * gelu(gate)."""
+    """DS_ACT_GEGLU: x W^T + b with the gate applied in the epilogue (generic and 8-wave LDS-DMA kernels) == value * gelu(gate)."""
     import ctypes as C
     from diff_sampler_amd import _lib, ops
     g = torch.Generator().manual_seed(rows + k)
