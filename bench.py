@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r1e_bench_pmc_hbm.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r1f_bench_pmc_hbm.json')
 KERNEL_NAMES = {0: 'igemm_f32_kernel<0> (generic gather conv / 1x1 / linear)', 128: 'conv3x3_halo_kernel<2> (128-pixel tiles)',
                 256: 'conv3x3_halo_kernel<4> (256-pixel tiles)', 2561: 'gemm_dma8_kernel (256x128 tiles, LDS-DMA, 1x1 / linear)'}
 PMC_KEYS = {0: 'void igemm::igemm_f32_kernel<0>(igemm::KParams)', 128: 'void igemm::conv3x3_halo_kernel<2, true, 2>(igemm::KParams)',
@@ -317,7 +317,7 @@ def main():
         alg_bytes = None
         roof = dict(bound='mfma', kernel=KERNEL_NAMES[dom[1]], achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
                     frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=(round(traffic) if traffic else None),
-                    traffic_unit='HBM bytes per launch (rocprofv3 PMC, profiles/r1e_bench_pmc_hbm.json)',
+                    traffic_unit='HBM bytes per launch (rocprofv3 PMC, profiles/r1f_bench_pmc_hbm.json)',
                     launches_per_step=launches, avg_launch_ms=round(ms / launches, 4), gflop_per_launch=round(fl / launches / 1e9, 2),
                     share_of_gpu_time=round(ms / total_ms, 4))
         if 'solver_update_kernel' in rec and ldm is None:
