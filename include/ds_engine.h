@@ -13,7 +13,10 @@
  * Tensor layouts
  *   user tensors (latents x, denoised D, history)  : NCHW fp32, exactly as the reference passes them
  *   denoiser activations (internal)                : NHWC fp32, "rows" = pixels (n*H*W + h*W + w), ld = floats/row
- *   conv / linear weights                          : packed [Cout_pad][taps*Cin] fp32, K index = tap*Cin + c
+ *   conv / linear weights                          : packed [Cout_pad128][K] fp32; 3x3: K index = (slab*9 + tap)*32 + c
+ *                                                    with slab = 32-channel block of the (concatenated) input; 1x1: K = c
+ *   network output F (EDM nets)                    : channel-planar NCHW (ds_conv_args.out_nchw), read in place by
+ *                                                    ds_solver_update
  */
 #ifndef DS_ENGINE_H
 #define DS_ENGINE_H
@@ -49,7 +52,7 @@ const char* ds_error_string(int code);
  * skip (networks_edm.py:353: two sources are read in place), the bias add (:81), the embedding add (:167), the
  * residual add and skip_scale (:170-171, :177-178).
  *
- *   out[m, co] = act( ( sum_{tap,c} X(m, tap, c) * W[co, tap*Ctot + c] + bias[co] + cbias[img(m), co] + res[m, co] )
+ *   out[m, co] = act( ( sum_{tap,c} X(m, tap, c) * W[co, k(tap, c)] + bias[co] + cbias[img(m), co] + res[m, co] )
  *                     * out_scale )
  *   X(m, tap, c): zero-padded 3x3 neighbourhood of pixel m in the channel-concatenation [x0 | x1].
  * Constraints: c0 % 32 == 0, c1 % 32 == 0, all leading dimensions % 4 == 0, pointers 16-byte aligned,
