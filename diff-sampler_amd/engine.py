@@ -19,7 +19,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Dict, List, Optional
+from typing import Dict, List
 
 import torch
 

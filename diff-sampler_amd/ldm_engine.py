@@ -20,12 +20,12 @@ reference runs this U-Net under autocast; fp32 is the stricter contract -- DESIG
 from __future__ import annotations
 
 import math
-from typing import Dict, Optional
+from typing import Dict
 
 import torch
 
 from . import _lib, ldm_arch, ops
-from ._lib import DS_ACT_GEGLU, DS_ACT_NONE, DS_ACT_SILU, DS_RESAMPLE_UP
+from ._lib import DS_ACT_GEGLU, DS_ACT_SILU, DS_RESAMPLE_UP
 from .ops import pack_conv_weight, pack_linear_weight, pack_stem_weight
 from .plan import Builder, Plan, ptr
 
