@@ -203,3 +203,34 @@ def test_png_sink_writes_reference_tree(tmp_path):
     bad.submit(arr[:1], [1], str(tmp_path / 'file_not_dir' / 'y'), subdirs=False)      # makedirs under a regular file
     with pytest.raises(OSError):
         bad.close()
+
+
+@pytest.mark.parametrize('predict_x0', [True, False])
+@pytest.mark.parametrize('variant', ['bh1', 'bh2'])
+@pytest.mark.parametrize('order', [1, 2, 3])
+def test_unipc_coefficient_compiler_matches_oracle_update(order, variant, predict_x0):
+    """solver_utils.unipc_coeffs (host, fp64) expands UniPC's predictor / corrector into plain linear combinations of
+    (x, buffered model outputs, model output at the predicted point); applying them must reproduce the oracle's
+    tensor-level restatement of unipc_update (solver_utils.py:174-287) on random tensors."""
+    from diff_sampler_amd import solver_utils
+    from oracle import solvers_ref
+    g = torch.Generator().manual_seed(order * 10 + (variant == 'bh2') * 3 + predict_x0)
+    times = [torch.tensor(v) for v in (9.0, 4.5, 2.0)][-order:]
+    t_next = torch.tensor(0.8)
+    x = torch.randn(2, 3, 4, 4, generator=g)
+    models = [torch.randn(2, 3, 4, 4, generator=g) for _ in range(order)]
+    model_t = torch.randn(2, 3, 4, 4, generator=g)
+    # oracle: `evaluate` returns the model output at the predicted point (x0 form) or a denoised D with (x_t - D) / t = model_t
+    seen = {}
+
+    def evaluate(x_t, t):
+        seen['x_pred'] = x_t.clone()
+        return model_t if predict_x0 else x_t - t * model_t
+    x_ref, m_ref = solvers_ref._unipc_update(x, models, times, t_next, order, variant, predict_x0, evaluate, True)
+    cf = solver_utils.unipc_coeffs([float(t) for t in times], float(t_next), order, predict_x0=predict_x0, variant=variant, use_corrector=True)
+    newest_first = models[::-1]
+    x_pred = cf['cx'] * x + sum(c * m for c, m in zip(cf['pred'], newest_first))
+    x_corr = cf['cx'] * x + sum(c * m for c, m in zip(cf['corr'][:-1], newest_first)) + cf['corr'][-1] * model_t
+    assert torch.allclose(x_pred, seen['x_pred'], rtol=1e-5, atol=1e-5)
+    assert torch.allclose(x_corr, x_ref, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(m_ref, model_t, rtol=1e-5, atol=1e-5)
