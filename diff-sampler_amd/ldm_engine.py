@@ -252,42 +252,18 @@ def _interp(x, xp, yp):
     return yp[i] + (x - xp[i]) * (yp[i + 1] - yp[i]) / (xp[i + 1] - xp[i])
 
 
-class CFGDenoiser:
-    """Drop-in for the reference ``CFGPrecond`` object (networks_edm.py:630-762): ``net(x, sigma, condition=...,
-    unconditional_condition=...)`` -> denoised latents NCHW fp32, plus the attributes and methods the samplers and
-    ``get_schedule('discrete')`` read (``guidance_type, guidance_rate, img_resolution, img_channels, label_dim, sigma_min,
-    sigma_max, sigma(), sigma_inv(), round_sigma()``)."""
-    host_sigma_ok = True       # solvers._Run: pass sigma as a Python float (c_noise is host math; nothing to copy or sync)
+class CFGSchedule:
+    """The host side of ``CFGPrecond`` (networks_edm.py:654-661, 692-714): sigma(t), its inverse and the schedule end points,
+    piecewise-linear over the ``alphas_cumprod`` table, evaluated in fp32 with the reference's formulas.  Pure host code."""
 
-    def __init__(self, spec: ldm_arch.LDMUNetSpec, params: Dict[str, torch.Tensor], device='cuda', guidance_rate=None,
-                 guidance_type=None):
-        self.spec = spec
-        self.engine = LDMUNetEngine(spec, params, device)
-        self.device = self.engine.device
-        self.guidance_rate = spec.guidance_rate if guidance_rate is None else guidance_rate
-        self.guidance_type = spec.guidance_type if guidance_type is None else guidance_type
-        self.img_resolution, self.img_channels, self.label_dim = spec.img_resolution, spec.in_channels, True
-        log_alphas = 0.5 * torch.log(ldm_arch.alphas_cumprod(spec))         # host tables (networks_edm.py:654-658)
+    def __init__(self, spec: ldm_arch.LDMUNetSpec):
+        log_alphas = 0.5 * torch.log(ldm_arch.alphas_cumprod(spec))
         self.M = len(log_alphas)
         self.t_array = torch.linspace(0., 1., self.M + 1)[1:]
         self.log_alpha_array = log_alphas
         self.sigma_min = float(self.sigma(spec.epsilon_t))
         self.sigma_max = float(self.sigma(1))
-        self.use_fp16 = False
 
-    @classmethod
-    def from_config(cls, name_or_kwargs, seed=0, device='cuda', **kw):
-        cfg = ldm_arch.NAMED_LDM_CONFIGS[name_or_kwargs] if isinstance(name_or_kwargs, str) else name_or_kwargs
-        spec = ldm_arch.ldm_unet_spec(**cfg)
-        return cls(spec, ldm_arch.init_ldm_params(spec, seed=seed), device, **kw)
-
-    def eval(self):
-        return self
-
-    def to(self, *a, **k):
-        return self
-
-    # -- noise schedule maps, evaluated on the host in fp32 like the reference's formulas (networks_edm.py:692-714) ---------
     def sigma(self, t):
         dev = t.device if isinstance(t, torch.Tensor) else None
         t = torch.as_tensor(t, dtype=torch.float32).detach().cpu().reshape(-1)
@@ -304,6 +280,37 @@ class CFGDenoiser:
 
     def round_sigma(self, sigma):
         return torch.as_tensor(sigma)
+
+
+class CFGDenoiser(CFGSchedule):
+    """Drop-in for the reference ``CFGPrecond`` object (networks_edm.py:630-762): ``net(x, sigma, condition=...,
+    unconditional_condition=...)`` -> denoised latents NCHW fp32, plus the attributes and methods the samplers and
+    ``get_schedule('discrete')`` read (``guidance_type, guidance_rate, img_resolution, img_channels, label_dim, sigma_min,
+    sigma_max, sigma(), sigma_inv(), round_sigma()``)."""
+    host_sigma_ok = True       # solvers._Run: pass sigma as a Python float (c_noise is host math; nothing to copy or sync)
+
+    def __init__(self, spec: ldm_arch.LDMUNetSpec, params: Dict[str, torch.Tensor], device='cuda', guidance_rate=None,
+                 guidance_type=None):
+        self.spec = spec
+        self.engine = LDMUNetEngine(spec, params, device)
+        self.device = self.engine.device
+        self.guidance_rate = spec.guidance_rate if guidance_rate is None else guidance_rate
+        self.guidance_type = spec.guidance_type if guidance_type is None else guidance_type
+        self.img_resolution, self.img_channels, self.label_dim = spec.img_resolution, spec.in_channels, True
+        CFGSchedule.__init__(self, spec)                                    # host tables (networks_edm.py:654-658)
+        self.use_fp16 = False
+
+    @classmethod
+    def from_config(cls, name_or_kwargs, seed=0, device='cuda', **kw):
+        cfg = ldm_arch.NAMED_LDM_CONFIGS[name_or_kwargs] if isinstance(name_or_kwargs, str) else name_or_kwargs
+        spec = ldm_arch.ldm_unet_spec(**cfg)
+        return cls(spec, ldm_arch.init_ldm_params(spec, seed=seed), device, **kw)
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
 
     # -- evaluation ----------------------------------------------------------------------------------------------------------
     def raw(self, x, sigma, condition=None, unconditional_condition=None):

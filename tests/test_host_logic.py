@@ -234,3 +234,19 @@ def test_unipc_coefficient_compiler_matches_oracle_update(order, variant, predic
     assert torch.allclose(x_pred, seen['x_pred'], rtol=1e-5, atol=1e-5)
     assert torch.allclose(x_corr, x_ref, rtol=1e-5, atol=1e-5)
     assert torch.allclose(m_ref, model_t, rtol=1e-5, atol=1e-5)
+
+
+def test_cfg_schedule_host_maps_match_reference_probes():
+    """ldm_engine.CFGSchedule (sigma, sigma_inv, end points, the 'discrete' schedule of get_schedule) against the values the
+    real reference CFGPrecond produced (tests/golden/ldm_sd15.npz) -- host math only, no GPU."""
+    import numpy as np
+    import diff_sampler_amd.ldm_arch as la
+    from diff_sampler_amd import solver_utils
+    from diff_sampler_amd.ldm_engine import CFGSchedule
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'ldm_sd15.npz'))
+    sch = CFGSchedule(la.ldm_unet_spec(**la.NAMED_LDM_CONFIGS['sd15']))
+    assert abs(sch.sigma_min - float(z['sigma_min'])) < 1e-7 and abs(sch.sigma_max - float(z['sigma_max'])) < 1e-5
+    assert np.allclose(sch.sigma_inv(torch.from_numpy(z['probe_sigma'])).numpy(), z['probe_sigma_inv'], rtol=2e-6, atol=1e-7)
+    assert np.allclose(sch.sigma(torch.from_numpy(z['probe_t'])).numpy(), z['probe_sigma_of_t'], rtol=2e-6, atol=1e-7)
+    ts = solver_utils.get_schedule(6, sch.sigma_min, sch.sigma_max, device='cpu', schedule_type='discrete', schedule_rho=1, net=sch)
+    assert np.allclose(ts.numpy(), z['sched_discrete_6'], rtol=5e-6)
