@@ -129,7 +129,7 @@ def load():
     # (same SONAME), so that torch's stream handles and allocations are valid in our launches.
     import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
-        raise DsError(f'{LIB_PATH} is missing: build it with `python diff-sampler_amd/build.py` '
+        raise DsError(f'{LIB_PATH} is missing: build it with `python diff_sampler_amd/build.py` '
                       f'(or __graft_entry__.build()).  The HIP engine has no CPU fallback.')
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():

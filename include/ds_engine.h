@@ -7,7 +7,7 @@
  * reference issues (cited per function as file:line under /root/reference/diff-solvers-main unless noted), takes
  * raw device pointers + sizes + a hipStream_t (passed as void*), returns 0 on success or a non-zero code
  * (positive = hipError_t, negative = argument error, see DS_E_*), never allocates, never synchronises.
- * The Python mirrors of the reference functions (diff-sampler_amd/solvers.py etc.) bind it with ctypes;
+ * The Python mirrors of the reference functions (diff_sampler_amd/solvers.py etc.) bind it with ctypes;
  * INTEGRATION.md shows the binding a reference maintainer would add.
  *
  * Tensor layouts

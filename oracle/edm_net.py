@@ -1,7 +1,7 @@
 """ORACLE (test infrastructure, not product code): CPU restatement of the EDM denoiser.
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
-file; the shipped path (``diff-sampler_amd/``) never does.
+file; the shipped path (``diff_sampler_amd/``) never does.
 
 What it restates (all citations relative to /root/reference/diff-solvers-main/):
   * ``EDMPrecond.forward``                models/networks_edm.py:482-496

@@ -1,7 +1,7 @@
 """ORACLE (test infrastructure, not product code): CPU restatement of the reference ODE samplers.
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
-file; the shipped path (``diff-sampler_amd/``) never does.
+file; the shipped path (``diff_sampler_amd/``) never does.
 
 Restated (citations relative to /root/reference/):
   * time schedules                 diff-solvers-main/solver_utils.py:6-52, gits-main/solver_utils.py:52-53
