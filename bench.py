@@ -1,9 +1,12 @@
 #!/usr/bin/env python
 """Headline benchmark: images/sec at NFE=10 on the EDM CIFAR-10 denoiser (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N --steps K --warmup W          # N > 1: starts the N ranks itself (one per GPU, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W              # the driver's form; WORLD_SIZE must equal --gpus
+
+`--gpus` is checked, never trusted: WORLD_SIZE != --gpus, fewer visible GPUs than ranks, or a communicator that counts a
+different number of ranks all exit non-zero (diff_sampler_amd/launch.py); `n_gpus` in the line comes from an all-reduce.
 
 One "step" = one full sampler call (DPM-Solver++(2M), 10 network evaluations, logSNR schedule -- BASELINE configs[1]
 at the NFE the metric is quoted on) over a batch of synthetic N(0,1) latents already resident in HBM, on the
@@ -20,8 +23,12 @@ Prints ONE JSON line on rank 0 with the driver's contract fields plus
   roofline_update  the fused solver-update kernel against HBM 8 TB/s at the benchmark's batch (latency-bound there), and
   roofline_update_large_batch  the same kernel measured in-process at 16 384 images per launch, where it is bandwidth-bound
   kernels          time share of every kernel class in the instrumented step
-  cpu_baseline     the oracle (CPU restatement of the reference, ``oracle/``) timed on this host's cores on a bounded
-                   sample of the same workload.
+  launch_modes     the same sampler call eager vs replayed from one captured hipGraph, at B=8 and at the benchmark batch
+  cpu_baseline     the oracle (CPU restatement of the reference, ``oracle/``; the real reference when /root/reference is
+                   importable) timed on this host's cores on a bounded sample of the same workload, at the best of a
+                   thread-count sweep (cores = the thread count used)
+  multi_gpu        (N > 1) per-rank ms/step min/max (barrier skew) and the timed FID moment all-reduce (16 KiB + 32 MiB
+                   fp64 SUM, fid.py:74-75) with algbw / busbw against the 153 GB/s xGMI link.
 """
 import argparse
 import ctypes as C
@@ -44,7 +51,7 @@ PMC_KEYS = {0: 'void igemm::igemm_f32_kernel<0>(igemm::KParams)', 128: 'void ige
             256: 'void igemm::conv3x3_halo_kernel<4, true, 2>(igemm::KParams)', 2561: 'igemm::gemm_dma8_kernel(igemm::KParams)'}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
@@ -57,7 +64,10 @@ def parse():
     ap.add_argument('--graph', action='store_true', help='replay the sampler call from a captured hipGraph')
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--cpu-calls', type=int, default=2)
-    return ap.parse_args()
+    ap.add_argument('--cpu-threads', default='sweep', help="'sweep' (8,16,32,64,all; best reported) or a thread count")
+    ap.add_argument('--no-launch-modes', action='store_true', help='skip the eager-vs-hipGraph comparison')
+    ap.add_argument('--stub', action='store_true', help=argparse.SUPPRESS)   # launcher self-test: gloo ranks on CPU, no kernels
+    return ap.parse_args(argv)
 
 
 def sampler_call(solvers, solver, net, latents, nfe, ldm=None):
@@ -214,98 +224,220 @@ def cpu_baseline_ldm(args, nfe):
                 sample=f'1 sampler call x batch 1 (2 U-Net images per evaluation), NFE={nfe}, same net/solver ({dt:.1f} s of CPU work)')
 
 
+def _thread_candidates(spec):
+    n = os.cpu_count() or 1
+    if spec != 'sweep':
+        return [max(1, min(int(spec), n))]
+    return sorted({t for t in (8, 16, 32, 64, n) if t <= n})
+
+
+def _reference_sampler(args, nfe):
+    """The REAL reference (diff-solvers-main) when it is importable here (build container); None on the GPU box."""
+    ref = '/root/reference/diff-solvers-main'
+    if not os.path.isdir(ref):
+        return None
+    try:
+        sys.path.insert(0, ref)
+        import solvers as ref_solvers
+        from models.networks_edm import EDMPrecond
+        import diff_sampler_amd.arch as arch
+        kw = dict(arch.NAMED_CONFIGS[args.config])
+        net = EDMPrecond(**kw).eval()
+        net.load_state_dict(arch.init_params(arch.edm_precond_spec(**kw), seed=0), strict=False)
+        fn = {'dpmpp': ref_solvers.dpm_pp_sampler, 'euler': ref_solvers.euler_sampler, 'ipndm': ref_solvers.ipndm_sampler,
+              'heun': ref_solvers.heun_sampler}[args.solver]
+        kws = dict(num_steps=nfe + 1, sigma_min=0.002, sigma_max=80.)
+        if args.solver == 'dpmpp':
+            kws.update(schedule_type='logsnr', max_order=2, predict_x0=True, lower_order_final=True)
+        elif args.solver == 'ipndm':
+            kws.update(max_order=4)
+        elif args.solver == 'heun':
+            kws.update(num_steps=nfe // 2 + 1)
+        return lambda lat: fn(net, lat, **kws)
+    except Exception:
+        return None
+    finally:
+        if sys.path and sys.path[0] == ref:
+            sys.path.pop(0)
+
+
 def cpu_baseline(args, nfe):
-    """Oracle (kind 'port') on the host cores: same net, same sampler, bounded sample."""
-    from oracle import solvers_ref
-    from oracle.edm_net import OracleNet
+    """Same net, same sampler on the host cores, bounded sample.  kind 'reference' = the reference's own code (only where
+    /root/reference exists), else 'port' = the oracle restatement.  One call per thread count of the sweep, the best is
+    reported with the thread count that produced it (128 threads on an 8-image batch is oversubscription)."""
     import diff_sampler_amd.arch as arch
     kw = dict(arch.NAMED_CONFIGS[args.config])
     spec = arch.edm_precond_spec(**kw)
-    net = OracleNet(arch.init_params(spec, seed=0), kw)
-    threads = torch.get_num_threads()
     g = torch.Generator().manual_seed(0)
     lat = torch.randn(args.cpu_batch, 3, spec.img_resolution, spec.img_resolution, generator=g)
-    ts = solvers_ref.schedule(nfe + 1, 0.002, 80., kind='logsnr' if args.solver == 'dpmpp' else 'polynomial', rho=7)
-    name = {'dpmpp': 'dpm_pp', 'euler': 'euler', 'ipndm': 'ipndm', 'heun': 'heun'}[args.solver]
-    kws = dict(max_order=2, predict_x0=True, lower_order_final=True, num_steps=nfe + 1) if args.solver == 'dpmpp' else \
-        (dict(max_order=4) if args.solver == 'ipndm' else {})
+    call, kind = _reference_sampler(args, nfe), 'reference'
+    if call is None:
+        from oracle import solvers_ref
+        from oracle.edm_net import OracleNet
+        net = OracleNet(arch.init_params(spec, seed=0), kw)
+        ts = solvers_ref.schedule(nfe + 1, 0.002, 80., kind='logsnr' if args.solver == 'dpmpp' else 'polynomial', rho=7)
+        name = {'dpmpp': 'dpm_pp', 'euler': 'euler', 'ipndm': 'ipndm', 'heun': 'heun'}[args.solver]
+        kws = dict(max_order=2, predict_x0=True, lower_order_final=True, num_steps=nfe + 1) if args.solver == 'dpmpp' else \
+            (dict(max_order=4) if args.solver == 'ipndm' else {})
+        call, kind = (lambda l: solvers_ref.sample(name, net, l, ts, **kws)), 'port'
+    default_threads = torch.get_num_threads()
+    sweep, total = {}, 0.0
     with torch.no_grad():
-        t0 = time.time()
-        for _ in range(args.cpu_calls):
-            solvers_ref.sample(name, net, lat, ts, **kws)
-        dt = time.time() - t0
-    return dict(value=round(args.cpu_batch * args.cpu_calls / dt, 3), unit='images/sec', cores=threads, kind='port',
-                sample=f'{args.cpu_calls} sampler calls x batch {args.cpu_batch}, NFE={nfe}, same net/solver ({dt:.1f} s of CPU work)')
+        for th in _thread_candidates(args.cpu_threads):
+            torch.set_num_threads(th)
+            t0 = time.time()
+            call(lat)
+            dt = time.time() - t0
+            total += dt
+            sweep[th] = round(args.cpu_batch / dt, 3)
+    torch.set_num_threads(default_threads)
+    best = max(sweep, key=sweep.get)
+    return dict(value=sweep[best], unit='images/sec', cores=best, kind=kind, host_cores=os.cpu_count(),
+                threads_sweep={str(k): v for k, v in sweep.items()},
+                sample=f'1 sampler call x batch {args.cpu_batch} per thread count, NFE={nfe}, same net/solver ({total:.1f} s of CPU work in all)')
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get('RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    local = int(os.environ.get('LOCAL_RANK', 0))
-    dist = None
+def launch_modes(args, solvers, net_factory, spec, dev):
+    """Eager vs hipGraph replay of the SAME sampler call (north_star: a hipGraph-captured step), ms per call."""
+    from diff_sampler_amd.graph import GraphedSampler
+
+    class _Rec:        # records the sampler function and kwargs sampler_call() would use
+        def __getattr__(self, name):
+            return lambda net_, lat_, **kw: (getattr(solvers, name), kw)
+
+    out = {}
+    for B in sorted({8, args.batch}):
+        net = net_factory()
+        lat = torch.randn(B, spec.in_channels, spec.img_resolution, spec.img_resolution, device=dev)
+        fn, kw = sampler_call(_Rec(), args.solver, net, lat, args.nfe)
+        graphed = GraphedSampler(fn, net, tuple(lat.shape), device=dev, **kw)
+        res = {}
+        for mode, step in (('eager_ms', lambda: sampler_call(solvers, args.solver, net, lat, args.nfe)),
+                           ('graph_ms', lambda: graphed(lat, clone=False))):
+            step(); torch.cuda.synchronize()
+            n = 2 if B > 64 else 5
+            t0 = time.perf_counter()
+            for _ in range(n):
+                step()
+            torch.cuda.synchronize()
+            res[mode] = round((time.perf_counter() - t0) / n * 1e3, 3)
+        out[f'batch_{B}'] = res
+        del graphed, net
+    return out
+
+
+def fid_allreduce_timing(dist, dev, world, reps=3):
+    """The only data collective of the scope (fid.py:74-75): SUM all-reduce of mu (16 KiB) and sigma (32 MiB), fp64."""
+    from diff_sampler_amd.fid import MomentAccumulator
+    acc = MomentAccumulator(2048, dev)
+    acc.mu.normal_(); acc.sigma.normal_()
+    acc.all_reduce()                                    # warm-up (communicator set-up, buffer registration)
+    mu_s = sg_s = 0.0
+    for _ in range(reps):
+        acc.all_reduce()
+        mu_s += acc.last_timing['mu_s']; sg_s += acc.last_timing['sigma_s']
+    mu_s /= reps; sg_s /= reps
+    byts = acc.sigma.numel() * 8
+    alg = byts / sg_s / 1e9
+    return dict(mu_16KiB_ms=round(mu_s * 1e3, 4), sigma_32MiB_ms=round(sg_s * 1e3, 4), sigma_algbw_GBs=round(alg, 2),
+                sigma_busbw_GBs=round(alg * 2 * (world - 1) / world, 2), xgmi_link_GBs=153.0, dtype='f64', op='SUM')
+
+
+def main(argv=None):
+    from diff_sampler_amd import launch
+    args = parse(argv)
+    try:
+        rank, world, local = launch.resolve(args.gpus, os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv))
+    except launch.LaunchError as e:
+        print(f'bench.py: {e}', file=sys.stderr)
+        raise SystemExit(2)
+    stub = args.stub
+    if not stub:
+        if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
+            print(f'bench.py: rank {rank} needs GPU {local}, {torch.cuda.device_count() if torch.cuda.is_available() else 0} visible',
+                  file=sys.stderr)
+            raise SystemExit(2)
+        torch.cuda.set_device(local)
+    dev = torch.device('cpu') if stub else torch.device('cuda', local)
+    dist, n_comm = None, 1
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', init_method='env://')
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
+        try:
+            dist, n_comm = launch.init_group(rank, world, local, 'gloo' if stub else 'nccl', dev)
+        except launch.LaunchError as e:
+            print(f'bench.py: {e}', file=sys.stderr)
+            raise SystemExit(2)
+    sync = (lambda: None) if stub else torch.cuda.synchronize
 
-    from diff_sampler_amd import solvers
-    from diff_sampler_amd.engine import EDMDenoiser
-
-    import diff_sampler_amd.ldm_arch as ldm_arch
     B = args.batch
     g = torch.Generator(device='cpu').manual_seed(1234 + rank)
     ldm = None
-    if args.config in ldm_arch.NAMED_LDM_CONFIGS:
-        from diff_sampler_amd.ldm_engine import CFGDenoiser
-        net = CFGDenoiser.from_config(args.config, seed=0, device=dev, guidance_rate=7.5)
-        spec = net.spec
-        ldm = (torch.randn(B, 77, spec.context_dim, generator=g).to(dev), torch.randn(B, 77, spec.context_dim, generator=g).to(dev))
-        args.solver = 'dpmpp'
-    else:
-        net = EDMDenoiser.from_config(args.config, seed=0, device=dev)
-        spec = net.spec
-    latents = torch.randn(B, spec.in_channels, spec.img_resolution, spec.img_resolution, generator=g).to(dev)
-
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline_ldm(args, args.nfe) if ldm is not None else cpu_baseline(args, args.nfe)
+    if stub:
+        solvers = net = spec = latents = None
+        run_step = lambda: time.sleep(0.002 * (1 + rank))
+    else:
+        from diff_sampler_amd import solvers
+        from diff_sampler_amd.engine import EDMDenoiser
+        import diff_sampler_amd.ldm_arch as ldm_arch
+        if args.config in ldm_arch.NAMED_LDM_CONFIGS:
+            from diff_sampler_amd.ldm_engine import CFGDenoiser
+            net_factory = lambda: CFGDenoiser.from_config(args.config, seed=0, device=dev, guidance_rate=7.5)
+            net = net_factory()
+            spec = net.spec
+            ldm = (torch.randn(B, 77, spec.context_dim, generator=g).to(dev), torch.randn(B, 77, spec.context_dim, generator=g).to(dev))
+            args.solver = 'dpmpp'
+        else:
+            net_factory = lambda: EDMDenoiser.from_config(args.config, seed=0, device=dev)
+            net = net_factory()
+            spec = net.spec
+        latents = torch.randn(B, spec.in_channels, spec.img_resolution, spec.img_resolution, generator=g).to(dev)
 
-    run_step = lambda: sampler_call(solvers, args.solver, net, latents, args.nfe, ldm)
-    if args.graph:
-        assert ldm is None, '--graph covers the EDM nets'
-        from diff_sampler_amd.graph import GraphedSampler
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline_ldm(args, args.nfe) if ldm is not None else cpu_baseline(args, args.nfe)
 
-        class _Rec:        # records the sampler function and kwargs sampler_call() would use
-            def __getattr__(self, name):
-                return lambda net_, lat_, **kw: (getattr(solvers, name), kw)
-        fn, kw = sampler_call(_Rec(), args.solver, net, latents, args.nfe)
-        graphed = GraphedSampler(fn, net, tuple(latents.shape), device=dev, **kw)
-        run_step = lambda: graphed(latents, clone=False)
+        run_step = lambda: sampler_call(solvers, args.solver, net, latents, args.nfe, ldm)
+        if args.graph:
+            assert ldm is None, '--graph covers the EDM nets'
+            from diff_sampler_amd.graph import GraphedSampler
+
+            class _Rec:        # records the sampler function and kwargs sampler_call() would use
+                def __getattr__(self, name):
+                    return lambda net_, lat_, **kw: (getattr(solvers, name), kw)
+            fn, kw = sampler_call(_Rec(), args.solver, net, latents, args.nfe)
+            graphed = GraphedSampler(fn, net, tuple(latents.shape), device=dev, **kw)
+            run_step = lambda: graphed(latents, clone=False)
     for _ in range(args.warmup):
         run_step()
-    torch.cuda.synchronize()
+    sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
+    out = None
     for _ in range(args.steps):
         out = run_step()
-    torch.cuda.synchronize()
+    sync()
+    dt_local = time.perf_counter() - t0                  # this rank's own K steps (before waiting for the others)
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
+    multi = None
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    assert torch.isfinite(out).all()
+        per = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(per, torch.tensor([dt_local], dtype=torch.float64, device=dev))
+        per_ms = [float(t.item()) / args.steps * 1e3 for t in per]
+        multi = dict(per_rank_ms_per_step_min=round(min(per_ms), 3), per_rank_ms_per_step_max=round(max(per_ms), 3),
+                     per_rank_ms_per_step=[round(v, 3) for v in per_ms], backend='gloo' if stub else 'nccl (RCCL)',
+                     fid_moment_allreduce=fid_allreduce_timing(dist, dev, world))
+    if not stub:
+        assert torch.isfinite(out).all()
 
     roof = roof_u = kernels = None
-    if rank == 0:
+    if rank == 0 and not stub:
         rec = instrumented_pass(net, solvers, args.solver, latents, args.nfe, ldm)
         total_ms = sum(v[0] for v in rec.values())
         kernels = {(KERNEL_NAMES[k[1]] if isinstance(k, tuple) else k): dict(ms=round(v[0], 2), launches=v[1], share=round(v[0] / total_ms, 4))
@@ -314,10 +446,9 @@ def main():
         dom, (ms, launches, fl) = max(convs.items(), key=lambda kv: kv[1][0])
         ach = fl / (ms * 1e-3) / 1e12
         traffic = pmc_traffic(dom[1]) if (args.config == 'cifar10' and B == 256) else None   # the PMC pass is of the default workload
-        alg_bytes = None
         roof = dict(bound='mfma', kernel=KERNEL_NAMES[dom[1]], achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
                     frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=(round(traffic) if traffic else None),
-                    traffic_unit='HBM bytes per launch (rocprofv3 PMC, profiles/r1f_bench_pmc_hbm.json)',
+                    traffic_unit='HBM bytes per launch (rocprofv3 PMC, %s)' % os.path.relpath(PMC_FILE, ROOT),
                     launches_per_step=launches, avg_launch_ms=round(ms / launches, 4), gflop_per_launch=round(fl / launches / 1e9, 2),
                     share_of_gpu_time=round(ms / total_ms, 4))
         if 'solver_update_kernel' in rec and ldm is None:
@@ -331,9 +462,11 @@ def main():
                           frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, launches_per_step=ul, avg_launch_ms=round(ums / ul, 4),
                           note='latency-bound at this batch (3 MB per operand); see DESIGN.md section 6 for the large-batch figure')
 
-    roof_ul = None
-    if rank == 0 and ldm is None:
+    roof_ul = modes = None
+    if rank == 0 and ldm is None and not stub:
         roof_ul = update_roofline_large_batch(dev)
+        if not args.no_launch_modes and world == 1:
+            modes = launch_modes(args, solvers, net_factory, spec, dev)
     if rank == 0:
         workload_name = {'cifar10': 'EDM CIFAR-10 32x32 SongUNet (55.7M params)', 'ffhq': 'EDM FFHQ-64 SongUNet (61.8M params)',
                          'afhqv2': 'EDM AFHQv2-64 SongUNet', 'imagenet64': 'EDM ImageNet-64 DhariwalUNet (295.9M params)',
@@ -341,7 +474,7 @@ def main():
         total_images = B * world * args.steps
         line = {
             'metric': 'images/sec (whole node) at NFE=%d, %s' % (args.nfe, 'EDM CIFAR-10' if args.config == 'cifar10' else workload_name.split(' (')[0]),
-            'value': round(total_images / dt, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'value': round(total_images / dt, 2), 'unit': 'images/sec', 'n_gpus': n_comm, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'fp32', 'data': 'synthetic N(0,1) latents, random-init (signal-carrying) weights',
             'config': {'workload': '%s, %s NFE=%d, batch %d/GPU' %
@@ -349,8 +482,12 @@ def main():
                         {'dpmpp': 'DPM-Solver++(2M) logSNR', 'euler': 'Euler', 'ipndm': 'iPNDM-4', 'heun': 'Heun'}[args.solver], args.nfe, B),
                        'images_per_step': B * world, 'sharding': 'independent image batches per rank, no collective',
                        'launch': 'hipGraph replay' if args.graph else 'eager'},
-            'roofline': roof, 'roofline_update': roof_u, 'roofline_update_large_batch': roof_ul, 'kernels': kernels, 'cpu_baseline': cpu,
+            'roofline': roof, 'roofline_update': roof_u, 'roofline_update_large_batch': roof_ul, 'kernels': kernels,
+            'launch_modes': modes, 'cpu_baseline': cpu, 'multi_gpu': multi,
         }
+        if stub:
+            line['stub'] = True
+            line['data'] = 'launcher self-test: no kernels ran, value is meaningless'
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -38,16 +38,20 @@ class MomentAccumulator:
         """SUM over ranks (fid.py:74-75).  Returns the wall time of the two collectives in seconds (informational)."""
         import time
         import torch.distributed as dist
+        self.last_timing = dict(mu_s=0.0, sigma_s=0.0)
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return 0.0
-        if self.mu.is_cuda:
-            torch.cuda.synchronize()
+        sync = torch.cuda.synchronize if self.mu.is_cuda else (lambda: None)
+        sync()
         t0 = time.perf_counter()
         dist.all_reduce(self.mu)
+        sync()
+        t1 = time.perf_counter()
         dist.all_reduce(self.sigma)
-        if self.mu.is_cuda:
-            torch.cuda.synchronize()
-        return time.perf_counter() - t0
+        sync()
+        t2 = time.perf_counter()
+        self.last_timing = dict(mu_s=t1 - t0, sigma_s=t2 - t1)
+        return t2 - t0
 
     def finalize(self, num_total: int):
         """fid.py:76-78 -> (mu, sigma) as numpy fp64."""

@@ -20,6 +20,10 @@ Parts
   gits      gits-main/gits_utils.py get_dp_list (cost matrix + dynamic programme) on a tiny net
   ldm       reference CFGPrecond + ldm UNetModel (tiny configs and full SD-1.5 size): denoiser outputs with
             classifier-free guidance, sigma / sigma_inv / discrete schedule probes, sampler trajectories
+  full      full-size pins of the BENCHMARKED configurations (round 2): CIFAR-10 net, DPM-Solver++(2M) logSNR NFE=10
+            at B=64 (the bench.py headline sampler; final images); one full-size evaluation each of the FFHQ-64
+            SongUNet and the ImageNet-64 DhariwalUNet (B=1, labels); one full-size SD-1.5 config-5 trajectory
+            (DPM-Solver++(2M) eps-prediction, discrete rho=1, num_steps=6, CFG 7.5, B=1)
 """
 import argparse
 import os
@@ -286,7 +290,44 @@ def part_ldm():
         print('ldm', name, float(np.abs(d['out_vec']).max()), net.sigma_min, net.sigma_max)
 
 
-PARTS = dict(net=part_net, sched=part_sched, samplers=part_samplers, amed=part_amed, gits=part_gits, ldm=part_ldm)
+def part_full():
+    sys.path.insert(0, os.path.join(REF, 'diff-solvers-main'))
+    import solvers
+    torch.set_grad_enabled(False)
+    # (1) the headline sampler of bench.py at a batch whose 32x32 layers dispatch to the 256-pixel-tile kernel
+    net, kw = _ref_net('cifar10', 31)
+    latents = torch.randn(64, 3, 32, 32, generator=torch.Generator().manual_seed(1))
+    out = solvers.dpm_pp_sampler(net, latents, num_steps=11, sigma_min=0.002, sigma_max=80., schedule_type='logsnr', schedule_rho=7,
+                                 max_order=2, predict_x0=True, lower_order_final=True)
+    np.savez_compressed(os.path.join(OUT, 'sampler_cifar10_dpmpp2m_nfe10_b64.npz'), seed=31, latent_seed=1, out=out.numpy())
+    print('full cifar10 dpmpp2m nfe10 b64', float(out.abs().max()), flush=True)
+    del net
+    # (2) one full-size evaluation of the other two EDM nets of BASELINE.json (configs 3 and 4)
+    for name, seed in [('ffhq', 61), ('imagenet64', 62)]:
+        net, kw = _ref_net(name, seed)
+        x, lab = _inputs(kw, 1, seed + 100)
+        sig = torch.tensor([1.3])
+        x = x * sig.reshape(-1, 1, 1, 1)
+        out = net(x, sig, class_labels=lab)
+        np.savez_compressed(os.path.join(OUT, f'net_{name}.npz'), config=name, seed=seed, x=x.numpy(), sigma=sig.numpy(),
+                            labels=(lab.numpy() if lab is not None else np.zeros(0, np.float32)), out_vec=out.numpy())
+        print('full net', name, float(out.abs().max()), flush=True)
+        del net
+    # (3) BASELINE config 5 at full size: one latent through the whole sampler call
+    net, unet, kw, spec = _ref_cfg_net('sd15', 23)
+    g = torch.Generator().manual_seed(223)
+    lat = torch.randn(1, 4, 64, 64, generator=g)
+    cond = torch.randn(1, 77, 768, generator=g)
+    uncond = torch.randn(1, 77, 768, generator=g)
+    tr = solvers.dpm_pp_sampler(net, lat, condition=cond, unconditional_condition=uncond, num_steps=6, sigma_min=net.sigma_min,
+                                sigma_max=net.sigma_max, schedule_type='discrete', schedule_rho=1, return_inters=True,
+                                max_order=2, predict_x0=False, lower_order_final=True)
+    np.savez_compressed(os.path.join(OUT, 'ldm_sd15_traj.npz'), seed=23, input_seed=223, latents=lat.numpy(), cond=cond.numpy(),
+                        uncond=uncond.numpy(), traj=tr.numpy())
+    print('full sd15 config-5 trajectory', tuple(tr.shape), float(tr[-1].abs().max()), flush=True)
+
+
+PARTS = dict(net=part_net, sched=part_sched, samplers=part_samplers, amed=part_amed, gits=part_gits, ldm=part_ldm, full=part_full)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

@@ -1,0 +1,90 @@
+"""bench.py --gpus N really runs N ranks and cannot mis-report (CPU: gloo ranks through the `--stub` self-test, which
+replaces the kernel work by a sleep and keeps the launcher, the world-size checks, the per-rank timing gather and the FID
+moment all-reduce)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from diff_sampler_amd import launch  # noqa: E402
+
+BENCH = os.path.join(ROOT, 'bench.py')
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['OMP_NUM_THREADS'] = '1'
+    return env
+
+
+def test_launch_command_is_torchrun_on_loopback():
+    cmd = launch.launch_command(4, 'bench.py', ['--gpus', '4', '--steps', '2'], port=12345, python='python')
+    assert cmd == ['python', '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=4', '--master-addr', '127.0.0.1',
+                   '--master-port', '12345', 'bench.py', '--gpus', '4', '--steps', '2']
+
+
+def test_resolve_rules():
+    assert launch.resolve(1, 'x.py', [], env={}) == (0, 1, 0)
+    assert launch.resolve(2, 'x.py', [], env=dict(WORLD_SIZE='2', RANK='1', LOCAL_RANK='1')) == (1, 2, 1)
+    with pytest.raises(launch.LaunchError):
+        launch.resolve(8, 'x.py', [], env=dict(WORLD_SIZE='1', RANK='0'))          # --gpus 8 under a 1-rank launcher
+    with pytest.raises(launch.LaunchError):
+        launch.resolve(1, 'x.py', [], env=dict(WORLD_SIZE='2', RANK='0'))
+    with pytest.raises(launch.LaunchError):
+        launch.resolve(0, 'x.py', [], env={})
+    seen = {}
+
+    def spawn(cmd, env=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return 7
+    with pytest.raises(SystemExit) as ex:                                          # un-launched parent: starts the ranks itself
+        launch.resolve(2, 'x.py', ['--gpus', '2'], env={}, spawn=spawn)
+    assert ex.value.code == 7
+    assert '--nproc-per-node=2' in seen['cmd'] and seen['cmd'][-3:] == ['x.py', '--gpus', '2']
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+def _line(out):
+    lines = [l for l in out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_bench_gpus2_self_launch_runs_two_ranks():
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--stub', '--steps', '2', '--warmup', '1'], env=_clean_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    line = _line(r.stdout)
+    assert line['n_gpus'] == 2 and line['stub'] is True and line['steps'] == 2
+    mg = line['multi_gpu']
+    assert len(mg['per_rank_ms_per_step']) == 2 and mg['per_rank_ms_per_step_min'] <= mg['per_rank_ms_per_step_max']
+    assert mg['per_rank_ms_per_step'][1] > mg['per_rank_ms_per_step'][0]            # the stub makes rank 1 slower: skew is visible
+    assert line['ms_per_step'] >= mg['per_rank_ms_per_step_max'] * 0.99             # max over ranks, barrier-bracketed
+    assert mg['fid_moment_allreduce']['sigma_32MiB_ms'] > 0
+    assert line['config']['images_per_step'] == 2 * 256
+
+
+def test_bench_driver_form_and_mismatch():
+    port = launch.free_port()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), BENCH, '--gpus', '2', '--stub', '--steps', '1', '--warmup', '0']
+    r = subprocess.run(cmd, env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert _line(r.stdout)['n_gpus'] == 2
+    env = _clean_env()
+    env.update(WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '8', '--stub'], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and 'WORLD_SIZE=1' in r.stderr and not r.stdout.strip()
+
+
+def test_bench_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '1', '--steps', '1'], env=_clean_env(), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and 'needs GPU' in r.stderr
