@@ -1,8 +1,15 @@
 """Batched generation CLI -- the reference's ``sample.py`` surface on the HIP engine.
 
 Same click options, defaults, seed sharding, per-seed RNG, NFE bookkeeping and output tree as
-diff-solvers-main/sample.py:125-320 (+ the GITS ``--dp/--metric/...`` and AMED ``--predictor_path`` options are
-accepted where they only select a schedule / predictor).  Differences, all host-side:
+diff-solvers-main/sample.py:125-320.  One CLI serves the three variants of the reference:
+  * plain (diff-solvers-main): ``--solver ... --num_steps ...``;
+  * GITS (gits-main/sample.py:135-170, :206-246): ``--dp True --metric/--coeff/--num_warmup/--solver_tea/--num_steps_tea``
+    search the schedule on the device, then sample with ``teacher_t[dp_list]``;
+  * AMED (amed-solver-main/sample.py:120-135, :160-185): ``--predictor_path`` loads the AMED predictor and EVERY solver
+    setting (sampler_stu, num_steps, afs, max_order, predict_x0, lower_order_final, schedule_type/rho, guidance, dataset_name)
+    is read back from it, exactly as the reference does; ``--predictor_path random:<seed> --random_init True`` builds a seeded
+    predictor from the CLI's own options instead (there are no trained predictors in this environment).
+Differences, all host-side:
   * the network object is an ``engine.EDMDenoiser`` (built from the unpickled EDM network when a pickle is given, or
     from the stated architecture with ``--random_init`` -- no pretrained weights exist in this environment);
   * uint8 conversion runs in a HIP kernel and PNG encoding is off the critical path only in the sense that it stays
@@ -63,15 +70,78 @@ def shard_seeds(seeds, max_batch_size: int, rank: int, world: int):
     return all_batches[rank::world]
 
 
-def compute_nfe(solver, num_steps, afs, denoise_to_zero, dataset_name):
-    """sample.py:211-219."""
+def compute_nfe(solver, num_steps, afs, denoise_to_zero, dataset_name, dp=False):
+    """sample.py:211-219; with a searched GITS schedule (``dp``) AFS INSERTS a step into the schedule instead of replacing
+    one (gits-main/sample.py:231-241): free for the 1-NFE solvers, one extra evaluation for dpm / heun."""
     if solver in ('dpm', 'heun'):
-        nfe = 2 * (num_steps - 1) - 1 if afs else 2 * (num_steps - 1)
+        nfe = 2 * (num_steps - 1)
+        if afs:
+            nfe = nfe + 1 if dp else nfe - 1
     else:
-        nfe = num_steps - 2 if afs else num_steps - 1
+        nfe = num_steps - 1
+        if afs:
+            nfe = nfe if dp else nfe - 1
     if denoise_to_zero:
         nfe += 1
     return 2 * nfe if dataset_name in ['ms_coco'] else nfe
+
+
+AMED_SOLVER_FNS = dict(amed='amed_sampler', euler='euler_sampler', dpm='dpm_2_sampler', ipndm='ipndm_sampler', dpmpp='dpm_pp_sampler')
+
+
+def find_predictor(predictor_path, exps_dir='./exps'):
+    """amed-solver-main/sample.py:148-163: a value that does not end in 'pkl' is an experiment number -- the newest snapshot of
+    ``exps/<5-digit number>-*/`` is used."""
+    if predictor_path.endswith(('pkl', '.pt')) or not os.path.isdir(exps_dir):
+        return predictor_path
+    want = '0' * (5 - len(predictor_path)) + predictor_path
+    for name in os.listdir(exps_dir):
+        if name.split('-')[0] == want:
+            best, best_idx = None, -1
+            for ck in (f for f in os.listdir(os.path.join(exps_dir, name)) if f.endswith('pkl')):
+                idx = int(ck.split('-')[-1].split('.')[0])
+                if idx > best_idx:
+                    best, best_idx = ck, idx
+            return os.path.join(exps_dir, name, best)
+    return predictor_path
+
+
+def load_predictor(predictor_path, device, random_init=False, **cli):
+    """-> solvers_amed.AMEDPredictor.
+      *.pkl          the reference's snapshot: ``pickle.load(f)['model']`` (needs training.networks importable), through
+                     ``AMEDPredictor.from_module`` (weights by state_dict key, settings by attribute);
+      *.pt           ``torch.save(dict(state_dict=..., **settings))`` -- the same content without pickled classes;
+      random:<seed>  (with --random_init) seeded weights of the reference architecture (training/networks.py:107-117: 8x8 map,
+                     64->128->4 encoder, 20->1 heads) with the settings taken from the CLI options."""
+    from .solvers_amed import AMEDPredictor
+    if predictor_path.startswith('random:'):
+        if not random_init:
+            raise ValueError("--predictor_path random:<seed> needs --random_init True (it is not a trained predictor)")
+        seed = int(predictor_path.split(':', 1)[1])
+        scale_dir = cli.get('scale_dir', 0.01) or 0
+        scale_time = cli.get('scale_time', 0) or 0
+        g = torch.Generator().manual_seed(seed)
+        shapes = [('map_layer0.weight', (8, 8)), ('map_layer0.bias', (8,)), ('enc_layer0.weight', (128, 64)), ('enc_layer0.bias', (128,)),
+                  ('enc_layer1.weight', (4, 128)), ('enc_layer1.bias', (4,)), ('fc_r.weight', (1, 20)), ('fc_r.bias', (1,))]
+        if scale_dir:
+            shapes += [('fc_scale_dir.weight', (1, 20)), ('fc_scale_dir.bias', (1,))]
+        if scale_time:
+            shapes += [('fc_scale_time.weight', (1, 20)), ('fc_scale_time.bias', (1,))]
+        sd = {k: torch.randn(sh, generator=g) * (0.3 if k.endswith('weight') else 0.1) for k, sh in shapes}
+        settings = dict(dataset_name=cli.get('dataset_name'), num_steps=cli.get('num_steps'), sampler_stu=cli.get('solver') or 'amed',
+                        sampler_tea='heun', M=1, guidance_type=cli.get('guidance_type'), guidance_rate=cli.get('guidance_rate'),
+                        schedule_type=cli.get('schedule_type', 'polynomial'), schedule_rho=cli.get('schedule_rho', 7),
+                        afs=bool(cli.get('afs', False)), scale_dir=scale_dir, scale_time=scale_time, max_order=cli.get('max_order'),
+                        predict_x0=cli.get('predict_x0', True), lower_order_final=cli.get('lower_order_final', True))
+        return AMEDPredictor(sd, device=device, **settings)
+    path = find_predictor(predictor_path)
+    if path.endswith('.pt'):
+        blob = torch.load(path, map_location='cpu')
+        sd = blob.pop('state_dict')
+        return AMEDPredictor(sd, device=device, **blob)
+    with open(path, 'rb') as f:
+        model = pickle.load(f)['model']
+    return AMEDPredictor.from_module(model, device=device)
 
 
 SOLVER_FNS = dict(euler='euler_sampler', heun='heun_sampler', dpm='dpm_2_sampler', ipndm='ipndm_sampler',
@@ -127,7 +197,10 @@ class PngSink:
             seed = int(seed)
             d = os.path.join(outdir, f'{seed - seed % 1000:06d}') if subdirs else outdir
             os.makedirs(d, exist_ok=True)
-            PIL.Image.fromarray(img, 'RGB' if img.shape[-1] == 3 else None).save(os.path.join(d, f'{seed:06d}.png'))
+            if img.shape[-1] == 1:                      # sample.py:314-315 of the reference: single channel -> mode 'L'
+                PIL.Image.fromarray(img[:, :, 0], 'L').save(os.path.join(d, f'{seed:06d}.png'))
+            else:
+                PIL.Image.fromarray(img, 'RGB').save(os.path.join(d, f'{seed:06d}.png'))
 
     def submit(self, arr, seeds, outdir, subdirs=True, chunk=64):
         seeds = [int(s) for s in seeds]
@@ -159,10 +232,18 @@ def save_images(images: torch.Tensor, batch_seeds, outdir, subdirs=True, sink: '
 
 
 def save_grid(images: torch.Tensor, outdir):
+    """``make_grid(images, nrows, padding=0)`` + ``save_image`` of the reference (sample.py:305-309): ``int(sqrt(B))`` images per
+    row, ``ceil(B / per_row)`` rows, a partial last row is padded with zeros (black), quantisation ``x*255 + 0.5`` clamped."""
     import PIL.Image
     x = torch.clamp(images / 2 + 0.5, 0, 1)
-    n = int(x.shape[0] ** 0.5)
-    rows = [torch.cat(list(x[r * n:(r + 1) * n]), dim=2) for r in range(max(1, x.shape[0] // n))]
+    B, C, H, W = x.shape
+    per_row = min(max(1, int(B ** 0.5)), B)
+    n_rows = -(-B // per_row)
+    if n_rows * per_row > B:
+        x = torch.cat([x, torch.zeros(n_rows * per_row - B, C, H, W, dtype=x.dtype, device=x.device)], dim=0)
+    if C == 1:
+        x = x.expand(-1, 3, -1, -1)                     # make_grid replicates single-channel images to 3 channels
+    rows = [torch.cat(list(x[r * per_row:(r + 1) * per_row]), dim=2) for r in range(n_rows)]
     grid = (torch.cat(rows, dim=1) * 255 + 0.5).clamp(0, 255).to(torch.uint8).permute(1, 2, 0).cpu().numpy()
     os.makedirs(outdir, exist_ok=True)
     PIL.Image.fromarray(grid, 'RGB').save(os.path.join(outdir, 'grid.png'))
@@ -178,8 +259,8 @@ def _dist():
     return None, 0, 1
 
 
-def run(dataset_name, max_batch_size=64, seeds='0-63', grid=False, outdir=None, subdirs=True, t_steps=None, model_path=None,
-        random_init=False, device=None, **solver_kwargs):
+def run(dataset_name=None, max_batch_size=64, seeds='0-63', grid=False, outdir=None, subdirs=True, t_steps=None, model_path=None,
+        random_init=False, device=None, predictor_path=None, **solver_kwargs):
     """Body of the CLI, importable (the tests call it directly)."""
     from . import solvers, solver_utils
     seeds = parse_int_list(seeds)
@@ -191,6 +272,25 @@ def run(dataset_name, max_batch_size=64, seeds='0-63', grid=False, outdir=None, 
 
     if dist is not None and rank != 0:
         dist.barrier()                                              # rank 0 goes first (sample.py:183-193)
+    predictor = None
+    if predictor_path is not None:
+        # AMED (amed-solver-main/sample.py:146-185): the predictor decides the dataset and every solver setting
+        log(f'Loading AMED predictor from "{predictor_path}"...')
+        predictor = load_predictor(predictor_path, device, random_init=random_init, dataset_name=dataset_name, **solver_kwargs)
+        prompt = solver_kwargs.get('prompt')
+        solver_kwargs = {k: v for k, v in solver_kwargs.items() if v is not None}
+        solver_kwargs.update(AMED_predictor=predictor, solver=predictor.sampler_stu, num_steps=predictor.num_steps,
+                             guidance_type=predictor.guidance_type, guidance_rate=predictor.guidance_rate, afs=predictor.afs,
+                             denoise_to_zero=False, max_order=predictor.max_order, predict_x0=predictor.predict_x0,
+                             lower_order_final=predictor.lower_order_final, schedule_type=predictor.schedule_type,
+                             schedule_rho=predictor.schedule_rho, prompt=prompt)
+        solver_kwargs['dataset_name'] = dataset_name = predictor.dataset_name
+        if solver_kwargs['solver'] not in AMED_SOLVER_FNS:
+            raise ValueError(f"AMED predictor was trained for sampler {solver_kwargs['solver']!r}; supported: {sorted(AMED_SOLVER_FNS)}")
+        solver_kwargs.pop('dp', None)
+        t_steps = None
+    if dataset_name is None:
+        raise ValueError('--dataset_name is required (or --predictor_path, which carries it)')
     net, solver_kwargs['model_source'] = create_model(dataset_name, model_path, random_init, device,
                                                       guidance_type=solver_kwargs.get('guidance_type'),
                                                       guidance_rate=solver_kwargs.get('guidance_rate'))
@@ -208,38 +308,53 @@ def run(dataset_name, max_batch_size=64, seeds='0-63', grid=False, outdir=None, 
                      guidance_type=None, guidance_rate=None, return_inters=False).items():
         solver_kwargs.setdefault(k, v)
     solver_kwargs['sigma_min'], solver_kwargs['sigma_max'] = net.sigma_min, net.sigma_max
-    if solver_kwargs.get('dp') and t_steps is None:
-        # GITS (gits-main/sample.py:206-224): search the schedule on the device, then sample with teacher_t[dp_list]
-        from . import gits_utils
-        for k, v in dict(metric='dev', coeff=1.15, num_warmup=256, solver_tea=solver_kwargs.get('solver'), num_steps_tea=61).items():
-            if solver_kwargs.get(k) is None:
-                solver_kwargs[k] = v
-        dp_list = gits_utils.get_dp_list(net, device, dataset_name=dataset_name, max_batch_size=max_batch_size, **solver_kwargs)
-        t_steps = solver_utils.get_schedule(solver_kwargs['num_steps_tea'], net.sigma_min, net.sigma_max, device=device,
-                                            schedule_type=solver_kwargs['schedule_type'], schedule_rho=solver_kwargs['schedule_rho'],
-                                            net=net, dp_list=dp_list)
-        solver_kwargs['num_steps'] = t_steps.shape[0]
-        log('GITS dp_list:', dp_list, 't_steps:', [round(float(v), 4) for v in t_steps])
-        solver_kwargs['t_steps'] = t_steps
-    elif t_steps is None:
-        t_steps = solver_utils.get_schedule(solver_kwargs['num_steps'], net.sigma_min, net.sigma_max, device=device,
-                                            schedule_type=solver_kwargs['schedule_type'], schedule_rho=solver_kwargs['schedule_rho'],
-                                            net=net)
+    dp = bool(solver_kwargs.get('dp'))
+    if predictor is not None:
+        # amed-solver-main/sample.py:196-199: two evaluations per step (the first one free under AFS); the samplers build
+        # their own schedule from the predictor's schedule_type / rho
+        solver = solver_kwargs['solver']
+        nfe = 2 * (solver_kwargs['num_steps'] - 1) - 1 if solver_kwargs['afs'] else 2 * (solver_kwargs['num_steps'] - 1)
+        nfe = 2 * nfe if dataset_name in ['ms_coco'] else nfe
+        solver_kwargs['nfe'] = nfe
+        from . import solvers_amed
+        sampler_fn = getattr(solvers_amed, AMED_SOLVER_FNS[solver])
+        log('Solver settings:', {k: v for k, v in solver_kwargs.items() if k != 'AMED_predictor' and v is not None})
     else:
-        t_list = ast.literal_eval(t_steps) if isinstance(t_steps, str) else list(t_steps)
-        t_steps = torch.tensor(t_list, device=device)               # all-int lists give an int64 tensor, as in the reference
-        solver_kwargs['num_steps'] = t_steps.shape[0]
-        solver_kwargs['sigma_max'], solver_kwargs['sigma_min'] = t_list[0], t_list[-1]
-        solver_kwargs['schedule_type'] = solver_kwargs['schedule_rho'] = None
-        log('Pre-specified t_steps:', t_list)
-    solver_kwargs['t_steps'] = t_steps
-    solver = solver_kwargs['solver']
-    nfe = compute_nfe(solver, solver_kwargs['num_steps'], solver_kwargs['afs'], solver_kwargs['denoise_to_zero'], dataset_name)
-    solver_kwargs['nfe'] = nfe
-    sampler_fn = getattr(solvers, SOLVER_FNS[solver])
-    if solver == 'deis':
-        solver_kwargs['coeff_list'] = solver_utils.get_deis_coeff_list(t_steps, solver_kwargs['max_order'],
-                                                                       deis_mode=solver_kwargs['deis_mode'])
+        if t_steps is None and dp:
+            # GITS (gits-main/sample.py:206-219): search the schedule on the device, then sample with teacher_t[dp_list];
+            # the reference's defaults: teacher ipndm on 21 points
+            from . import gits_utils
+            for k, v in dict(metric='dev', coeff=1.15, num_warmup=256, solver_tea='ipndm', num_steps_tea=21).items():
+                if solver_kwargs.get(k) is None:
+                    solver_kwargs[k] = v
+            dp_list = gits_utils.get_dp_list(net, device, dataset_name=dataset_name, max_batch_size=max_batch_size, **solver_kwargs)
+            t_steps = solver_utils.get_schedule(solver_kwargs['num_steps_tea'], net.sigma_min, net.sigma_max, device=device,
+                                                schedule_type=solver_kwargs['schedule_type'], schedule_rho=solver_kwargs['schedule_rho'],
+                                                net=net, dp_list=dp_list)
+            log('Selected dp_list:', dp_list)
+            log('Selected time schedule: ', [round(float(v), 4) for v in t_steps])
+        elif t_steps is None:
+            t_steps = solver_utils.get_schedule(solver_kwargs['num_steps'], net.sigma_min, net.sigma_max, device=device,
+                                                schedule_type=solver_kwargs['schedule_type'], schedule_rho=solver_kwargs['schedule_rho'],
+                                                net=net)
+        else:
+            if dp:
+                log('t_steps is specified, ignored DP')             # gits-main/sample.py:220-221
+            t_list = ast.literal_eval(t_steps) if isinstance(t_steps, str) else list(t_steps)
+            t_steps = torch.tensor(t_list, device=device)           # all-int lists give an int64 tensor, as in the reference
+            solver_kwargs['num_steps'] = t_steps.shape[0]
+            solver_kwargs['sigma_max'], solver_kwargs['sigma_min'] = t_list[0], t_list[-1]
+            solver_kwargs['schedule_type'] = solver_kwargs['schedule_rho'] = None
+            solver_kwargs['dp'] = dp = False
+            log('Pre-specified t_steps:', t_list)
+        solver_kwargs['t_steps'] = t_steps
+        solver = solver_kwargs['solver']
+        nfe = compute_nfe(solver, solver_kwargs['num_steps'], solver_kwargs['afs'], solver_kwargs['denoise_to_zero'], dataset_name, dp=dp)
+        solver_kwargs['nfe'] = nfe
+        sampler_fn = getattr(solvers, SOLVER_FNS[solver])
+        if solver == 'deis':
+            solver_kwargs['coeff_list'] = solver_utils.get_deis_coeff_list(t_steps, solver_kwargs['max_order'],
+                                                                           deis_mode=solver_kwargs['deis_mode'])
     if outdir is None:
         outdir = os.path.join(f'./samples/grids/{dataset_name}' if grid else f'./samples/{dataset_name}', f'{solver}_nfe{nfe}')
     log(f'Generating {len(seeds)} images to "{outdir}"...')
@@ -294,12 +409,15 @@ def run(dataset_name, max_batch_size=64, seeds='0-63', grid=False, outdir=None, 
 
 if click is not None:
     @click.command()
-    @click.option('--dataset_name', help='Name of the dataset', metavar='STR', type=str, required=True)
+    @click.option('--dataset_name', help='Name of the dataset (AMED: read from the predictor)', metavar='STR', type=str, default=None)
+    @click.option('--predictor_path', help='AMED: path (.pkl / .pt), experiment number, or random:<seed> with --random_init', metavar='DIR', type=str, default=None)
+    @click.option('--scale_dir', help='AMED random:<seed> predictor: scale_dir', type=float, default=None)
+    @click.option('--scale_time', help='AMED random:<seed> predictor: scale_time', type=float, default=None)
     @click.option('--model_path', help='Network filepath', metavar='PATH|URL', type=str)
     @click.option('--batch', 'max_batch_size', help='Maximum batch size', metavar='INT', type=click.IntRange(min=1), default=64, show_default=True)
     @click.option('--seeds', help='Random seeds (e.g. 1,2,5-10)', metavar='LIST', type=parse_int_list, default='0-63', show_default=True)
     @click.option('--prompt', help='Prompt for Stable Diffusion sampling', metavar='STR', type=str)
-    @click.option('--solver', help='Name of the solver', metavar='many solvers', type=click.Choice(list(SOLVER_FNS)))
+    @click.option('--solver', help='Name of the solver', metavar='many solvers', type=click.Choice(list(SOLVER_FNS) + ['amed']))
     @click.option('--num_steps', help='Number of sampling steps', metavar='INT', type=click.IntRange(min=1), default=6, show_default=True)
     @click.option('--afs', help='Whether to use AFS', metavar='BOOL', type=bool, default=False, show_default=True)
     @click.option('--guidance_type', help='Guidance type', type=click.Choice(['cg', 'cfg', 'uncond', None]), default=None, show_default=True)
@@ -327,8 +445,8 @@ if click is not None:
     @click.option('--metric', help='Metric of the GITS cost matrix', type=click.Choice(['l1', 'l2', 'dev']), default='dev')
     @click.option('--coeff', help='GITS coefficient', type=float, default=1.15)
     @click.option('--num_warmup', help='Number of warm-up trajectories', type=click.IntRange(min=1), default=256)
-    @click.option('--solver_tea', help='Teacher solver', type=click.Choice(list(SOLVER_FNS)), default=None)
-    @click.option('--num_steps_tea', help='Number of teacher time steps', type=click.IntRange(min=2), default=61)
+    @click.option('--solver_tea', help='Teacher solver', type=click.Choice(['euler', 'ipndm', 'ipndm_v', 'heun', 'dpm', 'dpmpp', 'deis']), default='ipndm', show_default=True)
+    @click.option('--num_steps_tea', help='Number of timestamps for teacher', type=click.IntRange(min=1), default=21, show_default=True)
     def main(**kw):
         run(**kw)
 

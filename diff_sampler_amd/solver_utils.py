@@ -1,7 +1,8 @@
 """Host side of the solvers: time schedules and the *coefficient compilers* that turn each ODE solver step into one
 row of scalars for the fused HIP update kernel (``ds_solver_update``), plus API-compatible wrappers of the helper
-functions other code imports from the reference's ``solver_utils`` (``get_schedule``, ``dynamic_thresholding_fn``,
-``dpm_pp_update``, ``get_deis_coeff_list``).
+functions other code imports from the reference's ``solver_utils`` (``get_schedule``, ``expand_dims``,
+``dynamic_thresholding_fn``, ``dpm_pp_update`` and its three order-specific updates, ``unipc_update``, ``edm2t``, ``cal_poly``,
+``t2alpha_fn``, ``cal_intergrand``, ``get_deis_coeff_list``) -- every public name of the reference module exists here.
 
 Reference: diff-solvers-main/solver_utils.py (schedules :6-52, thresholding :77-86, DPM-Solver++ :90-163, UniPC
 :174-287, DEIS :297-400), gits-main/solver_utils.py:52-53 (``dp_list``), amed-solver-main/solver_utils.py:90-160
@@ -139,12 +140,70 @@ def dpmpp_coeffs(t_hist: Sequence[float], t_next: float, order: int, predict_x0:
     raise ValueError("Solver order must be 1 or 2 or 3, got {}".format(order))
 
 
+def expand_dims(v, dims):
+    """[N] -> [N, 1, ..., 1] with ``dims`` dimensions (solver_utils.py:63-74); a view, no kernel."""
+    return v[(...,) + (None,) * (dims - 1)]
+
+
+def _times(*ts):
+    """Host values of solver times given as Python floats, 0-dim tensors or per-sample tensors ([B], [B,1,1,1]).
+    Returns (rows, list of lists): rows == 1 when every time is a scalar, else the common per-sample length."""
+    vals = [[float(v) for v in torch.as_tensor(t).detach().reshape(-1).to('cpu', torch.float64).tolist()] for t in ts]
+    rows = max(len(v) for v in vals)
+    assert all(len(v) in (1, rows) for v in vals), 'per-sample times must agree in length'
+    return rows, [v * rows if len(v) == 1 else v for v in vals]
+
+
+def _dpmpp_lincomb(x, models_newest_first, t_hist, t, order, predict_x0, scale):
+    """x' = cx x + sum_j c_j m_{n-j} in ONE fused launch.  Scalar times: coefficients by value; per-sample times (the AMED
+    plugins pass [B,1,1,1] tensors, amed-solver-main/solvers_amed.py:596-611): a [B, 8] coefficient table, one row per image."""
+    rows, vals = _times(*t_hist, t, scale)
+    th, tn, sc = vals[:-2], vals[-2], vals[-1]
+    if rows == 1:
+        cx, cm = dpmpp_coeffs([v[0] for v in th], tn[0], order, predict_x0, sc[0])
+        return lincomb(cx, x, [(cm[j], models_newest_first[j]) for j in range(order)])
+    assert rows == x.shape[0], 'one time per sample'
+    table = torch.zeros(rows, 8, dtype=torch.float32)
+    for b in range(rows):
+        cx, cm = dpmpp_coeffs([v[b] for v in th], tn[b], order, predict_x0, sc[b])
+        table[b, 0], table[b, 5] = cx, 1.0
+        for j, c in enumerate(cm):
+            table[b, 1 + j] = c
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    out = torch.empty_like(x)
+    ms = [m.contiguous() for m in models_newest_first[:order]]
+    a = ops.make_update_args(x, x, ms[0], B, C, H, W, out, raw=False, hist=ms[1:], coefs=table.to(x.device), coef_rows=rows,
+                             store_d=False)
+    ops.solver_update(a)
+    return out
+
+
+def dpm_solver_first_update(x, s, t, model_s=None, predict_x0=True, scale=1):
+    """DPM-Solver++ order 1 from time ``s`` to ``t`` (solver_utils.py:102-113; ``scale``: amed-solver-main :102)."""
+    return _dpmpp_lincomb(x, [model_s], [s], t, 1, predict_x0, scale)
+
+
+def multistep_dpm_solver_second_update(x, model_prev_list, t_prev_list, t, predict_x0=True, scale=1):
+    """DPM-Solver++(2M) (solver_utils.py:117-133)."""
+    return _dpmpp_lincomb(x, [model_prev_list[-1], model_prev_list[-2]], list(t_prev_list[-2:]), t, 2, predict_x0, scale)
+
+
+def multistep_dpm_solver_third_update(x, model_prev_list, t_prev_list, t, predict_x0=True, scale=1):
+    """DPM-Solver++(3M) (solver_utils.py:137-163)."""
+    return _dpmpp_lincomb(x, [model_prev_list[-1], model_prev_list[-2], model_prev_list[-3]], list(t_prev_list[-3:]), t, 3,
+                          predict_x0, scale)
+
+
 def dpm_pp_update(x, model_prev_list, t_prev_list, t, order, predict_x0=True, scale=1):
-    """API-compatible with the reference ``dpm_pp_update`` (tensors in, tensor out); one fused launch."""
-    th = [float(v) for v in t_prev_list[-order:]]
-    cx, cm = dpmpp_coeffs(th, float(t), order, predict_x0, float(scale))
-    terms = [(cm[j], model_prev_list[-1 - j]) for j in range(order)]
-    return lincomb(cx, x, terms)
+    """API-compatible with the reference ``dpm_pp_update`` (solver_utils.py:90-98; tensors in, tensor out); one fused launch."""
+    if order == 1:
+        return dpm_solver_first_update(x, t_prev_list[-1], t, model_s=model_prev_list[-1], predict_x0=predict_x0, scale=scale)
+    if order == 2:
+        return multistep_dpm_solver_second_update(x, model_prev_list, t_prev_list, t, predict_x0=predict_x0, scale=scale)
+    if order == 3:
+        return multistep_dpm_solver_third_update(x, model_prev_list, t_prev_list, t, predict_x0=predict_x0, scale=scale)
+    raise ValueError("Solver order must be 1 or 2 or 3, got {}".format(order))
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -308,3 +367,56 @@ def unipc_coeffs(t_hist: Sequence[float], t_next: float, order: int, predict_x0=
     pred = expand(rhos_p, None)
     corr = expand(rhos_c[:-1] if rhos_c is not None else None, rhos_c[-1]) if use_corrector else None
     return dict(cx=cx, pred=pred, corr=corr)
+
+
+
+def unipc_update(x, model_prev_list, t_prev_list, t, order, x_t=None, variant='bh1', predict_x0=True, net=None, class_labels=None,
+                 use_corrector=True):
+    """API-compatible with the reference ``unipc_update`` (solver_utils.py:174-287): returns ``(x_t, model_t)``.
+
+    Predictor (skipped when ``x_t`` is given), one evaluation ``net(x_t, t, class_labels)`` at the predicted point
+    (:260, :278), corrector.  Each of the two combinations is one fused launch with coefficients from ``unipc_coeffs``."""
+    assert order <= len(model_prev_list)
+    th = [float(tp) for tp in t_prev_list[-order:]]
+    tn = float(t)
+    k = unipc_coeffs(th, tn, order, predict_x0=predict_x0, variant=variant, use_corrector=use_corrector)
+    hs = [m.contiguous() for m in model_prev_list[::-1][:order]]          # newest first
+    if x_t is None:
+        x_t = lincomb(k['cx'], x, [(k['pred'][j], hs[j]) for j in range(order)])
+    model_t = None
+    if use_corrector:
+        tt = t if torch.is_tensor(t) else torch.tensor(tn, dtype=torch.float32, device=x.device)
+        den = net(x_t, tt, class_labels)
+        if predict_x0:
+            model_t = dynamic_thresholding_fn(den)
+        else:
+            model_t = lincomb(1.0 / tn, x_t, [(-1.0 / tn, den)])               # (x_t - denoised) / t
+        c = k['corr']
+        x_t = lincomb(k['cx'], x, [(c[-1], model_t)] + [(c[j], hs[j]) for j in range(order)])
+    return x_t, model_t
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# DEIS helper names of the reference module (host-side, CPU tensors; ``get_deis_coeff_list`` above does not need them).
+
+def cal_poly(prev_t, j, taus):
+    """Lagrange basis polynomial j over the nodes ``prev_t`` evaluated at ``taus`` (solver_utils.py:307-314)."""
+    poly = 1
+    for k in range(prev_t.shape[0]):
+        if k != j:
+            poly = poly * ((taus - prev_t[k]) / (prev_t[j] - prev_t[k]))
+    return poly
+
+
+def t2alpha_fn(beta_0, beta_1, t):
+    """alpha(t) of the VP-SDE (solver_utils.py:318-319)."""
+    return torch.exp(-0.5 * t ** 2 * (beta_1 - beta_0) - t * beta_0)
+
+
+def cal_intergrand(beta_0, beta_1, taus):
+    """-0.5 dlog(alpha)/dtau / sqrt(alpha (1 - alpha)) (solver_utils.py:323-331).  The reference differentiates log(alpha)
+    with autograd; its derivative is -(beta_1 - beta_0) tau - beta_0, evaluated here in closed form."""
+    taus = torch.as_tensor(taus)
+    alpha = t2alpha_fn(beta_0, beta_1, taus)
+    d_log_alpha_dtau = -taus * (beta_1 - beta_0) - beta_0
+    return -0.5 * d_log_alpha_dtau / torch.sqrt(alpha * (1 - alpha))

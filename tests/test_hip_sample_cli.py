@@ -67,3 +67,47 @@ def test_sample_run_ms_coco_latent_diffusion(tmp_path):
     assert n == 2
     z = np.load(os.path.join(out, '000000', '000001.npy'))
     assert z.shape == (4, 64, 64) and np.isfinite(z).all()
+
+
+def test_sample_run_amed_cli_config4_ffhq64(tmp_path):
+    """BASELINE config 4 the way the reference runs it (amed-solver-main/sample.py): only `--predictor_path` (+ seeds / batch) on
+    the command line, every solver setting read back from the predictor; images equal a direct `amed_sampler` call with the
+    same predictor and per-seed latents."""
+    import PIL.Image
+    from diff_sampler_amd import sample, solvers_amed
+    from diff_sampler_amd.engine import EDMDenoiser
+    from oracle import cases
+    dev = torch.device('cuda')
+    pp = cases.amed_predictor_params(43, 0.01, 0)
+    settings = dict(dataset_name='ffhq', num_steps=4, sampler_stu='amed', sampler_tea='heun', M=1, guidance_type=None, guidance_rate=None,
+                    schedule_type='time_uniform', schedule_rho=1, afs=True, scale_dir=0.01, scale_time=0, max_order=None,
+                    predict_x0=True, lower_order_final=True)
+    path = str(tmp_path / 'predictor.pt')
+    torch.save(dict(state_dict=pp, **settings), path)
+    out, n = sample.run(predictor_path=path, max_batch_size=2, seeds='5-7', outdir=str(tmp_path / 'amed'), random_init=True,
+                        num_steps=99, solver='euler', schedule_type='polynomial')       # CLI values must be overridden by the predictor
+    assert n == 3
+    imgs = _read(out)
+    assert sorted(imgs) == [5, 6, 7] and all(v.shape == (64, 64, 3) for v in imgs.values())
+    # default outdir naming uses the AMED NFE rule: 2*(4-1)-1 = 5
+    assert sample.AMED_SOLVER_FNS['amed'] == 'amed_sampler'
+    net = EDMDenoiser.from_config('ffhq', seed=0)
+    rnd = sample.StackedRandomGenerator(dev, [5, 6, 7])
+    lat = rnd.randn([3, 3, 64, 64], device=dev)
+    pred = solvers_amed.AMEDPredictor(pp, device=dev, **settings)
+    ref = solvers_amed.amed_sampler(net, lat, num_steps=4, sigma_min=0.002, sigma_max=80., schedule_type='time_uniform', schedule_rho=1,
+                                    afs=True, AMED_predictor=pred)
+    u8 = (ref * 127.5 + 128).clip(0, 255).to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy()
+    for i, seed in enumerate([5, 6, 7]):
+        assert np.abs(imgs[seed].astype(int) - u8[i].astype(int)).max() <= 1      # identical up to the batch-size-dependent split-K order
+
+
+def test_sample_run_amed_random_predictor_plugin(tmp_path):
+    """`--predictor_path random:<seed> --random_init True`: a seeded predictor built from the CLI options (AMED-Plugin on iPNDM)."""
+    from diff_sampler_amd import sample
+    out, n = sample.run('tiny_song_amed', predictor_path='random:7', max_batch_size=4, seeds='0-3', outdir=str(tmp_path / 'p'),
+                        random_init=True, solver='ipndm', num_steps=4, max_order=3, afs=False, schedule_type='polynomial', schedule_rho=7,
+                        scale_dir=0.01, scale_time=0)
+    assert n == 4 and len(_read(out)) == 4
+    with pytest.raises(ValueError):
+        sample.run('tiny_song_amed', predictor_path='random:7', seeds='0-1', outdir=str(tmp_path / 'q'), random_init=False, solver='amed')

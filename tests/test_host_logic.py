@@ -250,3 +250,96 @@ def test_cfg_schedule_host_maps_match_reference_probes():
     assert np.allclose(sch.sigma(torch.from_numpy(z['probe_t'])).numpy(), z['probe_sigma_of_t'], rtol=2e-6, atol=1e-7)
     ts = solver_utils.get_schedule(6, sch.sigma_min, sch.sigma_max, device='cpu', schedule_type='discrete', schedule_rho=1, net=sch)
     assert np.allclose(ts.numpy(), z['sched_discrete_6'], rtol=5e-6)
+
+
+def test_solver_utils_exports_every_public_name_of_the_reference_module():
+    """`import solver_utils` drop-in: each public function of diff-solvers-main/solver_utils.py (+ the GITS / AMED variants'
+    extra arguments) exists with the same leading parameters.  The reference signatures are written out here so that the
+    test also runs where /root/reference is absent."""
+    import inspect
+    from diff_sampler_amd import solver_utils as su
+    want = {
+        'get_schedule': ['num_steps', 'sigma_min', 'sigma_max', 'device', 'schedule_type', 'schedule_rho', 'net'],
+        'expand_dims': ['v', 'dims'],
+        'dynamic_thresholding_fn': ['x0'],
+        'dpm_pp_update': ['x', 'model_prev_list', 't_prev_list', 't', 'order', 'predict_x0'],
+        'dpm_solver_first_update': ['x', 's', 't', 'model_s', 'predict_x0'],
+        'multistep_dpm_solver_second_update': ['x', 'model_prev_list', 't_prev_list', 't', 'predict_x0'],
+        'multistep_dpm_solver_third_update': ['x', 'model_prev_list', 't_prev_list', 't', 'predict_x0'],
+        'unipc_update': ['x', 'model_prev_list', 't_prev_list', 't', 'order', 'x_t', 'variant', 'predict_x0', 'net', 'class_labels',
+                         'use_corrector'],
+        'edm2t': ['edm_steps', 'epsilon_s', 'sigma_min', 'sigma_max'],
+        'cal_poly': ['prev_t', 'j', 'taus'],
+        't2alpha_fn': ['beta_0', 'beta_1', 't'],
+        'cal_intergrand': ['beta_0', 'beta_1', 'taus'],
+        'get_deis_coeff_list': ['t_steps', 'max_order', 'N', 'deis_mode'],
+    }
+    for name, params in want.items():
+        got = list(inspect.signature(getattr(su, name)).parameters)
+        assert got[:len(params)] == params, (name, got)
+    ref = '/root/reference/diff-solvers-main/solver_utils.py'
+    if os.path.exists(ref):
+        import ast
+        names = [n.name for n in ast.parse(open(ref).read()).body if isinstance(n, ast.FunctionDef)]
+        assert set(names) <= set(want), set(names) - set(want)
+
+
+def test_deis_helper_functions_closed_form():
+    import math
+    from diff_sampler_amd import solver_utils as su
+    tau = torch.linspace(0.9, 0.2, 7, dtype=torch.float64)
+    b0, b1 = 0.1, 19.9
+    alpha = su.t2alpha_fn(b0, b1, tau)
+    assert torch.allclose(alpha, torch.exp(-0.5 * tau ** 2 * (b1 - b0) - tau * b0))
+    # numerical derivative of log(alpha)
+    eps = 1e-6
+    dl = (su.t2alpha_fn(b0, b1, tau + eps).log() - su.t2alpha_fn(b0, b1, tau - eps).log()) / (2 * eps)
+    assert torch.allclose(su.cal_intergrand(b0, b1, tau), -0.5 * dl / torch.sqrt(alpha * (1 - alpha)), rtol=1e-6)
+    nodes = torch.tensor([0.9, 0.7, 0.5], dtype=torch.float64)
+    for j in range(3):
+        p = su.cal_poly(nodes, j, nodes)
+        assert torch.allclose(p, torch.eye(3, dtype=torch.float64)[j])
+
+
+def test_png_single_channel_and_grid_like_make_grid(tmp_path):
+    """Single-channel images are saved in mode 'L' (sample.py:314 of the reference); the grid keeps a partial last row padded
+    with zeros like torchvision.make_grid(images, nrow=int(sqrt(B)), padding=0)."""
+    import PIL.Image
+    from diff_sampler_amd.sample import PngSink, save_grid
+    arr = (np.arange(2 * 8 * 8).reshape(2, 8, 8, 1) % 255).astype(np.uint8)
+    PngSink._write(arr, [3, 4], str(tmp_path), subdirs=False)
+    im = PIL.Image.open(tmp_path / '000003.png')
+    assert im.mode == 'L' and np.array_equal(np.asarray(im), arr[0, :, :, 0])
+    x = torch.rand(7, 3, 4, 4) * 2 - 1                         # 7 images: 2 per row -> 4 rows, last one half empty
+    save_grid(x, str(tmp_path / 'g'))
+    g = np.asarray(PIL.Image.open(tmp_path / 'g' / 'grid.png'))
+    assert g.shape == (16, 8, 3)
+    want = (torch.clamp(x / 2 + 0.5, 0, 1) * 255 + 0.5).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).numpy()
+    assert np.array_equal(g[12:16, 0:4], want[6]) and not g[12:16, 4:8].any()
+    assert np.array_equal(g[4:8, 4:8], want[3])
+
+
+def test_amed_predictor_loading_rules(tmp_path):
+    """amed-solver-main/sample.py:148-185: experiment-number lookup picks the newest snapshot; settings come from the predictor."""
+    from diff_sampler_amd import sample
+    from oracle import cases
+    exp = tmp_path / 'exps' / '00012-cifar10-4-5-amed-heun-1-uni1.0-afs'
+    exp.mkdir(parents=True)
+    for idx in (3, 20, 100):
+        (exp / f'network-snapshot-{idx:06d}.pkl').write_bytes(b'')
+    assert sample.find_predictor('12', str(tmp_path / 'exps')).endswith('network-snapshot-000100.pkl')
+    assert sample.find_predictor('a/b.pkl', str(tmp_path / 'exps')) == 'a/b.pkl'
+    pp = cases.amed_predictor_params(43, 0.01, 0)
+    path = str(tmp_path / 'p.pt')
+    torch.save(dict(state_dict=pp, dataset_name='cifar10', num_steps=4, sampler_stu='amed', schedule_type='time_uniform', schedule_rho=1,
+                    afs=True, scale_dir=0.01, scale_time=0), path)
+    p = sample.load_predictor(path, 'cpu')
+    assert (p.dataset_name, p.num_steps, p.sampler_stu, p.afs, p.schedule_type) == ('cifar10', 4, 'amed', True, 'time_uniform')
+    r = sample.load_predictor('random:5', 'cpu', random_init=True, dataset_name='ffhq', solver='dpmpp', num_steps=5, max_order=2,
+                              scale_dir=0.02, scale_time=0.1)
+    assert r.sampler_stu == 'dpmpp' and r.max_order == 2 and r.w['fc_scale_time.weight'] is not None
+    with pytest.raises(ValueError):
+        sample.load_predictor('random:5', 'cpu', random_init=False)
+    assert sample.compute_nfe('ipndm', 7, True, False, 'cifar10', dp=True) == 6      # GITS: AFS inserts a free step
+    assert sample.compute_nfe('heun', 7, True, False, 'cifar10', dp=True) == 13
+    assert sample.compute_nfe('heun', 7, True, False, 'cifar10') == 11
