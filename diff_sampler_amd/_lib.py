@@ -84,6 +84,7 @@ _SIGNATURES = {
     'ds_conv2d_nhwc': (C.c_int, [C.POINTER(ConvArgs), vp]),
     'ds_debug_force_generic_conv': (C.c_int, [C.c_int]),
     'ds_debug_force_splits': (C.c_int, [C.c_int]),
+    'ds_debug_conv_variant': (C.c_int, [C.c_int]),
     'ds_conv_kernel_id': (C.c_int, [C.POINTER(ConvArgs)]),
     'ds_conv3x3_halo_supported': (C.c_int, [C.c_int, C.c_int]),
     'ds_gemm_nt_batched': (C.c_int, [C.POINTER(GemmArgs), vp]),
@@ -136,6 +137,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
     _lib = lib
+    if os.environ.get('DS_CONV_VARIANT'):          # benchmarks / A-B test runs: kernel variant of the halo convolution
+        lib.ds_debug_conv_variant(int(os.environ['DS_CONV_VARIANT']))
     return lib
 
 

@@ -31,6 +31,42 @@ constexpr int ns_max(int wn) { return wn == 2 ? 10 : 18; }    // halo float4 slo
 
 __device__ float g_zero_page_halo[64];   // zero-initialised
 
+// ---- hand-ordered LDS fragment reads (VAR bit 0, "PIPE") ---------------------------------------------------------------------
+// hipcc emits `4-6 x ds_read_b128 -> s_waitcnt lgkmcnt(0) -> 16 x v_mfma` per K step of the tap loop: the LDS latency of every
+// fragment group is exposed to the issuing wave and is hidden only while the SIMD's other wave happens to be in its MFMA phase;
+// source-level double buffering is re-clustered by the machine scheduler.  Here the reads are inline asm (volatile asm statements
+// keep their order), the fragments of K step g+1 are requested BEFORE the MFMAs of step g, and the wait is a counted
+// `s_waitcnt lgkmcnt(4)` that leaves exactly those four newer reads in flight.  The wait statement names the fragment registers
+// "+v", so every consumer is data-dependent on it (cdna_hip_programming.md section 5.7, form (ii)); LDS operations return in
+// order, so compiler-issued LDS/SMEM traffic in between can only make a counted wait stricter, never wrong.
+struct Frag { f32x4 a0, a1, b0, b1; };
+
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_read_b128(unsigned addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int KS, int BOFF1>
+__device__ __forceinline__ void frag_read(Frag& f, unsigned va0, unsigned va1, unsigned vb) {
+    f.a0 = lds_read_b128<KS * 32>(va0);
+    f.a1 = lds_read_b128<KS * 32>(va1);
+    f.b0 = lds_read_b128<0>(vb);
+    f.b1 = lds_read_b128<BOFF1>(vb);
+}
+#define DS_FRAG_WAIT(N, f) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"((f).a0), "+v"((f).a1), "+v"((f).b0), "+v"((f).b1))
+
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+    typedef __attribute__((address_space(3))) const void* lcptr_t;
+    return (unsigned)(size_t)(lcptr_t)(p);
+}
+
+// Kernel variants (template VAR, selected at run time by ds_debug_conv_variant; 0 = the round-1 kernel, 1 = PIPE).  The other
+// bits are TIMING ABLATIONS that produce wrong results on purpose (tools/bench_conv.py --variants): 2 = no GroupNorm/SiLU
+// arithmetic in the halo writer, 4 = the halo is staged once and never again, 8 = the weight DMA is issued once and never
+// again, 16 = the epilogue stores nothing.
+constexpr int VAR_PIPE = 1, VAR_NO_NORM = 2, VAR_NO_HALO = 4, VAR_NO_DMA = 8, VAR_NO_EPI = 16;
+
 // GLDS = weight tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write).  The DMA
 // writes lane-linear (wave base + lane*16 B), so the LDS image is unpadded [row][32 floats] and the bank-conflict fix
 // moves to an XOR swizzle of the 16-B chunk index with (row >> 1) & 7, applied to the per-lane SOURCE address when
@@ -38,8 +74,10 @@ __device__ float g_zero_page_halo[64];   // zero-initialised
 // WN = wave columns: 2 = 128 output channels per tile (the normal shape), 1 = 64 (launched only for the ragged last
 // column tile of layers whose channel count is not a multiple of 128 -- 192, 320, 576 ... -- and for the few-channel
 // output conv, instead of multiplying a half-empty 128-wide tile; it starts at column p.n_begin).
-template <int WM, bool GLDS, int WN>
+template <int WM, bool GLDS, int WN, int VAR = 0>
 __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KParams p) {
+    constexpr bool PIPE = (VAR & VAR_PIPE) != 0;
+    static_assert(!PIPE || GLDS, "the pipelined tap loop reads the LDS-DMA weight image");
     constexpr int T = 64 * WM * WN;        // threads
     constexpr int TBM = 64 * WM;           // output pixels per tile
     constexpr int BNT = 64 * WN;           // output channels per tile
@@ -138,7 +176,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
         cbe = *reinterpret_cast<const f32x4*>(cp + 2 * st);
     };
     auto halo_store = [&](int chunk) {
-        const bool do_norm = norm_on && chunk < nchunks;
+        const bool do_norm = norm_on && chunk < nchunks && !(VAR & VAR_NO_NORM);
         const int cq = chunk * BK + ld_col;
 #pragma unroll
         for (int j = 0; j < NS_MAX; ++j) {
@@ -201,12 +239,14 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
     coef_load(c_begin);
     if (GLDS) {
         b_dma(kt0, kt0 & 1);
+        if (PIPE && kt0 + 1 < KT) b_dma(kt0 + 1, (kt0 + 1) & 1);   // the pipelined loop runs the weight DMA two taps ahead
     } else {
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b_addr(kt0, i));
     }
     halo_store(c_begin);
     if (!GLDS) b_store(kt0 & 1);
+    if (PIPE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the first two weight tiles (see the note in the tap loop)
     if (c_begin + 1 < NCH) { halo_load(c_begin + 1); coef_load(c_begin + 1); }
     __syncthreads();
 
@@ -217,6 +257,85 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
         return GLDS ? b_row * 32 + (((ks * 2 + (lane >> 5)) ^ b_swz) * 4) : b_row * LDSK + (lane >> 5) * 4 + ks * 8;
     };
     int kt = kt0;
+    if constexpr (PIPE) {
+        // Software-pipelined tap loop.  Per tap: K steps 0..3 alternate between fragment sets P and Q; the reads of step g+1 are in
+        // flight under the 16 MFMAs of step g.  The workgroup barrier sits BEFORE the last step's MFMAs: by then every wave has
+        // finished its LDS reads of this tap (weight buffer `cur`, and -- on a slab's last tap -- the halo), so right after it the
+        // weight tile of tap kt+2 is DMA'd into `cur` (a full tap of flight time before its `vmcnt(0)`), and the first fragments of
+        // tap kt+1 are requested under the last 16 MFMAs.
+        constexpr int BOFF1 = 32 * 32 * 4;                       // rows +32 of the weight tile
+        constexpr unsigned BBUF = BNT * 32 * 4;                  // bytes per weight buffer
+        const unsigned a_b0 = lds_addr(Ah) + (unsigned)a_foff[0] * 4, a_b1 = lds_addr(Ah) + (unsigned)a_foff[1] * 4;
+        const unsigned c0 = (unsigned)((lane >> 5) ^ b_swz);
+        unsigned bq[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) bq[ks] = lds_addr(Bs) + (unsigned)b_row * 128 + ((c0 ^ (2u * ks)) * 16);
+        auto tap_off = [&](int chunk, int t9) -> unsigned {      // byte offset of the tap inside the halo
+            const int tap = chunk < nchunks ? t9 : 4;
+            const int ty = tap / 3;
+            return (unsigned)(((ty - 1) * p.WP + (tap - ty * 3 - 1)) * LDSK * 4);
+        };
+        Frag P, Q;
+        {
+            const unsigned to = tap_off(c_begin, 0);
+            frag_read<0, BOFF1>(P, a_b0 + to, a_b1 + to, bq[0] + (unsigned)(kt & 1) * BBUF);
+        }
+        for (int chunk = c_begin; chunk < NCH; ++chunk) {
+            const int ntaps = chunk < nchunks ? 9 : 1;
+            for (int t9 = 0; t9 < ntaps; ++t9, ++kt) {
+                const unsigned to = tap_off(chunk, t9);
+                const unsigned va0 = a_b0 + to, va1 = a_b1 + to;
+                const unsigned cb = (unsigned)(kt & 1) * BBUF;
+#define DS_MFMA16(f)                                                                                            \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                             \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32((f).a0[r], (f).b0[r], acc[0][0], 0, 0, 0);             \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32((f).a0[r], (f).b1[r], acc[0][1], 0, 0, 0);             \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32((f).a1[r], (f).b0[r], acc[1][0], 0, 0, 0);             \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32((f).a1[r], (f).b1[r], acc[1][1], 0, 0, 0);             \
+    }
+                frag_read<1, BOFF1>(Q, va0, va1, bq[1] + cb);
+                DS_FRAG_WAIT(4, P);
+                DS_MFMA16(P)
+                __builtin_amdgcn_sched_barrier(0);
+                frag_read<2, BOFF1>(P, va0, va1, bq[2] + cb);
+                DS_FRAG_WAIT(4, Q);
+                DS_MFMA16(Q)
+                __builtin_amdgcn_sched_barrier(0);
+                frag_read<3, BOFF1>(Q, va0, va1, bq[3] + cb);
+                DS_FRAG_WAIT(4, P);
+                DS_MFMA16(P)
+                __builtin_amdgcn_sched_barrier(0);
+                DS_FRAG_WAIT(0, Q);
+                // hipcc waits for an LDS-DMA only in front of an LDS read it can see; this loop's reads are asm, so say it here
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                                 // all LDS reads of this tap done; weight tile kt+1 landed
+                if (!(VAR & VAR_NO_DMA) && kt + 2 < KT) b_dma(kt + 2, kt & 1);
+                {
+                    // first fragments of the next tap of this slab (past the slab's last tap: a harmless read of the dying halo
+                    // that is discarded -- the read is unconditional so that no fragment register is written on one side of a branch)
+                    const unsigned tn = tap_off(chunk, min(t9 + 1, ntaps - 1));
+                    frag_read<0, BOFF1>(P, a_b0 + tn, a_b1 + tn, bq[0] + (unsigned)((kt + 1) & 1) * BBUF);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                DS_MFMA16(Q)
+#undef DS_MFMA16
+            }
+            if (chunk + 1 < NCH) {
+                // slab boundary: the halo died at the barrier above; publish the next one (its conversion overlaps the last 16 MFMAs)
+                DS_FRAG_WAIT(0, P);
+                if (!(VAR & VAR_NO_HALO)) {
+                    halo_store(chunk + 1);
+                    if (chunk + 2 < NCH) { halo_load(chunk + 2); coef_load(chunk + 2); }
+                }
+                __syncthreads();
+                const unsigned tn = tap_off(chunk + 1, 0);
+                frag_read<0, BOFF1>(P, a_b0 + tn, a_b1 + tn, bq[0] + (unsigned)(kt & 1) * BBUF);
+            }
+        }
+        DS_FRAG_WAIT(0, P);                                      // drain the last (discarded) prefetch before LDS is reused
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else {
     for (int chunk = c_begin; chunk < NCH; ++chunk) {
         const int ntaps = chunk < nchunks ? 9 : 1;
         for (int t9 = 0; t9 < ntaps; ++t9, ++kt) {
@@ -228,7 +347,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
             const float* as0 = Ah + a_foff[0] + toff;
             const float* as1 = Ah + a_foff[1] + toff;
             const float* bs = Bs + cur * BNT * BLD;
-            if (GLDS) b_dma(nxt, cur ^ 1);                  // buffer cur^1 was last read in tap kt-1 (barrier passed)
+            if (GLDS && !(VAR & VAR_NO_DMA)) b_dma(nxt, cur ^ 1);   // buffer cur^1 was last read in tap kt-1 (barrier passed)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const f32x4 a0 = *reinterpret_cast<const f32x4*>(as0 + ks * 8);
@@ -251,16 +370,24 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
             if (!GLDS) b_store(cur ^ 1);
             __syncthreads();                                // with LDS-DMA in flight the compiler drains vmcnt(0) here
         }
-        if (chunk + 1 < NCH) {
+        if (chunk + 1 < NCH && !(VAR & VAR_NO_HALO)) {
             // every wave has passed the barrier of the slab's last tap: its halo is dead, publish the next one
             halo_store(chunk + 1);
             if (chunk + 2 < NCH) { halo_load(chunk + 2); coef_load(chunk + 2); }
             __syncthreads();
         }
     }
+    }
 
     // epilogue staging overlays the LDS allocation (the launcher sizes it for 4 x 64 or 8 x 32 staging rows per wave)
     constexpr bool HALF = (WM * WN == 8);            // 8 waves: 32-row staging halves; up to 4 waves: 64 rows each
+    if constexpr ((VAR & VAR_NO_EPI) != 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(acc[i][j]));      // keep the accumulators (and the K loop) alive
+        return;
+    }
     if (p.splits > 1) {
         const KParams q = split_params(p, blockIdx.y);
         epilogue<0, HALF>(q, acc, smem + wave * (HALF ? 32 : 64) * EPI_LD, lane, m0 + wr * 64, n0 + wc * 64, q.out);
@@ -285,9 +412,10 @@ Geo geometry(const KParams& p, int tbm, int wn = 2) {
 int g_tile_override = 0;       // 0 = heuristic, 128 / 256 = forced (benchmarks)
 
 int g_glds = 1;                // weight staging: 1 = LDS-DMA, 0 = through registers (A/B switch)
+int g_variant = 0;             // kernel variant of the 128-column LDS-DMA tiles (see VAR_*; benchmarks / ablations)
 int g_tail64 = 1;              // 64-column tiles for a ragged last column tile (A/B switch)
 
-template <int WM, bool GLDS, int WN>
+template <int WM, bool GLDS, int WN, int VAR = 0>
 int launch_one(KParams p, const Geo& g, int n_begin, int ntiles, hipStream_t stream) {
     constexpr int TBM = 64 * WM;
     constexpr int B_BYTES = 2 * 64 * WN * LDSK * (int)sizeof(float);
@@ -300,12 +428,12 @@ int launch_one(KParams p, const Geo& g, int n_begin, int ntiles, hipStream_t str
     if (smem < epi) smem = epi;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, GLDS, WN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, GLDS, WN, VAR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_halo_kernel<WM, GLDS, WN>), dim3(grid_1d(p.mtiles, p.ntiles), p.splits), dim3(64 * WM * WN), smem, stream, p);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<WM, GLDS, WN, VAR>), dim3(grid_1d(p.mtiles, p.ntiles), p.splits), dim3(64 * WM * WN), smem, stream, p);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }
@@ -318,7 +446,26 @@ int launch_wm(KParams& p, hipStream_t stream) {
     const bool tail64 = rem > 0 && rem <= 64 && geometry(p, 64 * WM, 1).ok && g_tail64;
     const int wide = tail64 ? full : (p.N + BN - 1) / BN;
     if (wide > 0) {
-        int rc = launch_one<WM, GLDS, 2>(p, geometry(p, 64 * WM, 2), 0, wide, stream);
+        const Geo g = geometry(p, 64 * WM, 2);
+        int rc;
+        if constexpr (GLDS) {
+            switch (g_variant) {
+                case 1: rc = launch_one<WM, GLDS, 2, 1>(p, g, 0, wide, stream); break;
+#ifdef DS_CONV_ABLATIONS
+                case 2: rc = launch_one<WM, GLDS, 2, 2>(p, g, 0, wide, stream); break;
+                case 4: rc = launch_one<WM, GLDS, 2, 4>(p, g, 0, wide, stream); break;
+                case 8: rc = launch_one<WM, GLDS, 2, 8>(p, g, 0, wide, stream); break;
+                case 16: rc = launch_one<WM, GLDS, 2, 16>(p, g, 0, wide, stream); break;
+                case 28: rc = launch_one<WM, GLDS, 2, 28>(p, g, 0, wide, stream); break;
+                case 5: rc = launch_one<WM, GLDS, 2, 5>(p, g, 0, wide, stream); break;
+                case 17: rc = launch_one<WM, GLDS, 2, 17>(p, g, 0, wide, stream); break;
+                case 29: rc = launch_one<WM, GLDS, 2, 29>(p, g, 0, wide, stream); break;
+#endif
+                default: rc = launch_one<WM, GLDS, 2, 0>(p, g, 0, wide, stream); break;
+            }
+        } else {
+            rc = launch_one<WM, GLDS, 2>(p, g, 0, wide, stream);
+        }
         if (rc) return rc;
     }
     if (tail64) {
@@ -335,6 +482,7 @@ bool conv3x3_halo_supported(const KParams& p) { return geometry(p, 128).ok; }
 
 void conv3x3_halo_set_tile(int tile) { g_tile_override = tile; }
 void conv3x3_halo_set_glds(int on) { g_glds = on; }
+void conv3x3_halo_set_variant(int v) { g_variant = v; }
 void conv3x3_halo_set_tail64(int on) { g_tail64 = on; }
 
 // Tile shape and split-K factor of a layer: the cheaper of the two tile shapes under the cost model (igemm_common.h); the

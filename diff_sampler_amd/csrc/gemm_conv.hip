@@ -289,6 +289,11 @@ extern "C" int ds_debug_force_generic_conv(int v) {
     return DS_OK;
 }
 
+extern "C" int ds_debug_conv_variant(int v) {
+    conv3x3_halo_set_variant(v);
+    return DS_OK;
+}
+
 extern "C" int ds_debug_force_splits(int s) {
     g_force_splits = s > 0 ? s : 0;
     return DS_OK;

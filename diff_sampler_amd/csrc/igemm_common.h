@@ -244,6 +244,7 @@ int launch_conv3x3_halo(KParams& p, hipStream_t stream);
 int conv3x3_halo_choice(const KParams& p);   // 0 / 128 / 256: which halo tile shape the launcher picks
 void conv3x3_halo_set_tile(int tile);     // 0 = heuristic, 128 / 256 = forced M tile (benchmarks)
 void conv3x3_halo_set_glds(int on);       // weight staging by LDS-DMA (default) or through registers
+void conv3x3_halo_set_variant(int v);     // kernel variant of the 128-column LDS-DMA tiles (conv3x3_halo.hip: VAR_*)
 void conv3x3_halo_set_tail64(int on);     // 64-column tiles for the ragged last column tile (default on)
 
 }  // namespace igemm

@@ -120,6 +120,11 @@ int ds_debug_force_generic_conv(int v);
  * allows); 0 restores the heuristic. */
 int ds_debug_force_splits(int s);
 
+/* Benchmark switch: kernel variant of the LDS-halo 3x3 convolution's 128-column tiles.  0 = default (set by the library),
+ * 1 = software-pipelined tap loop (LDS fragment reads of K step g+1 in flight under the MFMAs of step g), other values =
+ * timing ablations compiled only with -DDS_CONV_ABLATIONS (they compute wrong results on purpose). */
+int ds_debug_conv_variant(int v);
+
 /* Batched C[z] = act(alpha * A[z] * B[z]^T + rowbias + colbias) on the same MFMA core ("NT": both operands have k
  * contiguous).  Used for attention: S = Q K^T / sqrt(C) and O = P V (networks_edm.py:108, :176) and the transposed
  * V projection.  z = zb * heads + zh;  X_z = X + zb*x_bstride + zh*x_hstride. Constraints: k % 32 == 0. */

@@ -1,6 +1,8 @@
 """Micro-benchmark of the implicit-GEMM conv kernel on the CIFAR-10 denoiser's shapes (B images).
 
     python tools/bench_conv.py --batch 256 [--entry ds_conv2d_nhwc] [--check]
+    python tools/bench_conv.py --batch 256 --only 0 1 --variants 0 1 28 29 --rounds 7    # interleaved A/B of kernel variants
+                                                    (ds_debug_conv_variant; ablations need a -DDS_CONV_ABLATIONS build)
 """
 import argparse
 import ctypes as C
@@ -25,6 +27,9 @@ ap.add_argument('--entry', default='ds_conv2d_nhwc')
 ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--check', action='store_true')
 ap.add_argument('--only', type=int, nargs='*')
+ap.add_argument('--variants', type=int, nargs='*', default=None)
+ap.add_argument('--rounds', type=int, default=5)
+ap.add_argument('--norm', action='store_true', help='fused GroupNorm affine + SiLU in the halo loader, as the network uses it')
 args = ap.parse_args()
 
 lib = _lib.load()
@@ -48,7 +53,29 @@ for si, (res, c0, c1, cout, taps) in enumerate(SHAPES):
     out = torch.zeros(M, old, device=dev)
     a = ConvArgs(x0.data_ptr(), x1.data_ptr() if c1 else None, c0, c1, c0, c1, B, res, res, taps, wp.data_ptr(), cout, bias.data_ptr(),
                  None, 0, 1, res_t.data_ptr() if cout >= 4 else None, cout, 0.70710678, 0, out.data_ptr(), old)
+    if args.norm and taps == 9:
+        coefs = torch.randn(B, 3, c0 + c1, device=dev) * 0.1 + torch.tensor([0., 1., 0.], device=dev).reshape(1, 3, 1)
+        a.norm_coefs, a.norm_act = coefs.data_ptr(), 1
     st = _lib.stream_ptr()
+    if args.variants:
+        import statistics
+        fl = 2.0 * M * taps * (c0 + c1) * cout
+        times = {v: [] for v in args.variants}
+        for rnd in range(args.rounds + 1):
+            for v in args.variants:
+                lib.ds_debug_conv_variant(v)
+                fn(C.byref(a), st); torch.cuda.synchronize()
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.iters):
+                    fn(C.byref(a), st)
+                e1.record(); torch.cuda.synchronize()
+                if rnd:
+                    times[v].append(e0.elapsed_time(e1) / args.iters)
+        lib.ds_debug_conv_variant(0)
+        print(f'[{si}] {res}x{res} {c0}+{c1}->{cout} taps={taps} M={M} norm={int(args.norm)}: ' +
+              '  '.join(f'v{v}: {statistics.median(t):.3f} ms {fl / statistics.median(t) / 1e9:6.1f} TF (min {fl / min(t) / 1e9:6.1f})' for v, t in times.items()), flush=True)
+        continue
     rc = fn(C.byref(a), st); assert rc == 0, rc
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)

@@ -43,8 +43,25 @@ def pmc(db_fetch, db_write, out):
         print(k, v)
 
 
+def counters(out, *dbs):
+    """Generic: every counter of every pass, averaged per kernel launch -> JSON {kernel: {counter: avg, launches: n}}."""
+    res = {}
+    for db in dbs:
+        cur = sqlite3.connect(db).cursor()
+        q = 'select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name'
+        for n, cn, c, a in cur.execute(q):
+            r = res.setdefault(short(n), {})
+            r[cn] = a
+            r['launches'] = c
+    json.dump(res, open(out, 'w'), indent=1)
+    for k, v in res.items():
+        print(k, json.dumps(v))
+
+
 if __name__ == '__main__':
     if sys.argv[1] == 'stats':
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == 'counters':
+        counters(sys.argv[2], *sys.argv[3:])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
