@@ -215,12 +215,16 @@ def cpu_baseline_ldm(args, nfe):
     t_min, t_max = net.sigma_inv(torch.tensor(net.sigma_min)), net.sigma_inv(torch.tensor(net.sigma_max))
     n = nfe // 2 + 1
     ts = net.sigma(t_max + torch.arange(n) / (n - 1) * (t_min - t_max))
+    default_threads = torch.get_num_threads()
+    torch.set_num_threads(_thread_candidates('16' if args.cpu_threads == 'sweep' else args.cpu_threads)[0])   # see _thread_candidates
     with torch.no_grad():
         t0 = time.time()
         solvers_ref.sample('dpm_pp', net, lat, ts, condition=c, unconditional_condition=uc, max_order=2, predict_x0=False,
                            lower_order_final=True, num_steps=n)
         dt = time.time() - t0
-    return dict(value=round(1 / dt, 4), unit='images/sec', cores=torch.get_num_threads(), kind='port',
+    used = torch.get_num_threads()
+    torch.set_num_threads(default_threads)
+    return dict(value=round(1 / dt, 4), unit='images/sec', cores=used, kind='port', host_cores=os.cpu_count(),
                 sample=f'1 sampler call x batch 1 (2 U-Net images per evaluation), NFE={nfe}, same net/solver ({dt:.1f} s of CPU work)')
 
 
