@@ -85,6 +85,7 @@ _SIGNATURES = {
     'ds_debug_force_generic_conv': (C.c_int, [C.c_int]),
     'ds_debug_force_splits': (C.c_int, [C.c_int]),
     'ds_debug_conv_variant': (C.c_int, [C.c_int]),
+    'ds_debug_conv_halo2_launches': (C.c_longlong, []),
     'ds_conv_kernel_id': (C.c_int, [C.POINTER(ConvArgs)]),
     'ds_conv3x3_halo_supported': (C.c_int, [C.c_int, C.c_int]),
     'ds_gemm_nt_batched': (C.c_int, [C.POINTER(GemmArgs), vp]),

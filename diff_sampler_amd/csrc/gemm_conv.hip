@@ -294,6 +294,8 @@ extern "C" int ds_debug_conv_variant(int v) {
     return DS_OK;
 }
 
+extern "C" long long ds_debug_conv_halo2_launches(void) { return g_halo2_launches; }
+
 extern "C" int ds_debug_force_splits(int s) {
     g_force_splits = s > 0 ? s : 0;
     return DS_OK;

@@ -247,4 +247,9 @@ void conv3x3_halo_set_glds(int on);       // weight staging by LDS-DMA (default)
 void conv3x3_halo_set_variant(int v);     // kernel variant of the 128-column LDS-DMA tiles (conv3x3_halo.hip: VAR_*)
 void conv3x3_halo_set_tail64(int on);     // 64-column tiles for the ragged last column tile (default on)
 
+// conv3x3_halo2.hip: second-generation 256 x 128 tile (static tap schedule, double halo buffer)
+bool conv3x3_halo2_applicable(const KParams& p, int wide);
+int launch_conv3x3_halo2(KParams& p, int wide, hipStream_t stream);
+extern long long g_halo2_launches;
+
 }  // namespace igemm

@@ -121,9 +121,13 @@ int ds_debug_force_generic_conv(int v);
 int ds_debug_force_splits(int s);
 
 /* Benchmark switch: kernel variant of the LDS-halo 3x3 convolution's 128-column tiles.  0 = default (set by the library),
- * 1 = software-pipelined tap loop (LDS fragment reads of K step g+1 in flight under the MFMAs of step g), other values =
- * timing ablations compiled only with -DDS_CONV_ABLATIONS (they compute wrong results on purpose). */
+ * 1 = software-pipelined tap loop (LDS fragment reads of K step g+1 in flight under the MFMAs of step g), 3 = second-generation
+ * kernel (conv3x3_halo2.hip: static tap schedule, double halo buffer) where it applies, other values = timing ablations compiled
+ * only with -DDS_CONV_ABLATIONS (they compute wrong results on purpose). */
 int ds_debug_conv_variant(int v);
+
+/* Number of convolution launches routed to the second-generation 256 x 128 halo kernel so far (tests assert the routing). */
+long long ds_debug_conv_halo2_launches(void);
 
 /* Batched C[z] = act(alpha * A[z] * B[z]^T + rowbias + colbias) on the same MFMA core ("NT": both operands have k
  * contiguous).  Used for attention: S = Q K^T / sqrt(C) and O = P V (networks_edm.py:108, :176) and the transposed

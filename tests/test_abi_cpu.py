@@ -12,7 +12,7 @@ def test_library_builds_and_exports_header_symbols():
     build.build_lib(verbose=False)
     lib = _lib.load()
     header = open(os.path.join(ROOT, 'include', 'ds_engine.h')).read()
-    declared = set(re.findall(r'^(?:int|const char\*)\s+(ds_\w+)\s*\(', header, flags=re.M))
+    declared = set(re.findall(r'^(?:int|long long|const char\*)\s+(ds_\w+)\s*\(', header, flags=re.M))
     assert declared, 'no declarations parsed'
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in ds_engine.h but not exported'

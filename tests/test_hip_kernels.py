@@ -405,3 +405,81 @@ def test_geglu_fused_into_projection(rows, k, inner):
     torch.cuda.synchronize()
     y = F.linear(x, wt, bias)
     assert _rel(out.cpu(), y[:, :inner] * F.gelu(y[:, inner:])) < TOL
+
+
+HALO2_CASES = [
+    # B, H(=W), c0, c1, cout, (ec0, ec1), norm, act
+    (1, 16, 32, 0, 128, (0, 0), False, False),        # one tile, one slab
+    (2, 16, 64, 32, 128, (0, 0), True, True),          # dual source
+    (1, 32, 64, 0, 256, (0, 0), True, True),           # 4 row tiles x 2 column tiles per image
+    (2, 32, 32, 32, 128, (64, 32), True, True),        # fused 1x1 skip projection slabs (dual extra source)
+    (1, 32, 96, 0, 192, (32, 0), True, False),         # ragged channel count: 128-column tile here + 64-column tail on kernel 1
+    (1, 64, 32, 0, 128, (0, 0), True, True),           # W = 64 (7 halo slots per thread)
+    (1, 64, 32, 32, 128, (32, 0), False, False),
+    (3, 16, 288, 0, 128, (0, 0), True, True),          # 9 slabs (weight-buffer parity flips every slab)
+]
+
+
+@pytest.mark.parametrize('case', HALO2_CASES)
+def test_conv_halo2_kernel_matches_aten(case):
+    """Second-generation 256 x 128 halo kernel (conv3x3_halo2.hip), routed by ds_debug_conv_variant(3) with the 256-pixel tile
+    forced; the routing itself is asserted through the launch counter."""
+    import ctypes as C
+    from diff_sampler_amd import _lib, ops
+    B, H, c0, c1, cout, (ec0, ec1), use_norm, act = case
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(sum(case[:5]) + 7)
+    x = torch.randn(B, c0 + c1, H, H, generator=g)
+    e = torch.randn(B, ec0 + ec1, H, H, generator=g) if ec0 else None
+    w = torch.randn(cout, c0 + c1, 3, 3, generator=g) / (9 * (c0 + c1)) ** 0.5
+    we = torch.randn(cout, ec0 + ec1, 1, 1, generator=g) / (ec0 + ec1) ** 0.5 if ec0 else None
+    bias = torch.randn(cout, generator=g)
+    cb = torch.randn(B, cout, generator=g)
+    res = torch.randn(B, cout, H, H, generator=g)
+    mu = torch.randn(B, c0 + c1, generator=g) * 0.3
+    ga = 1 + 0.2 * torch.randn(B, c0 + c1, generator=g)
+    be = 0.2 * torch.randn(B, c0 + c1, generator=g)
+    xin = x
+    if use_norm:
+        xin = (x - mu[:, :, None, None]) * ga[:, :, None, None] + be[:, :, None, None]
+        xin = F.silu(xin) if act else xin
+    ref = F.conv2d(xin, w, padding=1)
+    if ec0:
+        ref = ref + F.conv2d(e, we)
+    ref = (ref + bias[None, :, None, None] + cb[:, :, None, None] + res) * 0.7071
+    dev = 'cuda'
+    xn = _nhwc(x).to(dev)
+    x0 = xn[:, :c0].contiguous()
+    x1 = xn[:, c0:].contiguous() if c1 else None
+    en = _nhwc(e).to(dev) if ec0 else None
+    e0 = en[:, :ec0].contiguous() if ec0 else None
+    e1 = en[:, ec0:].contiguous() if ec1 else None
+    wp = ops.pack_conv_weight(w.to(dev))
+    if ec0:
+        wp = torch.cat([wp, ops.pack_conv_weight(we.to(dev))], 1).contiguous()
+    coefs = torch.stack([mu, ga, be], 1).contiguous().to(dev) if use_norm else None
+    out = torch.full((B * H * H, cout), float('nan'), device=dev)
+    stats = torch.zeros(B * H * H // 64 * 2 * cout, device=dev)
+    biasd, cbd, resd = bias.to(dev), cb.to(dev), _nhwc(res).to(dev)
+    a = _lib.ConvArgs(x0.data_ptr(), x1.data_ptr() if c1 else None, c0, c1, c0, c1, B, H, H, 9, wp.data_ptr(), cout, biasd.data_ptr(),
+                      cbd.data_ptr(), cout, B, resd.data_ptr(), cout, 0.7071, 0, out.data_ptr(), cout,
+                      coefs.data_ptr() if use_norm else None, 1 if act else 0,
+                      e0.data_ptr() if ec0 else None, e1.data_ptr() if ec1 else None, ec0, ec1, ec0, ec1)
+    a.stats_out = stats.data_ptr()
+    before = lib.ds_debug_conv_halo2_launches()
+    lib.ds_debug_force_generic_conv(256)
+    lib.ds_debug_conv_variant(3)
+    try:
+        rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
+        torch.cuda.synchronize()
+    finally:
+        lib.ds_debug_force_generic_conv(0)
+        lib.ds_debug_conv_variant(0)
+    assert rc == 0, lib.ds_error_string(rc)
+    assert lib.ds_debug_conv_halo2_launches() == before + 1, 'the layer was not routed to the second-generation kernel'
+    want = _nhwc(ref)
+    assert _rel(out.cpu(), want) < TOL
+    if cout % 64 == 0:       # the epilogue's per-(64-row block, channel) sums feed the consumer's GroupNorm
+        st = stats.cpu().reshape(-1, 2, cout)
+        blocks = want.reshape(-1, 64, cout)
+        assert _rel(st[:, 0], blocks.sum(1)) < 1e-4 and _rel(st[:, 1], (blocks ** 2).sum(1)) < 1e-4

@@ -29,6 +29,7 @@ ap.add_argument('--check', action='store_true')
 ap.add_argument('--only', type=int, nargs='*')
 ap.add_argument('--variants', type=int, nargs='*', default=None)
 ap.add_argument('--rounds', type=int, default=5)
+ap.add_argument('--extra', action='store_true', help='append the fused 1x1 skip projection (ec0 = c0 + c1 raw columns) as conv1 of a block with a skip conv has it')
 ap.add_argument('--norm', action='store_true', help='fused GroupNorm affine + SiLU in the halo loader, as the network uses it')
 args = ap.parse_args()
 
@@ -53,13 +54,18 @@ for si, (res, c0, c1, cout, taps) in enumerate(SHAPES):
     out = torch.zeros(M, old, device=dev)
     a = ConvArgs(x0.data_ptr(), x1.data_ptr() if c1 else None, c0, c1, c0, c1, B, res, res, taps, wp.data_ptr(), cout, bias.data_ptr(),
                  None, 0, 1, res_t.data_ptr() if cout >= 4 else None, cout, 0.70710678, 0, out.data_ptr(), old)
+    if args.extra and taps == 9:
+        ec = c0 + c1
+        e0 = torch.randn(M, ec, device=dev)
+        wp = torch.cat([wp, ops.pack_conv_weight(torch.randn(cout, ec, 1, 1, device=dev) / ec ** 0.5)], 1).contiguous()
+        a.wgt, a.e0, a.ec0, a.eld0 = wp.data_ptr(), e0.data_ptr(), ec, ec
     if args.norm and taps == 9:
         coefs = torch.randn(B, 3, c0 + c1, device=dev) * 0.1 + torch.tensor([0., 1., 0.], device=dev).reshape(1, 3, 1)
         a.norm_coefs, a.norm_act = coefs.data_ptr(), 1
     st = _lib.stream_ptr()
     if args.variants:
         import statistics
-        fl = 2.0 * M * taps * (c0 + c1) * cout
+        fl = 2.0 * M * (taps * (c0 + c1) + (c0 + c1 if args.extra and taps == 9 else 0)) * cout
         times = {v: [] for v in args.variants}
         for rnd in range(args.rounds + 1):
             for v in args.variants:
@@ -99,4 +105,5 @@ for si, (res, c0, c1, cout, taps) in enumerate(SHAPES):
         err = float((out[:, :cout] - ref).abs().max() / ref.abs().max())
         msg += f'  relerr {err:.2e}'
     print(msg, flush=True)
-print(f'total {tot_t:.3f} ms, {tot_fl/tot_t/1e9:.1f} TFLOP/s aggregate (unweighted by layer counts)')
+if tot_t:
+    print(f'total {tot_t:.3f} ms, {tot_fl/tot_t/1e9:.1f} TFLOP/s aggregate (unweighted by layer counts)')
