@@ -1,0 +1,66 @@
+// Batched per-seed latent generator.
+//
+// The reference draws every image's latent from its own generator (diff-solvers-main/sample.py:22-36):
+//     torch.Generator(device).manual_seed(seed % 2**32)  ->  torch.randn([C, H, W], generator=g)
+// i.e. B generator constructions and B tiny launches per batch.  On ROCm that randn is ATen's
+// distribution_elementwise_grid_stride_kernel (ATen/native/cuda/DistributionTemplates.h) over hipRAND's Philox4x32-10:
+//     threads_total = 256 * min(CUs * (maxThreadsPerCU / 256), ceil(n / 256));   thread idx: rocrand_init(seed, idx, offset)
+//     element li = idx + threads_total * q  is component (q % 4) of that thread's (q / 4)-th rocrand_normal4 call
+//     (for n <= threads_total -- every latent of the scope -- that is: element i = rocrand_normal4(seed, subsequence i, offset).x)
+//     and the generator's offset then advances by ((n - 1) / (threads_total * 4) + 1) * 4.
+// This kernel produces the same bits for a whole batch of seeds in ONE launch by evaluating exactly that map with the same
+// rocRAND device functions (header-only: rocrand_philox4x32_10.h, rocrand_normal.h).  randint(label_dim, size=[]) of the same
+// generators (sample.py:283) is the first 32-bit output of the block at (seed, subsequence 0, offset) modulo the range
+// (ATen random_from_to, ranges below 2**32).
+#include <rocrand/rocrand_kernel.h>
+
+#include "ds_common.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256) philox_randn_kernel(const unsigned long long* __restrict__ seeds, unsigned long long offset,
+                                                           float* __restrict__ out, int batch, long long n, long long threads_total) {
+    const long long total = (long long)batch * n;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(g / n);
+        const long long li = g - (long long)b * n;
+        const long long q = li / threads_total;
+        const long long idx = li - q * threads_total;
+        rocrand_state_philox4x32_10 st;
+        rocrand_init(seeds[b], (unsigned long long)idx, offset + 4ull * (unsigned long long)(q >> 2), &st);
+        const float4 v = rocrand_normal4(&st);
+        const int c = (int)(q & 3);
+        out[g] = c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w));
+    }
+}
+
+__global__ void __launch_bounds__(256) philox_randint_kernel(const unsigned long long* __restrict__ seeds, unsigned long long offset,
+                                                             unsigned int range, int* __restrict__ out, int batch) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    rocrand_state_philox4x32_10 st;
+    rocrand_init(seeds[b], 0ull, offset, &st);
+    const uint4 v = rocrand4(&st);
+    out[b] = (int)(v.x % range);
+}
+
+}  // namespace
+
+extern "C" int ds_philox_randn(const unsigned long long* seeds, unsigned long long offset, float* out, int batch, long long n,
+                               long long threads_total, void* stream) {
+    if (!seeds || !out || batch < 1 || n < 1 || threads_total < 256 || threads_total % 256) return DS_E_ARG;
+    const long long total = (long long)batch * n;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(philox_randn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, seeds, offset, out, batch, n, threads_total);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+extern "C" int ds_philox_randint(const unsigned long long* seeds, unsigned long long offset, unsigned int range, int* out, int batch,
+                                 void* stream) {
+    if (!seeds || !out || batch < 1 || range < 1) return DS_E_ARG;
+    hipLaunchKernelGGL(philox_randint_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seeds, offset, range, out, batch);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}

@@ -18,7 +18,7 @@ from ._lib import (ConvArgs, GemmArgs, NormArgs, UpdateArgs, DS_ACT_NONE, DS_ACT
 def _p(t: Optional[torch.Tensor]):
     if t is None:
         return None
-    assert t.is_cuda and t.dtype in (torch.float32, torch.uint8, torch.int32), (t.device, t.dtype)
+    assert t.is_cuda and t.dtype in (torch.float32, torch.uint8, torch.int32, torch.int64), (t.device, t.dtype)
     return C.c_void_p(t.data_ptr())
 
 
@@ -171,3 +171,26 @@ def geglu(x, ldx, y, ldy, rows, inner):
 def cfg_denoise(x, f, f_ld, sigma, sigma_rows, guidance, doubled, n, c, h, w, out):
     _lib.check(_lib.load().ds_cfg_denoise(_p(x), _p(f), f_ld, _p(sigma), sigma_rows, float(guidance), int(doubled), n, c, h, w,
                                           _p(out), _lib.stream_ptr()), 'ds_cfg_denoise')
+
+
+def philox_threads_total(n: int, device) -> int:
+    """ATen's execution policy for an n-element distribution kernel on this device (DistributionTemplates.h: calc_execution_policy)."""
+    prop = torch.cuda.get_device_properties(device)
+    blocks = min(prop.multi_processor_count * (prop.max_threads_per_multi_processor // 256), -(-n // 256))
+    return 256 * blocks
+
+
+def philox_offset_step(n: int, threads_total: int) -> int:
+    return ((n - 1) // (threads_total * 4) + 1) * 4
+
+
+def philox_randn(seeds, offset, out, n):
+    """seeds: int64 tensor [B] on the device (values < 2**32 as sample.py seeds them); out: float32 [B, n]."""
+    tt = philox_threads_total(n, out.device)
+    _lib.check(_lib.load().ds_philox_randn(_p(seeds), int(offset), _p(out), seeds.numel(), n, tt, _lib.stream_ptr()), 'ds_philox_randn')
+    return philox_offset_step(n, tt)
+
+
+def philox_randint(seeds, offset, high, out):
+    _lib.check(_lib.load().ds_philox_randint(_p(seeds), int(offset), int(high), _p(out), seeds.numel(), _lib.stream_ptr()), 'ds_philox_randint')
+    return 4

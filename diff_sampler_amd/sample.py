@@ -35,20 +35,62 @@ except ImportError:                        # pragma: no cover
 # ------------------------------------------------------------------------------------------------------------------
 class StackedRandomGenerator:
     """One generator per sample, seeded ``seed % 2**32`` (sample.py:22-36): a batch is reproducible per image
-    regardless of how seeds are grouped into batches or sharded over ranks."""
+    regardless of how seeds are grouped into batches or sharded over ranks.
+
+    The reference constructs B ``torch.Generator`` objects and issues B ``randn`` launches per batch.  Here float32 ``randn`` /
+    ``randint`` on the GPU evaluate the same Philox4x32-10 streams for the whole batch in ONE launch (``ds_philox_randn`` /
+    ``ds_philox_randint``: bit-identical to the per-generator calls, tests/test_hip_rng.py) and only track the generators' common
+    Philox offset; anything else (CPU, other dtypes, ranges >= 2**32) goes through real per-seed generators as the reference does,
+    fast-forwarded to the same offset."""
 
     def __init__(self, device, seeds):
-        self.generators = [torch.Generator(device).manual_seed(int(seed) % (1 << 32)) for seed in seeds]
+        self.device = torch.device(device)
+        self.seeds = [int(seed) % (1 << 32) for seed in seeds]
+        self.offset = 0                      # Philox offset every generator of the stack has reached
+        self._seeds_dev = None
+        self._generators = None
+
+    @property
+    def generators(self):
+        if self._generators is None:
+            self._generators = [torch.Generator(self.device).manual_seed(s) for s in self.seeds]
+            if self.offset and self.device.type == 'cuda':
+                for g in self._generators:
+                    g.set_offset(self.offset)
+        return self._generators
+
+    def _fast(self, device, dtype):
+        return (self._generators is None and self.device.type == 'cuda' and torch.device(device if device is not None else self.device).type == 'cuda'
+                and dtype in (None, torch.float32))
+
+    def _dev_seeds(self):
+        if self._seeds_dev is None:
+            self._seeds_dev = torch.tensor(self.seeds, dtype=torch.int64, device=self.device)
+        return self._seeds_dev
 
     def randn(self, size, **kwargs):
-        assert size[0] == len(self.generators)
+        assert size[0] == len(self.seeds)
+        if self._fast(kwargs.get('device'), kwargs.get('dtype')) and kwargs.get('layout', torch.strided) == torch.strided:
+            from . import ops
+            n = 1
+            for d in size[1:]:
+                n *= int(d)
+            out = torch.empty([len(self.seeds)] + [int(d) for d in size[1:]], dtype=torch.float32, device=self.device)
+            self.offset += ops.philox_randn(self._dev_seeds(), self.offset, out, n)
+            return out
         return torch.stack([torch.randn(size[1:], generator=g, **kwargs) for g in self.generators])
 
     def randn_like(self, input):
         return self.randn(input.shape, dtype=input.dtype, layout=input.layout, device=input.device)
 
     def randint(self, *args, size, **kwargs):
-        assert size[0] == len(self.generators)
+        assert size[0] == len(self.seeds)
+        if (len(args) == 1 and len(size) == 1 and int(args[0]) < (1 << 32) and self._fast(kwargs.get('device'), None)
+                and kwargs.get('dtype') in (None, torch.int64)):
+            from . import ops
+            out = torch.empty(len(self.seeds), dtype=torch.int32, device=self.device)
+            self.offset += ops.philox_randint(self._dev_seeds(), self.offset, int(args[0]), out)
+            return out.to(torch.int64)
         return torch.stack([torch.randint(*args, size=size[1:], generator=g, **kwargs) for g in self.generators])
 
 

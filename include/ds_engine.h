@@ -112,6 +112,18 @@ int ds_conv_kernel_id(const ds_conv_args* a);
 /* 1 if a 3x3 convolution on h x w images runs on the LDS-halo kernel (needed for norm_coefs), else 0. */
 int ds_conv3x3_halo_supported(int h, int w);
 
+/* Batched per-seed latent generator: out[b][i], i < n, = the tensor `torch.randn([n], generator=g_b, device=<this GPU>)` of a generator
+ * with `g_b.manual_seed(seeds[b])` whose Philox offset is `offset` (0 for a fresh generator) -- bit for bit, for a whole batch of
+ * seeds in one launch.  Replaces B generator constructions + B launches per batch (diff-solvers-main/sample.py:22-36,
+ * StackedRandomGenerator.randn).  `threads_total` = 256 * min(CUs * (maxThreadsPerCU / 256), ceil(n / 256)), ATen's execution
+ * policy for n elements; afterwards each generator's offset has advanced by ((n - 1) / (threads_total * 4) + 1) * 4. */
+int ds_philox_randn(const unsigned long long* seeds, unsigned long long offset, float* out, int batch, long long n,
+                    long long threads_total, void* stream);
+
+/* out[b] = `torch.randint(range, size=[], generator=g_b)` at Philox offset `offset` (sample.py:283: class labels); range < 2**32;
+ * the offset then advances by 4. */
+int ds_philox_randint(const unsigned long long* seeds, unsigned long long offset, unsigned int range, int* out, int batch, void* stream);
+
 /* Benchmark/debug switch: v != 0 routes 3x3 convolutions through the generic gather kernel instead of the
  * LDS-halo kernel (both are exact fp32; used for A/B measurements and as a cross-check in the tests). */
 int ds_debug_force_generic_conv(int v);

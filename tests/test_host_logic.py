@@ -343,3 +343,46 @@ def test_amed_predictor_loading_rules(tmp_path):
     assert sample.compute_nfe('ipndm', 7, True, False, 'cifar10', dp=True) == 6      # GITS: AFS inserts a free step
     assert sample.compute_nfe('heun', 7, True, False, 'cifar10', dp=True) == 13
     assert sample.compute_nfe('heun', 7, True, False, 'cifar10') == 11
+
+
+def _toy_detector(device):
+    """module:factory detector for the FID CLI tests: 8 fixed random projections of the mean-pooled image (deterministic)."""
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(3 * 4 * 4, 8, generator=g).to(device)
+
+    def f(images):
+        x = torch.nn.functional.adaptive_avg_pool2d(images.to(torch.float32) / 255.0, 4).reshape(images.shape[0], -1)
+        return x @ w
+    return f
+
+
+def test_fid_cli_ref_then_calc_matches_numpy(tmp_path):
+    """`fid.py ref` + `fid.py calc` end to end on a folder of PNGs (detector injected as module:factory): the moments equal a
+    numpy fp64 computation, the subset rule is the reference's (dataset.py:44-48), and FID(x, x) = 0."""
+    import PIL.Image
+    from click.testing import CliRunner
+    rng = np.random.RandomState(3)
+    d = tmp_path / 'imgs' / '000000'
+    d.mkdir(parents=True)
+    imgs = rng.randint(0, 256, size=(23, 8, 8, 3), dtype=np.uint8)
+    for i, a in enumerate(imgs):
+        PIL.Image.fromarray(a, 'RGB').save(d / f'{i:06d}.png')
+    det = 'tests.test_host_logic:_toy_detector'
+    r = CliRunner().invoke(F.main, ['ref', '--data', str(tmp_path / 'imgs'), '--dest', str(tmp_path / 'ref.npz'), '--batch', '5',
+                                    '--detector', det, '--device', 'cpu'])
+    assert r.exit_code == 0, r.output
+    z = np.load(tmp_path / 'ref.npz')
+    feats = _toy_detector('cpu')(torch.from_numpy(imgs).permute(0, 3, 1, 2)).double().numpy()
+    assert np.allclose(z['mu'], feats.mean(0), rtol=1e-9, atol=1e-9)     # moments are accumulated in fp64 from fp32 features
+    assert np.allclose(z['sigma'], np.cov(feats, rowvar=False), rtol=1e-6, atol=1e-9)
+    r = CliRunner().invoke(F.main, ['calc', '--images', str(tmp_path / 'imgs'), '--ref', str(tmp_path / 'ref.npz'), '--batch', '7',
+                                    '--detector', det, '--device', 'cpu'])
+    assert r.exit_code == 0, r.output
+    assert abs(float(r.output.strip().splitlines()[-1])) < 1e-6
+    # --num selects the reference's subset: shuffle with RandomState(seed), first k, sorted
+    ds = F.ImageFolder(str(tmp_path / 'imgs'), max_size=10, random_seed=5)
+    idx = np.arange(23); np.random.RandomState(5).shuffle(idx)
+    assert list(ds.idx) == sorted(idx[:10].tolist()) and len(ds) == 10
+    r = CliRunner().invoke(F.main, ['calc', '--images', str(tmp_path / 'imgs'), '--ref', str(tmp_path / 'ref.npz'), '--num', '40',
+                                    '--detector', det, '--device', 'cpu'])
+    assert r.exit_code != 0            # fewer images than --num
