@@ -43,12 +43,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_FP16_MFMA_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md; measured 2495)
 PEAK_HBM_GBS = 8000.0
 PMC_FILE = os.path.join(ROOT, 'profiles', 'r1f_bench_pmc_hbm.json')
 KERNEL_NAMES = {0: 'igemm_f32_kernel<0> (generic gather conv / 1x1 / linear)', 128: 'conv3x3_halo_kernel<2> (128-pixel tiles)',
-                256: 'conv3x3_halo_kernel<4> (256-pixel tiles)', 2561: 'gemm_dma8_kernel (256x128 tiles, LDS-DMA, 1x1 / linear)'}
+                256: 'conv3x3_halo_kernel<4> (256-pixel tiles)', 2561: 'gemm_dma8_kernel (256x128 tiles, LDS-DMA, 1x1 / linear)',
+                2562: 'conv3x3_halo2_kernel<fp16 operands> (256-pixel tiles, v_mfma_f32_32x32x16_f16)'}
+KERNEL_PEAK = {2562: PEAK_FP16_MFMA_TFLOPS}
 PMC_KEYS = {0: 'void igemm::igemm_f32_kernel<0>(igemm::KParams)', 128: 'void igemm::conv3x3_halo_kernel<2, true, 2>(igemm::KParams)',
-            256: 'void igemm::conv3x3_halo_kernel<4, true, 2>(igemm::KParams)', 2561: 'igemm::gemm_dma8_kernel(igemm::KParams)'}
+            256: 'void igemm::conv3x3_halo_kernel<4, true, 2>(igemm::KParams)', 2561: 'igemm::gemm_dma8_kernel(igemm::KParams)',
+            2562: None}
 
 
 def parse(argv=None):
@@ -60,6 +64,8 @@ def parse(argv=None):
     ap.add_argument('--nfe', type=int, default=10)
     ap.add_argument('--solver', default='dpmpp', choices=['dpmpp', 'euler', 'ipndm', 'heun'])
     ap.add_argument('--config', default='cifar10')
+    ap.add_argument('--dtype', default='fp32', choices=['fp32', 'fp16'],
+                    help="fp16 = the reference's use_fp16 / autocast mode (configs 3 and 5): fp16 operands in the 3x3 convolutions, fp32 accumulation and storage")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay the sampler call from a captured hipGraph')
     ap.add_argument('--cpu-batch', type=int, default=8)
@@ -389,13 +395,13 @@ def main(argv=None):
         import diff_sampler_amd.ldm_arch as ldm_arch
         if args.config in ldm_arch.NAMED_LDM_CONFIGS:
             from diff_sampler_amd.ldm_engine import CFGDenoiser
-            net_factory = lambda: CFGDenoiser.from_config(args.config, seed=0, device=dev, guidance_rate=7.5)
+            net_factory = lambda: CFGDenoiser.from_config(args.config, seed=0, device=dev, guidance_rate=7.5, use_fp16=(args.dtype == 'fp16'))
             net = net_factory()
             spec = net.spec
             ldm = (torch.randn(B, 77, spec.context_dim, generator=g).to(dev), torch.randn(B, 77, spec.context_dim, generator=g).to(dev))
             args.solver = 'dpmpp'
         else:
-            net_factory = lambda: EDMDenoiser.from_config(args.config, seed=0, device=dev)
+            net_factory = lambda: EDMDenoiser.from_config(args.config, seed=0, device=dev, use_fp16=(args.dtype == 'fp16'))
             net = net_factory()
             spec = net.spec
         latents = torch.randn(B, spec.in_channels, spec.img_resolution, spec.img_resolution, generator=g).to(dev)
@@ -453,9 +459,10 @@ def main(argv=None):
         convs = {k: v for k, v in rec.items() if isinstance(k, tuple)}
         dom, (ms, launches, fl) = max(convs.items(), key=lambda kv: kv[1][0])
         ach = fl / (ms * 1e-3) / 1e12
-        traffic = pmc_traffic(dom[1]) if (args.config == 'cifar10' and B == 256) else None   # the PMC pass is of the default workload
-        roof = dict(bound='mfma', kernel=KERNEL_NAMES[dom[1]], achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
-                    frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=(round(traffic) if traffic else None),
+        traffic = pmc_traffic(dom[1]) if (args.config == 'cifar10' and B == 256 and args.dtype == 'fp32') else None   # the PMC pass is of the default workload
+        peak = KERNEL_PEAK.get(dom[1], PEAK_FP32_MFMA_TFLOPS)
+        roof = dict(bound='mfma', kernel=KERNEL_NAMES[dom[1]], achieved=round(ach, 2), peak=peak, unit='TFLOP/s',
+                    frac=round(ach / peak, 4), traffic=(round(traffic) if traffic else None),
                     traffic_unit='HBM bytes per launch (rocprofv3 PMC, %s)' % os.path.relpath(PMC_FILE, ROOT),
                     launches_per_step=launches, avg_launch_ms=round(ms / launches, 4), gflop_per_launch=round(fl / launches / 1e9, 2),
                     share_of_gpu_time=round(ms / total_ms, 4))
@@ -484,7 +491,8 @@ def main(argv=None):
             'metric': 'images/sec (whole node) at NFE=%d, %s' % (args.nfe, 'EDM CIFAR-10' if args.config == 'cifar10' else workload_name.split(' (')[0]),
             'value': round(total_images / dt, 2), 'unit': 'images/sec', 'n_gpus': n_comm, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'fp32', 'data': 'synthetic N(0,1) latents, random-init (signal-carrying) weights',
+            'dtype': 'fp32' if args.dtype == 'fp32' else 'fp16 operands in the 3x3 convolutions (fp32 accumulate, fp32 storage), rest fp32',
+            'data': 'synthetic N(0,1) latents, random-init (signal-carrying) weights',
             'config': {'workload': '%s, %s NFE=%d, batch %d/GPU' %
                        (workload_name, 'DPM-Solver++(2M) eps-prediction, discrete rho=1, CFG 7.5 (2 U-Net images per latent)' if ldm is not None else
                         {'dpmpp': 'DPM-Solver++(2M) logSNR', 'euler': 'Euler', 'ipndm': 'iPNDM-4', 'heun': 'Heun'}[args.solver], args.nfe, B),

@@ -352,6 +352,16 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     if (a->workspace && a->workspace_floats > 0 && ds_aligned16(a->workspace)) {
         p.part = a->workspace; p.part_cap = a->workspace_floats; p.vec_part = (p.N & 3) ? 0 : 1;
     }
+    if (a->wgt_f16) {
+        // fp16 operands: second-generation halo kernel only (every 128-column tile, the ragged last one included)
+        if (a->taps != 9 || stride != 1) return DS_E_ARG;
+        if ((p.K & 1) || p.part) { /* K is a multiple of 64; split-K scratch is ignored */ }
+        const int wide = (p.N + BN - 1) / BN;
+        p.ldb = p.K / 2;                         // row pitch of the fp16 weight matrix in float units
+        p.part = nullptr; p.part_cap = 0; p.splits = 1;
+        if (!conv3x3_halo2_applicable(p, wide, true)) return DS_E_SHAPE;
+        return launch_conv3x3_halo2(p, wide, true, (hipStream_t)stream);
+    }
     if (!g_force_generic && stride == 1 && conv3x3_halo_supported(p)) return launch_conv3x3_halo(p, (hipStream_t)stream);
     if (p.norm) return DS_E_SHAPE;           // fused input normalisation exists only in the halo kernel
     if (!g_force_generic && g_use_dma8 && gemm_dma8_applicable(p)) return launch_gemm_dma8(p, (hipStream_t)stream);
@@ -365,9 +375,18 @@ extern "C" int ds_conv_kernel_id(const ds_conv_args* a) {
     p.c0 = a->c0; p.c1 = a->c1; p.ec0 = a->ec0; p.ec1 = a->ec1;
     if (a->workspace && a->workspace_floats > 0) { p.part = a->workspace; p.part_cap = a->workspace_floats; }
     p.stride = a->stride ? a->stride : 1; p.K = a->taps * (a->c0 + a->c1) + a->ec0 + a->ec1; p.norm = a->norm_coefs;
+    if (a->wgt_f16) return 2562;
     if (g_force_generic) return 0;
     if (a->taps != 9 || a->stride > 1) return (g_use_dma8 && gemm_dma8_applicable(p)) ? 2561 : 0;
     return conv3x3_halo_choice(p);
+}
+
+extern "C" int ds_conv_f16_supported(int n, int h, int w, int c0, int c1, int ec0, int ec1) {
+    KParams p{};
+    p.taps = 9; p.H = h; p.W = w; p.HW = h * w; p.M = n * h * w; p.N = 128; p.c0 = c0; p.c1 = c1; p.ec0 = ec0; p.ec1 = ec1;
+    p.nrows_b = 128;
+    if (!conv3x3_halo2_applicable(p, 1, true)) return 0;
+    return w >= 16 ? 2 : 1;                      // 8x8: four images per tile, the per-image normalisation planes are not fused
 }
 
 extern "C" int ds_conv3x3_halo_supported(int h, int w) {

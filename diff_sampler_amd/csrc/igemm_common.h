@@ -248,8 +248,8 @@ void conv3x3_halo_set_variant(int v);     // kernel variant of the 128-column LD
 void conv3x3_halo_set_tail64(int on);     // 64-column tiles for the ragged last column tile (default on)
 
 // conv3x3_halo2.hip: second-generation 256 x 128 tile (static tap schedule, double halo buffer)
-bool conv3x3_halo2_applicable(const KParams& p, int wide);
-int launch_conv3x3_halo2(KParams& p, int wide, hipStream_t stream);
+bool conv3x3_halo2_applicable(const KParams& p, int wide, bool f16);
+int launch_conv3x3_halo2(KParams& p, int wide, bool f16, hipStream_t stream);
 extern long long g_halo2_launches;
 
 }  // namespace igemm

@@ -33,9 +33,14 @@ from .plan import Op as _Op, Plan as _Plan, ptr as _ptr, SPLITK_WORKSPACE_FLOATS
 
 
 class UNetEngine:
-    def __init__(self, spec: arch.UNetSpec, params: Dict[str, torch.Tensor], device='cuda'):
+    def __init__(self, spec: arch.UNetSpec, params: Dict[str, torch.Tensor], device='cuda', use_fp16=False):
+        """use_fp16: the reference's reduced-precision mode (networks_edm.py:486).  Stage 1 of it here: every 3x3 convolution the
+        fp16-operand kernel supports (ds_conv_f16_supported: 8x8 ... 64x64 images, 64-channel multiples) multiplies fp16-rounded
+        activations and weights on the fp16 matrix pipe with fp32 accumulation; activations in HBM, GroupNorm, SiLU, softmax, the
+        1x1 / Linear layers and the embedding path stay fp32 (the reference additionally rounds every activation tensor to fp16)."""
         self.spec = spec
         self.device = torch.device(device)
+        self.use_fp16 = bool(use_fp16)
         self.lib = _lib.load()
         self._plans: Dict[tuple, _Plan] = {}
         self._pack(params)
@@ -83,6 +88,10 @@ class UNetEngine:
                 w[f'{b.name}.{leaf}.g'] = g(f'{p}.{leaf}.weight'); w[f'{b.name}.{leaf}.b'] = g(f'{p}.{leaf}.bias')
             w[f'{b.name}.conv0.w'] = pack_conv_weight(g(f'{p}.conv0.weight')); w[f'{b.name}.conv0.b'] = g(f'{p}.conv0.bias')
             w[f'{b.name}.conv1.w'] = pack_conv_weight(g(f'{p}.conv1.weight')); w[f'{b.name}.conv1.b'] = g(f'{p}.conv1.bias')
+            if self.use_fp16 and b.cin % 64 == 0 and b.cout % 64 == 0:
+                from .ops import pack_conv_weight_f16
+                w[f'{b.name}.conv0.w16'] = pack_conv_weight_f16(g(f'{p}.conv0.weight'))
+                w[f'{b.name}.conv1.w16'] = pack_conv_weight_f16(g(f'{p}.conv1.weight'), g(f'{p}.skip.weight') if b.skip_conv else None)
             if b.skip_conv:
                 # skip projection fused into conv1: [3x3 columns | 1x1 columns] along K, biases summed
                 w[f'{b.name}.conv1s.w'] = torch.cat([w[f'{b.name}.conv1.w'], pack_conv_weight(g(f'{p}.skip.weight'))], dim=1).contiguous()
@@ -165,14 +174,24 @@ class UNetEngine:
         def add(fn, args, name, keep=()):
             P.ops.append(_Op(fn, args, name, keep))
 
+        def f16_level(n, h, wd, c0, c1, ec0, ec1):
+            """0 = this 3x3 layer stays fp32, 1 = fp16 operands on raw input, 2 = ... and with the fused input normalisation."""
+            if not self.use_fp16 or any(c % 64 for c in (c0, c1, ec0, ec1)):
+                return 0
+            return int(lib.ds_conv_f16_supported(n, h, wd, c0, c1, ec0, ec1))
+
         def conv(x0, c0, ld0, n, h, wd, wgt, cout, out, out_ld, taps, name, x1=None, c1=0, ld1=0, bias=None, cbias=None,
                  cbias_ld=0, cbias_rows=1, res=None, res_ld=0, scale=1.0, act_=DS_ACT_NONE, norm_coefs=None, norm_act=DS_ACT_NONE,
-                 e0=None, ec0=0, e1=None, ec1=0, out_nchw=0, stats=False):
+                 e0=None, ec0=0, e1=None, ec1=0, out_nchw=0, stats=False, w16=None):
+            f16 = w16 is not None and f16_level(n, h, wd, c0, c1, ec0, ec1) >= (2 if norm_coefs is not None else 1)
+            if f16:
+                wgt = w16
             a = ConvArgs(_ptr(x0), _ptr(x1), c0, c1, ld0, ld1, n, h, wd, taps, _ptr(wgt), cout, _ptr(bias), _ptr(cbias),
                          cbias_ld, cbias_rows, _ptr(res), res_ld, scale, act_, _ptr(out), out_ld, _ptr(norm_coefs), norm_act,
                          _ptr(e0), _ptr(e1), ec0, ec1, ec0, ec1)
             a.workspace, a.workspace_floats = _ptr(splitk_ws), splitk_ws.numel()
             a.out_nchw = out_nchw
+            a.wgt_f16 = 1 if f16 else 0
             stats_of.pop(out.data_ptr(), None)
             if stats and cout % 64 == 0 and out_ld == cout:
                 # the epilogue leaves the output's per-(64-row block, channel) sums for the consumer's GroupNorm
@@ -258,6 +277,9 @@ class UNetEngine:
             rs = DS_RESAMPLE_DOWN if b.down else (DS_RESAMPLE_UP if b.up else DS_RESAMPLE_NONE)
             nm = b.name
             fuse = bool(lib.ds_conv3x3_halo_supported(Ho, Ho))     # GroupNorm+SiLU applied by the conv's halo loader
+            w16_0, w16_1 = w.get(f'{nm}.conv0.w16'), w.get(f'{nm}.conv1.w16')
+            if w16_0 is not None and f16_level(n, Ho, Ho, cin, 0, 0, 0) == 1:
+                fuse = False        # fp16 operands without the fused normalisation (8x8: four images per tile): normalise in a pass
             aoff = self.aff_off[nm]
             cb = dict(cbias=aff[:, aoff:], cbias_ld=self.aff_total, cbias_rows=Bs) if not b.adaptive_scale else {}
             # norm0 + silu (+resample) -> conv0 (+bias, + per-image embedding for the non-adaptive variant)
@@ -265,12 +287,13 @@ class UNetEngine:
                 norm('stats', x0, c0, c0, n, Hin, Hin, nm + '.norm0.stats', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps,
                      gamma=w[f'{nm}.norm0.g'], beta=w[f'{nm}.norm0.b'], coefs=ncoef)
                 conv(x0, c0, c0, n, Ho, Ho, w[f'{nm}.conv0.w'], cout, hbuf, cout, 9, nm + '.conv0', x1=x1, c1=c1, ld1=c1,
-                     bias=w[f'{nm}.conv0.b'], norm_coefs=ncoef, norm_act=DS_ACT_SILU, stats=True, **cb)
+                     bias=w[f'{nm}.conv0.b'], norm_coefs=ncoef, norm_act=DS_ACT_SILU, stats=True, w16=w16_0, **cb)
             else:
                 norm('stats', x0, c0, c0, n, Hin, Hin, nm + '.norm0.stats', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps)
                 norm('apply', x0, c0, c0, n, Hin, Hin, nm + '.norm0', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps,
                      gamma=w[f'{nm}.norm0.g'], beta=w[f'{nm}.norm0.b'], act_=DS_ACT_SILU, resample=rs, out=act, out_ld=cin)
-                conv(act, cin, cin, n, Ho, Ho, w[f'{nm}.conv0.w'], cout, hbuf, cout, 9, nm + '.conv0', bias=w[f'{nm}.conv0.b'], stats=True, **cb)
+                conv(act, cin, cin, n, Ho, Ho, w[f'{nm}.conv0.w'], cout, hbuf, cout, 9, nm + '.conv0', bias=w[f'{nm}.conv0.b'], stats=True,
+                     w16=w16_0, **cb)
             # norm1 (+adaptive scale/shift) + silu
             ss = dict(scale=aff[:, aoff:], shift=aff[:, aoff + cout:], ss_ld=self.aff_total, ss_rows=Bs) if b.adaptive_scale else {}
             if fuse:
@@ -307,7 +330,7 @@ class UNetEngine:
                 mid = out
                 out2 = None
             conv(c1_in, cout, cout, n, Ho, Ho, c1_w, cout, out, cout, 9, nm + '.conv1', bias=c1_b, scale=b.skip_scale, stats=True,
-                 **c1_norm, **c1_skip)
+                 w16=w16_1, **c1_norm, **c1_skip)
             if b.heads:
                 S = Ho * Ho
                 hd = b.heads
@@ -363,9 +386,9 @@ class EDMDenoiser:
     """
     edm_raw_output = True      # solvers._Run: ds_solver_update applies the EDM preconditioning to the raw output itself
 
-    def __init__(self, spec: arch.UNetSpec, params: Dict[str, torch.Tensor], device='cuda'):
+    def __init__(self, spec: arch.UNetSpec, params: Dict[str, torch.Tensor], device='cuda', use_fp16=False):
         self.spec = spec
-        self.engine = UNetEngine(spec, params, device)
+        self.engine = UNetEngine(spec, params, device, use_fp16=use_fp16)
         self.device = self.engine.device
         self.img_resolution = spec.img_resolution
         self.img_channels = spec.in_channels
@@ -373,21 +396,24 @@ class EDMDenoiser:
         self.sigma_min = spec.sigma_min
         self.sigma_max = spec.sigma_max
         self.sigma_data = spec.sigma_data
-        self.use_fp16 = False
+        self.use_fp16 = bool(use_fp16)   # read-only after construction (weights are packed for the mode), like net.use_fp16 of the reference
         self.bottleneck_name = None      # set by the AMED path: 'enc.8x8_block3' / 'enc.8x8_block2'
 
     @classmethod
-    def from_config(cls, name_or_kwargs, seed=0, mode='signal', device='cuda'):
+    def from_config(cls, name_or_kwargs, seed=0, mode='signal', device='cuda', use_fp16=False):
         kw = arch.NAMED_CONFIGS[name_or_kwargs] if isinstance(name_or_kwargs, str) else name_or_kwargs
         spec = arch.edm_precond_spec(**kw)
-        return cls(spec, arch.init_params(spec, seed=seed, mode=mode), device)
+        return cls(spec, arch.init_params(spec, seed=seed, mode=mode), device, use_fp16=use_fp16)
 
     @classmethod
-    def from_reference_module(cls, net, device='cuda'):
+    def from_reference_module(cls, net, device='cuda', use_fp16=None):
         """Build from a live reference ``EDMPrecond`` instance (duck-typed: pickled EDM classes are exec'd from
-        source, so ``isinstance`` is useless -- persistence.py:222-233)."""
+        source, so ``isinstance`` is useless -- persistence.py:222-233).  ``use_fp16`` None: follow the module's own flag
+        (networks_edm.py:472, :486 -- the public ImageNet-64 checkpoint carries use_fp16=True)."""
         spec = spec_from_module(net)
-        return cls(spec, {k: v for k, v in net.state_dict().items() if 'resample_filter' not in k}, device)
+        if use_fp16 is None:
+            use_fp16 = bool(getattr(net, 'use_fp16', False))
+        return cls(spec, {k: v for k, v in net.state_dict().items() if 'resample_filter' not in k}, device, use_fp16=use_fp16)
 
     def eval(self):
         return self

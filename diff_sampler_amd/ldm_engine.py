@@ -31,9 +31,13 @@ from .plan import Builder, Plan, ptr
 
 
 class LDMUNetEngine:
-    def __init__(self, spec: ldm_arch.LDMUNetSpec, params: Dict[str, torch.Tensor], device='cuda'):
+    def __init__(self, spec: ldm_arch.LDMUNetSpec, params: Dict[str, torch.Tensor], device='cuda', use_fp16=False):
+        """use_fp16: the reference samples this U-Net under ``autocast("cuda")`` (diff-solvers-main/sample.py:296).  Stage 1 of that
+        mode here: the 3x3 convolutions of the ResBlocks / Upsample layers multiply fp16-rounded operands on the fp16 matrix pipe
+        with fp32 accumulation where the fp16-operand kernel takes the geometry; everything else stays fp32."""
         self.spec = spec
         self.device = torch.device(device)
+        self.use_fp16 = bool(use_fp16)
         self.lib = _lib.load()
         self._plans: Dict[tuple, Plan] = {}
         self._pack(params)
@@ -70,6 +74,11 @@ class LDMUNetEngine:
                         c1 = torch.cat([c1, pack_conv_weight(g(f'{p}.skip_connection.weight'))], dim=1).contiguous()
                         b1 = (b1 + g(f'{p}.skip_connection.bias')).contiguous()
                     w[f'{p}.c1.w'], w[f'{p}.c1.b'] = c1, b1
+                    if self.use_fp16 and l.cin % 64 == 0 and l.cout % 64 == 0:
+                        from .ops import pack_conv_weight_f16
+                        w[f'{p}.c0.w16'] = pack_conv_weight_f16(g(f'{p}.in_layers.2.weight'))
+                        w[f'{p}.c1.w16'] = pack_conv_weight_f16(g(f'{p}.out_layers.3.weight'),
+                                                                g(f'{p}.skip_connection.weight') if l.skip_conv else None)
                 elif l.kind == 'st':
                     t = f'{p}.transformer_blocks.0'
                     w[f'{p}.n.g'], w[f'{p}.n.b'] = g(f'{p}.norm.weight'), g(f'{p}.norm.bias')
@@ -96,6 +105,9 @@ class LDMUNetEngine:
                     w[f'{p}.w'], w[f'{p}.b'] = pack_conv_weight(g(f'{p}.op.weight')), g(f'{p}.op.bias')
                 elif l.kind == 'up':
                     w[f'{p}.w'], w[f'{p}.b'] = pack_conv_weight(g(f'{p}.conv.weight')), g(f'{p}.conv.bias')
+                    if self.use_fp16 and l.cin % 64 == 0:
+                        from .ops import pack_conv_weight_f16
+                        w[f'{p}.w16'] = pack_conv_weight_f16(g(f'{p}.conv.weight'))
         w['out.g'], w['out.b'] = g('out.0.weight'), g('out.0.bias')
         w['outc.w'], w['outc.b'] = pack_conv_weight(g('out.2.weight')), g('out.2.bias')
         self.w = w
@@ -129,21 +141,23 @@ class LDMUNetEngine:
         bd.linear(e0, E, emb_rows, w['te2.w'], E, emb, 'time_embed.2', bias=w['te2.b'], act=DS_ACT_SILU)   # SiLU of emb_layers[0]
         bd.linear(emb, E, emb_rows, w['aff.w'], self.aff_total, aff, 'emb_layers_all', bias=w['aff.b'])
 
-        def gn_conv(x0, c0, x1, c1, side, gk, bk, eps, wgt, bias, cout, out, out_ld, name, **kw):
+        def gn_conv(x0, c0, x1, c1, side, gk, bk, eps, wgt, bias, cout, out, out_ld, name, w16=None, **kw):
             """GroupNorm(32) + SiLU + 3x3 conv over the concatenation [x0 | x1]; the normalisation rides in the conv's loader
-            when the LDS-halo kernel takes the shape, otherwise it is a separate pass."""
+            when the LDS-halo kernel takes the shape, otherwise it is a separate pass (also when the fp16-operand kernel is
+            available for the normalised tensor but not with the fused normalisation: 8x8 images)."""
             cin = c0 + c1
-            if lib.ds_conv3x3_halo_supported(side, side):
+            unfused_f16 = w16 is not None and bd.f16_level(N, side, side, cin, 0, kw.get('ec0', 0), kw.get('ec1', 0)) == 1
+            if lib.ds_conv3x3_halo_supported(side, side) and not unfused_f16:
                 bd.norm('stats', x0, c0, c0, N, side, side, name + '.gn.stats', x1=x1, c1=c1, ld1=c1, groups=32, eps=eps, gamma=gk,
                         beta=bk, coefs=ncoef)
                 bd.conv(x0, c0, c0, N, side, side, wgt, cout, out, out_ld, 9, name, x1=x1, c1=c1, ld1=c1, bias=bias, norm_coefs=ncoef,
-                        norm_act=DS_ACT_SILU, stats=True, **kw)
+                        norm_act=DS_ACT_SILU, stats=True, w16=w16, **kw)
             else:
                 tmp = new(N * side * side, cin)
                 bd.norm('stats', x0, c0, c0, N, side, side, name + '.gn.stats', x1=x1, c1=c1, ld1=c1, groups=32, eps=eps)
                 bd.norm('apply', x0, c0, c0, N, side, side, name + '.gn', x1=x1, c1=c1, ld1=c1, groups=32, eps=eps, gamma=gk, beta=bk,
                         act=DS_ACT_SILU, out=tmp, out_ld=cin)
-                bd.conv(tmp, cin, cin, N, side, side, wgt, cout, out, out_ld, 9, name, bias=bias, stats=True, **kw)
+                bd.conv(tmp, cin, cin, N, side, side, wgt, cout, out, out_ld, 9, name, bias=bias, stats=True, w16=w16, **kw)
 
         def res_layer(l, x0, c0, x1, c1):
             p, res, cout = l.key, l.res_out, l.cout
@@ -151,14 +165,14 @@ class LDMUNetEngine:
             h1, out = new(M, cout), new(M, cout)
             ao = self.aff_off[p]
             gn_conv(x0, c0, x1, c1, res, w[f'{p}.n0.g'], w[f'{p}.n0.b'], 1e-5, w[f'{p}.c0.w'], w[f'{p}.c0.b'], cout, h1, cout,
-                    p + '.in_layers', cbias=aff[:, ao:], cbias_ld=self.aff_total, cbias_rows=emb_rows)
+                    p + '.in_layers', w16=w.get(f'{p}.c0.w16'), cbias=aff[:, ao:], cbias_ld=self.aff_total, cbias_rows=emb_rows)
             if l.skip_conv:
                 skip = dict(e0=x0, ec0=c0, e1=x1, ec1=c1)
             else:
                 assert x1 is None and c0 == cout
                 skip = dict(res=x0, res_ld=cout)
             gn_conv(h1, cout, None, 0, res, w[f'{p}.n1.g'], w[f'{p}.n1.b'], 1e-5, w[f'{p}.c1.w'], w[f'{p}.c1.b'], cout, out, cout,
-                    p + '.out_layers', **skip)
+                    p + '.out_layers', w16=w.get(f'{p}.c1.w16'), **skip)
             return out, cout
 
         def st_layer(l, x_in, c):
@@ -229,7 +243,7 @@ class LDMUNetEngine:
                             resample=DS_RESAMPLE_UP, out=up, out_ld=l.cin)
                     out = new(N * l.res_out ** 2, l.cout)
                     bd.conv(up, l.cin, l.cin, N, l.res_out, l.res_out, w[f'{p}.w'], l.cout, out, l.cout, 9, p + '.conv', bias=w[f'{p}.b'],
-                            stats=True)
+                            stats=True, w16=w.get(f'{p}.w16'))
                     cur = (out, l.cout)
                 bufs[p] = cur[0]
             if b.pushes_skip:
@@ -290,15 +304,15 @@ class CFGDenoiser(CFGSchedule):
     host_sigma_ok = True       # solvers._Run: pass sigma as a Python float (c_noise is host math; nothing to copy or sync)
 
     def __init__(self, spec: ldm_arch.LDMUNetSpec, params: Dict[str, torch.Tensor], device='cuda', guidance_rate=None,
-                 guidance_type=None):
+                 guidance_type=None, use_fp16=False):
         self.spec = spec
-        self.engine = LDMUNetEngine(spec, params, device)
+        self.engine = LDMUNetEngine(spec, params, device, use_fp16=use_fp16)
         self.device = self.engine.device
         self.guidance_rate = spec.guidance_rate if guidance_rate is None else guidance_rate
         self.guidance_type = spec.guidance_type if guidance_type is None else guidance_type
         self.img_resolution, self.img_channels, self.label_dim = spec.img_resolution, spec.in_channels, True
         CFGSchedule.__init__(self, spec)                                    # host tables (networks_edm.py:654-658)
-        self.use_fp16 = False
+        self.use_fp16 = bool(use_fp16)      # the reference's autocast mode (sample.py:296); fixed at construction
 
     @classmethod
     def from_config(cls, name_or_kwargs, seed=0, device='cuda', **kw):

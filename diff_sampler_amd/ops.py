@@ -41,6 +41,23 @@ def pack_conv_weight(w: torch.Tensor, row_pad: int = 128, k_pad: int = 32) -> to
     return out.contiguous()
 
 
+def pack_conv_weight_f16(w: torch.Tensor, extra: Optional[torch.Tensor] = None, row_pad: int = 128) -> torch.Tensor:
+    """fp16 weights of the reduced-precision 3x3 convolution (ds_conv_args.wgt_f16): [Cout, Cin, 3, 3] (+ optional 1x1 skip
+    projection [Cout, Ce, 1, 1] appended along K) -> [Cout_pad, K] halfs, K = (slab*9 + tap)*64 + cc with c = slab*64 + cc,
+    then the extra columns in 64-channel blocks; rows zero-padded to the N tile.  Rounded to nearest even like ``w.to(float16)``
+    (networks_edm.py:79: ``w.to(x.dtype)``).  Returned as a float32-typed view of the same bytes (the ABI carries ``const float*``)."""
+    cout, cin, kh, kw = w.shape
+    assert kh == 3 and kw == 3 and cin % 64 == 0
+    m = w.permute(0, 2, 3, 1).reshape(cout, 9, cin // 64, 64).permute(0, 2, 1, 3).reshape(cout, 9 * cin)
+    if extra is not None:
+        assert extra.shape[0] == cout and extra.shape[1] % 64 == 0
+        m = torch.cat([m, extra.reshape(cout, -1)], dim=1)
+    rows = -(-cout // row_pad) * row_pad
+    out = torch.zeros(rows, m.shape[1], dtype=torch.float16, device=w.device)
+    out[:cout] = m.to(torch.float16)
+    return out.contiguous().view(torch.float32)
+
+
 def pack_stem_weight(w: torch.Tensor, row_pad: int = 128, k_pad: int = 32) -> torch.Tensor:
     """Stem conv [Cout, C, 3, 3] for the im2col'd input of ds_stem_im2col: K = tap*C + c, zero-padded to 32."""
     cout, cin, kh, kw = w.shape

@@ -65,21 +65,33 @@ class Builder:
 
     def conv(self, x0, c0, ld0, n, h, w, wgt, cout, out, out_ld, taps, name, x1=None, c1=0, ld1=0, bias=None, cbias=None,
              cbias_ld=0, cbias_rows=1, res=None, res_ld=0, scale=1.0, act=DS_ACT_NONE, norm_coefs=None, norm_act=DS_ACT_NONE,
-             e0=None, ec0=0, e1=None, ec1=0, stride=1, stats=False):
+             e0=None, ec0=0, e1=None, ec1=0, stride=1, stats=False, w16=None):
         """stats=True: the epilogue also leaves the output's per-(64-row block, channel) sums for the consumer's GroupNorm
-        (honoured when cout % 64 == 0; otherwise the consumer falls back to a ds_gn_stats pass)."""
+        (honoured when cout % 64 == 0; otherwise the consumer falls back to a ds_gn_stats pass).
+        w16: fp16 weights of the same layer (ops.pack_conv_weight_f16); used -- with the fp16-operand kernel -- when the
+        geometry supports it (f16_level), else the fp32 weights `wgt` are."""
+        f16 = w16 is not None and taps == 9 and stride == 1 and self.f16_level(n, h, w, c0, c1, ec0, ec1) >= (2 if norm_coefs is not None else 1)
+        if f16:
+            wgt = w16
         a = ConvArgs(ptr(x0), ptr(x1), c0, c1, ld0, ld1, n, h, w, taps, ptr(wgt), cout, ptr(bias), ptr(cbias), cbias_ld,
                      cbias_rows, ptr(res), res_ld, scale, act, ptr(out), out_ld, ptr(norm_coefs), norm_act, ptr(e0), ptr(e1),
                      ec0, ec1, ec0, ec1, stride)
         if self.ws is None:
             self.ws = self.new(SPLITK_WORKSPACE_FLOATS)
         a.workspace, a.workspace_floats = ptr(self.ws), self.ws.numel()
+        a.wgt_f16 = 1 if f16 else 0
         self.stats_of.pop(out.data_ptr(), None)
         if stats and cout % 64 == 0 and out_ld == cout:
             sb = self.new(-(-(n * h * w) // 64) * 2 * cout)
             a.stats_out = ptr(sb)
             self.stats_of[out.data_ptr()] = (sb, cout)
         self.add(self.lib.ds_conv2d_nhwc, (C.byref(a),), name, keep=(a,))
+
+    def f16_level(self, n, h, w, c0, c1, ec0, ec1):
+        """0 = no fp16-operand kernel for this 3x3 layer, 1 = on raw input only, 2 = also with the fused input normalisation."""
+        if any(c % 64 for c in (c0, c1, ec0, ec1)):
+            return 0
+        return int(self.lib.ds_conv_f16_supported(n, h, w, c0, c1, ec0, ec1))
 
     def linear(self, x, k, rows, wgt, cout, out, name, ldx=None, out_ld=None, **kw):
         """out[rows, cout] = x[rows, k] W^T (+bias +res ...): a 1x1 'convolution' over rows."""

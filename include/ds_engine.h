@@ -100,17 +100,29 @@ typedef struct ds_conv_args {
      * sum of squares (k = 1) of out[rb * 64 .. rb * 64 + 63][co]; ceil(n*h*w / 64) * 2 * cout floats, consumed by
      * ds_gn_finalize.  Requires cout % 64 == 0 and the aligned (float4) epilogue; NULL = not needed. */
     float* stats_out;
+    /* 1: REDUCED-PRECISION OPERANDS, the reference's `use_fp16` / autocast mode (networks_edm.py:486, sample.py:296): `wgt` holds fp16
+     * weights packed for 64-channel slabs ([cout_pad][K] halfs, K = (slab64 * 9 + tap) * 64 + c, then the 1x1 extra columns in
+     * 64-channel blocks), the kernel rounds the (normalised, activated) input to fp16 while it stages it and multiplies on
+     * v_mfma_f32_32x32x16_f16 with fp32 accumulation; inputs, bias / residual / output tensors stay fp32.  taps == 9 only, and only
+     * where ds_conv_f16_supported() says so -- otherwise DS_E_SHAPE (there is no silent fp32 fallback). */
+    int wgt_f16;
 } ds_conv_args;
 
 int ds_conv2d_nhwc(const ds_conv_args* a, void* stream);
 
 /* Which kernel ds_conv2d_nhwc dispatches this call to: 0 = generic gather kernel (igemm_f32_kernel<0>), 128 / 256 =
  * LDS-halo kernel with that M tile (conv3x3_halo_kernel<2> / <4>), 2561 = 8-wave LDS-DMA 1x1 / Linear kernel
- * (gemm_dma8_kernel).  Used by bench.py to attribute time per kernel. */
+ * (gemm_dma8_kernel), 2562 = fp16-operand halo kernel (conv3x3_halo2_kernel<W, true>).  Used by bench.py to attribute time per
+ * kernel. */
 int ds_conv_kernel_id(const ds_conv_args* a);
 
 /* 1 if a 3x3 convolution on h x w images runs on the LDS-halo kernel (needed for norm_coefs), else 0. */
 int ds_conv3x3_halo_supported(int h, int w);
+
+/* fp16-operand 3x3 convolution (ds_conv_args.wgt_f16): returns 0 = not available for this geometry, 1 = available, 2 = available
+ * and the fused input normalisation (norm_coefs) too.  n, h, w: images and size; cin = c0 + c1 and ecin = ec0 + ec1 with every
+ * source a multiple of 64 channels. */
+int ds_conv_f16_supported(int n, int h, int w, int c0, int c1, int ec0, int ec1);
 
 /* Batched per-seed latent generator: out[b][i], i < n, = the tensor `torch.randn([n], generator=g_b, device=<this GPU>)` of a generator
  * with `g_b.manual_seed(seeds[b])` whose Philox offset is `offset` (0 for a fresh generator) -- bit for bit, for a whole batch of

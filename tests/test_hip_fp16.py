@@ -1,0 +1,115 @@
+"""GPU: the reference's reduced-precision modes (networks_edm.py:486 `use_fp16` for the EDM nets -- the public ImageNet-64 ADM
+checkpoint carries it; sample.py:296 `autocast("cuda")` around the LDM sampler), stage 1: fp16 operands on the fp16 matrix pipe in
+every 3x3 convolution the fp16-operand kernel supports, fp32 accumulation, fp32 everywhere else.
+
+Two comparisons, both stated:
+  * bound against the fp32 CPU oracle: 2e-2 of the output scale per evaluation (fp16 operand rounding, 2**-11 relative per
+    product, through ~50 layers; observed values are written to gpurun_out/fp16_parity.json);
+  * against the oracle's restatement executed by PyTorch-ROCm under torch.autocast(float16) on the same GPU -- what the reference's
+    own reduced-precision arithmetic gives here -- 3e-2 (both sides carry an fp16 rounding error of the same size)."""
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+import diff_sampler_amd.arch as arch  # noqa: E402
+
+REPORT = {}
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-6))
+
+
+def _count_f16(plan, lib):
+    n16 = n32 = 0
+    for op in plan.ops:
+        if op.fn is lib.ds_conv2d_nhwc and op.keep[0].taps == 9:
+            if op.keep[0].wgt_f16:
+                n16 += 1
+            else:
+                n32 += 1
+    return n16, n32
+
+
+@pytest.mark.parametrize('name,B', [('cifar10', 4), ('imagenet64', 4), ('ffhq', 4)])
+def test_edm_use_fp16_within_bound_of_fp32_oracle_and_of_torch_autocast(name, B):
+    from diff_sampler_amd import _lib
+    from diff_sampler_amd.engine import EDMDenoiser
+    from oracle.edm_net import edm_denoise
+    dev = torch.device('cuda')
+    cfg = dict(arch.NAMED_CONFIGS[name])
+    spec = arch.edm_precond_spec(**cfg)
+    params = arch.init_params(spec, seed=9)
+    g = torch.Generator().manual_seed(12)
+    R = cfg['img_resolution']
+    sig = torch.tensor([30.0, 2.5, 0.3, 0.02][:B])
+    x = torch.randn(B, 3, R, R, generator=g) * sig.reshape(-1, 1, 1, 1)
+    lab = torch.eye(spec.label_dim)[torch.randint(spec.label_dim, (B,), generator=g)] if spec.label_dim else None
+    with torch.no_grad():
+        ref32 = edm_denoise(params, cfg, x, sig, lab)
+    net = EDMDenoiser(spec, params, use_fp16=True)
+    assert net.use_fp16
+    out = net(x.to(dev), sig.to(dev), class_labels=(lab.to(dev) if lab is not None else None))
+    torch.cuda.synchronize()
+    n16, n32 = _count_f16(net.engine.plan(B, B), _lib.load())
+    assert n16 >= 20, (n16, n32)                      # the mode is really on: most 3x3 convolutions run with fp16 operands
+    e32 = _rel(out.cpu(), ref32)
+    assert e32 < 2e-2, e32
+    p_dev = {k: v.to(dev) for k, v in params.items()}
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
+        ref16 = edm_denoise(p_dev, cfg, x.to(dev), sig.to(dev), lab.to(dev) if lab is not None else None)
+    e16 = _rel(out.cpu(), ref16.float().cpu())
+    e_torch = _rel(ref16.float().cpu(), ref32)
+    assert e16 < 3e-2, e16
+    net32 = EDMDenoiser(spec, params)
+    e_fp32_engine = _rel(net32(x.to(dev), sig.to(dev), class_labels=(lab.to(dev) if lab is not None else None)).cpu(), ref32)
+    REPORT[name] = dict(batch=B, f16_convs=n16, fp32_convs=n32, hip_fp16_vs_fp32_oracle=e32, hip_fp16_vs_torch_autocast=e16,
+                        torch_autocast_vs_fp32_oracle=e_torch, hip_fp32_vs_fp32_oracle=e_fp32_engine)
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    json.dump(REPORT, open(os.path.join(ROOT, 'gpurun_out', 'fp16_parity.json'), 'w'), indent=1)
+
+
+def test_use_fp16_sampler_trajectory_stays_close_to_fp32():
+    """Config 3's solver (iPNDM-4, NFE 10) on the CIFAR-10 net in both modes: the end images differ by fp16-rounding noise only."""
+    from diff_sampler_amd import solvers
+    from diff_sampler_amd.engine import EDMDenoiser
+    dev = torch.device('cuda')
+    lat = torch.randn(8, 3, 32, 32, generator=torch.Generator().manual_seed(3)).to(dev)
+    a = solvers.ipndm_sampler(EDMDenoiser.from_config('cifar10', seed=2), lat, num_steps=11, max_order=4)
+    b = solvers.ipndm_sampler(EDMDenoiser.from_config('cifar10', seed=2, use_fp16=True), lat, num_steps=11, max_order=4)
+    torch.cuda.synchronize()
+    assert torch.isfinite(b).all()
+    assert _rel(b, a) < 5e-2
+
+
+def test_sd15_autocast_mode_within_bound():
+    """SD-1.5 latent U-Net under classifier-free guidance, use_fp16 (the reference's autocast mode) vs the fp32 HIP path."""
+    from diff_sampler_amd import _lib
+    from diff_sampler_amd.ldm_engine import CFGDenoiser
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(5)
+    B = 2
+    x = (torch.randn(B, 4, 64, 64, generator=g) * 3).to(dev)
+    c, uc = torch.randn(B, 77, 768, generator=g).to(dev), torch.randn(B, 77, 768, generator=g).to(dev)
+    n32 = CFGDenoiser.from_config('sd15', seed=4, guidance_rate=7.5)
+    ref = n32(x, 2.5, condition=c, unconditional_condition=uc).clone()
+    del n32
+    n16 = CFGDenoiser.from_config('sd15', seed=4, guidance_rate=7.5, use_fp16=True)
+    out = n16(x, 2.5, condition=c, unconditional_condition=uc)
+    torch.cuda.synchronize()
+    lib = _lib.load()
+    plan = next(iter(n16.engine._plans.values()))
+    k16, k32 = _count_f16(plan, lib)
+    assert k16 >= 30, (k16, k32)
+    e = _rel(out, ref)
+    assert e < 3e-2, e
+    REPORT['sd15'] = dict(batch=B, f16_convs=k16, fp32_convs=k32, hip_fp16_vs_hip_fp32=e)
+    json.dump(REPORT, open(os.path.join(ROOT, 'gpurun_out', 'fp16_parity.json'), 'w'), indent=1)

@@ -483,3 +483,93 @@ def test_conv_halo2_kernel_matches_aten(case):
         st = stats.cpu().reshape(-1, 2, cout)
         blocks = want.reshape(-1, 64, cout)
         assert _rel(st[:, 0], blocks.sum(1)) < 1e-4 and _rel(st[:, 1], (blocks ** 2).sum(1)) < 1e-4
+
+
+F16_CASES = [
+    # B, H(=W), c0, c1, cout, (ec0, ec1), norm, act
+    (1, 16, 64, 0, 128, (0, 0), False, False),
+    (2, 16, 128, 64, 128, (0, 0), True, True),          # dual source, 3 slabs
+    (1, 32, 64, 0, 256, (0, 0), True, True),
+    (2, 32, 64, 64, 192, (128, 64), True, True),        # skip-projection slabs; ragged 192 = one full + one half-empty tile
+    (1, 64, 64, 0, 128, (64, 0), True, False),          # W = 64
+    (4, 8, 128, 0, 128, (0, 0), False, False),          # 8x8: four images per tile, raw input
+    (8, 8, 64, 64, 320, (64, 0), False, False),
+    (3, 16, 576, 0, 64, (0, 0), True, True),            # 9 slabs, cout below one tile
+]
+
+
+@pytest.mark.parametrize('case', F16_CASES)
+def test_conv_f16_operands_matches_fp16_rounded_reference(case):
+    """Reduced-precision mode (ds_conv_args.wgt_f16): fp16 operands on v_mfma_f32_32x32x16_f16, fp32 accumulation.  The reference
+    is the SAME arithmetic on the CPU: input normalised/activated in fp32, rounded to fp16; weights rounded to fp16; products summed
+    in fp64.  Tolerance 2e-3 of the output scale (a device exp that differs in the last bit can move an operand by one fp16 ulp);
+    the distance to the pure fp32 convolution is reported against the fp16 rounding bound 3e-3."""
+    import ctypes as C
+    from diff_sampler_amd import _lib, ops
+    B, H, c0, c1, cout, (ec0, ec1), use_norm, act = case
+    lib = _lib.load()
+    sup = lib.ds_conv_f16_supported(B, H, H, c0, c1, ec0, ec1)
+    assert sup >= (2 if use_norm else 1)
+    g = torch.Generator().manual_seed(sum(case[:5]) + 11)
+    x = torch.randn(B, c0 + c1, H, H, generator=g)
+    e = torch.randn(B, ec0 + ec1, H, H, generator=g) if ec0 else None
+    w = torch.randn(cout, c0 + c1, 3, 3, generator=g) / (9 * (c0 + c1)) ** 0.5
+    we = torch.randn(cout, ec0 + ec1, 1, 1, generator=g) / (ec0 + ec1) ** 0.5 if ec0 else None
+    bias = torch.randn(cout, generator=g)
+    cb = torch.randn(B, cout, generator=g)
+    res = torch.randn(B, cout, H, H, generator=g)
+    mu = torch.randn(B, c0 + c1, generator=g) * 0.3
+    ga = 1 + 0.2 * torch.randn(B, c0 + c1, generator=g)
+    be = 0.2 * torch.randn(B, c0 + c1, generator=g)
+    xin = x
+    if use_norm:
+        xin = (x - mu[:, :, None, None]) * ga[:, :, None, None] + be[:, :, None, None]
+        xin = F.silu(xin) if act else xin
+    h16 = lambda t: t.to(torch.float16).to(torch.float64)
+    ref16 = F.conv2d(h16(xin), h16(w), padding=1)
+    ref32 = F.conv2d(xin, w, padding=1)
+    if ec0:
+        ref16 = ref16 + F.conv2d(h16(e), h16(we))
+        ref32 = ref32 + F.conv2d(e, we)
+    tail = (bias[None, :, None, None] + cb[:, :, None, None] + res)
+    ref16 = ((ref16 + tail.double()) * 0.7071).float()
+    ref32 = (ref32 + tail) * 0.7071
+    dev = 'cuda'
+    xn = _nhwc(x).to(dev)
+    x0 = xn[:, :c0].contiguous()
+    x1 = xn[:, c0:].contiguous() if c1 else None
+    en = _nhwc(e).to(dev) if ec0 else None
+    e0 = en[:, :ec0].contiguous() if ec0 else None
+    e1 = en[:, ec0:].contiguous() if ec1 else None
+    wp = ops.pack_conv_weight_f16(w.to(dev), we.to(dev) if ec0 else None)
+    coefs = torch.stack([mu, ga, be], 1).contiguous().to(dev) if use_norm else None
+    old = cout if cout % 4 == 0 else -(-cout // 4) * 4
+    out = torch.full((B * H * H, old), float('nan'), device=dev)
+    biasd, cbd, resd = bias.to(dev), cb.to(dev), _nhwc(res).to(dev)
+    a = _lib.ConvArgs(x0.data_ptr(), x1.data_ptr() if c1 else None, c0, c1, c0, c1, B, H, H, 9, wp.data_ptr(), cout, biasd.data_ptr(),
+                      cbd.data_ptr(), cout, B, resd.data_ptr(), cout, 0.7071, 0, out.data_ptr(), old,
+                      coefs.data_ptr() if use_norm else None, 1 if act else 0,
+                      e0.data_ptr() if ec0 else None, e1.data_ptr() if ec1 else None, ec0, ec1, ec0, ec1)
+    a.wgt_f16 = 1
+    before = lib.ds_debug_conv_halo2_launches()
+    rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    assert rc == 0, lib.ds_error_string(rc)
+    assert lib.ds_debug_conv_halo2_launches() == before + 1
+    got = out[:, :cout].cpu()
+    assert _rel(got, _nhwc(ref16)) < 2e-3
+    assert _rel(got, _nhwc(ref32)) < 3e-3
+
+
+def test_conv_f16_unsupported_geometry_fails_loudly():
+    import ctypes as C
+    from diff_sampler_amd import _lib
+    lib = _lib.load()
+    assert lib.ds_conv_f16_supported(1, 32, 32, 96, 0, 0, 0) == 0          # 96 channels: not a multiple of 64
+    assert lib.ds_conv_f16_supported(3, 8, 8, 64, 0, 0, 0) == 0            # 8x8 needs whole tiles of four images
+    assert lib.ds_conv_f16_supported(1, 4, 4, 64, 0, 0, 0) == 0
+    assert lib.ds_conv_f16_supported(4, 8, 8, 64, 0, 0, 0) == 1 and lib.ds_conv_f16_supported(1, 16, 16, 64, 64, 64, 0) == 2
+    x = torch.zeros(3 * 64, 64, device='cuda'); w = torch.zeros(128, 64 * 9 // 2, device='cuda'); o = torch.zeros(3 * 64, 64, device='cuda')
+    a = _lib.ConvArgs(x.data_ptr(), None, 64, 0, 64, 0, 3, 8, 8, 9, w.data_ptr(), 64, None, None, 0, 1, None, 0, 1.0, 0, o.data_ptr(), 64)
+    a.wgt_f16 = 1
+    assert lib.ds_conv2d_nhwc(C.byref(a), None) == -3                       # DS_E_SHAPE, no silent fp32 fallback
