@@ -102,6 +102,7 @@ _SIGNATURES = {
     'ds_noise_embed': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp]),
     'ds_stem_im2col': (C.c_int, [vp, vp, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     'ds_solver_update': (C.c_int, [C.POINTER(UpdateArgs), vp]),
+    'ds_dpmpp_x0_step': (C.c_int, [C.POINTER(UpdateArgs), C.c_float, vp]),
     'ds_table_select': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp]),
     'ds_dynamic_threshold': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp]),
     'ds_scale': (C.c_int, [vp, C.c_float, vp, C.c_longlong, vp]),

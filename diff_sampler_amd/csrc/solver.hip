@@ -286,6 +286,66 @@ __global__ void __launch_bounds__(512) dynamic_threshold_kernel(const float* __r
     }
 }
 
+// One DPM-Solver++ step in data-prediction form in ONE launch (solvers.py:674-702 + solver_utils.py:77-86, :102-163): per sample
+//   D = c_skip x + c_out F (or the given denoised tensor, or the AFS direction)   -> m0 = clamp(D, -s, s) / s with s = max(q_0.995(|D|), 1)
+//   x' = cx xb + cm m0 + ch0 m1 + ch1 m2
+// One block per sample: |D| bit patterns go to LDS for the same radix select as dynamic_threshold_kernel, D itself is recomputed
+// from x and F (L2-resident) when it is clamped.  Replaces three launches (D pass, threshold, combination).
+__global__ void __launch_bounds__(512) dpmpp_x0_step_kernel(const ds_update_args a, float p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned sm[];
+    const int HW = a.h * a.w, per = a.c * HW;
+    unsigned* vals = sm;
+    unsigned* hist = sm + per;
+    __shared__ unsigned s_cnt;
+    __shared__ unsigned s_min;
+    const int img = blockIdx.x;
+    const Coefs k = load_coefs(a, img);
+    float cskip = 0.f, cout_ = 0.f;
+    if (a.raw) { cskip = ds_c_skip(k.sig, a.sigma_data); cout_ = ds_c_out(k.sig, a.sigma_data); }
+    const float afs_div = sqrtf(1.0f + k.t * k.t);
+    const size_t base = (size_t)img * per;
+    auto denoised = [&](int i) -> float {
+        const float x = a.xe[base + i];
+        if (a.afs) return x - k.t * (x / afs_div);                      // solvers.py:77, :680
+        const float f = a.f[base + i];
+        return a.raw ? cskip * x + cout_ * f : f;                       // networks_edm.py:495
+    };
+    for (int i = threadIdx.x; i < per; i += blockDim.x) vals[i] = __float_as_uint(fabsf(denoised(i)));
+    if (threadIdx.x == 0) { s_cnt = 0; s_min = 0xffffffffu; }
+    __syncthreads();
+    const float rank = p * (float)(per - 1);
+    const float lo_f = floorf(rank);
+    const float w = rank - lo_f;
+    const unsigned lo = (unsigned)lo_f;
+    const unsigned hi = (unsigned)ceilf(rank);
+    const unsigned v_lo = radix_select(vals, per, lo, hist);
+    unsigned v_hi = v_lo;
+    if (hi != lo) {
+        unsigned cnt = 0, mn = 0xffffffffu;
+        for (int i = threadIdx.x; i < per; i += blockDim.x) {
+            const unsigned v = vals[i];
+            if (v <= v_lo) ++cnt; else mn = min(mn, v);
+        }
+        atomicAdd(&s_cnt, cnt);
+        atomicMin(&s_min, mn);
+        __syncthreads();
+        v_hi = (s_cnt >= hi + 1) ? v_lo : s_min;
+    }
+    const float qa = __uint_as_float(v_lo), qb = __uint_as_float(v_hi);
+    float s = (w < 0.5f) ? qa + w * (qb - qa) : qb - (qb - qa) * (1.0f - w);
+    s = fmaxf(s, 1.0f);
+    for (int i = threadIdx.x; i < per; i += blockDim.x) {
+        const float m = fminf(fmaxf(denoised(i), -s), s) / s;
+        if (a.m_out) a.m_out[base + i] = m;
+        if (a.x_out) {
+            float acc = k.cx * a.xb[base + i] + k.cm * m;
+            if (a.hist[0]) acc += k.ch0 * a.hist[0][base + i];
+            if (a.hist[1]) acc += k.ch1 * a.hist[1][base + i];
+            a.x_out[base + i] = acc;
+        }
+    }
+}
+
 // CFGPrecond epilogue: D = x - sigma * F, F = Fu + g (Fc - Fu) for a doubled evaluation.  Thread = one pixel (all channels):
 // the NHWC row of F is one 16-B load when f_ld == 4.
 __global__ void __launch_bounds__(256) cfg_denoise_kernel(const float* __restrict__ x, const float* __restrict__ f, int f_ld,
@@ -354,6 +414,28 @@ extern "C" int ds_dynamic_threshold(const float* x0, float* out, int n, int per,
         attr_set = true;
     }
     hipLaunchKernelGGL(dynamic_threshold_kernel, dim3(n), dim3(512), smem, (hipStream_t)stream, x0, out, per, p);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+extern "C" int ds_dpmpp_x0_step(const ds_update_args* a, float p, void* stream) {
+    (void)hipGetLastError();
+    if (!a || !a->xe || !a->xb || (!a->afs && !a->f)) return DS_E_ARG;
+    if (!a->x_out && !a->m_out) return DS_E_ARG;
+    if (a->n <= 0 || a->c <= 0 || a->h <= 0 || a->w <= 0) return DS_E_ARG;
+    if (a->raw && !a->afs && a->f_ld != 0) return DS_E_ARG;                  // the raw network output must be channel-planar here
+    if (a->coefs && a->coef_rows != 1 && a->coef_rows != a->n) return DS_E_ARG;
+    const long long per = (long long)a->c * a->h * a->w;
+    const size_t smem = ((size_t)per + 256) * sizeof(unsigned);
+    if (per <= 1 || smem > 150 * 1024) return DS_E_SHAPE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dpmpp_x0_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           150 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(dpmpp_x0_step_kernel, dim3(a->n), dim3(512), smem, (hipStream_t)stream, *a, p);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }

@@ -142,6 +142,10 @@ def solver_update(args: UpdateArgs):
     _lib.check(_lib.load().ds_solver_update(C.byref(args), _lib.stream_ptr()), 'ds_solver_update')
 
 
+def dpmpp_x0_step(args: UpdateArgs, p=0.995):
+    _lib.check(_lib.load().ds_dpmpp_x0_step(C.byref(args), float(p), _lib.stream_ptr()), 'ds_dpmpp_x0_step')
+
+
 def table_select(table, row_floats, step, advance, dst):
     _lib.check(_lib.load().ds_table_select(_p(table), row_floats, _p(step), int(advance), _p(dst), _lib.stream_ptr()),
                'ds_table_select')

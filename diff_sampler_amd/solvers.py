@@ -46,6 +46,7 @@ class _Run:
         self.fused = bool(getattr(net, 'edm_raw_output', False))   # engine.EDMDenoiser: raw F consumed by the update kernel
         self.latents = latents.to(torch.float32).contiguous()
         self.B, self.C, self.H, self.W = self.latents.shape
+        self.per_sample = self.C * self.H * self.W
         self.cl, self.cond, self.ucond = class_labels, condition, unconditional_condition
         self.ts = host_times(t_steps)
         self.sigma_data = float(getattr(net, 'sigma_data', 0.5))
@@ -100,6 +101,16 @@ class _Run:
                                  store_d=store_d, coefs=coefs, coef_rows=(self.B if coefs is not None else 1))
         ops.solver_update(a)
 
+    def dpmpp_x0_step(self, xe, xb, t, sigma, cx, cm, x_out, m_out, hist=(), ch=(), afs=False):
+        """D -> dynamic threshold -> multistep combination of one data-prediction step in ONE launch (ds_dpmpp_x0_step)."""
+        hc = [0.0] * 8
+        hc[0], hc[1], hc[5], hc[6] = cx, cm, t, sigma
+        for i, c in enumerate(ch):
+            hc[2 + i] = c
+        a = ops.make_update_args(xe, xb, None if afs else self._f, self.B, self.C, self.H, self.W, x_out, raw=(self._raw and not afs),
+                                 f_ld=0, hist=list(hist), hcoefs=hc, afs=afs, sigma_data=self.sigma_data, m_out=m_out, store_d=False)
+        ops.dpmpp_x0_step(a)
+
     def record(self, x, d=None):
         if self.return_inters:
             self.inters.append(x.clone())
@@ -118,6 +129,9 @@ class _Run:
                 return tr, torch.stack(self.eps, dim=0).to(dev)
             return tr
         return x
+
+
+_FUSED_X0_MAX = 37000      # elements per sample the one-launch data-prediction step holds in LDS (ds_dpmpp_x0_step)
 
 
 def _schedule(t_steps, num_steps, sigma_min, sigma_max, latents, schedule_type, schedule_rho, net):
@@ -305,8 +319,8 @@ def dpm_pp_sampler(net, latents, class_labels=None, condition=None, unconditiona
                    sigma_min=0.002, sigma_max=80, schedule_type='polynomial', schedule_rho=7, afs=False,
                    denoise_to_zero=False, return_inters=False, return_eps=False, max_order=3, predict_x0=True,
                    lower_order_final=True, t_steps=None, **kwargs):
-    """Multistep DPM-Solver++ (solvers.py:613-713).  x0-prediction: D -> dynamic threshold -> fused 1/2M/3M update
-    (3 launches per step); noise-prediction: one launch per step."""
+    """Multistep DPM-Solver++ (solvers.py:613-713).  One launch per step in both modes: x0-prediction fuses D -> dynamic
+    threshold -> 1/2M/3M update per sample (ds_dpmpp_x0_step; three launches only for samples too large for one workgroup's LDS)."""
     assert max_order >= 1 and max_order <= 3
     t_steps = _schedule(t_steps, num_steps, sigma_min, sigma_max, latents, schedule_type, schedule_rho, net)
     run = _Run(net, latents, class_labels, condition, unconditional_condition, t_steps, return_inters, return_eps)
@@ -326,7 +340,15 @@ def dpm_pp_sampler(net, latents, class_labels=None, condition=None, unconditiona
         cx, cm = dpmpp_coeffs(t_hist, tn, order, predict_x0)
         xn = run.new() if return_inters else x
         d_rec = run.new() if return_eps else None
-        if predict_x0:
+        if predict_x0 and run.per_sample <= _FUSED_X0_MAX:
+            # one launch: D -> dynamic threshold -> 1/2M/3M combination (m is both the history entry and an operand)
+            m = ring.slot()
+            if return_eps:
+                run.update(xe=x, xb=x, t=t, sigma=t, cx=0.0, cm=0.0, x_out=None, m_out=d_rec, store_d=True, afs=use_afs)
+            hs = ring.newest_first()
+            run.dpmpp_x0_step(xe=x, xb=x, t=t, sigma=t, cx=cx, cm=cm[0], x_out=xn, m_out=m, hist=hs[:order - 1], ch=cm[1:], afs=use_afs)
+            ring.push()
+        elif predict_x0:
             m = ring.slot()
             run.update(xe=x, xb=x, t=t, sigma=t, cx=0.0, cm=0.0, x_out=None, m_out=m, store_d=False, afs=use_afs)     # D
             if return_eps:

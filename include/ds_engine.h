@@ -291,6 +291,14 @@ typedef struct ds_update_args {
 
 int ds_solver_update(const ds_update_args* a, void* stream);
 
+/* One DPM-Solver++ step in data-prediction form in ONE launch (solvers.py:674-702, solver_utils.py:77-86, :102-163): per sample
+ *   D  = as in ds_solver_update (EDM preconditioning of the raw planar network output, a given denoised tensor, or the AFS direction)
+ *   m0 = clamp(D, -s, s) / s,  s = max(quantile_p(|D|), 1)      (dynamic thresholding; the same radix select as ds_dynamic_threshold)
+ *   x' = hcoefs[0] * xb + hcoefs[1] * m0 + hcoefs[2] * hist[0] + hcoefs[3] * hist[1]
+ * m_out receives m0 (the solver's history entry), x_out receives x'.  Replaces the three launches D pass -> threshold -> combination.
+ * c * h * w <= ~38 000 elements per sample (LDS); f_ld must be 0 (channel-planar F). */
+int ds_dpmpp_x0_step(const ds_update_args* a, float p, void* stream);
+
 /* dst[0..row_floats) = table[(*step) * row_floats ...]; then optionally (*step)++ when advance != 0.  The only
  * per-step state of a captured sampler step: every kernel of the step reads its scalars (sigma, coefficients) from
  * `dst`, so one hipGraph replays for all steps. */
