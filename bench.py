@@ -155,6 +155,8 @@ def instrumented_pass(net, solvers, solver, latents, nfe, ldm=None):
         return w
 
     cfg = ops.cfg_denoise
+    x0s = ops.dpmpp_x0_step
+    ops.dpmpp_x0_step = timed_call('dpmpp_x0_step_kernel (D -> dynamic threshold -> multistep update, one launch)', x0s)
     engine._Plan.run = timed_plan_run
     ops.solver_update = timed_call('solver_update_kernel', upd)
     ops.dynamic_threshold = timed_call('dynamic_threshold_kernel', thr)
@@ -167,6 +169,7 @@ def instrumented_pass(net, solvers, solver, latents, nfe, ldm=None):
         ops.solver_update = upd
         ops.dynamic_threshold = thr
         ops.cfg_denoise = cfg
+        ops.dpmpp_x0_step = x0s
     return rec
 
 

@@ -114,6 +114,7 @@ _SIGNATURES = {
     'ds_traj_moments': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     'ds_traj_pair_cost': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     'ds_philox_randn': (C.c_int, [vp, C.c_ulonglong, vp, C.c_int, C.c_longlong, C.c_longlong, vp]),
+    'ds_debug_philox_probe': (C.c_int, [C.c_ulonglong, C.c_ulonglong, vp, C.c_int, C.c_int, vp]),
     'ds_philox_randint': (C.c_int, [vp, C.c_ulonglong, C.c_uint, vp, C.c_int, vp]),
     'ds_channel_mean': (C.c_int, [vp, C.c_int, C.c_int, C.c_longlong, vp, vp]),
 }

@@ -44,7 +44,57 @@ __global__ void __launch_bounds__(256) philox_randint_kernel(const unsigned long
     out[b] = (int)(v.x % range);
 }
 
+// ---- diagnostic: Box-Muller with selectable math-function variants (which build of logf / sqrtf / sincos does the installed torch
+// use?  -- tools/probe_rng.py).  variant = ((contract * 3 + sincos) * 4 + sqrt) * 4 + log.
+__device__ float bm_log(float u, int v) {
+    switch (v) {
+        case 0: return logf(u);
+        case 1: return __ocml_log_f32(u);
+        case 2: return __ocml_native_log_f32(u);
+        default: return __builtin_amdgcn_logf(u) * 0.69314718055994530942f;
+    }
+}
+__device__ float bm_sqrt(float x, int v) {
+    switch (v) {
+        case 0: return sqrtf(x);
+        case 1: return __ocml_sqrt_f32(x);
+        case 2: return __ocml_native_sqrt_f32(x);
+        default: return __builtin_amdgcn_sqrtf(x);
+    }
+}
+__global__ void __launch_bounds__(256) philox_probe_kernel(unsigned long long seed, unsigned long long offset, float* __restrict__ out, int n,
+                                                           int variant) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int vl = variant & 3, vs = (variant >> 2) & 3, vc = (variant >> 4) % 3, vf = (variant >> 4) / 3;
+    rocrand_state_philox4x32_10 st;
+    rocrand_init(seed, (unsigned long long)i, offset, &st);
+    const uint4 r = rocrand4(&st);
+    float u, v;
+    if (vf == 0) {
+        u = __builtin_fmaf((float)r.x, ROCRAND_2POW32_INV, ROCRAND_2POW32_INV);
+        v = __builtin_fmaf((float)r.y, ROCRAND_2POW32_INV_2PI, ROCRAND_2POW32_INV_2PI);
+    } else {
+        volatile float a = (float)r.x * ROCRAND_2POW32_INV, b = (float)r.y * ROCRAND_2POW32_INV_2PI;
+        u = ROCRAND_2POW32_INV + a;
+        v = ROCRAND_2POW32_INV_2PI + b;
+    }
+    const float s = bm_sqrt(-2.0f * bm_log(u, vl), vs);
+    float sn;
+    if (vc == 0) sn = __ocml_native_sin_f32(v);
+    else if (vc == 1) sn = __ocml_sin_f32(v);
+    else { float c; sincosf(v, &sn, &c); }
+    out[i] = sn * s;
+}
+
 }  // namespace
+
+extern "C" int ds_debug_philox_probe(unsigned long long seed, unsigned long long offset, float* out, int n, int variant, void* stream) {
+    if (!out || n < 1 || variant < 0 || variant >= 96) return DS_E_ARG;
+    hipLaunchKernelGGL(philox_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, offset, out, n, variant);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
 
 extern "C" int ds_philox_randn(const unsigned long long* seeds, unsigned long long offset, float* out, int batch, long long n,
                                long long threads_total, void* stream) {

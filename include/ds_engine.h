@@ -132,6 +132,10 @@ int ds_conv_f16_supported(int n, int h, int w, int c0, int c1, int ec0, int ec1)
 int ds_philox_randn(const unsigned long long* seeds, unsigned long long offset, float* out, int batch, long long n,
                     long long threads_total, void* stream);
 
+/* Diagnostic (tools/probe_rng.py): element i = first Box-Muller output of Philox (seed, subsequence i, offset) with a selectable
+ * build of log / sqrt / sin (variant in [0, 96)), to identify which one the installed torch's randn was compiled with. */
+int ds_debug_philox_probe(unsigned long long seed, unsigned long long offset, float* out, int n, int variant, void* stream);
+
 /* out[b] = `torch.randint(range, size=[], generator=g_b)` at Philox offset `offset` (sample.py:283: class labels); range < 2**32;
  * the offset then advances by 4. */
 int ds_philox_randint(const unsigned long long* seeds, unsigned long long offset, unsigned int range, int* out, int batch, void* stream);

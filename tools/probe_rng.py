@@ -31,4 +31,18 @@ rep['offset_after_3072'] = int(g.get_offset())
 g = torch.Generator(dev).manual_seed(0)
 torch.randint(1000, size=[], generator=g, device=dev)
 rep['offset_after_randint'] = int(g.get_offset())
+import ctypes as C
+from diff_sampler_amd import _lib
+lib = _lib.load()
+n = 4096
+ref = torch.randn(n, generator=torch.Generator(dev).manual_seed(0), device=dev)
+out = torch.empty(n, device=dev)
+match = {}
+for variant in range(96):
+    lib.ds_debug_philox_probe(0, 0, C.c_void_p(out.data_ptr()), n, variant, _lib.stream_ptr())
+    torch.cuda.synchronize()
+    mism = int((out != ref).sum())
+    match[variant] = mism
+rep['probe_mismatches_by_variant'] = match
+rep['probe_best'] = sorted(match.items(), key=lambda kv: kv[1])[:6]
 print(json.dumps(rep, indent=1))
