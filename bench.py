@@ -48,11 +48,13 @@ PEAK_HBM_GBS = 8000.0
 PMC_FILE = os.path.join(ROOT, 'profiles', 'r1f_bench_pmc_hbm.json')
 KERNEL_NAMES = {0: 'igemm_f32_kernel<0> (generic gather conv / 1x1 / linear)', 128: 'conv3x3_halo_kernel<2> (128-pixel tiles)',
                 256: 'conv3x3_halo_kernel<4> (256-pixel tiles)', 2561: 'gemm_dma8_kernel (256x128 tiles, LDS-DMA, 1x1 / linear)',
-                2562: 'conv3x3_halo2_kernel<fp16 operands> (256-pixel tiles, v_mfma_f32_32x32x16_f16)'}
-KERNEL_PEAK = {2562: PEAK_FP16_MFMA_TFLOPS}
+                2562: 'conv3x3_halo2_kernel<fp16 operands> (256-pixel tiles, v_mfma_f32_32x32x16_f16)',
+                2563: 'conv3x3_halo2_kernel<split fp16 hi/lo operands, fp32-emulated> (256-pixel tiles, 3 x v_mfma_f32_32x32x16_f16 per product)'}
+# roofline peaks by kernel: the split mode issues three fp16 MFMAs per algorithmic multiply-add, so its ceiling in ALGORITHMIC FLOPs is a third
+KERNEL_PEAK = {2562: PEAK_FP16_MFMA_TFLOPS, 2563: PEAK_FP16_MFMA_TFLOPS / 3}
 PMC_KEYS = {0: 'void igemm::igemm_f32_kernel<0>(igemm::KParams)', 128: 'void igemm::conv3x3_halo_kernel<2, true, 2>(igemm::KParams)',
             256: 'void igemm::conv3x3_halo_kernel<4, true, 2>(igemm::KParams)', 2561: 'igemm::gemm_dma8_kernel(igemm::KParams)',
-            2562: None}
+            2562: None, 2563: None}
 
 
 def parse(argv=None):
@@ -64,8 +66,8 @@ def parse(argv=None):
     ap.add_argument('--nfe', type=int, default=10)
     ap.add_argument('--solver', default='dpmpp', choices=['dpmpp', 'euler', 'ipndm', 'heun'])
     ap.add_argument('--config', default='cifar10')
-    ap.add_argument('--dtype', default='fp32', choices=['fp32', 'fp16'],
-                    help="fp16 = the reference's use_fp16 / autocast mode (configs 3 and 5): fp16 operands in the 3x3 convolutions, fp32 accumulation and storage")
+    ap.add_argument('--dtype', default='fp32', choices=['fp32', 'fp16', 'fp16x3'],
+                    help="fp16 = the reference's use_fp16 / autocast mode (configs 3 and 5): fp16 operands in the 3x3 convolutions, fp32 accumulation and storage; fp16x3 = fp32 EMULATED in the 3x3 convolutions by split fp16 hi/lo operands (3 MFMA products, fp32 tolerances)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay the sampler call from a captured hipGraph')
     ap.add_argument('--cpu-batch', type=int, default=8)
@@ -404,7 +406,8 @@ def main(argv=None):
             ldm = (torch.randn(B, 77, spec.context_dim, generator=g).to(dev), torch.randn(B, 77, spec.context_dim, generator=g).to(dev))
             args.solver = 'dpmpp'
         else:
-            net_factory = lambda: EDMDenoiser.from_config(args.config, seed=0, device=dev, use_fp16=(args.dtype == 'fp16'))
+            net_factory = lambda: EDMDenoiser.from_config(args.config, seed=0, device=dev, use_fp16=(args.dtype == 'fp16'),
+                                                          split_fp16=(args.dtype == 'fp16x3'))
             net = net_factory()
             spec = net.spec
         latents = torch.randn(B, spec.in_channels, spec.img_resolution, spec.img_resolution, generator=g).to(dev)
@@ -494,7 +497,8 @@ def main(argv=None):
             'metric': 'images/sec (whole node) at NFE=%d, %s' % (args.nfe, 'EDM CIFAR-10' if args.config == 'cifar10' else workload_name.split(' (')[0]),
             'value': round(total_images / dt, 2), 'unit': 'images/sec', 'n_gpus': n_comm, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'fp32' if args.dtype == 'fp32' else 'fp16 operands in the 3x3 convolutions (fp32 accumulate, fp32 storage), rest fp32',
+            'dtype': {'fp32': 'fp32', 'fp16': 'fp16 operands in the 3x3 convolutions (fp32 accumulate, fp32 storage), rest fp32',
+                      'fp16x3': 'fp16x3 (fp32-emulated: split fp16 hi/lo operands, 3 MFMA products, fp32 accumulate) in the 3x3 convolutions, rest fp32'}[args.dtype],
             'data': 'synthetic N(0,1) latents, random-init (signal-carrying) weights',
             'config': {'workload': '%s, %s NFE=%d, batch %d/GPU' %
                        (workload_name, 'DPM-Solver++(2M) eps-prediction, discrete rho=1, CFG 7.5 (2 U-Net images per latent)' if ldm is not None else

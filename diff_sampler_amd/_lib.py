@@ -27,7 +27,7 @@ class ConvArgs(C.Structure):
                 ('norm_coefs', vp), ('norm_act', C.c_int),
                 ('e0', vp), ('e1', vp), ('ec0', C.c_int), ('ec1', C.c_int), ('eld0', C.c_int), ('eld1', C.c_int),
                 ('stride', C.c_int), ('workspace', vp), ('workspace_floats', C.c_longlong),
-                ('out_nchw', C.c_int), ('stats_out', vp), ('wgt_f16', C.c_int)]
+                ('out_nchw', C.c_int), ('stats_out', vp), ('wgt_f16', C.c_int), ('wgt_shift', C.c_int)]
 
 
 class GemmArgs(C.Structure):
@@ -89,6 +89,7 @@ _SIGNATURES = {
     'ds_conv_kernel_id': (C.c_int, [C.POINTER(ConvArgs)]),
     'ds_conv3x3_halo_supported': (C.c_int, [C.c_int, C.c_int]),
     'ds_conv_f16_supported': (C.c_int, [C.c_int] * 7),
+    'ds_conv_split_supported': (C.c_int, [C.c_int] * 7),
     'ds_gemm_nt_batched': (C.c_int, [C.POINTER(GemmArgs), vp]),
     'ds_gn_stats': (C.c_int, [C.POINTER(NormArgs), vp]),
     'ds_norm_act': (C.c_int, [C.POINTER(NormArgs), vp]),

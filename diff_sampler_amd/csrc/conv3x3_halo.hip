@@ -448,9 +448,9 @@ int launch_wm(KParams& p, hipStream_t stream) {
     if (wide > 0) {
         const Geo g = geometry(p, 64 * WM, 2);
         int rc;
-        if (WM == 4 && GLDS && g_variant == 3 && p.splits == 1 && conv3x3_halo2_applicable(p, wide, false)) {
+        if (WM == 4 && GLDS && g_variant == 3 && p.splits == 1 && conv3x3_halo2_applicable(p, wide, 0)) {
             KParams q = p;
-            rc = launch_conv3x3_halo2(q, wide, false, stream);
+            rc = launch_conv3x3_halo2(q, wide, 0, stream);
         } else if constexpr (GLDS) {
             switch (g_variant) {
                 case 1: rc = launch_one<WM, GLDS, 2, 1>(p, g, 0, wide, stream); break;

@@ -73,6 +73,31 @@ __device__ __forceinline__ void frag_read2(Frag2& f, unsigned va0, unsigned va1,
     f.b1 = lds_rd<4096>(vb);
 }
 
+// Split mode ("fp32 emulated on the fp16 pipe", MODE 2): every operand is hi + lo with hi = fp16(x), lo = fp16(x - hi); a product is the
+// three MFMAs hi*hi + hi*lo + lo*hi (the dropped lo*lo term and the rounding of lo are 2**-22 relative, fp32 class).  One 128-B LDS
+// row holds a 32-channel slab as [32 hi | 32 lo] halfs, so the byte offsets 0 / 32 / 64 / 96 of the fp32 kernel's four K steps now
+// select (hi, k 0..15), (hi, k 16..31), (lo, k 0..15), (lo, k 16..31).
+struct Frag2S { f32x4 a0h, a1h, b0h, b1h, a0l, a1l, b0l, b1l; };
+template <int AOFF>
+__device__ __forceinline__ void frag_read2s(Frag2S& f, unsigned va0, unsigned va1, unsigned vbh, unsigned vbl) {
+    f.a0h = lds_rd<AOFF>(va0);
+    f.a1h = lds_rd<AOFF>(va1);
+    f.a0l = lds_rd<AOFF + 64>(va0);
+    f.a1l = lds_rd<AOFF + 64>(va1);
+    f.b0h = lds_rd<0>(vbh);
+    f.b1h = lds_rd<4096>(vbh);
+    f.b0l = lds_rd<0>(vbl);
+    f.b1l = lds_rd<4096>(vbl);
+}
+#define DS2_FRAG_WAIT_S(N, f)                                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"((f).a0h), "+v"((f).a1h), "+v"((f).b0h), "+v"((f).b1h), "+v"((f).a0l), "+v"((f).a1l), \
+                 "+v"((f).b0l), "+v"((f).b1l))
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ void lds_wr64(unsigned addr, const f32x2& v) {
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+
 template <int W>
 struct Geo2 {
     static constexpr int T = 512;
@@ -94,8 +119,9 @@ __device__ __forceinline__ float pack_h2(float a, float b) {            // two f
     return __builtin_bit_cast(float, pk);
 }
 
-template <int W, bool F16>
+template <int W, int MODE>
 __global__ void __launch_bounds__(512, 2) conv3x3_halo2_kernel(const KParams p) {
+    constexpr bool F16 = (MODE == 1), SPLIT = (MODE == 2);          // MODE 0: fp32 operands (exact fp32 MFMA)
     using G = Geo2<W>;
     constexpr int T = G::T, WP = G::WP, HP = G::HP, TH = G::TH, NIMG = G::NIMG, NP = G::NP, NS = G::NS;
     constexpr unsigned ROW = G::ROW, HALO_B = G::HALO_B, BS_B = G::BS_B;
@@ -129,7 +155,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo2_kernel(const KParams p) 
         h_pix[j] = ok ? ((img0 + sl) * p.H + y) * W + x : -1;
     }
     const bool last_slot_valid = (tid >> 3) + (NS - 1) * 64 < NP;
-    const unsigned st_base = lds0 + BS_B + (unsigned)(tid >> 3) * 144 + (unsigned)(tid & 7) * 16;   // + j * 9216 (+ HALO_B)
+    const unsigned st_base = lds0 + BS_B + (unsigned)(tid >> 3) * 144 + (unsigned)(tid & 7) * (SPLIT ? 8 : 16);   // + j * 9216 (+ HALO_B)
 
     // ---- fragment addresses -----------------------------------------------------------------------------------------------------
     unsigned abase[2];
@@ -206,19 +232,32 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo2_kernel(const KParams p) 
     // conversion of one element of slot j (GroupNorm affine + SiLU, networks_edm.py:160,167; fp16: then RNE rounding, two
     // elements per dword), then the 16-B store of the slot
     f32x4 cvt;
-    float cvt_even = 0.f;
+    float cvt_even = 0.f, cvt_even_lo = 0.f;
     auto convert_elem = [&](auto jc, auto ec, bool act) {
         constexpr int j = decltype(jc)::value, e = decltype(ec)::value;
         float v = fmaf(hreg[j][e >> 2][e & 3] - cmu[e >> 2][e & 3], cga[e >> 2][e & 3], cbe[e >> 2][e & 3]);
         if (act) v = ds_silu(v);
         v = h_pix[j] >= 0 ? v : 0.f;
-        if constexpr (!F16) cvt[e] = v;
+        if constexpr (SPLIT) {
+            const float hi = (float)(_Float16)v;
+            const float lo = v - hi;                     // exact in fp32
+            if constexpr ((e & 1) == 0) { cvt_even = hi; cvt_even_lo = lo; }
+            else { cvt[e >> 1] = pack_h2(cvt_even, hi); cvt[2 + (e >> 1)] = pack_h2(cvt_even_lo, lo); }
+        } else if constexpr (!F16) cvt[e] = v;
         else if constexpr ((e & 1) == 0) cvt_even = v;
         else cvt[e >> 1] = pack_h2(cvt_even, v);
     };
     auto store_slot = [&](auto jc, unsigned st_addr) {
         constexpr int j = decltype(jc)::value;
-        if (j < NS - 1 || last_slot_valid) lds_wr<j * 9216>(st_addr, cvt);
+        if (j < NS - 1 || last_slot_valid) {
+            if constexpr (SPLIT) {
+                const f32x2 hi = {cvt[0], cvt[1]}, lo = {cvt[2], cvt[3]};
+                lds_wr64<j * 9216>(st_addr, hi);          // channels ld_col .. ld_col+3 of the hi half-row
+                lds_wr64<j * 9216 + 64>(st_addr, lo);     // and of the lo half-row
+            } else {
+                lds_wr<j * 9216>(st_addr, cvt);
+            }
+        }
     };
     constexpr int NE = 4 * H;                         // elements (channels) per slot
     // "+v" pseudo-uses that tie the asm-loaded registers to the point where their data has landed (asm operands inside lambdas do
@@ -260,10 +299,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo2_kernel(const KParams p) 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                    // first halo and both weight tiles are in LDS (vmcnt(0) above)
 
-    Frag2 P_, Q_;
     int kt = 0;                      // global tap counter = weight K tile
     unsigned hb = 0;                 // byte offset of the CURRENT halo buffer (0 or HALO_B); the other one is being filled
     const unsigned first_off = nchunks > 0 ? 0u : ROW + 144u;
+    if constexpr (!SPLIT) {
+    Frag2 P_, Q_;
     frag_read2<0>(P_, abase[0] + first_off, abase[1] + first_off, bq[0]);
 
 #define DS2_M(i, j, r, f) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((f).a##i[r], (f).b##j[r], acc[i][j], 0, 0, 0)
@@ -409,9 +449,109 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo2_kernel(const KParams p) 
 #undef DS2_M
 #undef DS2_MH
 #undef DS2_GROUP
+    DS2_FRAG_WAIT(0, P_);                             // drain the last (discarded) fragment prefetch
 
-    // drain: the last (discarded) fragment prefetch and the unconditional raw loads of the clamped "slab after next"
-    DS2_FRAG_WAIT(0, P_);
+    } else {
+    Frag2S P_, Q_;
+    frag_read2s<0>(P_, abase[0] + first_off, abase[1] + first_off, bq[0], bq[2]);
+#define DS2_MS(i, j, x, y, f) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, (f).a##i##x), __builtin_bit_cast(h8, (f).b##j##y), acc[i][j], 0, 0, 0)
+    // 12 MFMAs of one K step of 16 channels: hi*hi, hi*lo, lo*hi for the 2 x 2 tiles (the accumulators rotate, so that consecutive
+    // MFMAs never depend on each other), a hook after each
+#define DS2_GROUP_S(f, hook)                                                                                                      \
+    DS2_MS(0, 0, h, h, f); hook(IC<0>{}); DS2_MS(0, 1, h, h, f); hook(IC<1>{}); DS2_MS(1, 0, h, h, f); hook(IC<2>{}); DS2_MS(1, 1, h, h, f); hook(IC<3>{});   \
+    DS2_MS(0, 0, h, l, f); hook(IC<4>{}); DS2_MS(0, 1, h, l, f); hook(IC<5>{}); DS2_MS(1, 0, h, l, f); hook(IC<6>{}); DS2_MS(1, 1, h, l, f); hook(IC<7>{});   \
+    DS2_MS(0, 0, l, h, f); hook(IC<8>{}); DS2_MS(0, 1, l, h, f); hook(IC<9>{}); DS2_MS(1, 0, l, h, f); hook(IC<10>{}); DS2_MS(1, 1, l, h, f); hook(IC<11>{});
+    // One tap of the split mode = two K steps of 16 channels.  Step 0 (fragments P, prefetched after the previous barrier) carries
+    // the halo-conversion hooks; then lgkmcnt(0) + vmcnt + barrier; step 1 (fragments Q) carries the weight DMA of tap kt+2, the
+    // fragment prefetch of tap kt+1 and the raw loads, exactly as the other modes' last K step does.
+    auto tap = [&](auto t9c, int chunk) {
+        Frag2S &P = P_, &Q = Q_;
+        constexpr int T9 = decltype(t9c)::value;
+        constexpr bool X = (T9 == 9);
+        constexpr int TY = X ? 1 : T9 / 3, TX = X ? 1 : T9 % 3;
+        constexpr int AOFF = TY * (int)ROW + TX * 144;
+        constexpr bool SLAB_END = X || T9 == 8;
+        constexpr bool LOADS = X || T9 == 7;
+        constexpr int SE = NE + 1, NPOS = 12;
+        constexpr int NSTEP = (X ? NS : 1) * SE;
+        constexpr int SPP = (NSTEP + NPOS - 1) / NPOS;
+        const unsigned va0 = abase[0] + hb, va1 = abase[1] + hb;
+        const unsigned cb = (unsigned)(kt & 1) * 16384u;
+        const unsigned st_addr = st_base + (hb ^ HALO_B);
+        const bool conv_act = silu && p.norm != nullptr && (chunk + 1) < nchunks;
+        auto conv_step = [&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            constexpr int j = X ? h / SE : T9 - 1, s = X ? h % SE : h;
+            if constexpr (h >= 0 && h < NSTEP && j >= 0 && j < NS) {
+                if constexpr (h == 0 || (!X && s == 0 && j == 0)) {
+                    if constexpr (X) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    touch_coefs();
+                }
+                if constexpr (s == 0) touch_slot(IC<j>{});
+                if constexpr (s < NE) convert_elem(IC<j>{}, IC<s>{}, conv_act);
+                else store_slot(IC<j>{}, st_addr);
+            }
+        };
+        auto hookA = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            constexpr int first = X ? NSTEP - (NPOS - q) * SPP : q * SPP;
+            if constexpr (first + SPP > 0 && first < NSTEP) {
+                DS2_FENCE();
+                static_for<SPP>([&](auto ic) { conv_step(IC<first + decltype(ic)::value>{}); });
+                DS2_FENCE();
+            }
+        };
+        DS2_FRAG_WAIT_S(0, P);
+        frag_read2s<AOFF + 32>(Q, va0, va1, bq[1] + cb, bq[3] + cb);
+        DS2_GROUP_S(P, hookA)
+        DS2_FENCE();
+        DS2_FRAG_WAIT_S(0, Q);
+        if constexpr (!X && T9 == 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if constexpr (SLAB_END) hb ^= HALO_B;
+        const bool next_is_x = SLAB_END ? (chunk + 1 >= nchunks) : false;
+        auto hookD = [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (k == 0) {
+                DS2_FENCE();
+                if (kt + 2 < KT) b_dma(kt + 2, kt & 1);
+                DS2_FENCE();
+            } else if constexpr (k == 1) {
+                DS2_FENCE();
+                const unsigned nb = (unsigned)((kt + 1) & 1) * 16384u;
+                if constexpr (SLAB_END) {
+                    const unsigned off = next_is_x ? ROW + 144u : 0u;
+                    frag_read2s<0>(P, abase[0] + hb + off, abase[1] + hb + off, bq[0] + nb, bq[2] + nb);
+                } else {
+                    constexpr int NY = (T9 + 1) / 3, NX = (T9 + 1) % 3;
+                    frag_read2s<NY * (int)ROW + NX * 144>(P, va0, va1, bq[0] + nb, bq[2] + nb);
+                }
+                DS2_FENCE();
+            } else if constexpr (LOADS && k >= 2 && k < 2 + NS + 1) {
+                DS2_FENCE();
+                if constexpr (k == 2) load_coefs(chunk + 2);
+                else load_slot(IC<k - 3>{});
+                DS2_FENCE();
+            }
+        };
+        DS2_GROUP_S(Q, hookD)
+        DS2_FENCE();
+        ++kt;
+    };
+    int chunk = 0;
+    for (; chunk < nchunks; ++chunk) {
+        tap(IC<0>{}, chunk); tap(IC<1>{}, chunk); tap(IC<2>{}, chunk);
+        tap(IC<3>{}, chunk); tap(IC<4>{}, chunk); tap(IC<5>{}, chunk);
+        tap(IC<6>{}, chunk); tap(IC<7>{}, chunk); tap(IC<8>{}, chunk);
+    }
+    for (; chunk < NCH; ++chunk) tap(IC<9>{}, chunk);
+#undef DS2_MS
+#undef DS2_GROUP_S
+    DS2_FRAG_WAIT_S(0, P_);                           // drain the last (discarded) fragment prefetch
+    }
+
+    // drain the unconditional raw loads of the clamped "slab after next"
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     touch_coefs();
     static_for<NS>([&](auto jc) { touch_slot(jc); });
@@ -419,7 +559,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo2_kernel(const KParams p) 
     epilogue<0, true>(p, acc, smem + wave * 32 * EPI_LD, lane, m0 + wr * 64, n0 + wc * 64, p.out);
 }
 
-template <int W, bool F16>
+template <int W, int MODE>
 int launch_halo2_w(KParams p, int wide, hipStream_t stream) {
     using G = Geo2<W>;
     p.TH = G::TH; p.nimg = G::NIMG; p.HP = G::HP; p.WP = G::WP; p.NP = G::NP;
@@ -432,11 +572,11 @@ int launch_halo2_w(KParams p, int wide, hipStream_t stream) {
     if (smem < epi) smem = epi;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo2_kernel<W, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo2_kernel<W, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_halo2_kernel<W, F16>), dim3(grid_1d(p.mtiles, p.ntiles), 1), dim3(512), smem, stream, p);
+    hipLaunchKernelGGL((conv3x3_halo2_kernel<W, MODE>), dim3(grid_1d(p.mtiles, p.ntiles), 1), dim3(512), smem, stream, p);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }
@@ -446,8 +586,8 @@ int launch_halo2_w(KParams p, int wide, hipStream_t stream) {
 // Layers this kernel takes: see the header comment.  `wide` = number of 128-column tiles the caller wants from it (fp32: the full
 // tiles, a ragged 64-column tail goes to the first-generation kernel; fp16: ALL tiles, a ragged last tile multiplies the zero rows the
 // weight packing pads to 128 and its epilogue guards the columns).  `f16`: the weights at p.b are fp16 in the 64-channel K order.
-bool conv3x3_halo2_applicable(const KParams& p, int wide, bool f16) {
-    const int bkc = f16 ? 64 : 32;
+bool conv3x3_halo2_applicable(const KParams& p, int wide, int mode) {
+    const int bkc = mode == 1 ? 64 : 32;
     if (p.taps != 9 || wide < 1) return false;
     if (!(p.W == 8 || p.W == 16 || p.W == 32 || p.W == 64)) return false;
     if (p.HW != p.H * p.W || p.M % 256) return false;
@@ -461,22 +601,22 @@ bool conv3x3_halo2_applicable(const KParams& p, int wide, bool f16) {
 
 long long g_halo2_launches = 0;     // how many launches went to this kernel (tests assert the routing)
 
-int launch_conv3x3_halo2(KParams& p, int wide, bool f16, hipStream_t stream) {
-    ++g_halo2_launches;
-    if (f16) {
-        switch (p.W) {
-            case 8: return launch_halo2_w<8, true>(p, wide, stream);
-            case 16: return launch_halo2_w<16, true>(p, wide, stream);
-            case 32: return launch_halo2_w<32, true>(p, wide, stream);
-            default: return launch_halo2_w<64, true>(p, wide, stream);
-        }
-    }
+template <int MODE>
+static int launch_mode(KParams& p, int wide, hipStream_t stream) {
     switch (p.W) {
-        case 8: return launch_halo2_w<8, false>(p, wide, stream);
-        case 16: return launch_halo2_w<16, false>(p, wide, stream);
-        case 32: return launch_halo2_w<32, false>(p, wide, stream);
-        default: return launch_halo2_w<64, false>(p, wide, stream);
+        case 8: return launch_halo2_w<8, MODE>(p, wide, stream);
+        case 16: return launch_halo2_w<16, MODE>(p, wide, stream);
+        case 32: return launch_halo2_w<32, MODE>(p, wide, stream);
+        default: return launch_halo2_w<64, MODE>(p, wide, stream);
     }
+}
+
+// mode: 0 = fp32 operands, 1 = fp16 operands (64-channel slabs), 2 = split fp16 hi/lo operands (fp32-emulated, 32-channel slabs)
+int launch_conv3x3_halo2(KParams& p, int wide, int mode, hipStream_t stream) {
+    ++g_halo2_launches;
+    if (mode == 1) return launch_mode<1>(p, wide, stream);
+    if (mode == 2) return launch_mode<2>(p, wide, stream);
+    return launch_mode<0>(p, wide, stream);
 }
 
 }  // namespace igemm

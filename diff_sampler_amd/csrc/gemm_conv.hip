@@ -332,7 +332,7 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     p.colbias = a->bias; p.rowbias = nullptr;
     p.cbias = a->cbias; p.cbias_ld = a->cbias_ld; p.cbias_bcast = (a->cbias_rows == 1);
     p.res = a->res; p.res_ld = a->res_ld;
-    p.scale = a->out_scale; p.act = a->act; p.heads = 1;
+    p.scale = a->out_scale; p.act = a->act; p.heads = 1; p.acc_scale = 1.0f;
     p.vec_ok = vec_epilogue_ok(p) ? 1 : 0;
     p.stats = nullptr;
     if (a->stats_out) {
@@ -353,14 +353,17 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
         p.part = a->workspace; p.part_cap = a->workspace_floats; p.vec_part = (p.N & 3) ? 0 : 1;
     }
     if (a->wgt_f16) {
-        // fp16 operands: second-generation halo kernel only (every 128-column tile, the ragged last one included)
-        if (a->taps != 9 || stride != 1) return DS_E_ARG;
-        if ((p.K & 1) || p.part) { /* K is a multiple of 64; split-K scratch is ignored */ }
+        // fp16 operands (1) or split fp16 hi/lo operands (2): second-generation halo kernel only, every 128-column tile (the ragged
+        // last one included)
+        if (a->taps != 9 || stride != 1 || (a->wgt_f16 != 1 && a->wgt_f16 != 2)) return DS_E_ARG;
+        if (a->wgt_shift < 0 || a->wgt_shift > 24 || (a->wgt_f16 == 1 && a->wgt_shift)) return DS_E_ARG;
         const int wide = (p.N + BN - 1) / BN;
-        p.ldb = p.K / 2;                         // row pitch of the fp16 weight matrix in float units
+        // row pitch of the fp16 weight matrix in float units: fp16 = K halfs per row, split = 2 K halfs (hi and lo)
+        p.ldb = a->wgt_f16 == 1 ? p.K / 2 : p.K;
+        p.acc_scale = 1.0f / (float)(1 << a->wgt_shift);
         p.part = nullptr; p.part_cap = 0; p.splits = 1;
-        if (!conv3x3_halo2_applicable(p, wide, true)) return DS_E_SHAPE;
-        return launch_conv3x3_halo2(p, wide, true, (hipStream_t)stream);
+        if (!conv3x3_halo2_applicable(p, wide, a->wgt_f16)) return DS_E_SHAPE;
+        return launch_conv3x3_halo2(p, wide, a->wgt_f16, (hipStream_t)stream);
     }
     if (!g_force_generic && stride == 1 && conv3x3_halo_supported(p)) return launch_conv3x3_halo(p, (hipStream_t)stream);
     if (p.norm) return DS_E_SHAPE;           // fused input normalisation exists only in the halo kernel
@@ -375,19 +378,21 @@ extern "C" int ds_conv_kernel_id(const ds_conv_args* a) {
     p.c0 = a->c0; p.c1 = a->c1; p.ec0 = a->ec0; p.ec1 = a->ec1;
     if (a->workspace && a->workspace_floats > 0) { p.part = a->workspace; p.part_cap = a->workspace_floats; }
     p.stride = a->stride ? a->stride : 1; p.K = a->taps * (a->c0 + a->c1) + a->ec0 + a->ec1; p.norm = a->norm_coefs;
-    if (a->wgt_f16) return 2562;
+    if (a->wgt_f16) return a->wgt_f16 == 2 ? 2563 : 2562;
     if (g_force_generic) return 0;
     if (a->taps != 9 || a->stride > 1) return (g_use_dma8 && gemm_dma8_applicable(p)) ? 2561 : 0;
     return conv3x3_halo_choice(p);
 }
 
-extern "C" int ds_conv_f16_supported(int n, int h, int w, int c0, int c1, int ec0, int ec1) {
+static int reduced_supported(int mode, int n, int h, int w, int c0, int c1, int ec0, int ec1) {
     KParams p{};
     p.taps = 9; p.H = h; p.W = w; p.HW = h * w; p.M = n * h * w; p.N = 128; p.c0 = c0; p.c1 = c1; p.ec0 = ec0; p.ec1 = ec1;
     p.nrows_b = 128;
-    if (!conv3x3_halo2_applicable(p, 1, true)) return 0;
+    if (!conv3x3_halo2_applicable(p, 1, mode)) return 0;
     return w >= 16 ? 2 : 1;                      // 8x8: four images per tile, the per-image normalisation planes are not fused
 }
+extern "C" int ds_conv_f16_supported(int n, int h, int w, int c0, int c1, int ec0, int ec1) { return reduced_supported(1, n, h, w, c0, c1, ec0, ec1); }
+extern "C" int ds_conv_split_supported(int n, int h, int w, int c0, int c1, int ec0, int ec1) { return reduced_supported(2, n, h, w, c0, c1, ec0, ec1); }
 
 extern "C" int ds_conv3x3_halo_supported(int h, int w) {
     KParams p{};
@@ -410,7 +415,7 @@ extern "C" int ds_gemm_nt_batched(const ds_gemm_args* a, void* stream) {
     p.M = a->m; p.N = a->n; p.K = a->k; p.HW = 1; p.H = p.W = 1; p.taps = 1; p.c0 = a->k; p.c1 = 0;
     p.stride = 1; p.IH = p.IW = 1;
     p.colbias = a->colbias; p.rowbias = a->rowbias; p.cbias = nullptr; p.res = nullptr;
-    p.scale = a->alpha; p.act = a->act; p.heads = a->heads;
+    p.scale = a->alpha; p.act = a->act; p.heads = a->heads; p.acc_scale = 1.0f;
     p.vec_ok = vec_epilogue_ok(p) ? 1 : 0; p.out_planar = 0; p.stats = nullptr;
     p.splits = 1; p.part = nullptr; p.part_cap = 0; p.vec_part = 0;
     return launch<1>(p, a->batch * a->heads, (hipStream_t)stream);

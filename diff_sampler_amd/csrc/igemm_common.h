@@ -33,6 +33,7 @@ struct KParams {
     const float* cbias; int cbias_ld; int cbias_bcast;
     const float* res; int res_ld;
     float scale; int act; int heads;
+    float acc_scale;                                               // conv epilogue: accumulators are multiplied by this first (1; 2**-shift for pre-scaled split-fp16 weights)
     int vec_ok;                                                    // float4 epilogue allowed (alignment, ld % 4)
     int out_planar;                                                // scalar epilogue writes out[(img * N + col) * HW + pixel]
     // optional per-(64-row block, column) sums of the OUTPUT for the consumer's GroupNorm: stats[(rb * 2 + {0: sum, 1: sum of
@@ -82,6 +83,7 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
                 const int row = wm0 + (HALF ? half * 32 : 0) + rr;
                 if (row >= p.M) continue;
                 f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * EPI_LD + c4);
+                if (MODE == 0) v *= p.acc_scale;
                 if (MODE == 1) v *= p.scale;
                 v += cb;
                 if (p.rowbias) v += p.rowbias[row];
@@ -136,6 +138,7 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
                 const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row >= p.M) continue;
                 float v = acc[i][j][r];
+                if (MODE == 0) v *= p.acc_scale;
                 if (MODE == 1) v *= p.scale;
                 v += cb;
                 if (p.rowbias) v += p.rowbias[row];
@@ -248,8 +251,8 @@ void conv3x3_halo_set_variant(int v);     // kernel variant of the 128-column LD
 void conv3x3_halo_set_tail64(int on);     // 64-column tiles for the ragged last column tile (default on)
 
 // conv3x3_halo2.hip: second-generation 256 x 128 tile (static tap schedule, double halo buffer)
-bool conv3x3_halo2_applicable(const KParams& p, int wide, bool f16);
-int launch_conv3x3_halo2(KParams& p, int wide, bool f16, hipStream_t stream);
+bool conv3x3_halo2_applicable(const KParams& p, int wide, int mode);   // mode 0 fp32 / 1 fp16 / 2 split-fp16
+int launch_conv3x3_halo2(KParams& p, int wide, int mode, hipStream_t stream);
 extern long long g_halo2_launches;
 
 }  // namespace igemm

@@ -8,8 +8,9 @@
 //     element li = idx + threads_total * q  is component (q % 4) of that thread's (q / 4)-th rocrand_normal4 call
 //     (for n <= threads_total -- every latent of the scope -- that is: element i = rocrand_normal4(seed, subsequence i, offset).x)
 //     and the generator's offset then advances by ((n - 1) / (threads_total * 4) + 1) * 4.
-// This kernel produces the same bits for a whole batch of seeds in ONE launch by evaluating exactly that map with the same
-// rocRAND device functions (header-only: rocrand_philox4x32_10.h, rocrand_normal.h).  randint(label_dim, size=[]) of the same
+// This kernel produces the same bits for a whole batch of seeds in ONE launch by evaluating exactly that map with rocRAND's
+// Philox4x32-10 device functions (header-only: rocrand_philox4x32_10.h) and a Box-Muller pinned to the math functions of the installed
+// torch build (box_muller_torch below).  randint(label_dim, size=[]) of the same
 // generators (sample.py:283) is the first 32-bit output of the block at (seed, subsequence 0, offset) modulo the range
 // (ATen random_from_to, ranges below 2**32).
 #include <rocrand/rocrand_kernel.h>
@@ -17,6 +18,27 @@
 #include "ds_common.h"
 
 namespace {
+
+// Box-Muller exactly as the INSTALLED torch (2.10 + ROCm 7.0 build) evaluates rocRAND's rocrand_normal4: same formula as
+// rocrand_normal.h:53-68, but with the math functions that build resolved them to.  tools/probe_rng.py ran all 96 combinations of
+// {logf builtin, OCML log, native log, log2-based} x {4 sqrt} x {3 sin/cos} x {fma-contracted, separate mul+add} against torch.randn
+// on the GPU: the OCML library logarithm (__ocml_log_f32), the correctly rounded sqrtf, the native sin/cos and the contracted form
+// reproduce it with 0 mismatches of 4096 (profiles/r2_rng_probe.json); this toolchain's own `logf` (an LLVM builtin expansion since
+// ROCm 7.2) is 1-2 ulp off in ~40 % of the values.
+__device__ __forceinline__ float2 box_muller_torch(unsigned int x, unsigned int y) {
+    const float u = __builtin_fmaf((float)x, ROCRAND_2POW32_INV, ROCRAND_2POW32_INV);
+    const float v = __builtin_fmaf((float)y, ROCRAND_2POW32_INV_2PI, ROCRAND_2POW32_INV_2PI);
+    const float s = sqrtf(-2.0f * __ocml_log_f32(u));
+    float2 r;
+    r.x = __ocml_native_sin_f32(v) * s;
+    r.y = __ocml_native_cos_f32(v) * s;
+    return r;
+}
+__device__ __forceinline__ float4 normal4_torch(rocrand_state_philox4x32_10* st) {
+    const uint4 r = rocrand4(st);
+    const float2 a = box_muller_torch(r.x, r.y), b = box_muller_torch(r.z, r.w);
+    return float4{a.x, a.y, b.x, b.y};
+}
 
 __global__ void __launch_bounds__(256) philox_randn_kernel(const unsigned long long* __restrict__ seeds, unsigned long long offset,
                                                            float* __restrict__ out, int batch, long long n, long long threads_total) {
@@ -28,7 +50,7 @@ __global__ void __launch_bounds__(256) philox_randn_kernel(const unsigned long l
         const long long idx = li - q * threads_total;
         rocrand_state_philox4x32_10 st;
         rocrand_init(seeds[b], (unsigned long long)idx, offset + 4ull * (unsigned long long)(q >> 2), &st);
-        const float4 v = rocrand_normal4(&st);
+        const float4 v = normal4_torch(&st);
         const int c = (int)(q & 3);
         out[g] = c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w));
     }

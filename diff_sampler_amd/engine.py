@@ -33,14 +33,20 @@ from .plan import Op as _Op, Plan as _Plan, ptr as _ptr, SPLITK_WORKSPACE_FLOATS
 
 
 class UNetEngine:
-    def __init__(self, spec: arch.UNetSpec, params: Dict[str, torch.Tensor], device='cuda', use_fp16=False):
-        """use_fp16: the reference's reduced-precision mode (networks_edm.py:486).  Stage 1 of it here: every 3x3 convolution the
+    def __init__(self, spec: arch.UNetSpec, params: Dict[str, torch.Tensor], device='cuda', use_fp16=False, split_fp16=False):
+        """split_fp16: fp32 EMULATED on the fp16 matrix pipe in the 3x3 convolutions -- every operand as fp16 hi + lo, three MFMA
+        products per multiplication, fp32 accumulation (ds_conv_args.wgt_f16 == 2); 2**-22 relative per product, i.e. inside every
+        fp32 tolerance of this engine, at 16/3 of the fp32 matrix rate.  Not a reduced-precision mode: it is tested against the same
+        fp32 goldens and tolerances as the exact fp32 path.
+        use_fp16: the reference's reduced-precision mode (networks_edm.py:486).  Stage 1 of it here: every 3x3 convolution the
         fp16-operand kernel supports (ds_conv_f16_supported: 8x8 ... 64x64 images, 64-channel multiples) multiplies fp16-rounded
         activations and weights on the fp16 matrix pipe with fp32 accumulation; activations in HBM, GroupNorm, SiLU, softmax, the
         1x1 / Linear layers and the embedding path stay fp32 (the reference additionally rounds every activation tensor to fp16)."""
         self.spec = spec
         self.device = torch.device(device)
         self.use_fp16 = bool(use_fp16)
+        self.split_fp16 = bool(split_fp16) and not self.use_fp16
+        self.conv_mode = 1 if self.use_fp16 else (2 if self.split_fp16 else 0)      # ds_conv_args.wgt_f16 of the eligible 3x3 layers
         self.lib = _lib.load()
         self._plans: Dict[tuple, _Plan] = {}
         self._pack(params)
@@ -88,10 +94,14 @@ class UNetEngine:
                 w[f'{b.name}.{leaf}.g'] = g(f'{p}.{leaf}.weight'); w[f'{b.name}.{leaf}.b'] = g(f'{p}.{leaf}.bias')
             w[f'{b.name}.conv0.w'] = pack_conv_weight(g(f'{p}.conv0.weight')); w[f'{b.name}.conv0.b'] = g(f'{p}.conv0.bias')
             w[f'{b.name}.conv1.w'] = pack_conv_weight(g(f'{p}.conv1.weight')); w[f'{b.name}.conv1.b'] = g(f'{p}.conv1.bias')
-            if self.use_fp16 and b.cin % 64 == 0 and b.cout % 64 == 0:
+            if self.conv_mode == 1 and b.cin % 64 == 0 and b.cout % 64 == 0:
                 from .ops import pack_conv_weight_f16
-                w[f'{b.name}.conv0.w16'] = pack_conv_weight_f16(g(f'{p}.conv0.weight'))
-                w[f'{b.name}.conv1.w16'] = pack_conv_weight_f16(g(f'{p}.conv1.weight'), g(f'{p}.skip.weight') if b.skip_conv else None)
+                w[f'{b.name}.conv0.w16'] = (pack_conv_weight_f16(g(f'{p}.conv0.weight')), 0)
+                w[f'{b.name}.conv1.w16'] = (pack_conv_weight_f16(g(f'{p}.conv1.weight'), g(f'{p}.skip.weight') if b.skip_conv else None), 0)
+            elif self.conv_mode == 2:
+                from .ops import pack_conv_weight_split
+                w[f'{b.name}.conv0.w16'] = pack_conv_weight_split(g(f'{p}.conv0.weight'))
+                w[f'{b.name}.conv1.w16'] = pack_conv_weight_split(g(f'{p}.conv1.weight'), g(f'{p}.skip.weight') if b.skip_conv else None)
             if b.skip_conv:
                 # skip projection fused into conv1: [3x3 columns | 1x1 columns] along K, biases summed
                 w[f'{b.name}.conv1s.w'] = torch.cat([w[f'{b.name}.conv1.w'], pack_conv_weight(g(f'{p}.skip.weight'))], dim=1).contiguous()
@@ -110,6 +120,9 @@ class UNetEngine:
                 w[f'{b.name}.proj.w'] = pack_conv_weight(g(f'{p}.proj.weight')); w[f'{b.name}.proj.b'] = g(f'{p}.proj.bias')
         w['out.g'] = g(f'{m}.{spec.out_norm}.weight'); w['out.b'] = g(f'{m}.{spec.out_norm}.bias')
         w['outc.w'] = pack_conv_weight(g(f'{m}.{spec.out_conv}.weight')); w['outc.b'] = g(f'{m}.{spec.out_conv}.bias')
+        if self.conv_mode == 2:
+            from .ops import pack_conv_weight_split
+            w['outc.w16'] = pack_conv_weight_split(g(f'{m}.{spec.out_conv}.weight'))
         self.w = w
 
     # ------------------------------------------------------------------------------------------ plan
@@ -176,22 +189,24 @@ class UNetEngine:
 
         def f16_level(n, h, wd, c0, c1, ec0, ec1):
             """0 = this 3x3 layer stays fp32, 1 = fp16 operands on raw input, 2 = ... and with the fused input normalisation."""
-            if not self.use_fp16 or any(c % 64 for c in (c0, c1, ec0, ec1)):
+            if self.conv_mode == 0 or any(c % (64 if self.conv_mode == 1 else 32) for c in (c0, c1, ec0, ec1)):
                 return 0
-            return int(lib.ds_conv_f16_supported(n, h, wd, c0, c1, ec0, ec1))
+            fn = lib.ds_conv_f16_supported if self.conv_mode == 1 else lib.ds_conv_split_supported
+            return int(fn(n, h, wd, c0, c1, ec0, ec1))
 
         def conv(x0, c0, ld0, n, h, wd, wgt, cout, out, out_ld, taps, name, x1=None, c1=0, ld1=0, bias=None, cbias=None,
                  cbias_ld=0, cbias_rows=1, res=None, res_ld=0, scale=1.0, act_=DS_ACT_NONE, norm_coefs=None, norm_act=DS_ACT_NONE,
                  e0=None, ec0=0, e1=None, ec1=0, out_nchw=0, stats=False, w16=None):
             f16 = w16 is not None and f16_level(n, h, wd, c0, c1, ec0, ec1) >= (2 if norm_coefs is not None else 1)
+            shift = 0
             if f16:
-                wgt = w16
+                wgt, shift = w16
             a = ConvArgs(_ptr(x0), _ptr(x1), c0, c1, ld0, ld1, n, h, wd, taps, _ptr(wgt), cout, _ptr(bias), _ptr(cbias),
                          cbias_ld, cbias_rows, _ptr(res), res_ld, scale, act_, _ptr(out), out_ld, _ptr(norm_coefs), norm_act,
                          _ptr(e0), _ptr(e1), ec0, ec1, ec0, ec1)
             a.workspace, a.workspace_floats = _ptr(splitk_ws), splitk_ws.numel()
             a.out_nchw = out_nchw
-            a.wgt_f16 = 1 if f16 else 0
+            a.wgt_f16, a.wgt_shift = (self.conv_mode, shift) if f16 else (0, 0)
             stats_of.pop(out.data_ptr(), None)
             if stats and cout % 64 == 0 and out_ld == cout:
                 # the epilogue leaves the output's per-(64-row block, channel) sums for the consumer's GroupNorm
@@ -364,7 +379,7 @@ class UNetEngine:
             norm('stats', xo, co, co, B, R, R, 'out.norm.stats', groups=arch.num_groups(co), eps=spec.out_eps, gamma=w['out.g'],
                  beta=w['out.b'], coefs=ncoef)
             conv(xo, co, co, B, R, R, w['outc.w'], spec.out_channels, bufs['out'], 4, 9, 'out.conv', bias=w['outc.b'],
-                 norm_coefs=ncoef, norm_act=DS_ACT_SILU, out_nchw=1)
+                 norm_coefs=ncoef, norm_act=DS_ACT_SILU, out_nchw=1, w16=w.get('outc.w16'))
         else:
             norm('stats', xo, co, co, B, R, R, 'out.norm.stats', groups=arch.num_groups(co), eps=spec.out_eps)
             norm('apply', xo, co, co, B, R, R, 'out.norm', groups=arch.num_groups(co), eps=spec.out_eps, gamma=w['out.g'],
@@ -386,9 +401,9 @@ class EDMDenoiser:
     """
     edm_raw_output = True      # solvers._Run: ds_solver_update applies the EDM preconditioning to the raw output itself
 
-    def __init__(self, spec: arch.UNetSpec, params: Dict[str, torch.Tensor], device='cuda', use_fp16=False):
+    def __init__(self, spec: arch.UNetSpec, params: Dict[str, torch.Tensor], device='cuda', use_fp16=False, split_fp16=False):
         self.spec = spec
-        self.engine = UNetEngine(spec, params, device, use_fp16=use_fp16)
+        self.engine = UNetEngine(spec, params, device, use_fp16=use_fp16, split_fp16=split_fp16)
         self.device = self.engine.device
         self.img_resolution = spec.img_resolution
         self.img_channels = spec.in_channels
@@ -400,10 +415,10 @@ class EDMDenoiser:
         self.bottleneck_name = None      # set by the AMED path: 'enc.8x8_block3' / 'enc.8x8_block2'
 
     @classmethod
-    def from_config(cls, name_or_kwargs, seed=0, mode='signal', device='cuda', use_fp16=False):
+    def from_config(cls, name_or_kwargs, seed=0, mode='signal', device='cuda', use_fp16=False, split_fp16=False):
         kw = arch.NAMED_CONFIGS[name_or_kwargs] if isinstance(name_or_kwargs, str) else name_or_kwargs
         spec = arch.edm_precond_spec(**kw)
-        return cls(spec, arch.init_params(spec, seed=seed, mode=mode), device, use_fp16=use_fp16)
+        return cls(spec, arch.init_params(spec, seed=seed, mode=mode), device, use_fp16=use_fp16, split_fp16=split_fp16)
 
     @classmethod
     def from_reference_module(cls, net, device='cuda', use_fp16=None):

@@ -76,9 +76,9 @@ class LDMUNetEngine:
                     w[f'{p}.c1.w'], w[f'{p}.c1.b'] = c1, b1
                     if self.use_fp16 and l.cin % 64 == 0 and l.cout % 64 == 0:
                         from .ops import pack_conv_weight_f16
-                        w[f'{p}.c0.w16'] = pack_conv_weight_f16(g(f'{p}.in_layers.2.weight'))
-                        w[f'{p}.c1.w16'] = pack_conv_weight_f16(g(f'{p}.out_layers.3.weight'),
-                                                                g(f'{p}.skip_connection.weight') if l.skip_conv else None)
+                        w[f'{p}.c0.w16'] = (pack_conv_weight_f16(g(f'{p}.in_layers.2.weight')), 0)
+                        w[f'{p}.c1.w16'] = (pack_conv_weight_f16(g(f'{p}.out_layers.3.weight'),
+                                                                 g(f'{p}.skip_connection.weight') if l.skip_conv else None), 0)
                 elif l.kind == 'st':
                     t = f'{p}.transformer_blocks.0'
                     w[f'{p}.n.g'], w[f'{p}.n.b'] = g(f'{p}.norm.weight'), g(f'{p}.norm.bias')
@@ -107,7 +107,7 @@ class LDMUNetEngine:
                     w[f'{p}.w'], w[f'{p}.b'] = pack_conv_weight(g(f'{p}.conv.weight')), g(f'{p}.conv.bias')
                     if self.use_fp16 and l.cin % 64 == 0:
                         from .ops import pack_conv_weight_f16
-                        w[f'{p}.w16'] = pack_conv_weight_f16(g(f'{p}.conv.weight'))
+                        w[f'{p}.w16'] = (pack_conv_weight_f16(g(f'{p}.conv.weight')), 0)
         w['out.g'], w['out.b'] = g('out.0.weight'), g('out.0.bias')
         w['outc.w'], w['outc.b'] = pack_conv_weight(g('out.2.weight')), g('out.2.bias')
         self.w = w
@@ -119,7 +119,7 @@ class LDMUNetEngine:
         if key in self._plans:
             return self._plans[key]
         spec, w, lib = self.spec, self.w, self.lib
-        bd = Builder(self.device)
+        bd = Builder(self.device, conv_mode=(1 if self.use_fp16 else 0))
         P, new = bd.P, bd.new
         bufs = P.bufs
         R, Cin, MC, E = spec.img_resolution, spec.in_channels, spec.model_channels, spec.time_embed_dim

@@ -58,6 +58,39 @@ def pack_conv_weight_f16(w: torch.Tensor, extra: Optional[torch.Tensor] = None, 
     return out.contiguous().view(torch.float32)
 
 
+def pack_conv_weight_split(w: torch.Tensor, extra: Optional[torch.Tensor] = None, row_pad: int = 128):
+    """Split-fp16 weights of the fp32-emulated 3x3 convolution (ds_conv_args.wgt_f16 == 2) -> (packed tensor, shift).
+
+    The weights are multiplied by 2**shift (exact; chosen so that the largest magnitude lands in [2**13, 2**14): hi and lo then
+    sit in fp16's normal range for every weight down to 2**-14 of the largest), split as hi = fp16(w'), lo = fp16(w' - hi), and
+    laid out per 32-channel slab and tap as 32 hi halfs followed by 32 lo halfs: K = (slab*9 + tap)*64 + {cc | 32 + cc}; the 1x1
+    extra columns follow in 32-channel blocks of the same [hi | lo] form.  Float32-typed view of the bytes (the ABI carries float*)."""
+    cout, cin, kh, kw = w.shape
+    assert kh == 3 and kw == 3 and cin % 32 == 0
+    wmax = float(w.abs().max())
+    if extra is not None:
+        wmax = max(wmax, float(extra.abs().max()))
+    import math
+    shift = 0 if wmax == 0 else max(0, min(24, 13 - math.floor(math.log2(wmax))))
+    sc = float(1 << shift)
+
+    def split(m):                      # [cout, nblk, 32] -> [cout, nblk, 64] halfs
+        m = m * sc
+        hi = m.to(torch.float16)
+        lo = (m - hi.to(torch.float32)).to(torch.float16)
+        return torch.cat([hi, lo], dim=-1)
+    m = w.permute(0, 2, 3, 1).reshape(cout, 9, cin // 32, 32).permute(0, 2, 1, 3).reshape(cout, 9 * (cin // 32), 32)
+    parts = [split(m).reshape(cout, -1)]
+    if extra is not None:
+        assert extra.shape[0] == cout and extra.shape[1] % 32 == 0
+        parts.append(split(extra.reshape(cout, -1, 32)).reshape(cout, -1))
+    m = torch.cat(parts, dim=1)
+    rows = -(-cout // row_pad) * row_pad
+    out = torch.zeros(rows, m.shape[1], dtype=torch.float16, device=w.device)
+    out[:cout] = m
+    return out.contiguous().view(torch.float32), shift
+
+
 def pack_stem_weight(w: torch.Tensor, row_pad: int = 128, k_pad: int = 32) -> torch.Tensor:
     """Stem conv [Cout, C, 3, 3] for the im2col'd input of ds_stem_im2col: K = tap*C + c, zero-padded to 32."""
     cout, cin, kh, kw = w.shape

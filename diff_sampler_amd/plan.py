@@ -44,9 +44,10 @@ class Plan:
 
 
 class Builder:
-    def __init__(self, device):
+    def __init__(self, device, conv_mode=0):
         self.P = Plan()
         self.dev = device
+        self.conv_mode = conv_mode          # 0 fp32 / 1 fp16 operands / 2 split-fp16 (fp32-emulated) in the eligible 3x3 convolutions
         self.lib = _lib.load()
         self.mean = self.rstd = None
         self.gn_partial = self.gn_counters = None
@@ -71,15 +72,16 @@ class Builder:
         w16: fp16 weights of the same layer (ops.pack_conv_weight_f16); used -- with the fp16-operand kernel -- when the
         geometry supports it (f16_level), else the fp32 weights `wgt` are."""
         f16 = w16 is not None and taps == 9 and stride == 1 and self.f16_level(n, h, w, c0, c1, ec0, ec1) >= (2 if norm_coefs is not None else 1)
+        shift = 0
         if f16:
-            wgt = w16
+            wgt, shift = w16
         a = ConvArgs(ptr(x0), ptr(x1), c0, c1, ld0, ld1, n, h, w, taps, ptr(wgt), cout, ptr(bias), ptr(cbias), cbias_ld,
                      cbias_rows, ptr(res), res_ld, scale, act, ptr(out), out_ld, ptr(norm_coefs), norm_act, ptr(e0), ptr(e1),
                      ec0, ec1, ec0, ec1, stride)
         if self.ws is None:
             self.ws = self.new(SPLITK_WORKSPACE_FLOATS)
         a.workspace, a.workspace_floats = ptr(self.ws), self.ws.numel()
-        a.wgt_f16 = 1 if f16 else 0
+        a.wgt_f16, a.wgt_shift = (self.conv_mode, shift) if f16 else (0, 0)
         self.stats_of.pop(out.data_ptr(), None)
         if stats and cout % 64 == 0 and out_ld == cout:
             sb = self.new(-(-(n * h * w) // 64) * 2 * cout)
@@ -89,9 +91,10 @@ class Builder:
 
     def f16_level(self, n, h, w, c0, c1, ec0, ec1):
         """0 = no fp16-operand kernel for this 3x3 layer, 1 = on raw input only, 2 = also with the fused input normalisation."""
-        if any(c % 64 for c in (c0, c1, ec0, ec1)):
+        if self.conv_mode == 0 or any(c % (64 if self.conv_mode == 1 else 32) for c in (c0, c1, ec0, ec1)):
             return 0
-        return int(self.lib.ds_conv_f16_supported(n, h, w, c0, c1, ec0, ec1))
+        fn = self.lib.ds_conv_f16_supported if self.conv_mode == 1 else self.lib.ds_conv_split_supported
+        return int(fn(n, h, w, c0, c1, ec0, ec1))
 
     def linear(self, x, k, rows, wgt, cout, out, name, ldx=None, out_ld=None, **kw):
         """out[rows, cout] = x[rows, k] W^T (+bias +res ...): a 1x1 'convolution' over rows."""

@@ -106,14 +106,22 @@ typedef struct ds_conv_args {
      * v_mfma_f32_32x32x16_f16 with fp32 accumulation; inputs, bias / residual / output tensors stay fp32.  taps == 9 only, and only
      * where ds_conv_f16_supported() says so -- otherwise DS_E_SHAPE (there is no silent fp32 fallback). */
     int wgt_f16;
+    /* wgt_f16 == 2: SPLIT-fp16 OPERANDS, fp32 emulated on the fp16 matrix pipe.  Every operand x is represented as hi + lo with
+     * hi = fp16(x), lo = fp16(x - hi); a product is hi*hi + hi*lo + lo*hi with fp32 accumulation (the dropped lo*lo term and the
+     * rounding of lo are 2**-22 relative: fp32 class, far inside the engine's fp32 tolerances -- which is the condition for using
+     * it).  `wgt` then holds [cout_pad][K] PAIRS: per 32-channel slab and tap 32 hi halfs followed by 32 lo halfs
+     * (K order (slab32 * 9 + tap) * 64, then the 1x1 extra columns in 32-channel blocks), of the weights MULTIPLIED by 2**wgt_shift
+     * (keeps hi and lo in fp16's normal range); the epilogue multiplies the accumulators by 2**-wgt_shift.  Available where
+     * ds_conv_split_supported() says so, else DS_E_SHAPE. */
+    int wgt_shift;
 } ds_conv_args;
 
 int ds_conv2d_nhwc(const ds_conv_args* a, void* stream);
 
 /* Which kernel ds_conv2d_nhwc dispatches this call to: 0 = generic gather kernel (igemm_f32_kernel<0>), 128 / 256 =
  * LDS-halo kernel with that M tile (conv3x3_halo_kernel<2> / <4>), 2561 = 8-wave LDS-DMA 1x1 / Linear kernel
- * (gemm_dma8_kernel), 2562 = fp16-operand halo kernel (conv3x3_halo2_kernel<W, true>).  Used by bench.py to attribute time per
- * kernel. */
+ * (gemm_dma8_kernel), 2562 = fp16-operand halo kernel (conv3x3_halo2_kernel<W, 1>), 2563 = split-fp16 (fp32-emulated) halo kernel
+ * (conv3x3_halo2_kernel<W, 2>).  Used by bench.py to attribute time per kernel. */
 int ds_conv_kernel_id(const ds_conv_args* a);
 
 /* 1 if a 3x3 convolution on h x w images runs on the LDS-halo kernel (needed for norm_coefs), else 0. */
@@ -123,6 +131,9 @@ int ds_conv3x3_halo_supported(int h, int w);
  * and the fused input normalisation (norm_coefs) too.  n, h, w: images and size; cin = c0 + c1 and ecin = ec0 + ec1 with every
  * source a multiple of 64 channels. */
 int ds_conv_f16_supported(int n, int h, int w, int c0, int c1, int ec0, int ec1);
+
+/* The same for the split-fp16 (fp32-emulated) operands of wgt_f16 == 2; every source a multiple of 32 channels. */
+int ds_conv_split_supported(int n, int h, int w, int c0, int c1, int ec0, int ec1);
 
 /* Batched per-seed latent generator: out[b][i], i < n, = the tensor `torch.randn([n], generator=g_b, device=<this GPU>)` of a generator
  * with `g_b.manual_seed(seeds[b])` whose Philox offset is `offset` (0 for a fresh generator) -- bit for bit, for a whole batch of

@@ -573,3 +573,70 @@ def test_conv_f16_unsupported_geometry_fails_loudly():
     a = _lib.ConvArgs(x.data_ptr(), None, 64, 0, 64, 0, 3, 8, 8, 9, w.data_ptr(), 64, None, None, 0, 1, None, 0, 1.0, 0, o.data_ptr(), 64)
     a.wgt_f16 = 1
     assert lib.ds_conv2d_nhwc(C.byref(a), None) == -3                       # DS_E_SHAPE, no silent fp32 fallback
+
+
+SPLIT_CASES = [
+    (1, 16, 32, 0, 128, (0, 0), False, False),
+    (2, 16, 64, 32, 128, (0, 0), True, True),
+    (1, 32, 96, 0, 256, (0, 0), True, True),
+    (2, 32, 32, 32, 192, (64, 32), True, True),
+    (1, 64, 32, 0, 128, (32, 0), True, False),
+    (4, 8, 64, 0, 128, (0, 0), False, False),
+    (3, 16, 288, 0, 3, (0, 0), True, True),            # output-conv shape (3 channels), 9 slabs
+]
+
+
+@pytest.mark.parametrize('case', SPLIT_CASES)
+def test_conv_split_fp16_emulates_fp32_within_the_fp32_tolerance(case):
+    """wgt_f16 == 2: fp32 emulated by split fp16 hi/lo operands (three MFMA products).  Same reference and the SAME tolerance as the
+    exact fp32 kernel's test (TOL = 2e-5 of the output scale): this mode is only acceptable if it is indistinguishable from fp32."""
+    import ctypes as C
+    from diff_sampler_amd import _lib, ops
+    B, H, c0, c1, cout, (ec0, ec1), use_norm, act = case
+    lib = _lib.load()
+    assert lib.ds_conv_split_supported(B, H, H, c0, c1, ec0, ec1) >= (2 if use_norm else 1)
+    g = torch.Generator().manual_seed(sum(case[:5]) + 13)
+    x = torch.randn(B, c0 + c1, H, H, generator=g)
+    e = torch.randn(B, ec0 + ec1, H, H, generator=g) if ec0 else None
+    w = torch.randn(cout, c0 + c1, 3, 3, generator=g) / (9 * (c0 + c1)) ** 0.5
+    w[0, 0, 0, 0] = 3e-6                                   # a weight 2**-15 of the largest: lands in fp16's subnormal range after scaling
+    we = torch.randn(cout, ec0 + ec1, 1, 1, generator=g) / (ec0 + ec1) ** 0.5 if ec0 else None
+    bias = torch.randn(cout, generator=g)
+    cb = torch.randn(B, cout, generator=g)
+    res = torch.randn(B, cout, H, H, generator=g)
+    mu = torch.randn(B, c0 + c1, generator=g) * 0.3
+    ga = 1 + 0.2 * torch.randn(B, c0 + c1, generator=g)
+    be = 0.2 * torch.randn(B, c0 + c1, generator=g)
+    xin = x
+    if use_norm:
+        xin = (x - mu[:, :, None, None]) * ga[:, :, None, None] + be[:, :, None, None]
+        xin = F.silu(xin) if act else xin
+    ref = F.conv2d(xin.double(), w.double(), padding=1)
+    if ec0:
+        ref = ref + F.conv2d(e.double(), we.double())
+    ref = ((ref + (bias[None, :, None, None] + cb[:, :, None, None] + res).double()) * 0.7071).float()
+    dev = 'cuda'
+    xn = _nhwc(x).to(dev)
+    x0 = xn[:, :c0].contiguous()
+    x1 = xn[:, c0:].contiguous() if c1 else None
+    en = _nhwc(e).to(dev) if ec0 else None
+    e0 = en[:, :ec0].contiguous() if ec0 else None
+    e1 = en[:, ec0:].contiguous() if ec1 else None
+    wp, shift = ops.pack_conv_weight_split(w.to(dev), we.to(dev) if ec0 else None)
+    coefs = torch.stack([mu, ga, be], 1).contiguous().to(dev) if use_norm else None
+    old = cout if cout % 4 == 0 else -(-cout // 4) * 4
+    out = torch.full((B * H * H, old), float('nan'), device=dev)
+    biasd, cbd, resd = bias.to(dev), cb.to(dev), _nhwc(res).to(dev)
+    if cout < 4:
+        resd = torch.cat([resd, torch.zeros(resd.shape[0], old - cout, device=dev)], 1).contiguous()
+    a = _lib.ConvArgs(x0.data_ptr(), x1.data_ptr() if c1 else None, c0, c1, c0, c1, B, H, H, 9, wp.data_ptr(), cout, biasd.data_ptr(),
+                      cbd.data_ptr(), cout, B, resd.data_ptr(), old, 0.7071, 0, out.data_ptr(), old,
+                      coefs.data_ptr() if use_norm else None, 1 if act else 0,
+                      e0.data_ptr() if ec0 else None, e1.data_ptr() if ec1 else None, ec0, ec1, ec0, ec1)
+    a.wgt_f16, a.wgt_shift = 2, shift
+    before = lib.ds_debug_conv_halo2_launches()
+    rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    assert rc == 0, lib.ds_error_string(rc)
+    assert lib.ds_debug_conv_halo2_launches() == before + 1
+    assert _rel(out[:, :cout].cpu(), _nhwc(ref)) < TOL

@@ -29,6 +29,7 @@ ap.add_argument('--check', action='store_true')
 ap.add_argument('--only', type=int, nargs='*')
 ap.add_argument('--variants', type=int, nargs='*', default=None)
 ap.add_argument('--rounds', type=int, default=5)
+ap.add_argument('--split', action='store_true', help='split-fp16 fp32-emulated kernel (wgt_f16 = 2), 3x3 shapes only')
 ap.add_argument('--f16', action='store_true', help='fp16-operand kernel (ds_conv_args.wgt_f16), 3x3 shapes only')
 ap.add_argument('--extra', action='store_true', help='append the fused 1x1 skip projection (ec0 = c0 + c1 raw columns) as conv1 of a block with a skip conv has it')
 ap.add_argument('--norm', action='store_true', help='fused GroupNorm affine + SiLU in the halo loader, as the network uses it')
@@ -55,19 +56,25 @@ for si, (res, c0, c1, cout, taps) in enumerate(SHAPES):
     out = torch.zeros(M, old, device=dev)
     a = ConvArgs(x0.data_ptr(), x1.data_ptr() if c1 else None, c0, c1, c0, c1, B, res, res, taps, wp.data_ptr(), cout, bias.data_ptr(),
                  None, 0, 1, res_t.data_ptr() if cout >= 4 else None, cout, 0.70710678, 0, out.data_ptr(), old)
-    if args.f16 and (taps != 9 or cout < 64):
+    if (args.f16 or args.split) and (taps != 9 or cout < 64 or (args.norm and res < 16)):
         continue
     if args.extra and taps == 9:
         ec = c0 + c1
         e0 = torch.randn(M, ec, device=dev)
         we = torch.randn(cout, ec, 1, 1, device=dev) / ec ** 0.5
-        wp = ops.pack_conv_weight_f16(w, we) if args.f16 else torch.cat([wp, ops.pack_conv_weight(we)], 1).contiguous()
+        if args.split:
+            wp, a.wgt_shift = ops.pack_conv_weight_split(w, we)
+        else:
+            wp = ops.pack_conv_weight_f16(w, we) if args.f16 else torch.cat([wp, ops.pack_conv_weight(we)], 1).contiguous()
         a.wgt, a.e0, a.ec0, a.eld0 = wp.data_ptr(), e0.data_ptr(), ec, ec
+    elif args.split:
+        wp, a.wgt_shift = ops.pack_conv_weight_split(w)
+        a.wgt = wp.data_ptr()
     elif args.f16:
         wp = ops.pack_conv_weight_f16(w)
         a.wgt = wp.data_ptr()
-    if args.f16:
-        a.wgt_f16 = 1
+    if args.f16 or args.split:
+        a.wgt_f16 = 2 if args.split else 1
     if args.norm and taps == 9:
         coefs = torch.randn(B, 3, c0 + c1, device=dev) * 0.1 + torch.tensor([0., 1., 0.], device=dev).reshape(1, 3, 1)
         a.norm_coefs, a.norm_act = coefs.data_ptr(), 1
