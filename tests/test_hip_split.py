@@ -35,7 +35,7 @@ def test_split_denoiser_matches_reference_goldens_within_fp32_tolerance(name):
     lib = _lib.load()
     plan = next(iter(net.engine._plans.values()))
     modes = [op.keep[0].wgt_f16 for op in plan.ops if op.fn is lib.ds_conv2d_nhwc and op.keep[0].taps == 9]
-    assert modes.count(2) >= 0.7 * len(modes), modes          # the mode is on (8x8 layers need whole tiles of four images)
+    assert modes.count(2) >= 0.5 * len(modes), modes          # the mode is on (at B = 1..2 the 8x8 layers cannot form tiles of four images and stay exact fp32)
 
 
 def test_split_headline_sampler_matches_reference_golden():
