@@ -90,6 +90,7 @@ _SIGNATURES = {
     'ds_conv3x3_halo_supported': (C.c_int, [C.c_int, C.c_int]),
     'ds_conv_f16_supported': (C.c_int, [C.c_int] * 7),
     'ds_conv_split_supported': (C.c_int, [C.c_int] * 7),
+    'ds_gemm_f16_supported': (C.c_int, [C.c_longlong, C.c_int, C.c_int]),
     'ds_gemm_nt_batched': (C.c_int, [C.POINTER(GemmArgs), vp]),
     'ds_gn_stats': (C.c_int, [C.POINTER(NormArgs), vp]),
     'ds_norm_act': (C.c_int, [C.POINTER(NormArgs), vp]),

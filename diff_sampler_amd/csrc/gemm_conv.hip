@@ -355,6 +355,14 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     if (a->wgt_f16) {
         // fp16 operands (1) or split fp16 hi/lo operands (2): second-generation halo kernel only, every 128-column tile (the ragged
         // last one included)
+        if (a->wgt_f16 == 1 && a->taps == 1 && stride == 1) {
+            // 1x1 / Linear with fp16 operands: weights [cout_pad][K] halfs in plain K order
+            if (a->wgt_shift) return DS_E_ARG;
+            p.ldb = p.K / 2;
+            p.part = nullptr; p.part_cap = 0; p.splits = 1;
+            if (!gemm_f16_applicable(p)) return DS_E_SHAPE;
+            return launch_gemm_f16(p, (hipStream_t)stream);
+        }
         if (a->taps != 9 || stride != 1 || (a->wgt_f16 != 1 && a->wgt_f16 != 2)) return DS_E_ARG;
         if (a->wgt_shift < 0 || a->wgt_shift > 24 || (a->wgt_f16 == 1 && a->wgt_shift)) return DS_E_ARG;
         const int wide = (p.N + BN - 1) / BN;
@@ -378,7 +386,7 @@ extern "C" int ds_conv_kernel_id(const ds_conv_args* a) {
     p.c0 = a->c0; p.c1 = a->c1; p.ec0 = a->ec0; p.ec1 = a->ec1;
     if (a->workspace && a->workspace_floats > 0) { p.part = a->workspace; p.part_cap = a->workspace_floats; }
     p.stride = a->stride ? a->stride : 1; p.K = a->taps * (a->c0 + a->c1) + a->ec0 + a->ec1; p.norm = a->norm_coefs;
-    if (a->wgt_f16) return a->wgt_f16 == 2 ? 2563 : 2562;
+    if (a->wgt_f16) return a->wgt_f16 == 2 ? 2563 : (a->taps == 1 ? 2564 : 2562);
     if (g_force_generic) return 0;
     if (a->taps != 9 || a->stride > 1) return (g_use_dma8 && gemm_dma8_applicable(p)) ? 2561 : 0;
     return conv3x3_halo_choice(p);
@@ -392,6 +400,12 @@ static int reduced_supported(int mode, int n, int h, int w, int c0, int c1, int 
     return w >= 16 ? 2 : 1;                      // 8x8: four images per tile, the per-image normalisation planes are not fused
 }
 extern "C" int ds_conv_f16_supported(int n, int h, int w, int c0, int c1, int ec0, int ec1) { return reduced_supported(1, n, h, w, c0, c1, ec0, ec1); }
+extern "C" int ds_gemm_f16_supported(long long rows, int c0, int c1) {
+    KParams p{};
+    if (rows > 0x7fffffffLL) return 0;
+    p.taps = 1; p.stride = 1; p.M = (int)rows; p.N = 128; p.K = c0 + c1; p.c0 = c0; p.c1 = c1; p.nrows_b = 128;
+    return gemm_f16_applicable(p) ? 1 : 0;
+}
 extern "C" int ds_conv_split_supported(int n, int h, int w, int c0, int c1, int ec0, int ec1) { return reduced_supported(2, n, h, w, c0, c1, ec0, ec1); }
 
 extern "C" int ds_conv3x3_halo_supported(int h, int w) {

@@ -255,4 +255,8 @@ bool conv3x3_halo2_applicable(const KParams& p, int wide, int mode);   // mode 0
 int launch_conv3x3_halo2(KParams& p, int wide, int mode, hipStream_t stream);
 extern long long g_halo2_launches;
 
+// gemm_f16.hip: 1x1 / Linear with fp16 operands (A rounded while staged, W packed fp16)
+bool gemm_f16_applicable(const KParams& p);
+int launch_gemm_f16(KParams& p, hipStream_t stream);
+
 }  // namespace igemm

@@ -26,7 +26,7 @@ import torch
 from . import _lib, arch
 from ._lib import (AttnArgs, ConvArgs, GemmArgs, GnFinalizeArgs, NormArgs, DS_ACT_NONE, DS_ACT_SILU, DS_RESAMPLE_NONE, DS_RESAMPLE_DOWN,
                    DS_RESAMPLE_UP)
-from .ops import pack_conv_weight, pack_linear_weight, pack_stem_weight
+from .ops import pack_conv_weight, pack_linear_weight, pack_linear_weight_f16, pack_stem_weight
 
 
 from .plan import Op as _Op, Plan as _Plan, ptr as _ptr, SPLITK_WORKSPACE_FLOATS  # noqa: E402
@@ -46,6 +46,7 @@ class UNetEngine:
         self.device = torch.device(device)
         self.use_fp16 = bool(use_fp16)
         self.split_fp16 = bool(split_fp16) and not self.use_fp16
+        self._w16_cache = {}
         self.conv_mode = 1 if self.use_fp16 else (2 if self.split_fp16 else 0)      # ds_conv_args.wgt_f16 of the eligible 3x3 layers
         self.lib = _lib.load()
         self._plans: Dict[tuple, _Plan] = {}
@@ -194,6 +195,14 @@ class UNetEngine:
             fn = lib.ds_conv_f16_supported if self.conv_mode == 1 else lib.ds_conv_split_supported
             return int(fn(n, h, wd, c0, c1, ec0, ec1))
 
+        def linear_w16(wgt, rows, c0, c1):
+            """fp16 packing (cached per weight) of a 1x1 layer where gemm_f16_kernel covers the shape, else the fp32 weights."""
+            if wgt.dim() != 2 or wgt.shape[0] % 128 or wgt.shape[1] != c0 + c1 or not lib.ds_gemm_f16_supported(rows, c0, c1):
+                return wgt, False
+            if wgt.data_ptr() not in self._w16_cache:
+                self._w16_cache[wgt.data_ptr()] = (pack_linear_weight_f16(wgt), wgt)
+            return self._w16_cache[wgt.data_ptr()][0], True
+
         def conv(x0, c0, ld0, n, h, wd, wgt, cout, out, out_ld, taps, name, x1=None, c1=0, ld1=0, bias=None, cbias=None,
                  cbias_ld=0, cbias_rows=1, res=None, res_ld=0, scale=1.0, act_=DS_ACT_NONE, norm_coefs=None, norm_act=DS_ACT_NONE,
                  e0=None, ec0=0, e1=None, ec1=0, out_nchw=0, stats=False, w16=None):
@@ -201,6 +210,8 @@ class UNetEngine:
             shift = 0
             if f16:
                 wgt, shift = w16
+            elif self.conv_mode == 1 and taps == 1 and norm_coefs is None and not ec0 and not ec1 and not out_nchw:
+                wgt, f16 = linear_w16(wgt, n * h * wd, c0, c1)
             a = ConvArgs(_ptr(x0), _ptr(x1), c0, c1, ld0, ld1, n, h, wd, taps, _ptr(wgt), cout, _ptr(bias), _ptr(cbias),
                          cbias_ld, cbias_rows, _ptr(res), res_ld, scale, act_, _ptr(out), out_ld, _ptr(norm_coefs), norm_act,
                          _ptr(e0), _ptr(e1), ec0, ec1, ec0, ec1)

@@ -38,6 +38,7 @@ class LDMUNetEngine:
         self.spec = spec
         self.device = torch.device(device)
         self.use_fp16 = bool(use_fp16)
+        self._w16_cache = {}        # fp16 packings of the Linear / 1x1 weights (plan.Builder.linear_w16), shared by every plan
         self.lib = _lib.load()
         self._plans: Dict[tuple, Plan] = {}
         self._pack(params)
@@ -119,7 +120,7 @@ class LDMUNetEngine:
         if key in self._plans:
             return self._plans[key]
         spec, w, lib = self.spec, self.w, self.lib
-        bd = Builder(self.device, conv_mode=(1 if self.use_fp16 else 0))
+        bd = Builder(self.device, conv_mode=(1 if self.use_fp16 else 0), w16_cache=self._w16_cache)
         P, new = bd.P, bd.new
         bufs = P.bufs
         R, Cin, MC, E = spec.img_resolution, spec.in_channels, spec.model_channels, spec.time_embed_dim

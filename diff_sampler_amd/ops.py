@@ -58,6 +58,14 @@ def pack_conv_weight_f16(w: torch.Tensor, extra: Optional[torch.Tensor] = None, 
     return out.contiguous().view(torch.float32)
 
 
+def pack_linear_weight_f16(w_padded: torch.Tensor) -> torch.Tensor:
+    """fp16 weights of the reduced-precision 1x1 convolution / Linear (ds_conv_args.wgt_f16 == 1 with taps == 1): the row-padded
+    fp32 matrix [Cout_pad, K] of pack_linear_weight / pack_conv_weight rounded like ``w.to(float16)`` (networks_edm.py:79; torch
+    autocast casts nn.Linear weights the same way), K order unchanged.  Float32-typed view of the bytes."""
+    assert w_padded.dim() == 2 and w_padded.shape[0] % 128 == 0 and w_padded.shape[1] % 64 == 0
+    return w_padded.to(torch.float16).contiguous().view(torch.float32)
+
+
 def pack_conv_weight_split(w: torch.Tensor, extra: Optional[torch.Tensor] = None, row_pad: int = 128):
     """Split-fp16 weights of the fp32-emulated 3x3 convolution (ds_conv_args.wgt_f16 == 2) -> (packed tensor, shift).
 

@@ -44,7 +44,10 @@ class Plan:
 
 
 class Builder:
-    def __init__(self, device, conv_mode=0):
+    def __init__(self, device, conv_mode=0, w16_cache=None):
+        """w16_cache: dict owned by the engine (it outlives the per-batch plans): data_ptr of a row-padded fp32 1x1 / Linear weight
+        -> its fp16 packing, made on first use when conv_mode == 1."""
+        self.w16_cache = w16_cache if w16_cache is not None else {}
         self.P = Plan()
         self.dev = device
         self.conv_mode = conv_mode          # 0 fp32 / 1 fp16 operands / 2 split-fp16 (fp32-emulated) in the eligible 3x3 convolutions
@@ -75,6 +78,8 @@ class Builder:
         shift = 0
         if f16:
             wgt, shift = w16
+        elif self.conv_mode == 1 and taps == 1 and stride == 1 and norm_coefs is None and not ec0 and not ec1:
+            wgt, f16 = self.linear_w16(wgt, n * h * w, c0, c1)
         a = ConvArgs(ptr(x0), ptr(x1), c0, c1, ld0, ld1, n, h, w, taps, ptr(wgt), cout, ptr(bias), ptr(cbias), cbias_ld,
                      cbias_rows, ptr(res), res_ld, scale, act, ptr(out), out_ld, ptr(norm_coefs), norm_act, ptr(e0), ptr(e1),
                      ec0, ec1, ec0, ec1, stride)
@@ -88,6 +93,18 @@ class Builder:
             a.stats_out = ptr(sb)
             self.stats_of[out.data_ptr()] = (sb, cout)
         self.add(self.lib.ds_conv2d_nhwc, (C.byref(a),), name, keep=(a,))
+
+    def linear_w16(self, wgt, rows, c0, c1):
+        """(weights, use the fp16-operand GEMM?) of a 1x1 / Linear layer in fp16 mode: the fp16 packing of `wgt` (cached per weight
+        tensor) where gemm_f16_kernel covers the shape, else the fp32 weights unchanged."""
+        if wgt.dtype != torch.float32 or wgt.dim() != 2 or wgt.shape[0] % 128 or wgt.shape[1] != c0 + c1 \
+                or not self.lib.ds_gemm_f16_supported(rows, c0, c1):
+            return wgt, False
+        key = wgt.data_ptr()
+        if key not in self.w16_cache:
+            from .ops import pack_linear_weight_f16
+            self.w16_cache[key] = (pack_linear_weight_f16(wgt), wgt)       # keep the source alive: its address is the key
+        return self.w16_cache[key][0], True
 
     def f16_level(self, n, h, w, c0, c1, ec0, ec1):
         """0 = no fp16-operand kernel for this 3x3 layer, 1 = on raw input only, 2 = also with the fused input normalisation."""

@@ -121,7 +121,7 @@ int ds_conv2d_nhwc(const ds_conv_args* a, void* stream);
 /* Which kernel ds_conv2d_nhwc dispatches this call to: 0 = generic gather kernel (igemm_f32_kernel<0>), 128 / 256 =
  * LDS-halo kernel with that M tile (conv3x3_halo_kernel<2> / <4>), 2561 = 8-wave LDS-DMA 1x1 / Linear kernel
  * (gemm_dma8_kernel), 2562 = fp16-operand halo kernel (conv3x3_halo2_kernel<W, 1>), 2563 = split-fp16 (fp32-emulated) halo kernel
- * (conv3x3_halo2_kernel<W, 2>).  Used by bench.py to attribute time per kernel. */
+ * (conv3x3_halo2_kernel<W, 2>), 2564 = fp16-operand 1x1 / Linear kernel (gemm_f16_kernel).  Used by bench.py to attribute time per kernel. */
 int ds_conv_kernel_id(const ds_conv_args* a);
 
 /* 1 if a 3x3 convolution on h x w images runs on the LDS-halo kernel (needed for norm_coefs), else 0. */
@@ -131,6 +131,10 @@ int ds_conv3x3_halo_supported(int h, int w);
  * and the fused input normalisation (norm_coefs) too.  n, h, w: images and size; cin = c0 + c1 and ecin = ec0 + ec1 with every
  * source a multiple of 64 channels. */
 int ds_conv_f16_supported(int n, int h, int w, int c0, int c1, int ec0, int ec1);
+
+/* 1x1 convolution / Linear with fp16 operands (wgt_f16 == 1 and taps == 1: `wgt` = [cout_pad][K] halfs in plain K order; the fp32
+ * input rows are rounded to fp16 while they are staged): 1 if rows % 256 == 0 and every source is a multiple of 64 channels. */
+int ds_gemm_f16_supported(long long rows, int c0, int c1);
 
 /* The same for the split-fp16 (fp32-emulated) operands of wgt_f16 == 2; every source a multiple of 32 channels. */
 int ds_conv_split_supported(int n, int h, int w, int c0, int c1, int ec0, int ec1);

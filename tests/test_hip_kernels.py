@@ -640,3 +640,88 @@ def test_conv_split_fp16_emulates_fp32_within_the_fp32_tolerance(case):
     assert rc == 0, lib.ds_error_string(rc)
     assert lib.ds_debug_conv_halo2_launches() == before + 1
     assert _rel(out[:, :cout].cpu(), _nhwc(ref)) < TOL
+
+
+GEMM_F16_CASES = [
+    # rows, c0, c1, cout, flavour
+    (256, 64, 0, 128, 'plain'),                # one tile, one tap
+    (512, 128, 0, 128, 'bias_res'),            # two taps (both register sets)
+    (1024, 192, 0, 320, 'bias_res'),           # odd tap count; ragged 320 = two full + one half-empty column tile
+    (768, 128, 64, 192, 'dual'),               # dual source
+    (4096, 320, 0, 2560, 'geglu'),             # SD-1.5 ff.proj_geglu shape at 64x64
+    (2048, 1280, 0, 320, 'bias_res'),          # K = 20 taps
+    (256, 576, 0, 1728, 'bias_res'),           # ImageNet-64 qkv at 8x8 x 4 images
+]
+
+
+@pytest.mark.parametrize('case', GEMM_F16_CASES)
+def test_gemm_f16_operands_matches_fp16_rounded_reference(case):
+    """1x1 / Linear in the reduced-precision mode (wgt_f16 == 1, taps == 1 -> gemm_f16_kernel): the reference is the same arithmetic
+    on the CPU (operands rounded to fp16, products summed in fp64).  Tolerance 1e-5 of the output scale against that (the kernel's
+    only other error is the fp32 accumulation order); against the pure fp32 layer the fp16 rounding bound 3e-3."""
+    import ctypes as C
+    from diff_sampler_amd import _lib, ops
+    rows, c0, c1, cout, kind = case
+    lib = _lib.load()
+    assert lib.ds_gemm_f16_supported(rows, c0, c1) == 1
+    k = c0 + c1
+    g = torch.Generator().manual_seed(rows + k + cout)
+    x = torch.randn(rows, k, generator=g)
+    wt = torch.randn(cout, k, generator=g) / k ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.3
+    h16 = lambda t: t.to(torch.float16).to(torch.float64)
+    y16 = h16(x) @ h16(wt).T + bias.double()
+    y32 = F.linear(x, wt, bias)
+    dev = 'cuda'
+    x0 = x[:, :c0].contiguous().to(dev)
+    x1 = x[:, c0:].contiguous().to(dev) if c1 else None
+    if kind == 'geglu':
+        inner = cout // 2
+        perm = torch.arange(cout).reshape(-1, 2, 32)
+        perm = (perm[:, 0] // 64 * 32 + perm[:, 0] % 32).reshape(-1, 1, 32).repeat(1, 2, 1)
+        perm[:, 1] += inner
+        perm = perm.reshape(-1)
+        wp = ops.pack_linear_weight_f16(ops.pack_linear_weight(wt[perm].to(dev)))
+        bd = bias[perm].contiguous().to(dev)
+        out = torch.full((rows, inner), float('nan'), device=dev)
+        a = _lib.ConvArgs(x0.data_ptr(), None, c0, 0, c0, 0, rows, 1, 1, 1, wp.data_ptr(), cout, bd.data_ptr(), None, 0, 1, None, 0, 1.0,
+                          _lib.DS_ACT_GEGLU, out.data_ptr(), inner)
+        ref16 = (y16[:, :inner] * F.gelu(y16[:, inner:])).float()
+        ref32 = y32[:, :inner] * F.gelu(y32[:, inner:])
+        ncol = inner
+    else:
+        wp = ops.pack_linear_weight_f16(ops.pack_linear_weight(wt.to(dev)))
+        bd = bias.to(dev) if kind != 'plain' else None
+        res = torch.randn(rows, cout, generator=g)
+        resd = res.to(dev) if kind != 'plain' else None
+        out = torch.full((rows, cout), float('nan'), device=dev)
+        sc = 0.7071 if kind != 'plain' else 1.0
+        a = _lib.ConvArgs(x0.data_ptr(), x1.data_ptr() if c1 else None, c0, c1, c0, c1, rows, 1, 1, 1, wp.data_ptr(), cout,
+                          bd.data_ptr() if bd is not None else None, None, 0, 1, resd.data_ptr() if resd is not None else None, cout, sc,
+                          0, out.data_ptr(), cout)
+        if kind == 'plain':
+            ref16, ref32 = (y16 - bias.double()).float(), y32 - bias
+        else:
+            ref16, ref32 = ((y16 + res.double()) * sc).float(), (y32 + res) * sc
+        ncol = cout
+    a.wgt_f16 = 1
+    assert lib.ds_conv_kernel_id(C.byref(a)) == 2564
+    rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    assert rc == 0, lib.ds_error_string(rc)
+    got = out[:, :ncol].cpu()
+    assert _rel(got, ref16) < 1e-5
+    assert _rel(got, ref32) < 3e-3
+
+
+def test_gemm_f16_rejects_unsupported_shapes():
+    import ctypes as C
+    from diff_sampler_amd import _lib
+    lib = _lib.load()
+    assert lib.ds_gemm_f16_supported(77, 768, 0) == 0          # ragged rows (the text-context projection)
+    assert lib.ds_gemm_f16_supported(256, 96, 0) == 0          # K not a multiple of 64
+    assert lib.ds_gemm_f16_supported(256, 96, 32) == 0
+    x = torch.zeros(77, 64, device='cuda'); w = torch.zeros(128, 32, device='cuda'); out = torch.zeros(77, 128, device='cuda')
+    a = _lib.ConvArgs(x.data_ptr(), None, 64, 0, 64, 0, 77, 1, 1, 1, w.data_ptr(), 128, None, None, 0, 1, None, 0, 1.0, 0, out.data_ptr(), 128)
+    a.wgt_f16 = 1
+    assert lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr()) == -3         # DS_E_SHAPE: no silent fp32 fallback
