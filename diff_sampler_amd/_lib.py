@@ -98,6 +98,8 @@ _SIGNATURES = {
     'ds_softmax_rows': (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp]),
     'ds_attention': (C.c_int, [C.POINTER(AttnArgs), vp]),
     'ds_attention_supported': (C.c_int, [C.c_int]),
+    'ds_attention_f16': (C.c_int, [C.POINTER(AttnArgs), vp]),
+    'ds_attention_f16_supported': (C.c_int, [C.c_int]),
     'ds_layernorm_rows': (C.c_int, [vp, C.c_int, vp, vp, C.c_float, vp, C.c_int, C.c_longlong, C.c_int, vp]),
     'ds_geglu': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_longlong, C.c_int, vp]),
     'ds_cfg_denoise': (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),

@@ -1,0 +1,286 @@
+// Fused softmax(Q K^T * scale) V with fp16 operands on v_mfma_f32_32x32x16_f16 -- the attention of the reference's fp16 / autocast
+// mode: networks_edm.py:98-110 (AttentionOp: fp16 q, k multiplied with fp32 accumulation, fp32 softmax, weights cast back to fp16,
+// fp16 w v product) and ldm/modules/attention.py:168-194 under torch.autocast (diff-solvers-main/sample.py:296).
+//
+// q / k / v / out stay fp32 in HBM (the engine's activation format); operands are rounded to fp16 (RNE) while they are staged, the
+// scores, the softmax statistics and both accumulators are fp32.  Same transposed online-softmax formulation as attention.hip
+// (a query is a lane; the C/D layout of S^T is directly the B operand of the P V product), re-tiled for the 16-deep fp16 MFMA:
+//   * workgroup = 256 queries of one (image, head), 8 waves x 32 queries; K/V stream through LDS in 64-key tiles, DOUBLE buffered
+//     (one barrier per tile), register-prefetched one tile ahead;
+//   * S^T[key, q] = sum_d K[key, d] Q[q, d]:   A = K tile rows (ds_read_b128 = 8 halfs of one key), B = Q (registers, scale * log2 e
+//     folded in before rounding); d is zero padded to a multiple of 16 (d = 40 -> 48: 3 MFMAs per 32 keys instead of 20 fp32 ones);
+//   * O^T[d, q] += sum_key V[key, d] P^T[key, q]:  the contraction index must be contiguous in the A operand's registers, so V is
+//     TRANSPOSED while it is staged (each thread transposes a 4-key x 4-channel patch in registers, four ds_write_b64) into
+//     Vt[d][position(key)], where position() swaps key bits 2 and 3: with that order the 8 keys lane-half hb contracts in MFMA
+//     step s are exactly the registers 8 (s & 1) ... + 7 of the S^T accumulator it already holds (keys (r & 3) + 8 (r >> 2) + 4 hb),
+//     so P goes from the exp2 to the P V product through one v_cvt_pk_f16_f32 per pair, no shuffles and no LDS round trip;
+//   * the O^T rescale runs only on tiles where some lane's running maximum moved (wave-uniform branch);
+//   * XCD-aware 1-D grid: linear workgroup id % 8 is the XCD, so the (image, head) index is id % 8 + 8 * (...) and all query blocks
+//     of one (image, head) share an L2 (its K/V, <= 1.3 MB at 4096 x 40, are fetched from HBM once, not once per XCD).
+// Head sizes: d % 8 == 0, d <= 160 (registers / LDS); other sizes keep the fp32 kernel (ds_attention_f16_supported).
+#include "ds_common.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pk2(float x, float y) {          // two fp32 -> two fp16 (round to nearest even) in one dword
+    const h2 p = {(_Float16)x, (_Float16)y};
+    return __builtin_bit_cast(unsigned, p);
+}
+
+template <int D>
+__global__ void __launch_bounds__(512) flash_attn_f16_kernel(const ds_attn_args a, const int qblocks, const int pairs) {
+    constexpr int DP = (D + 15) / 16 * 16;           // contraction length of S^T, zero padded
+    constexpr int NKS = DP / 16;
+    constexpr int DB = (D + 31) / 32;                // 32-row blocks of O^T
+    constexpr int KT = 64;                           // keys per tile
+    constexpr int KLD = DP + 8;                      // halfs; row stride / 16 B odd: conflict-free ds_read_b128 over 32 rows
+    constexpr int VLD = KT + 8;
+    constexpr int KBYTES = KT * KLD * 2, VBYTES = DB * 32 * VLD * 2, TILE_B = KBYTES + VBYTES;
+    constexpr int D8 = D / 8, D4 = D / 4;
+    constexpr int KCH = KT * D8;                     // (key, 8 channels) chunks of a K tile
+    constexpr int NLK = (KCH + 511) / 512;
+    constexpr int VTS = (KT / 4) * D4;               // (4 keys, 4 channels) patches of a V tile
+    constexpr int NLV = (VTS + 511) / 512;
+    constexpr bool PREFETCH = D <= 96;               // larger heads: no registers left to hold a staged tile across the MFMAs
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    float* Es = reinterpret_cast<float*>(smem_b + 2 * TILE_B);      // epilogue transposition patches, 32 x 33 floats per wave
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hb = lane >> 5, l31 = lane & 31;
+    const int L = blockIdx.x, slot = L >> 3;
+    const int qb = slot % qblocks, pair = (slot / qblocks) * 8 + (L & 7);
+    if (pair >= pairs) return;
+    const int b = pair / a.heads, h = pair - b * a.heads;
+    const int q0 = qb * 256 + wave * 32;
+    const bool active = q0 < a.sq;
+    const float* qp = a.q + (size_t)b * a.q_bs + h * D;
+    const float* kp = a.k + (size_t)b * a.k_bs + h * D;
+    const float* vp = a.v + (size_t)b * a.v_bs + h * D;
+
+    if (DP != D) {          // the zero padding of K's contraction columns (never overwritten by the staging below)
+        if (tid < 2 * KT) *reinterpret_cast<u32x4*>(smem_b + (tid >> 6) * TILE_B + ((tid & 63) * KLD + D) * 2) = u32x4{0u, 0u, 0u, 0u};
+    }
+
+    const float sc = a.scale * 1.4426950408889634f;
+    h8 qf[NKS];
+    {
+        const int qrow = min(q0 + l31, a.sq - 1);
+        const float* qr = qp + (size_t)qrow * a.ldq + 8 * hb;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            u32x4 w = {0u, 0u, 0u, 0u};
+            if (16 * ks + 8 * hb < D) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(qr + 16 * ks) * sc;
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(qr + 16 * ks + 4) * sc;
+                w = u32x4{pk2(lo[0], lo[1]), pk2(lo[2], lo[3]), pk2(hi[0], hi[1]), pk2(hi[2], hi[3])};
+            }
+            qf[ks] = __builtin_bit_cast(h8, w);
+        }
+    }
+    f32x16 ot[DB];
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
+    float m = -1e30f, l = 0.f;
+
+    f32x4 kr[NLK][2], vr[NLV][4];
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < NLK; ++j) {
+            const int idx = tid + 512 * j;
+            if (NLK * 512 == KCH || idx < KCH) {
+                const int row = idx / D8, c8 = idx - row * D8;
+                const float* p = kp + (size_t)min(t * KT + row, a.skv - 1) * a.ldk + c8 * 8;
+                kr[j][0] = *reinterpret_cast<const f32x4*>(p);
+                kr[j][1] = *reinterpret_cast<const f32x4*>(p + 4);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NLV; ++j) {
+            const int idx = tid + 512 * j;
+            if (NLV * 512 == VTS || idx < VTS) {
+                const int g = idx & 15, d4 = idx >> 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    vr[j][i] = *reinterpret_cast<const f32x4*>(vp + (size_t)min(t * KT + 4 * g + i, a.skv - 1) * a.ldv + 4 * d4);
+            }
+        }
+    };
+    auto sstore = [&](int buf) {
+        unsigned char* base = smem_b + buf * TILE_B;
+#pragma unroll
+        for (int j = 0; j < NLK; ++j) {
+            const int idx = tid + 512 * j;
+            if (NLK * 512 == KCH || idx < KCH) {
+                const int row = idx / D8, c8 = idx - row * D8;
+                const f32x4 lo = kr[j][0], hi = kr[j][1];
+                *reinterpret_cast<u32x4*>(base + (row * KLD + 8 * c8) * 2) =
+                    u32x4{pk2(lo[0], lo[1]), pk2(lo[2], lo[3]), pk2(hi[0], hi[1]), pk2(hi[2], hi[3])};
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NLV; ++j) {
+            const int idx = tid + 512 * j;
+            if (NLV * 512 == VTS || idx < VTS) {
+                const int g = idx & 15, d4 = idx >> 4;
+                const int pos = 4 * ((g & ~3) | ((g & 1) << 1) | ((g & 2) >> 1));      // key bits 2 and 3 swapped
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    *reinterpret_cast<u32x2*>(base + KBYTES + ((4 * d4 + c) * VLD + pos) * 2) =
+                        u32x2{pk2(vr[j][0][c], vr[j][1][c]), pk2(vr[j][2][c], vr[j][3][c])};
+            }
+        }
+    };
+
+    const int ntiles = (a.skv + KT - 1) / KT;
+    gload(0);
+    sstore(0);
+    if (PREFETCH && ntiles > 1) gload(1);
+    __syncthreads();
+    const unsigned kfrag = (unsigned)(l31 * KLD + 8 * hb) * 2;
+    const unsigned vfrag = (unsigned)KBYTES + (unsigned)(l31 * VLD + 8 * hb) * 2;
+    for (int t = 0; t < ntiles; ++t) {
+        const unsigned char* base = smem_b + (t & 1) * TILE_B;
+        f32x16 st[2];
+        h8 pf[4];
+        if (active) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const h8 kv = *reinterpret_cast<const h8*>(base + kfrag + (kb * 32 * KLD + 16 * ks) * 2);
+                    st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kv, qf[ks], st[kb], 0, 0, 0);
+                }
+            }
+            if (t == ntiles - 1) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (t * KT + kb * 32 + 4 * hb + (r & 3) + 8 * (r >> 2) >= a.skv) st[kb][r] = -1e30f;
+            }
+            float mx = st[0][0];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mn = fmaxf(m, mx);
+            const bool moved = mn > m;
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            m = mn;
+            float rs = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { st[kb][r] = __builtin_amdgcn_exp2f(st[kb][r] - mn); rs += st[kb][r]; }
+            l = l * alpha + rs;
+            if (__any(moved)) {
+#pragma unroll
+                for (int i = 0; i < DB; ++i) ot[i] *= alpha;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const f32x16& p = st[s >> 1];
+                const int r0 = 8 * (s & 1);
+                pf[s] = __builtin_bit_cast(h8, (u32x4{pk2(p[r0], p[r0 + 1]), pk2(p[r0 + 2], p[r0 + 3]), pk2(p[r0 + 4], p[r0 + 5]),
+                                                      pk2(p[r0 + 6], p[r0 + 7])}));
+            }
+        }
+        if (t + 1 < ntiles) {            // next tile into the other buffer (nobody reads it before the barrier below)
+            if (!PREFETCH) gload(t + 1);
+            sstore((t + 1) & 1);
+            if (PREFETCH && t + 2 < ntiles) gload(t + 2);
+        }
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < DB; ++i)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const h8 vv = *reinterpret_cast<const h8*>(base + vfrag + (i * 32 * VLD + 16 * s) * 2);
+                    ot[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vv, pf[s], ot[i], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+
+    const float inv = 1.0f / (l + __shfl_xor(l, 32));
+    float* patch = Es + wave * (32 * 33);
+    float* op = a.out + (size_t)b * a.o_bs + h * D;
+#pragma unroll
+    for (int i = 0; i < DB; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) patch[l31 * 33 + (r & 3) + 8 * (r >> 2) + 4 * hb] = ot[i][r] * inv;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int c4 = (lane & 7) * 4;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int q = pass * 8 + (lane >> 3);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = patch[q * 33 + c4 + j];
+            if (q0 + q < a.sq && i * 32 + c4 < D)
+                *reinterpret_cast<f32x4*>(op + (size_t)(q0 + q) * a.ldo + i * 32 + c4) = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int D>
+int launch(const ds_attn_args* a, hipStream_t stream) {
+    constexpr int DP = (D + 15) / 16 * 16, DB = (D + 31) / 32;
+    constexpr int bytes = 2 * (64 * (DP + 8) * 2 + DB * 32 * 72 * 2) + 8 * 32 * 33 * (int)sizeof(float);
+    static_assert(bytes <= 160 * 1024, "LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_f16_kernel<D>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int qblocks = (a->sq + 255) / 256, pairs = a->batch * a->heads;
+    const long long blocks = (long long)qblocks * ((pairs + 7) / 8) * 8;
+    if (blocks > 0x7fffffffLL) return DS_E_SHAPE;
+    hipLaunchKernelGGL(flash_attn_f16_kernel<D>, dim3((unsigned)blocks), dim3(512), bytes, stream, *a, qblocks, pairs);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+}  // namespace
+
+extern "C" int ds_attention_f16_supported(int d) {
+    switch (d) {
+        case 32: case 40: case 64: case 80: case 96: case 128: case 160: return 1;
+        default: return 0;
+    }
+}
+
+extern "C" int ds_attention_f16(const ds_attn_args* a, void* stream) {
+    (void)hipGetLastError();
+    if (!a || !a->q || !a->k || !a->v || !a->out) return DS_E_ARG;
+    if (a->batch <= 0 || a->heads <= 0 || a->sq <= 0 || a->skv <= 0) return DS_E_ARG;
+    if ((a->ldq & 3) || (a->ldk & 3) || (a->ldv & 3) || (a->ldo & 3) || (a->q_bs & 3) || (a->k_bs & 3) || (a->v_bs & 3) || (a->o_bs & 3))
+        return DS_E_ALIGN;
+    if (!ds_aligned16(a->q) || !ds_aligned16(a->k) || !ds_aligned16(a->v) || !ds_aligned16(a->out)) return DS_E_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    switch (a->d) {
+        case 32: return launch<32>(a, s);
+        case 40: return launch<40>(a, s);
+        case 64: return launch<64>(a, s);
+        case 80: return launch<80>(a, s);
+        case 96: return launch<96>(a, s);
+        case 128: return launch<128>(a, s);
+        case 160: return launch<160>(a, s);
+        default: return DS_E_SHAPE;
+    }
+}

@@ -368,7 +368,8 @@ class UNetEngine:
                 # softmax(Q K^T / sqrt(ch)) V per (image, head), scores kept on chip (networks_edm.py:171-176)
                 at = AttnArgs(_ptr(qk), _ptr(qk[cout:]), _ptr(qk[2 * cout:]), _ptr(ao), 3 * cout, 3 * cout, 3 * cout, cout,
                               S * 3 * cout, S * 3 * cout, S * 3 * cout, S * cout, B, hd, S, S, ch, 1.0 / math.sqrt(ch))
-                add(lib.ds_attention, (C.byref(at),), nm + '.attention', keep=(at,))
+                f16_attn = self.conv_mode == 1 and lib.ds_attention_f16_supported(ch)     # networks_edm.py:98-110 with fp16 q / k / v
+                add(lib.ds_attention_f16 if f16_attn else lib.ds_attention, (C.byref(at),), nm + '.attention', keep=(at,))
                 if b.pushes_skip:
                     out2 = new(M, cout)
                 else:

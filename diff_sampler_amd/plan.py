@@ -150,7 +150,8 @@ class Builder:
 
     def attention(self, q, k, v, out, name, *, batch, heads, sq, skv, d, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, scale):
         a = AttnArgs(ptr(q), ptr(k), ptr(v), ptr(out), ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, batch, heads, sq, skv, d, scale)
-        self.add(self.lib.ds_attention, (C.byref(a),), name, keep=(a,))
+        f16 = self.conv_mode == 1 and self.lib.ds_attention_f16_supported(d)      # fp16 mode: fp16-operand kernel where it covers the head size
+        self.add(self.lib.ds_attention_f16 if f16 else self.lib.ds_attention, (C.byref(a),), name, keep=(a,))
 
     def layernorm(self, x, ldx, gamma, beta, eps, y, ldy, rows, cols, name):
         self.add(self.lib.ds_layernorm_rows, (ptr(x), ldx, ptr(gamma), ptr(beta), eps, ptr(y), ldy, rows, cols), name)

@@ -253,6 +253,14 @@ typedef struct ds_attn_args {
 int ds_attention(const ds_attn_args* a, void* stream);
 int ds_attention_supported(int d);
 
+/* The same operation with fp16 operands on the fp16 matrix pipe -- the attention of the reference's fp16 / autocast mode
+ * (networks_edm.py:98-110 with use_fp16; ldm/modules/attention.py:168-194 under autocast, sample.py:296): q / k / v / out stay fp32
+ * in memory, are rounded to fp16 (nearest even) while staged; scores, softmax statistics and accumulators are fp32; the softmax
+ * weights are rounded to fp16 before the P V product as the reference casts them.  Head sizes: ds_attention_f16_supported(d)
+ * (d % 8 == 0, d <= 160); otherwise DS_E_SHAPE -- the caller picks ds_attention, there is no silent fallback. */
+int ds_attention_f16(const ds_attn_args* a, void* stream);
+int ds_attention_f16_supported(int d);
+
 /* LayerNorm over the last dimension (ldm/modules/attention.py:206-208): y[r, :] = (x[r, :] - mean) / sqrt(var + eps)
  * * gamma + beta, cols % 4 == 0, cols <= 2048. */
 int ds_layernorm_rows(const float* x, int ldx, const float* gamma, const float* beta, float eps, float* y, int ldy,

@@ -725,3 +725,51 @@ def test_gemm_f16_rejects_unsupported_shapes():
     a = _lib.ConvArgs(x.data_ptr(), None, 64, 0, 64, 0, 77, 1, 1, 1, w.data_ptr(), 128, None, None, 0, 1, None, 0, 1.0, 0, out.data_ptr(), 128)
     a.wgt_f16 = 1
     assert lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr()) == -3         # DS_E_SHAPE: no silent fp32 fallback
+
+
+@pytest.mark.parametrize('d,bz,heads,sq,skv', [(40, 1, 8, 1024, 1024), (40, 2, 8, 300, 77), (64, 3, 3, 256, 256), (64, 2, 6, 64, 64),
+                                               (80, 1, 2, 1024, 1000), (160, 2, 2, 256, 256), (32, 1, 2, 128, 65), (96, 1, 1, 40, 200),
+                                               (128, 1, 2, 520, 130), (40, 1, 2, 4096, 4096)])
+def test_fused_attention_f16_operands(d, bz, heads, sq, skv):
+    """ds_attention_f16 (fp16 operands, fp32 scores / statistics / accumulation) against softmax(q k^T * scale) v in fp64:
+      * with q * scale, k, v rounded to fp16 first -- the kernel's own operand rounding; what remains is the fp16 rounding of the
+        softmax weights and the fp32 accumulation order: 1e-3 of the output scale;
+      * against the unrounded fp64 result: the fp16 operand bound, 4e-3 (logits of magnitude ~ 5 move by ~ 5 * 2**-11 each).
+    Non-symmetric random inputs, strided q/k/v inside wider rows, ragged lengths, (image, head) counts off the 8-XCD grid multiple."""
+    from diff_sampler_amd import ops, _lib
+    assert _lib.load().ds_attention_f16_supported(d)
+    g = torch.Generator().manual_seed(d * 1000 + sq + skv)
+    C_ = heads * d
+    qkv = torch.randn(bz, sq, 3 * C_ + 4, generator=g)
+    kv = torch.randn(bz, skv, 2 * C_, generator=g) * 1.5
+    q = qkv[:, :, :C_]
+    k, v = kv[:, :, :C_], kv[:, :, C_:]
+    scale = d ** -0.5
+    qd, kvd = qkv.cuda().contiguous(), kv.cuda().contiguous()
+    out = torch.full((bz, sq, C_), float('nan'), device='cuda')
+    ops.attention(qd, kvd, kvd[:, :, C_:], out, batch=bz, heads=heads, sq=sq, skv=skv, d=d, ldq=3 * C_ + 4, ldk=2 * C_, ldv=2 * C_,
+                  ldo=C_, q_bs=sq * (3 * C_ + 4), k_bs=skv * 2 * C_, v_bs=skv * 2 * C_, o_bs=sq * C_, scale=scale, f16=True)
+    torch.cuda.synchronize()
+
+    def ref(qq, kk, vv, sc):
+        qh, kh, vh = (t.reshape(bz, -1, heads, d).double() for t in (qq, kk, vv))
+        w = (torch.einsum('bqhd,bkhd->bhqk', qh, kh) * sc).softmax(-1)
+        return torch.einsum('bhqk,bkhd->bqhd', w, vh).reshape(bz, sq, C_).float()
+
+    h16 = lambda t: t.to(torch.float16).to(torch.float32)
+    log2e = 1.4426950408889634
+    ref16 = ref(h16(q * (scale * log2e)), h16(k), h16(v), 1.0 / log2e)
+    got = out.cpu()
+    assert torch.isfinite(got).all()
+    assert _rel(got, ref16) < 1e-3
+    assert _rel(got, ref(q, k, v, scale)) < 4e-3
+
+
+def test_attention_f16_rejects_uncovered_head_sizes():
+    import ctypes as C
+    from diff_sampler_amd import _lib
+    lib = _lib.load()
+    assert lib.ds_attention_f16_supported(256) == 0 and lib.ds_attention_f16_supported(8) == 0
+    x = torch.zeros(64, 3 * 256, device='cuda'); o = torch.zeros(64, 256, device='cuda')
+    a = _lib.AttnArgs(x.data_ptr(), x.data_ptr(), x.data_ptr(), o.data_ptr(), 768, 768, 768, 256, 0, 0, 0, 0, 1, 1, 64, 64, 256, 1.0)
+    assert lib.ds_attention_f16(C.byref(a), _lib.stream_ptr()) == -3
