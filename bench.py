@@ -68,7 +68,7 @@ def parse(argv=None):
     ap.add_argument('--solver', default='dpmpp', choices=['dpmpp', 'euler', 'ipndm', 'heun'])
     ap.add_argument('--config', default='cifar10')
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'fp16', 'fp16x3'],
-                    help="fp16 = the reference's use_fp16 / autocast mode (configs 3 and 5): fp16 operands in the 3x3 convolutions, fp32 accumulation and storage; fp16x3 = fp32 EMULATED in the 3x3 convolutions by split fp16 hi/lo operands (3 MFMA products, fp32 tolerances)")
+                    help="fp16 = the reference's use_fp16 / autocast mode (configs 3 and 5): fp16 operands in the 3x3 convolutions, 1x1 / Linear layers and attention, fp32 accumulation and storage; fp16x3 = fp32 EMULATED in the 3x3 convolutions by split fp16 hi/lo operands (3 MFMA products, fp32 tolerances)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay the sampler call from a captured hipGraph')
     ap.add_argument('--cpu-batch', type=int, default=8)
@@ -498,7 +498,7 @@ def main(argv=None):
             'metric': 'images/sec (whole node) at NFE=%d, %s' % (args.nfe, 'EDM CIFAR-10' if args.config == 'cifar10' else workload_name.split(' (')[0]),
             'value': round(total_images / dt, 2), 'unit': 'images/sec', 'n_gpus': n_comm, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'fp32': 'fp32', 'fp16': 'fp16 operands in the 3x3 convolutions (fp32 accumulate, fp32 storage), rest fp32',
+            'dtype': {'fp32': 'fp32', 'fp16': 'fp16 operands in the 3x3 convolutions, 1x1 / Linear layers and attention (fp32 accumulate, fp32 softmax / norms / storage)',
                       'fp16x3': 'fp16x3 (fp32-emulated: split fp16 hi/lo operands, 3 MFMA products, fp32 accumulate) in the 3x3 convolutions, rest fp32'}[args.dtype],
             'data': 'synthetic N(0,1) latents, random-init (signal-carrying) weights',
             'config': {'workload': '%s, %s NFE=%d, batch %d/GPU' %
