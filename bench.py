@@ -126,6 +126,11 @@ def instrumented_pass(net, solvers, solver, latents, nfe, ldm=None):
         if op.fn is lib.ds_attention:
             t = op.keep[0]
             return 'flash_attn_kernel (fused attention)', 4.0 * t.batch * t.heads * t.sq * t.skv * t.d
+        if op.fn is lib.ds_attention_f16:
+            t = op.keep[0]
+            return 'flash_attn_f16_kernel (fused attention, fp16 operands)', 4.0 * t.batch * t.heads * t.sq * t.skv * t.d
+        if op.fn is lib.ds_layernorm_rows:
+            return 'layernorm_rows_kernel', 0.0
         if op.fn is lib.ds_gn_stats:
             return 'gn_stats_kernel', 0.0
         if op.fn is lib.ds_gn_finalize:

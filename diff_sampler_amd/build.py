@@ -31,14 +31,19 @@ def build_lib(force=False, verbose=True):
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not os.path.exists(hipcc):
         raise RuntimeError('hipcc not found: libdsamd.so cannot be built on this machine')
-    objs = []
-    for src in sources():
+    from concurrent.futures import ThreadPoolExecutor
+
+    def compile_one(src):
         obj = src[:-4] + '.o'
         cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC'] + EXTRA_FLAGS + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
-        objs.append(obj)
+        return obj
+
+    # one hipcc per translation unit, in parallel (the two convolution files dominate: ~2-3 min each)
+    with ThreadPoolExecutor(max_workers=max(1, min(len(sources()), os.cpu_count() or 1))) as pool:
+        objs = list(pool.map(compile_one, sources()))
     cmd = [hipcc, f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', LIB] + objs
     if verbose:
         print(' '.join(cmd), flush=True)

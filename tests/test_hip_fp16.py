@@ -1,6 +1,6 @@
 """GPU: the reference's reduced-precision modes (networks_edm.py:486 `use_fp16` for the EDM nets -- the public ImageNet-64 ADM
 checkpoint carries it; sample.py:296 `autocast("cuda")` around the LDM sampler), stage 1: fp16 operands on the fp16 matrix pipe in
-every 3x3 convolution the fp16-operand kernel supports, fp32 accumulation, fp32 everywhere else.
+every 3x3 convolution, 1x1 / Linear layer and attention the fp16-operand kernels support, fp32 accumulation, fp32 storage / norms / softmax.
 
 Two comparisons, both stated:
   * bound against the fp32 CPU oracle: 2e-2 of the output scale per evaluation (fp16 operand rounding, 2**-11 relative per
@@ -39,6 +39,15 @@ def _count_f16(plan, lib):
     return n16, n32
 
 
+def _count_f16_other(plan, lib):
+    """(1x1 / Linear launches with fp16 operands, with fp32 operands, attention launches on the fp16 kernel, on the fp32 kernel)"""
+    g16 = sum(1 for op in plan.ops if op.fn is lib.ds_conv2d_nhwc and op.keep[0].taps == 1 and op.keep[0].wgt_f16)
+    g32 = sum(1 for op in plan.ops if op.fn is lib.ds_conv2d_nhwc and op.keep[0].taps == 1 and not op.keep[0].wgt_f16)
+    a16 = sum(1 for op in plan.ops if op.fn is lib.ds_attention_f16)
+    a32 = sum(1 for op in plan.ops if op.fn is lib.ds_attention)
+    return g16, g32, a16, a32
+
+
 @pytest.mark.parametrize('name,B', [('cifar10', 4), ('imagenet64', 4), ('ffhq', 4)])
 def test_edm_use_fp16_within_bound_of_fp32_oracle_and_of_torch_autocast(name, B):
     from diff_sampler_amd import _lib
@@ -61,6 +70,9 @@ def test_edm_use_fp16_within_bound_of_fp32_oracle_and_of_torch_autocast(name, B)
     torch.cuda.synchronize()
     n16, n32 = _count_f16(net.engine.plan(B, B), _lib.load())
     assert n16 >= 20, (n16, n32)                      # the mode is really on: most 3x3 convolutions run with fp16 operands
+    g16, g32, a16, a32 = _count_f16_other(net.engine.plan(B, B), _lib.load())
+    if name == 'imagenet64':                          # 64-channel heads, 384 / 576 / 768-wide projections: all on the fp16 kernels
+        assert a16 > 0 and a32 == 0 and g16 > 0, (g16, g32, a16, a32)
     e32 = _rel(out.cpu(), ref32)
     assert e32 < 2e-2, e32
     p_dev = {k: v.to(dev) for k, v in params.items()}
@@ -71,7 +83,8 @@ def test_edm_use_fp16_within_bound_of_fp32_oracle_and_of_torch_autocast(name, B)
     assert e16 < 3e-2, e16
     net32 = EDMDenoiser(spec, params)
     e_fp32_engine = _rel(net32(x.to(dev), sig.to(dev), class_labels=(lab.to(dev) if lab is not None else None)).cpu(), ref32)
-    REPORT[name] = dict(batch=B, f16_convs=n16, fp32_convs=n32, hip_fp16_vs_fp32_oracle=e32, hip_fp16_vs_torch_autocast=e16,
+    REPORT[name] = dict(batch=B, f16_convs=n16, fp32_convs=n32, f16_linears=g16, fp32_linears=g32, f16_attention=a16, fp32_attention=a32,
+                        hip_fp16_vs_fp32_oracle=e32, hip_fp16_vs_torch_autocast=e16,
                         torch_autocast_vs_fp32_oracle=e_torch, hip_fp32_vs_fp32_oracle=e_fp32_engine)
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     json.dump(REPORT, open(os.path.join(ROOT, 'gpurun_out', 'fp16_parity.json'), 'w'), indent=1)
@@ -109,7 +122,11 @@ def test_sd15_autocast_mode_within_bound():
     plan = next(iter(n16.engine._plans.values()))
     k16, k32 = _count_f16(plan, lib)
     assert k16 >= 30, (k16, k32)
+    g16, g32, a16, a32 = _count_f16_other(plan, lib)
+    assert a16 == 32 and a32 == 0, (a16, a32)         # 16 transformer blocks x (self + cross attention), d = 40 / 80 / 160
+    assert g16 > 100, (g16, g32)                      # every Linear / 1x1 over the image rows; context and time projections stay fp32
     e = _rel(out, ref)
     assert e < 3e-2, e
-    REPORT['sd15'] = dict(batch=B, f16_convs=k16, fp32_convs=k32, hip_fp16_vs_hip_fp32=e)
+    REPORT['sd15'] = dict(batch=B, f16_convs=k16, fp32_convs=k32, f16_linears=g16, fp32_linears=g32, f16_attention=a16, fp32_attention=a32,
+                         hip_fp16_vs_hip_fp32=e)
     json.dump(REPORT, open(os.path.join(ROOT, 'gpurun_out', 'fp16_parity.json'), 'w'), indent=1)
