@@ -29,7 +29,7 @@ from ._lib import (AttnArgs, ConvArgs, GemmArgs, GnFinalizeArgs, NormArgs, DS_AC
 from .ops import pack_conv_weight, pack_linear_weight, pack_linear_weight_f16, pack_stem_weight
 
 
-from .plan import Op as _Op, Plan as _Plan, ptr as _ptr, SPLITK_WORKSPACE_FLOATS  # noqa: E402
+from .plan import Builder, Plan as _Plan, ptr as _ptr  # noqa: E402
 
 
 class UNetEngine:
@@ -132,13 +132,8 @@ class UNetEngine:
         if key in self._plans:
             return self._plans[key]
         spec, dev, w, lib = self.spec, self.device, self.w, self.lib
-        P = _Plan()
-        def new(*shape):
-            # The argument structs hold raw pointers: the plan must own every tensor they point into, otherwise the
-            # caching allocator would hand the memory to the next torch.empty() while the plan still uses it.
-            t = torch.empty(*shape, dtype=torch.float32, device=dev)
-            P.keep.append(t)
-            return t
+        bd = Builder(dev, conv_mode=self.conv_mode, w16_cache=self._w16_cache)      # owns the plan, its workspaces and the emitters
+        P, new = bd.P, bd.new
         R = spec.img_resolution
         Bs = emb_rows
         E, NC = spec.emb_channels, spec.noise_channels
@@ -174,82 +169,19 @@ class UNetEngine:
         hbuf = new(B * max_h)
         sres = new(B * max_h)            # resampled skip-path input
         sproj = new(B * max_h)           # projected skip
-        mean = new(B * 64); rstd = new(B * 64)
         ncoef = new(B * 3 * max(max(b.cin, b.cout) for b in spec.blocks))      # {mu, A, B} planes of the fused GroupNorm
         if max_attn:
             n2 = new(B * max_attn // 2); qk = new(B * max_attn // 2 * 3); ao = new(B * max_attn // 2)
         bufs.update(act=act, hbuf=hbuf, sres=sres, sproj=sproj)
-        gn_partial = torch.empty(B * _lib.DS_GN_MAX_CHUNKS * 128, dtype=torch.float64, device=dev)   # multi-workgroup GroupNorm
-        gn_counters = torch.zeros(B, dtype=torch.int32, device=dev)                                  # statistics at small batch
-        P.keep += [gn_partial, gn_counters]
-        stats_of: Dict[int, tuple] = {}               # data_ptr of an activation -> (epilogue column-sum buffer, channels)
-        splitk_ws = new(SPLITK_WORKSPACE_FLOATS)      # scratch of the split-K path (under-filled layers at small batch)
+        # ---- launch emitters: plan.Builder (shared with ldm_engine); thin adapters keep this file's argument names --------------
+        f16_level = bd.f16_level
+        add = bd.add
 
-        def add(fn, args, name, keep=()):
-            P.ops.append(_Op(fn, args, name, keep))
+        def conv(x0, c0, ld0, n, h, wd, wgt, cout, out, out_ld, taps, name, act_=DS_ACT_NONE, **kw):
+            bd.conv(x0, c0, ld0, n, h, wd, wgt, cout, out, out_ld, taps, name, act=act_, **kw)
 
-        def f16_level(n, h, wd, c0, c1, ec0, ec1):
-            """0 = this 3x3 layer stays fp32, 1 = fp16 operands on raw input, 2 = ... and with the fused input normalisation."""
-            if self.conv_mode == 0 or any(c % (64 if self.conv_mode == 1 else 32) for c in (c0, c1, ec0, ec1)):
-                return 0
-            fn = lib.ds_conv_f16_supported if self.conv_mode == 1 else lib.ds_conv_split_supported
-            return int(fn(n, h, wd, c0, c1, ec0, ec1))
-
-        def linear_w16(wgt, rows, c0, c1):
-            """fp16 packing (cached per weight) of a 1x1 layer where gemm_f16_kernel covers the shape, else the fp32 weights."""
-            if wgt.dim() != 2 or wgt.shape[0] % 128 or wgt.shape[1] != c0 + c1 or not lib.ds_gemm_f16_supported(rows, c0, c1):
-                return wgt, False
-            if wgt.data_ptr() not in self._w16_cache:
-                self._w16_cache[wgt.data_ptr()] = (pack_linear_weight_f16(wgt), wgt)
-            return self._w16_cache[wgt.data_ptr()][0], True
-
-        def conv(x0, c0, ld0, n, h, wd, wgt, cout, out, out_ld, taps, name, x1=None, c1=0, ld1=0, bias=None, cbias=None,
-                 cbias_ld=0, cbias_rows=1, res=None, res_ld=0, scale=1.0, act_=DS_ACT_NONE, norm_coefs=None, norm_act=DS_ACT_NONE,
-                 e0=None, ec0=0, e1=None, ec1=0, out_nchw=0, stats=False, w16=None):
-            f16 = w16 is not None and f16_level(n, h, wd, c0, c1, ec0, ec1) >= (2 if norm_coefs is not None else 1)
-            shift = 0
-            if f16:
-                wgt, shift = w16
-            elif self.conv_mode == 1 and taps == 1 and norm_coefs is None and not ec0 and not ec1 and not out_nchw:
-                wgt, f16 = linear_w16(wgt, n * h * wd, c0, c1)
-            a = ConvArgs(_ptr(x0), _ptr(x1), c0, c1, ld0, ld1, n, h, wd, taps, _ptr(wgt), cout, _ptr(bias), _ptr(cbias),
-                         cbias_ld, cbias_rows, _ptr(res), res_ld, scale, act_, _ptr(out), out_ld, _ptr(norm_coefs), norm_act,
-                         _ptr(e0), _ptr(e1), ec0, ec1, ec0, ec1)
-            a.workspace, a.workspace_floats = _ptr(splitk_ws), splitk_ws.numel()
-            a.out_nchw = out_nchw
-            a.wgt_f16, a.wgt_shift = (self.conv_mode, shift) if f16 else (0, 0)
-            stats_of.pop(out.data_ptr(), None)
-            if stats and cout % 64 == 0 and out_ld == cout:
-                # the epilogue leaves the output's per-(64-row block, channel) sums for the consumer's GroupNorm
-                sb = new(-(-(n * h * wd) // 64) * 2 * cout)
-                a.stats_out = _ptr(sb)
-                stats_of[out.data_ptr()] = (sb, cout)
-            add(lib.ds_conv2d_nhwc, (C.byref(a),), name, keep=(a,))
-
-        def norm(kind, x0, c0, ld0, n, h, wd, name, x1=None, c1=0, ld1=0, groups=1, eps=1e-5, use_stats=True, gamma=None,
-                 beta=None, scale=None, shift=None, ss_ld=0, ss_rows=1, act_=DS_ACT_NONE, resample=DS_RESAMPLE_NONE,
-                 out=None, out_ld=0, coefs=None):
-            a = NormArgs(_ptr(x0), _ptr(x1), c0, c1, ld0, ld1, n, h, wd, groups, eps,
-                         _ptr(mean) if use_stats else None, _ptr(rstd) if use_stats else None, _ptr(gamma), _ptr(beta),
-                         _ptr(scale), _ptr(shift), ss_ld, ss_rows, act_, resample, _ptr(out), out_ld, _ptr(coefs))
-            if kind == 'stats':
-                s0 = stats_of.get(x0.data_ptr())
-                s1 = stats_of.get(x1.data_ptr()) if x1 is not None else None
-                if s0 is not None and s0[1] == c0 == ld0 and (x1 is None or (s1 is not None and s1[1] == c1 == ld1)) and (h * wd) % 64 == 0:
-                    # statistics already produced by the convolutions that wrote these tensors: only finalise them
-                    f = GnFinalizeArgs(_ptr(s0[0]), _ptr(s1[0]) if s1 else None, c0, c1, n, h * wd, groups, eps, _ptr(gamma), _ptr(beta),
-                                       _ptr(scale), _ptr(shift), ss_ld, ss_rows, _ptr(mean), _ptr(rstd), _ptr(coefs))
-                    add(lib.ds_gn_finalize, (C.byref(f),), name + '.finalize', keep=(f,))
-                    return
-            if kind == 'stats' and n < 256:
-                a.partial, a.counters = _ptr(gn_partial), _ptr(gn_counters)
-            add(lib.ds_gn_stats if kind == 'stats' else lib.ds_norm_act, (C.byref(a),), name, keep=(a,))
-
-        def gemm(a_, lda, b_, ldb, c_, ldc, m_, n_, k_, name, batch=1, heads=1, a_bs=0, a_hs=0, b_bs=0, b_hs=0, c_bs=0, c_hs=0,
-                 alpha=1.0, rowbias=None, colbias=None):
-            g_ = GemmArgs(_ptr(a_), lda, a_bs, a_hs, _ptr(b_), ldb, b_bs, b_hs, _ptr(c_), ldc, c_bs, c_hs, m_, n_, k_, batch,
-                          heads, alpha, _ptr(rowbias), _ptr(colbias), DS_ACT_NONE)
-            add(lib.ds_gemm_nt_batched, (C.byref(g_),), name, keep=(g_,))
+        def norm(kind, x0, c0, ld0, n, h, wd, name, act_=DS_ACT_NONE, **kw):
+            bd.norm(kind, x0, c0, ld0, n, h, wd, name, act=act_, **kw)
 
         # ---- embedding path (networks_edm.py:314-324 / :429-439) -----------------------------------------------
         pos = new(Bs, NC); e0 = new(Bs, E); emb = new(Bs, E); aff = new(Bs, self.aff_total)

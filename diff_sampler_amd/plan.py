@@ -69,7 +69,7 @@ class Builder:
 
     def conv(self, x0, c0, ld0, n, h, w, wgt, cout, out, out_ld, taps, name, x1=None, c1=0, ld1=0, bias=None, cbias=None,
              cbias_ld=0, cbias_rows=1, res=None, res_ld=0, scale=1.0, act=DS_ACT_NONE, norm_coefs=None, norm_act=DS_ACT_NONE,
-             e0=None, ec0=0, e1=None, ec1=0, stride=1, stats=False, w16=None):
+             e0=None, ec0=0, e1=None, ec1=0, stride=1, stats=False, w16=None, out_nchw=0):
         """stats=True: the epilogue also leaves the output's per-(64-row block, channel) sums for the consumer's GroupNorm
         (honoured when cout % 64 == 0; otherwise the consumer falls back to a ds_gn_stats pass).
         w16: fp16 weights of the same layer (ops.pack_conv_weight_f16); used -- with the fp16-operand kernel -- when the
@@ -78,7 +78,7 @@ class Builder:
         shift = 0
         if f16:
             wgt, shift = w16
-        elif self.conv_mode == 1 and taps == 1 and stride == 1 and norm_coefs is None and not ec0 and not ec1:
+        elif self.conv_mode == 1 and taps == 1 and stride == 1 and norm_coefs is None and not ec0 and not ec1 and not out_nchw:
             wgt, f16 = self.linear_w16(wgt, n * h * w, c0, c1)
         a = ConvArgs(ptr(x0), ptr(x1), c0, c1, ld0, ld1, n, h, w, taps, ptr(wgt), cout, ptr(bias), ptr(cbias), cbias_ld,
                      cbias_rows, ptr(res), res_ld, scale, act, ptr(out), out_ld, ptr(norm_coefs), norm_act, ptr(e0), ptr(e1),
@@ -86,6 +86,7 @@ class Builder:
         if self.ws is None:
             self.ws = self.new(SPLITK_WORKSPACE_FLOATS)
         a.workspace, a.workspace_floats = ptr(self.ws), self.ws.numel()
+        a.out_nchw = out_nchw               # network output written channel-planar (NCHW) by the epilogue
         a.wgt_f16, a.wgt_shift = (self.conv_mode, shift) if f16 else (0, 0)
         self.stats_of.pop(out.data_ptr(), None)
         if stats and cout % 64 == 0 and out_ld == cout:

@@ -191,9 +191,15 @@ SOLVER_FNS = dict(euler='euler_sampler', heun='heun_sampler', dpm='dpm_2_sampler
 
 
 # ------------------------------------------------------------------------------------------------------------------
-def create_model(dataset_name=None, model_path=None, random_init=False, device=None, seed=0, guidance_type=None, guidance_rate=None):
+def create_model(dataset_name=None, model_path=None, random_init=False, device=None, seed=0, guidance_type=None, guidance_rate=None,
+                 use_fp16=False):
     """EDM networks (cifar10 / ffhq / afhqv2 / imagenet64; sample.py:80-85) -> (net, 'edm'); Stable Diffusion v1.x latent
-    U-Net under classifier-free guidance (ms_coco; sample.py:111-116) -> (net, 'ldm')."""
+    U-Net under classifier-free guidance (ms_coco; sample.py:111-116) -> (net, 'ldm').
+
+    use_fp16: the fp16-operand kernels (fp32 accumulation and storage).  The reference leaves `--use_fp16` unwired
+    (sample.py:188-189): an EDM checkpoint's own `use_fp16` attribute decides (ImageNet-64 ADM: True) and the LDM sampler always runs
+    under autocast (sample.py:296).  Here True selects that arithmetic; False (default) is exact fp32 for random-init / LDM nets and
+    "follow the checkpoint" for a loaded EDM pickle."""
     from . import arch
     from .engine import EDMDenoiser
     if dataset_name == 'ms_coco':
@@ -208,16 +214,16 @@ def create_model(dataset_name=None, model_path=None, random_init=False, device=N
             sd = sd.get('state_dict', sd)
             pre = 'model.diffusion_model.'
             params = {k[len(pre):]: v.float() for k, v in sd.items() if k.startswith(pre)}
-        return CFGDenoiser(spec, params, device, guidance_rate=(7.5 if guidance_rate is None else guidance_rate)), 'ldm'
+        return CFGDenoiser(spec, params, device, guidance_rate=(7.5 if guidance_rate is None else guidance_rate), use_fp16=bool(use_fp16)), 'ldm'
     if dataset_name not in arch.NAMED_CONFIGS:
         raise ValueError(f'dataset {dataset_name!r}: only the EDM networks are in scope of the HIP engine '
                          f'({sorted(k for k in arch.NAMED_CONFIGS if not k.startswith("tiny"))} and ms_coco); CM / ADM-classifier-guided / LSUN-LDM models run on the reference')
     if random_init or model_path is None:
-        net = EDMDenoiser.from_config(dataset_name, seed=seed, device=device)
+        net = EDMDenoiser.from_config(dataset_name, seed=seed, device=device, use_fp16=bool(use_fp16))
     else:
         with open(model_path, 'rb') as f:       # needs the reference's torch_utils/dnnlib importable for unpickling
             ref = pickle.load(f)['ema']
-        net = EDMDenoiser.from_reference_module(ref, device=device)
+        net = EDMDenoiser.from_reference_module(ref, device=device, use_fp16=(True if use_fp16 else None))
     net.sigma_min, net.sigma_max = 0.002, 80.0
     return net, 'edm'
 
@@ -335,7 +341,8 @@ def run(dataset_name=None, max_batch_size=64, seeds='0-63', grid=False, outdir=N
         raise ValueError('--dataset_name is required (or --predictor_path, which carries it)')
     net, solver_kwargs['model_source'] = create_model(dataset_name, model_path, random_init, device,
                                                       guidance_type=solver_kwargs.get('guidance_type'),
-                                                      guidance_rate=solver_kwargs.get('guidance_rate'))
+                                                      guidance_rate=solver_kwargs.get('guidance_rate'),
+                                                      use_fp16=solver_kwargs.get('use_fp16', False))
     ldm = solver_kwargs['model_source'] == 'ldm'
     cond_table = None
     if ldm and solver_kwargs.get('condition_path'):

@@ -111,3 +111,17 @@ def test_sample_run_amed_random_predictor_plugin(tmp_path):
     assert n == 4 and len(_read(out)) == 4
     with pytest.raises(ValueError):
         sample.run('tiny_song_amed', predictor_path='random:7', seeds='0-1', outdir=str(tmp_path / 'q'), random_init=False, solver='amed')
+
+
+def test_sample_run_use_fp16_flag_selects_the_fp16_kernels(tmp_path):
+    """--use_fp16=True (left unwired in the reference, sample.py:188-189): the CIFAR-10 net on the fp16-operand kernels; images equal
+    the fp32 run up to fp16 operand rounding (a few grey levels on a handful of pixels)."""
+    from diff_sampler_amd import sample
+    kw = dict(max_batch_size=4, seeds='0-3', solver='ipndm', num_steps=6, max_order=3, random_init=True)
+    a, _ = sample.run('cifar10', outdir=str(tmp_path / 'f32'), **kw)
+    b, _ = sample.run('cifar10', outdir=str(tmp_path / 'f16'), use_fp16=True, **kw)
+    ia, ib = _read(a), _read(b)
+    assert sorted(ia) == sorted(ib) == [0, 1, 2, 3]
+    diff = np.stack([np.abs(ia[k].astype(np.int32) - ib[k].astype(np.int32)) for k in ia])
+    assert diff.max() <= 8 and (diff > 1).mean() < 0.05, (diff.max(), (diff > 1).mean())
+    assert diff.max() > 0                       # it is a different arithmetic, not the same kernels again
