@@ -66,32 +66,39 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
         const bool geglu = (MODE == 0) && p.act == DS_ACT_GEGLU;      // columns [0,32) of the wave tile: values, [32,64): their gates
         f32x4 cbg = {0.f, 0.f, 0.f, 0.f};
         if (geglu && p.colbias && c4 < 32) cbg = *reinterpret_cast<const f32x4*>(p.colbias + col + 32);
+        // Residual rows and the per-image bias of a whole group of 8 passes (32 rows) are requested BEFORE the tile goes through
+        // LDS: one memory latency per group instead of one per unrolled quartet of passes, and no per-row integer division where
+        // the rows of a group belong to one image (H*W a multiple of 32: every convolution; Linear layers have H*W = 1).
+        constexpr int NP = 8;
+        const bool cb_uniform = p.cbias && (p.cbias_bcast || p.HW % 32 == 0);
+        f32x4 rv[NP], cvu = {0.f, 0.f, 0.f, 0.f};
+        auto prefetch = [&](int rbase) {
+            if (p.res) {
 #pragma unroll
-        for (int half = 0; half < (HALF ? 2 : 1); ++half) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (HALF && i != half) continue;
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        stage[((HALF ? 0 : i * 32) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_LD + j * 32 + (lane & 31)] = acc[i][j][r];
+                for (int pass = 0; pass < NP; ++pass) {
+                    const int row = min(rbase + pass * 4 + (lane >> 4), p.M - 1);
+                    rv[pass] = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.res_ld + col);
+                }
             }
-#pragma unroll 4
-            for (int pass = 0; pass < (HALF ? 8 : 16); ++pass) {
-                const int rr = pass * 4 + (lane >> 4);
-                const int row = wm0 + (HALF ? half * 32 : 0) + rr;
+            if (cb_uniform) {
+                const int img = p.cbias_bcast ? 0 : __builtin_amdgcn_readfirstlane(min(rbase, p.M - 1)) / p.HW;
+                cvu = *reinterpret_cast<const f32x4*>(p.cbias + (size_t)img * p.cbias_ld + col);
+            }
+        };
+        auto process = [&](int rr0, int rbase) {                        // rows rbase .. rbase + 31 = staging rows rr0 .. rr0 + 31
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
+                const int rr = rr0 + pass * 4 + (lane >> 4);
+                const int row = rbase + pass * 4 + (lane >> 4);
                 if (row >= p.M) continue;
                 f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * EPI_LD + c4);
                 if (MODE == 0) v *= p.acc_scale;
                 if (MODE == 1) v *= p.scale;
                 v += cb;
                 if (p.rowbias) v += p.rowbias[row];
-                if (p.cbias) {
-                    const int img = p.cbias_bcast ? 0 : row / p.HW;
-                    v += *reinterpret_cast<const f32x4*>(p.cbias + (size_t)img * p.cbias_ld + col);
-                }
-                if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.res_ld + col);
+                if (cb_uniform) v += cvu;
+                else if (p.cbias) v += *reinterpret_cast<const f32x4*>(p.cbias + (size_t)(row / p.HW) * p.cbias_ld + col);
+                if (p.res) v += rv[pass];
                 if (MODE == 0) v *= p.scale;
                 if (geglu) {
                     if (c4 < 32) {
@@ -108,6 +115,24 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
                 }
                 *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col) = v;
                 st_s += v; st_q += v * v;
+            }
+        };
+#pragma unroll
+        for (int half = 0; half < (HALF ? 2 : 1); ++half) {
+            prefetch(wm0 + half * 32);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (HALF && i != half) continue;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        stage[((HALF ? 0 : i * 32) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_LD + j * 32 + (lane & 31)] = acc[i][j][r];
+            }
+            process(0, wm0 + half * 32);
+            if (!HALF) {                                                // 4-wave tiles stage all 64 rows at once: second group
+                prefetch(wm0 + 32);
+                process(32, wm0 + 32);
             }
         }
         if (p.stats && wm0 < p.M) {
