@@ -74,16 +74,20 @@ constexpr int VAR_PIPE = 1, VAR_NO_NORM = 2, VAR_NO_HALO = 4, VAR_NO_DMA = 8, VA
 // WN = wave columns: 2 = 128 output channels per tile (the normal shape), 1 = 64 (launched only for the ragged last
 // column tile of layers whose channel count is not a multiple of 128 -- 192, 320, 576 ... -- and for the few-channel
 // output conv, instead of multiplying a half-empty 128-wide tile; it starts at column p.n_begin).
-template <int WM, bool GLDS, int WN, int VAR = 0>
+// NT = 32-column MFMA tiles per wave: 2 = 64 x 64 per wave (the normal shape), 4 = 64 x 128 per wave, i.e. a 256-pixel x 256-channel
+// tile for the 8-wave shape: the halo of a slab is staged (normalised, SiLU'd) once for 256 output channels instead of twice, a K step
+// reads 6 fragments for 32 MFMAs instead of 4 for 16, and a tap has 128 MFMAs per wave between barriers (128 accumulator registers).
+template <int WM, bool GLDS, int WN, int VAR = 0, int NT = 2>
 __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KParams p) {
+    static_assert(NT == 2 || (NT == 4 && WM == 4 && WN == 2 && GLDS && VAR == 0), "wide-N tiles: 8-wave LDS-DMA shape only");
     constexpr bool PIPE = (VAR & VAR_PIPE) != 0;
     static_assert(!PIPE || GLDS, "the pipelined tap loop reads the LDS-DMA weight image");
     constexpr int T = 64 * WM * WN;        // threads
     constexpr int TBM = 64 * WM;           // output pixels per tile
-    constexpr int BNT = 64 * WN;           // output channels per tile
+    constexpr int BNT = 32 * NT * WN;      // output channels per tile
     constexpr int BROWS = BNT * 8 / T;     // weight float4 per thread per tap (4 or 2)
     constexpr int BLD = GLDS ? 32 : LDSK;  // floats per weight row in LDS
-    constexpr int NS_MAX = ns_max(WN);
+    constexpr int NS_MAX = (NT == 4) ? 6 : ns_max(WN);      // wide-N tiles: 16- and 32-column images only (6 slots per thread)
     constexpr int B_FLOATS = 2 * BNT * LDSK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Bs = smem;                               // [2][BNT][LDSK]
@@ -218,13 +222,14 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][2];                                // columns 0..63 of the wave tile
+    f32x16 acc_hi[2][2];                             // columns 64..127 (NT == 4 only; two plain arrays so that both stay in registers)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acc_hi[i][j][r] = 0.f; }
 
     const int NCH_all = nchunks + nextra;            // slabs: 3x3 ones (9 taps each) then 1x1 ones (centre tap only)
     // split-K: this block contracts slabs [c_begin, NCH) only (splits == 1: everything)
@@ -251,7 +256,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
     __syncthreads();
 
     // weight fragment offsets: padded rows (register staging) or swizzled 16-B chunks (LDS-DMA)
-    const int b_row = wc * 64 + (lane & 31);
+    const int b_row = wc * 32 * NT + (lane & 31);
     const int b_swz = ((lane & 31) >> 1) & 7;
     auto b_frag = [&](int ks) -> int {
         return GLDS ? b_row * 32 + (((ks * 2 + (lane >> 5)) ^ b_swz) * 4) : b_row * LDSK + (lane >> 5) * 4 + ks * 8;
@@ -352,19 +357,32 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
             for (int ks = 0; ks < 4; ++ks) {
                 const f32x4 a0 = *reinterpret_cast<const f32x4*>(as0 + ks * 8);
                 const f32x4 a1 = *reinterpret_cast<const f32x4*>(as1 + ks * 8);
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bs + b_frag(ks));
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bs + 32 * BLD + b_frag(ks));
                 // register staging: the weight loads ride in the shadow of the MFMA groups
                 if (!GLDS) {
                     if (BROWS == 4) rb[ks] = *reinterpret_cast<const f32x4*>(b_addr(nxt, ks));
                     else if (ks < BROWS) rb[ks] = *reinterpret_cast<const f32x4*>(b_addr(nxt, ks));
                 }
+                {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bs + b_frag(ks));
+                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(bs + 32 * BLD + b_frag(ks));
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[r], b0[r], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[r], b1[r], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], b0[r], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], b1[r], acc[1][1], 0, 0, 0);
+                    for (int r = 0; r < 4; ++r) {
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[r], b0[r], acc[0][0], 0, 0, 0);
+                        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[r], b1[r], acc[0][1], 0, 0, 0);
+                        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], b0[r], acc[1][0], 0, 0, 0);
+                        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], b1[r], acc[1][1], 0, 0, 0);
+                    }
+                }
+                if constexpr (NT == 4) {                        // second 64-column half: 2 + 2 fragments live at a time
+                    const f32x4 b2 = *reinterpret_cast<const f32x4*>(bs + 64 * BLD + b_frag(ks));
+                    const f32x4 b3 = *reinterpret_cast<const f32x4*>(bs + 96 * BLD + b_frag(ks));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc_hi[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[r], b2[r], acc_hi[0][0], 0, 0, 0);
+                        acc_hi[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[r], b3[r], acc_hi[0][1], 0, 0, 0);
+                        acc_hi[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], b2[r], acc_hi[1][0], 0, 0, 0);
+                        acc_hi[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], b3[r], acc_hi[1][1], 0, 0, 0);
+                    }
                 }
             }
             if (!GLDS) b_store(cur ^ 1);
@@ -393,7 +411,10 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
         epilogue<0, HALF>(q, acc, smem + wave * (HALF ? 32 : 64) * EPI_LD, lane, m0 + wr * 64, n0 + wc * 64, q.out);
         return;
     }
-    epilogue<0, HALF>(p, acc, smem + wave * (HALF ? 32 : 64) * EPI_LD, lane, m0 + wr * 64, n0 + wc * 64, p.out);
+    // one 64-column half of the wave tile at a time through the wave's private staging rows
+    epilogue<0, HALF>(p, acc, smem + wave * (HALF ? 32 : 64) * EPI_LD, lane, m0 + wr * 64, n0 + wc * 32 * NT, p.out);
+    if constexpr (NT == 4)
+        epilogue<0, HALF>(p, acc_hi, smem + wave * (HALF ? 32 : 64) * EPI_LD, lane, m0 + wr * 64, n0 + wc * 32 * NT + 64, p.out);
 }
 
 struct Geo { int TH, nimg, NP; bool ok; };
@@ -415,10 +436,21 @@ int g_glds = 1;                // weight staging: 1 = LDS-DMA, 0 = through regis
 int g_variant = 0;             // kernel variant of the 128-column LDS-DMA tiles (see VAR_*; benchmarks / ablations)
 int g_tail64 = 1;              // 64-column tiles for a ragged last column tile (A/B switch)
 
-template <int WM, bool GLDS, int WN, int VAR = 0>
+// 256-pixel x 256-channel tiles (64 x 128 per wave, NT = 4) instead of 256 x 128: taken where the channel count is a multiple of 256,
+// the image is 16 or 32 columns wide (6 halo slots per thread: the kernel sits at 255 VGPRs), there is no split-K, and the tiles
+// still give every CU a workgroup.  Measured +4.1 ... +4.5 % on the CIFAR-10 / FFHQ 32x32 and 16x16 layers (129 -> 136 TFLOP/s
+// network average, profiles/r2_conv_wide_n.txt).  g_variant 7 switches it off (A/B runs), 6 forces it regardless of the tile count.
+bool wide_n_tiles(const KParams& p, const Geo& g) {
+    if (g_variant != 0 && g_variant != 6) return false;
+    if (p.splits != 1 || p.N % 256 || p.W > 32 || g.NP * 8 > 6 * 512 || g.nimg != 1) return false;
+    const long long blocks = (long long)((p.M + 255) / 256) * (p.N / 256);
+    return g_variant == 6 || blocks >= 256;
+}
+
+template <int WM, bool GLDS, int WN, int VAR = 0, int NT = 2>
 int launch_one(KParams p, const Geo& g, int n_begin, int ntiles, hipStream_t stream) {
     constexpr int TBM = 64 * WM;
-    constexpr int B_BYTES = 2 * 64 * WN * LDSK * (int)sizeof(float);
+    constexpr int B_BYTES = 2 * 32 * NT * WN * LDSK * (int)sizeof(float);
     p.TH = g.TH; p.nimg = g.nimg; p.HP = g.TH + 2; p.WP = p.W + 2; p.NP = g.NP;
     p.mtiles = (p.M + TBM - 1) / TBM;
     p.ntiles = ntiles;
@@ -428,12 +460,12 @@ int launch_one(KParams p, const Geo& g, int n_begin, int ntiles, hipStream_t str
     if (smem < epi) smem = epi;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, GLDS, WN, VAR>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, GLDS, WN, VAR, NT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_halo_kernel<WM, GLDS, WN, VAR>), dim3(grid_1d(p.mtiles, p.ntiles), p.splits), dim3(64 * WM * WN), smem, stream, p);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<WM, GLDS, WN, VAR, NT>), dim3(grid_1d(p.mtiles, p.ntiles), p.splits), dim3(64 * WM * WN), smem, stream, p);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }
@@ -451,6 +483,9 @@ int launch_wm(KParams& p, hipStream_t stream) {
         if (WM == 4 && GLDS && g_variant == 3 && p.splits == 1 && conv3x3_halo2_applicable(p, wide, 0)) {
             KParams q = p;
             rc = launch_conv3x3_halo2(q, wide, 0, stream);
+        } else if (WM == 4 && GLDS && wide_n_tiles(p, g)) {
+            if constexpr (WM == 4 && GLDS) rc = launch_one<4, true, 2, 0, 4>(p, g, 0, p.N / 256, stream);     // 256 x 256 tiles
+            else rc = DS_E_SHAPE;
         } else if constexpr (GLDS) {
             switch (g_variant) {
                 case 1: rc = launch_one<WM, GLDS, 2, 1>(p, g, 0, wide, stream); break;
@@ -511,7 +546,17 @@ HaloPlan plan_halo(const KParams& p) {
     return hp;
 }
 
-int conv3x3_halo_choice(const KParams& p) { return plan_halo(p).tile; }   // 0 = unsupported, 128 / 256 = M tile
+// 0 = unsupported, 128 / 256 = M tile of the 128-column kernels, 2565 = the 256 x 256-tile kernel
+int conv3x3_halo_choice(const KParams& p) {
+    const HaloPlan hp = plan_halo(p);
+    if (hp.tile == 256 && g_glds) {
+        KParams q = p;
+        q.splits = hp.splits;
+        const int full = p.N / BN, rem = p.N - full * BN;
+        if (rem == 0 && wide_n_tiles(q, geometry(p, 256, 2))) return 2565;
+    }
+    return hp.tile;
+}
 
 int launch_conv3x3_halo(KParams& p, hipStream_t stream) {
     const HaloPlan hp = plan_halo(p);

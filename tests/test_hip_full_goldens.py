@@ -42,7 +42,8 @@ def test_headline_sampler_b64_matches_reference_and_uses_the_256_tile_kernel(dev
                                  max_order=2, predict_x0=True, lower_order_final=True)
     torch.cuda.synchronize()
     assert _rel(out.cpu(), torch.from_numpy(z['out'])) < 5e-4
-    # which kernel ran: every 3x3 layer at 32x32 with a multiple-of-128 channel count must be on the 256-pixel tile (kernel <4>)
+    # which kernel ran: every 3x3 layer at 32x32 with a multiple-of-128 channel count must be on the 256-pixel tile -- the 8-wave
+    # kernel <4>: 256 = its 128-column tiles, 2565 = its 256-column tiles (the benchmarked kernel at 256 output channels)
     lib = _lib.load()
     plan = net.engine.plan(64, 1)
     ids = []
@@ -51,7 +52,7 @@ def test_headline_sampler_b64_matches_reference_and_uses_the_256_tile_kernel(dev
             a = op.keep[0]
             if a.taps == 9 and a.h == 32 and a.cout % 128 == 0:
                 ids.append(lib.ds_conv_kernel_id(C.byref(a)))
-    assert len(ids) >= 20 and all(i == 256 for i in ids), ids
+    assert len(ids) >= 20 and all(i in (256, 2565) for i in ids) and sum(i == 2565 for i in ids) >= 20, ids
 
 
 @pytest.mark.parametrize('name', ['ffhq', 'imagenet64'])
