@@ -442,8 +442,8 @@ int g_tail64 = 1;              // 64-column tiles for a ragged last column tile 
 // network average, profiles/r2_conv_wide_n.txt).  g_variant 7 switches it off (A/B runs), 6 forces it regardless of the tile count.
 bool wide_n_tiles(const KParams& p, const Geo& g) {
     if (g_variant != 0 && g_variant != 6) return false;
-    if (p.splits != 1 || p.N % 256 || p.W > 32 || g.NP * 8 > 6 * 512 || g.nimg != 1) return false;
-    const long long blocks = (long long)((p.M + 255) / 256) * (p.N / 256);
+    if (p.splits != 1 || p.N < 256 || p.W > 32 || g.NP * 8 > 6 * 512 || g.nimg != 1) return false;
+    const long long blocks = (long long)((p.M + 255) / 256) * (p.N / 256);       // the 256-column tiles (a remainder keeps 128 / 64-column tiles)
     return g_variant == 6 || blocks >= 256;
 }
 
@@ -474,21 +474,30 @@ int launch_one(KParams p, const Geo& g, int n_begin, int ntiles, hipStream_t str
 // 64-column tiles for them (WN = 1); the split-K partial planes are shared and reduced once.
 template <int WM, bool GLDS>
 int launch_wm(KParams& p, hipStream_t stream) {
-    const int full = p.N / BN, rem = p.N - full * BN;
+    // columns [0, n256): 256-column tiles of the 8-wave kernel where they apply (channel counts such as 384 = 256 + 128,
+    // 576 = 2 x 256 + 64, 320 = 256 + 64 get them for their first 256-multiples); the rest as before from column n256 on
+    int n256 = 0;
+    if constexpr (WM == 4 && GLDS) {
+        const Geo g4 = geometry(p, 256, 2);
+        if (wide_n_tiles(p, g4)) {
+            n256 = (p.N / 256) * 256;
+            int rc = launch_one<4, true, 2, 0, 4>(p, g4, 0, n256 / 256, stream);
+            if (rc) return rc;
+        }
+    }
+    const int nrest = p.N - n256;
+    const int full = nrest / BN, rem = nrest - full * BN;
     const bool tail64 = rem > 0 && rem <= 64 && geometry(p, 64 * WM, 1).ok && g_tail64;
-    const int wide = tail64 ? full : (p.N + BN - 1) / BN;
+    const int wide = tail64 ? full : (nrest + BN - 1) / BN;
     if (wide > 0) {
         const Geo g = geometry(p, 64 * WM, 2);
         int rc;
-        if (WM == 4 && GLDS && g_variant == 3 && p.splits == 1 && conv3x3_halo2_applicable(p, wide, 0)) {
+        if (WM == 4 && GLDS && g_variant == 3 && p.splits == 1 && n256 == 0 && conv3x3_halo2_applicable(p, wide, 0)) {
             KParams q = p;
             rc = launch_conv3x3_halo2(q, wide, 0, stream);
-        } else if (WM == 4 && GLDS && wide_n_tiles(p, g)) {
-            if constexpr (WM == 4 && GLDS) rc = launch_one<4, true, 2, 0, 4>(p, g, 0, p.N / 256, stream);     // 256 x 256 tiles
-            else rc = DS_E_SHAPE;
         } else if constexpr (GLDS) {
             switch (g_variant) {
-                case 1: rc = launch_one<WM, GLDS, 2, 1>(p, g, 0, wide, stream); break;
+                case 1: rc = launch_one<WM, GLDS, 2, 1>(p, g, n256, wide, stream); break;
 #ifdef DS_CONV_ABLATIONS
                 case 2: rc = launch_one<WM, GLDS, 2, 2>(p, g, 0, wide, stream); break;
                 case 4: rc = launch_one<WM, GLDS, 2, 4>(p, g, 0, wide, stream); break;
@@ -499,15 +508,15 @@ int launch_wm(KParams& p, hipStream_t stream) {
                 case 17: rc = launch_one<WM, GLDS, 2, 17>(p, g, 0, wide, stream); break;
                 case 29: rc = launch_one<WM, GLDS, 2, 29>(p, g, 0, wide, stream); break;
 #endif
-                default: rc = launch_one<WM, GLDS, 2, 0>(p, g, 0, wide, stream); break;
+                default: rc = launch_one<WM, GLDS, 2, 0>(p, g, n256, wide, stream); break;
             }
         } else {
-            rc = launch_one<WM, GLDS, 2>(p, g, 0, wide, stream);
+            rc = launch_one<WM, GLDS, 2>(p, g, n256, wide, stream);
         }
         if (rc) return rc;
     }
     if (tail64) {
-        int rc = launch_one<WM, GLDS, 1>(p, geometry(p, 64 * WM, 1), full * BN, 1, stream);
+        int rc = launch_one<WM, GLDS, 1>(p, geometry(p, 64 * WM, 1), n256 + full * BN, 1, stream);
         if (rc) return rc;
     }
     if (p.splits > 1) return launch_splitk_reduce(p, stream);
@@ -552,8 +561,7 @@ int conv3x3_halo_choice(const KParams& p) {
     if (hp.tile == 256 && g_glds) {
         KParams q = p;
         q.splits = hp.splits;
-        const int full = p.N / BN, rem = p.N - full * BN;
-        if (rem == 0 && wide_n_tiles(q, geometry(p, 256, 2))) return 2565;
+        if (wide_n_tiles(q, geometry(p, 256, 2))) return 2565;         // (its first N / 256 column tiles; a remainder stays on 128 / 64 columns)
     }
     return hp.tile;
 }
