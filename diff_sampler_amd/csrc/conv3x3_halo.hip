@@ -552,6 +552,7 @@ HaloPlan plan_halo(const KParams& p) {
         const int s256 = choose_splits(blocks256, true, units, 9, cap, mn, &c256);
         if (g_tile_override == 256 || 0.97 * c256 < c128) { hp.tile = 256; hp.splits = s256; }
     }
+    if (g_variant == 6 && hp.tile == 256) hp.splits = 1;      // forced 256 x 256 tiles (tests at small sizes): no split-K
     return hp;
 }
 

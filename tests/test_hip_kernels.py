@@ -420,10 +420,9 @@ HALO2_CASES = [
 ]
 
 
-@pytest.mark.parametrize('case', HALO2_CASES)
-def test_conv_halo2_kernel_matches_aten(case):
-    """Second-generation 256 x 128 halo kernel (conv3x3_halo2.hip), routed by ds_debug_conv_variant(3) with the 256-pixel tile
-    forced; the routing itself is asserted through the launch counter."""
+def _run_halo_case(case, variant):
+    """One fused 3x3 layer (dual source, fused normalisation + SiLU, 1x1 skip columns, bias, per-image bias, residual, scale,
+    epilogue statistics) through ds_conv2d_nhwc with the 256-pixel tile forced and the given kernel variant; checked against ATen."""
     import ctypes as C
     from diff_sampler_amd import _lib, ops
     B, H, c0, c1, cout, (ec0, ec1), use_norm, act = case
@@ -468,21 +467,50 @@ def test_conv_halo2_kernel_matches_aten(case):
     a.stats_out = stats.data_ptr()
     before = lib.ds_debug_conv_halo2_launches()
     lib.ds_debug_force_generic_conv(256)
-    lib.ds_debug_conv_variant(3)
+    lib.ds_debug_conv_variant(variant)
     try:
+        kid = lib.ds_conv_kernel_id(C.byref(a))
         rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
         torch.cuda.synchronize()
     finally:
         lib.ds_debug_force_generic_conv(0)
         lib.ds_debug_conv_variant(0)
     assert rc == 0, lib.ds_error_string(rc)
-    assert lib.ds_debug_conv_halo2_launches() == before + 1, 'the layer was not routed to the second-generation kernel'
+    if variant == 3:
+        assert lib.ds_debug_conv_halo2_launches() == before + 1, 'the layer was not routed to the second-generation kernel'
+    if variant == 6:
+        assert kid == 2565, 'the layer was not routed to the 256 x 256-tile kernel'
     want = _nhwc(ref)
     assert _rel(out.cpu(), want) < TOL
     if cout % 64 == 0:       # the epilogue's per-(64-row block, channel) sums feed the consumer's GroupNorm
         st = stats.cpu().reshape(-1, 2, cout)
         blocks = want.reshape(-1, 64, cout)
         assert _rel(st[:, 0], blocks.sum(1)) < 1e-4 and _rel(st[:, 1], (blocks ** 2).sum(1)) < 1e-4
+
+
+@pytest.mark.parametrize('case', HALO2_CASES)
+def test_conv_halo2_kernel_matches_aten(case):
+    """Second-generation 256 x 128 halo kernel (conv3x3_halo2.hip), routed by ds_debug_conv_variant(3) with the 256-pixel tile
+    forced; the routing itself is asserted through the launch counter."""
+    _run_halo_case(case, 3)
+
+
+WIDE_N_CASES = [
+    # B, H(=W), c0, c1, cout, (ec0, ec1), norm, act
+    (1, 32, 32, 0, 256, (0, 0), False, False),         # one 256-column tile per row tile
+    (2, 16, 64, 32, 256, (0, 0), True, True),          # dual source, fused normalisation
+    (1, 32, 64, 0, 512, (32, 0), True, True),          # two 256-column tiles, fused 1x1 skip columns
+    (2, 32, 32, 32, 384, (64, 32), True, False),       # 384 = 256 + 128: second launch of 128-column tiles from column 256
+    (1, 16, 96, 0, 320, (0, 0), True, True),           # 320 = 256 + 64: 64-column tail tiles from column 256
+    (3, 16, 288, 0, 576, (0, 0), False, False),        # 576 = 2 x 256 + 64, nine slabs
+]
+
+
+@pytest.mark.parametrize('case', WIDE_N_CASES)
+def test_conv_wide_n_tiles_match_aten(case):
+    """conv3x3_halo_kernel<4, NT = 4>: 256-pixel x 256-channel tiles (64 x 128 per wave) for the 256-multiples of the channel
+    count, the remainder on 128- / 64-column tiles of the same layer (ds_debug_conv_variant(6) forces the shape at test sizes)."""
+    _run_halo_case(case, 6)
 
 
 F16_CASES = [
