@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
     constexpr int BNT = 32 * NT * WN;      // output channels per tile
     constexpr int BROWS = BNT * 8 / T;     // weight float4 per thread per tap (4 or 2)
     constexpr int BLD = GLDS ? 32 : LDSK;  // floats per weight row in LDS
-    constexpr int NS_MAX = (NT == 4) ? 6 : ns_max(WN);      // wide-N tiles: 16- and 32-column images only (6 slots per thread)
+    constexpr int NS_MAX = (NT == 4) ? 7 : ns_max(WN);      // wide-N tiles: one image per tile, at most 7 slots per thread (64-column images)
     constexpr int B_FLOATS = 2 * BNT * LDSK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Bs = smem;                               // [2][BNT][LDSK]
@@ -436,13 +436,13 @@ int g_glds = 1;                // weight staging: 1 = LDS-DMA, 0 = through regis
 int g_variant = 0;             // kernel variant of the 128-column LDS-DMA tiles (see VAR_*; benchmarks / ablations)
 int g_tail64 = 1;              // 64-column tiles for a ragged last column tile (A/B switch)
 
-// 256-pixel x 256-channel tiles (64 x 128 per wave, NT = 4) instead of 256 x 128: taken where the channel count is a multiple of 256,
-// the image is 16 or 32 columns wide (6 halo slots per thread: the kernel sits at 255 VGPRs), there is no split-K, and the tiles
-// still give every CU a workgroup.  Measured +4.1 ... +4.5 % on the CIFAR-10 / FFHQ 32x32 and 16x16 layers (129 -> 136 TFLOP/s
+// 256-pixel x 256-channel tiles (64 x 128 per wave, NT = 4) instead of 256 x 128: taken where the channel count reaches 256, the
+// tile lies in one image (16-, 32- or 64-column images: at most 7 halo slots per thread -- the kernel sits at 256 VGPRs), there is
+// no split-K, and the tiles still give every CU a workgroup.  Measured +4.1 ... +4.5 % on the CIFAR-10 / FFHQ 32x32 and 16x16 layers (129 -> 136 TFLOP/s
 // network average, profiles/r2_conv_wide_n.txt).  g_variant 7 switches it off (A/B runs), 6 forces it regardless of the tile count.
 bool wide_n_tiles(const KParams& p, const Geo& g) {
     if (g_variant != 0 && g_variant != 6) return false;
-    if (p.splits != 1 || p.N < 256 || p.W > 32 || g.NP * 8 > 6 * 512 || g.nimg != 1) return false;
+    if (p.splits != 1 || p.N < 256 || g.NP * 8 > 7 * 512 || g.nimg != 1) return false;
     const long long blocks = (long long)((p.M + 255) / 256) * (p.N / 256);       // the 256-column tiles (a remainder keeps 128 / 64-column tiles)
     return g_variant == 6 || blocks >= 256;
 }

@@ -503,6 +503,7 @@ WIDE_N_CASES = [
     (2, 32, 32, 32, 384, (64, 32), True, False),       # 384 = 256 + 128: second launch of 128-column tiles from column 256
     (1, 16, 96, 0, 320, (0, 0), True, True),           # 320 = 256 + 64: 64-column tail tiles from column 256
     (3, 16, 288, 0, 576, (0, 0), False, False),        # 576 = 2 x 256 + 64, nine slabs
+    (1, 64, 32, 32, 320, (32, 0), True, True),         # W = 64 (7 halo slots per thread), SD-1.5's 320 channels
 ]
 
 
