@@ -66,6 +66,14 @@ __device__ __forceinline__ unsigned lds_addr(const float* p) {
 // arithmetic in the halo writer, 4 = the halo is staged once and never again, 8 = the weight DMA is issued once and never
 // again, 16 = the epilogue stores nothing.
 constexpr int VAR_PIPE = 1, VAR_NO_NORM = 2, VAR_NO_HALO = 4, VAR_NO_DMA = 8, VAR_NO_EPI = 16;
+// Round-2 options of the 256 x 256 tile (NT = 4), A/B-selectable through ds_debug_conv_variant (bits 5 and 7; bits 8..15 of the
+// variant word = KParams::stagger_us):
+//   VAR_LEAN  the weight DMA of a tap is addressed as (uniform SGPR base of the tap and row group) + (ONE constant 32-bit per-lane
+//             offset) with the LDS destination computed on the scalar unit: the compiled loop otherwise spends 22 VALU instructions
+//             per tap on 64-bit pointer arithmetic, zero-page selects and v_readfirstlane of a wave-uniform value, and on this chip
+//             a VALU instruction costs ~3.3 cycles of fp32-matrix issue time (profiles/r2_probe_mfma_valu.txt).
+//   VAR_NTEPI residual loads / output stores of the epilogue carry the non-temporal hint.
+constexpr int VAR_LEAN = 32, VAR_NTEPI = 128;
 
 // GLDS = weight tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write).  The DMA
 // writes lane-linear (wave base + lane*16 B), so the LDS image is unpadded [row][32 floats] and the bank-conflict fix
@@ -79,7 +87,9 @@ constexpr int VAR_PIPE = 1, VAR_NO_NORM = 2, VAR_NO_HALO = 4, VAR_NO_DMA = 8, VA
 // reads 6 fragments for 32 MFMAs instead of 4 for 16, and a tap has 128 MFMAs per wave between barriers (128 accumulator registers).
 template <int WM, bool GLDS, int WN, int VAR = 0, int NT = 2>
 __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KParams p) {
-    static_assert(NT == 2 || (NT == 4 && WM == 4 && WN == 2 && GLDS && VAR == 0), "wide-N tiles: 8-wave LDS-DMA shape only");
+    static_assert(NT == 2 || (NT == 4 && WM == 4 && WN == 2 && GLDS && (VAR & ~(VAR_LEAN | VAR_NTEPI | VAR_NO_NORM | VAR_NO_HALO | VAR_NO_DMA | VAR_NO_EPI)) == 0), "wide-N tiles: 8-wave LDS-DMA shape only");
+    static_assert(NT == 4 || (VAR & (VAR_LEAN | VAR_NTEPI)) == 0, "lean addressing / non-temporal epilogue: 256 x 256 tiles only");
+    constexpr bool LEAN = (VAR & VAR_LEAN) != 0, NTEPI = (VAR & VAR_NTEPI) != 0;
     constexpr bool PIPE = (VAR & VAR_PIPE) != 0;
     static_assert(!PIPE || GLDS, "the pipelined tap loop reads the LDS-DMA weight image");
     constexpr int T = 64 * WM * WN;        // threads
@@ -98,6 +108,13 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
     int mt, nt;
     if (!decode_tile(blockIdx.x, p.mtiles, p.ntiles, mt, nt, blockIdx.y)) return;
     const int m0 = mt * TBM, n0 = p.n_begin + nt * BNT;
+    if (p.stagger_us > 0 && blockIdx.x < 256 && blockIdx.y == 0) {
+        // experiment: the first round's workgroups (one per CU) start up to 3 * stagger_us apart, so that the CUs of an XCD are not
+        // all in their epilogue (the only HBM-heavy phase of a tile) at the same moment; the offsets persist through later rounds
+        const long long ticks = (long long)((blockIdx.x >> 3) & 3) * p.stagger_us * 100;     // wall_clock64: 100 MHz
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    }
     const int ld_row = tid >> 3, ld_col = (tid & 7) * 4;
     const float* zero = g_zero_page_halo;
 
@@ -222,6 +239,22 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
         }
     };
 
+    // VAR_LEAN: every row of the tile exists (the launcher only takes 256-column tiles below N <= nrows_b), so there is no zero-page
+    // select; row group i of a tap = scalar base + i * 64 rows, lane offset constant for the whole kernel
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned b_voff = (unsigned)((ld_row * p.ldb + (((tid & 7) ^ ((ld_row >> 1) & 7)) * 4)) * (int)sizeof(float));
+    auto b_dma_lean = [&](int kt, int buf) {
+        const char* tap = reinterpret_cast<const char*>(p.b + (size_t)n0 * p.ldb + (size_t)kt * BK);
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) {
+            float* dst = Bs + buf * BNT * 32 + (wave_u * 8 + (T / 8) * i) * 32;
+            const char* src = tap + (size_t)i * (T / 8) * p.ldb * sizeof(float) + (size_t)b_voff;
+            typedef const __attribute__((address_space(1))) void* gptr_t;
+            typedef __attribute__((address_space(3))) void* lptr_t;
+            __builtin_amdgcn_global_load_lds((gptr_t)(src), (lptr_t)(dst), 16, 0, 0);
+        }
+    };
+
     f32x16 acc[2][2];                                // columns 0..63 of the wave tile
     f32x16 acc_hi[2][2];                             // columns 64..127 (NT == 4 only; two plain arrays so that both stay in registers)
 #pragma unroll
@@ -242,7 +275,9 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
     // ---- prologue ----------------------------------------------------------------------------------------------
     halo_load(c_begin);
     coef_load(c_begin);
-    if (GLDS) {
+    if (LEAN) {
+        b_dma_lean(kt0, kt0 & 1);
+    } else if (GLDS) {
         b_dma(kt0, kt0 & 1);
         if (PIPE && kt0 + 1 < KT) b_dma(kt0 + 1, (kt0 + 1) & 1);   // the pipelined loop runs the weight DMA two taps ahead
     } else {
@@ -352,7 +387,8 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
             const float* as0 = Ah + a_foff[0] + toff;
             const float* as1 = Ah + a_foff[1] + toff;
             const float* bs = Bs + cur * BNT * BLD;
-            if (GLDS && !(VAR & VAR_NO_DMA)) b_dma(nxt, cur ^ 1);   // buffer cur^1 was last read in tap kt-1 (barrier passed)
+            if (LEAN) b_dma_lean(nxt, cur ^ 1);
+            else if (GLDS && !(VAR & VAR_NO_DMA)) b_dma(nxt, cur ^ 1);   // buffer cur^1 was last read in tap kt-1 (barrier passed)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const f32x4 a0 = *reinterpret_cast<const f32x4*>(as0 + ks * 8);
@@ -403,7 +439,10 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(acc[i][j]));      // keep the accumulators (and the K loop) alive
+            for (int j = 0; j < 2; ++j) {                                         // keep the accumulators (and the K loop) alive
+                asm volatile("" :: "v"(acc[i][j]));
+                if constexpr (NT == 4) asm volatile("" :: "v"(acc_hi[i][j]));
+            }
         return;
     }
     if (p.splits > 1) {
@@ -412,9 +451,9 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
         return;
     }
     // one 64-column half of the wave tile at a time through the wave's private staging rows
-    epilogue<0, HALF>(p, acc, smem + wave * (HALF ? 32 : 64) * EPI_LD, lane, m0 + wr * 64, n0 + wc * 32 * NT, p.out);
+    epilogue<0, HALF, NTEPI>(p, acc, smem + wave * (HALF ? 32 : 64) * EPI_LD, lane, m0 + wr * 64, n0 + wc * 32 * NT, p.out);
     if constexpr (NT == 4)
-        epilogue<0, HALF>(p, acc_hi, smem + wave * (HALF ? 32 : 64) * EPI_LD, lane, m0 + wr * 64, n0 + wc * 32 * NT + 64, p.out);
+        epilogue<0, HALF, NTEPI>(p, acc_hi, smem + wave * (HALF ? 32 : 64) * EPI_LD, lane, m0 + wr * 64, n0 + wc * 32 * NT + 64, p.out);
 }
 
 struct Geo { int TH, nimg, NP; bool ok; };
@@ -441,10 +480,14 @@ int g_tail64 = 1;              // 64-column tiles for a ragged last column tile 
 // no split-K, and the tiles still give every CU a workgroup.  Measured +4.1 ... +4.5 % on the CIFAR-10 / FFHQ 32x32 and 16x16 layers (129 -> 136 TFLOP/s
 // network average, profiles/r2_conv_wide_n.txt).  g_variant 7 switches it off (A/B runs), 6 forces it regardless of the tile count.
 bool wide_n_tiles(const KParams& p, const Geo& g) {
-    if (g_variant != 0 && g_variant != 6) return false;
-    if (p.splits != 1 || p.N < 256 || g.NP * 8 > 7 * 512 || g.nimg != 1) return false;
+    const int v = g_variant & 31;                    // bits 5.. select options of the 256 x 256 tile itself
+#ifdef DS_CONV_ABLATIONS
+    if (g_variant & 0x10000) { if (p.splits != 1 || p.N < 256 || g.NP * 8 > 7 * 512 || g.nimg != 1) return false; return true; }
+#endif
+    if (v != 0 && v != 6) return false;
+    if (p.splits != 1 || p.N < 256 || g.NP * 8 > 7 * 512 || g.nimg != 1 || p.nrows_b < (p.N / 256) * 256) return false;
     const long long blocks = (long long)((p.M + 255) / 256) * (p.N / 256);       // the 256-column tiles (a remainder keeps 128 / 64-column tiles)
-    return g_variant == 6 || blocks >= 256;
+    return v == 6 || blocks >= 256;
 }
 
 template <int WM, bool GLDS, int WN, int VAR = 0, int NT = 2>
@@ -481,8 +524,30 @@ int launch_wm(KParams& p, hipStream_t stream) {
         const Geo g4 = geometry(p, 256, 2);
         if (wide_n_tiles(p, g4)) {
             n256 = (p.N / 256) * 256;
-            int rc = launch_one<4, true, 2, 0, 4>(p, g4, 0, n256 / 256, stream);
+            KParams q = p;
+            q.stagger_us = (g_variant >> 8) & 255;
+            int rc;
+#ifdef DS_CONV_ABLATIONS
+            if (g_variant & 0x10000) {                 // timing ablations of the 256 x 256 tile (wrong results on purpose)
+                switch (g_variant & 31) {
+                    case 4: rc = launch_one<4, true, 2, 4, 4>(q, g4, 0, n256 / 256, stream); break;
+                    case 16: rc = launch_one<4, true, 2, 16, 4>(q, g4, 0, n256 / 256, stream); break;
+                    case 20: rc = launch_one<4, true, 2, 20, 4>(q, g4, 0, n256 / 256, stream); break;
+                    case 28: rc = launch_one<4, true, 2, 28, 4>(q, g4, 0, n256 / 256, stream); break;
+                    default: rc = launch_one<4, true, 2, 0, 4>(q, g4, 0, n256 / 256, stream); break;
+                }
+                if (rc) return rc;
+            } else
+#endif
+            {
+            switch (g_variant & (VAR_LEAN | VAR_NTEPI)) {
+                case VAR_LEAN: rc = launch_one<4, true, 2, VAR_LEAN, 4>(q, g4, 0, n256 / 256, stream); break;
+                case VAR_NTEPI: rc = launch_one<4, true, 2, VAR_NTEPI, 4>(q, g4, 0, n256 / 256, stream); break;
+                case VAR_LEAN | VAR_NTEPI: rc = launch_one<4, true, 2, VAR_LEAN | VAR_NTEPI, 4>(q, g4, 0, n256 / 256, stream); break;
+                default: rc = launch_one<4, true, 2, 0, 4>(q, g4, 0, n256 / 256, stream); break;
+            }
             if (rc) return rc;
+            }
         }
     }
     const int nrest = p.N - n256;
@@ -492,11 +557,11 @@ int launch_wm(KParams& p, hipStream_t stream) {
     if (wide > 0) {
         const Geo g = geometry(p, 64 * WM, 2);
         int rc;
-        if (WM == 4 && GLDS && g_variant == 3 && p.splits == 1 && n256 == 0 && conv3x3_halo2_applicable(p, wide, 0)) {
+        if (WM == 4 && GLDS && (g_variant & 31) == 3 && p.splits == 1 && n256 == 0 && conv3x3_halo2_applicable(p, wide, 0)) {
             KParams q = p;
             rc = launch_conv3x3_halo2(q, wide, 0, stream);
         } else if constexpr (GLDS) {
-            switch (g_variant) {
+            switch (g_variant & 31) {
                 case 1: rc = launch_one<WM, GLDS, 2, 1>(p, g, n256, wide, stream); break;
 #ifdef DS_CONV_ABLATIONS
                 case 2: rc = launch_one<WM, GLDS, 2, 2>(p, g, 0, wide, stream); break;
@@ -552,7 +617,7 @@ HaloPlan plan_halo(const KParams& p) {
         const int s256 = choose_splits(blocks256, true, units, 9, cap, mn, &c256);
         if (g_tile_override == 256 || 0.97 * c256 < c128) { hp.tile = 256; hp.splits = s256; }
     }
-    if (g_variant == 6 && hp.tile == 256) hp.splits = 1;      // forced 256 x 256 tiles (tests at small sizes): no split-K
+    if ((g_variant & 31) == 6 && hp.tile == 256) hp.splits = 1;      // forced 256 x 256 tiles (tests at small sizes): no split-K
     return hp;
 }
 

@@ -42,6 +42,7 @@ struct KParams {
     // split-K (small-M layers): blockIdx.y = split; each split contracts a contiguous range of K slabs / tiles and writes
     // its raw partial tile to part[split][M][N]; splitk_reduce_kernel sums them and applies the epilogue
     int splits; float* part; int vec_part; long long part_cap;     // part_cap: workspace capacity in floats (host side only)
+    int stagger_us;                                                // halo kernel, experiment: first-round workgroups start (b / 8 % 4) * stagger_us late
 };
 
 // Fused epilogue of one wave's 64x64 accumulator tile (2x2 MFMA 32x32 tiles).
@@ -51,7 +52,8 @@ struct KParams {
 // Vector path: the tile is transposed through LDS (`stage`, 64 x EPI_LD floats owned by this wave, free once every
 // wave of the block has passed the K loop's last barrier) so that bias / residual / output are accessed as float4
 // rows (16 B per lane, 256 B contiguous per 16 lanes) instead of 64 dword accesses per lane.
-template <int MODE, bool HALF = false>
+// NTS: residual loads and output stores carry the non-temporal hint (read-once / write-once streams of a tile's epilogue).
+template <int MODE, bool HALF = false, bool NTS = false>
 __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2][2], float* stage, int lane, int wm0, int wn0,
                                          float* o_base) {
     // HALF: the staging area holds 32 x EPI_LD floats per wave (8-wave blocks) and the two 32-row halves go one after
@@ -77,7 +79,8 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
 #pragma unroll
                 for (int pass = 0; pass < NP; ++pass) {
                     const int row = min(rbase + pass * 4 + (lane >> 4), p.M - 1);
-                    rv[pass] = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.res_ld + col);
+                    const f32x4* rp = reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.res_ld + col);
+                    rv[pass] = NTS ? __builtin_nontemporal_load(rp) : *rp;
                 }
             }
             if (cb_uniform) {
@@ -113,7 +116,8 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = ds_silu(v[q]);
                 }
-                *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col) = v;
+                if (NTS) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col));
+                else *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col) = v;
                 st_s += v; st_q += v * v;
             }
         };

@@ -478,7 +478,7 @@ def _run_halo_case(case, variant):
     assert rc == 0, lib.ds_error_string(rc)
     if variant == 3:
         assert lib.ds_debug_conv_halo2_launches() == before + 1, 'the layer was not routed to the second-generation kernel'
-    if variant == 6:
+    if (variant & 31) == 6:
         assert kid == 2565, 'the layer was not routed to the 256 x 256-tile kernel'
     want = _nhwc(ref)
     assert _rel(out.cpu(), want) < TOL
@@ -512,6 +512,14 @@ def test_conv_wide_n_tiles_match_aten(case):
     """conv3x3_halo_kernel<4, NT = 4>: 256-pixel x 256-channel tiles (64 x 128 per wave) for the 256-multiples of the channel
     count, the remainder on 128- / 64-column tiles of the same layer (ds_debug_conv_variant(6) forces the shape at test sizes)."""
     _run_halo_case(case, 6)
+
+
+@pytest.mark.parametrize('variant', [6 | 32, 6 | 128, 6 | 32 | 128, 6 | 32 | (2 << 8)])
+@pytest.mark.parametrize('case', [WIDE_N_CASES[1], WIDE_N_CASES[2], WIDE_N_CASES[3], WIDE_N_CASES[6]])
+def test_conv_wide_n_tile_options_match_aten(case, variant):
+    """Options of the 256 x 256 tile (conv3x3_halo.hip VAR_LEAN = scalar-addressed weight DMA, VAR_NTEPI = non-temporal epilogue,
+    bits 8.. = staggered first round): same results as the plain kernel."""
+    _run_halo_case(case, variant)
 
 
 F16_CASES = [
