@@ -56,7 +56,7 @@ KERNEL_NAMES = {0: 'igemm_f32_kernel<0> (generic gather conv / 1x1 / linear)', 1
 KERNEL_PEAK = {2562: PEAK_FP16_MFMA_TFLOPS, 2563: PEAK_FP16_MFMA_TFLOPS / 3, 2564: PEAK_FP16_MFMA_TFLOPS}
 PMC_KEYS = {0: 'void igemm::igemm_f32_kernel<0>(igemm::KParams)', 128: 'void igemm::conv3x3_halo_kernel<2, true, 2, 0, 2>(igemm::KParams)',
             256: 'void igemm::conv3x3_halo_kernel<4, true, 2, 0, 2>(igemm::KParams)', 2561: 'igemm::gemm_dma8_kernel(igemm::KParams)',
-            2562: None, 2563: None, 2564: None, 2565: 'void igemm::conv3x3_halo_kernel<4, true, 2, 0, 4>(igemm::KParams)'}
+            2562: None, 2563: None, 2564: None, 2565: 'void igemm::conv3x3_halo_kernel<4, true, 2, 160, 4>(igemm::KParams)'}
 
 
 def parse(argv=None):

@@ -66,14 +66,19 @@ __device__ __forceinline__ unsigned lds_addr(const float* p) {
 // arithmetic in the halo writer, 4 = the halo is staged once and never again, 8 = the weight DMA is issued once and never
 // again, 16 = the epilogue stores nothing.
 constexpr int VAR_PIPE = 1, VAR_NO_NORM = 2, VAR_NO_HALO = 4, VAR_NO_DMA = 8, VAR_NO_EPI = 16;
-// Round-2 options of the 256 x 256 tile (NT = 4), A/B-selectable through ds_debug_conv_variant (bits 5 and 7; bits 8..15 of the
-// variant word = KParams::stagger_us):
+// Round-2 options of the 256 x 256 tile (NT = 4).  VAR_LEAN | VAR_NTEPI is the DEFAULT kernel of that tile (+1.3 % on the main
+// shapes, +1.1 % on the headline, profiles/r2_conv_tile_options.txt); ds_debug_conv_variant(256) selects the plain one (A/B runs),
+// bit 6 adds VAR_LATE_DMA:
 //   VAR_LEAN  the weight DMA of a tap is addressed as (uniform SGPR base of the tap and row group) + (ONE constant 32-bit per-lane
 //             offset) with the LDS destination computed on the scalar unit: the compiled loop otherwise spends 22 VALU instructions
 //             per tap on 64-bit pointer arithmetic, zero-page selects and v_readfirstlane of a wave-uniform value, and on this chip
 //             a VALU instruction costs ~3.3 cycles of fp32-matrix issue time (profiles/r2_probe_mfma_valu.txt).
 //   VAR_NTEPI residual loads / output stores of the epilogue carry the non-temporal hint.
-constexpr int VAR_LEAN = 32, VAR_NTEPI = 128;
+//   VAR_LATE_DMA the weight DMA of tap kt+1 is issued after the second K step of tap kt instead of at its top: right after the tap
+//             barrier all 8 waves request their first fragments (48-64 KB of LDS reads in one burst) and the 32 KB of DMA writes
+//             would land in the same window.
+constexpr int VAR_LEAN = 32, VAR_LATE_DMA = 64, VAR_NTEPI = 128;
+constexpr int VAR_TILE_OPTS = VAR_LEAN | VAR_LATE_DMA | VAR_NTEPI;
 
 // GLDS = weight tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write).  The DMA
 // writes lane-linear (wave base + lane*16 B), so the LDS image is unpadded [row][32 floats] and the bank-conflict fix
@@ -87,9 +92,10 @@ constexpr int VAR_LEAN = 32, VAR_NTEPI = 128;
 // reads 6 fragments for 32 MFMAs instead of 4 for 16, and a tap has 128 MFMAs per wave between barriers (128 accumulator registers).
 template <int WM, bool GLDS, int WN, int VAR = 0, int NT = 2>
 __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KParams p) {
-    static_assert(NT == 2 || (NT == 4 && WM == 4 && WN == 2 && GLDS && (VAR & ~(VAR_LEAN | VAR_NTEPI | VAR_NO_NORM | VAR_NO_HALO | VAR_NO_DMA | VAR_NO_EPI)) == 0), "wide-N tiles: 8-wave LDS-DMA shape only");
-    static_assert(NT == 4 || (VAR & (VAR_LEAN | VAR_NTEPI)) == 0, "lean addressing / non-temporal epilogue: 256 x 256 tiles only");
-    constexpr bool LEAN = (VAR & VAR_LEAN) != 0, NTEPI = (VAR & VAR_NTEPI) != 0;
+    static_assert(NT == 2 || (NT == 4 && WM == 4 && WN == 2 && GLDS && (VAR & ~(VAR_TILE_OPTS | VAR_NO_NORM | VAR_NO_HALO | VAR_NO_DMA | VAR_NO_EPI)) == 0), "wide-N tiles: 8-wave LDS-DMA shape only");
+    static_assert(NT == 4 || (VAR & VAR_TILE_OPTS) == 0, "lean addressing / late DMA / non-temporal epilogue: 256 x 256 tiles only");
+    static_assert(!(VAR & VAR_LATE_DMA) || (VAR & VAR_LEAN), "the late DMA is issued by the lean addressing path");
+    constexpr bool LEAN = (VAR & VAR_LEAN) != 0, NTEPI = (VAR & VAR_NTEPI) != 0, LATE = (VAR & VAR_LATE_DMA) != 0;
     constexpr bool PIPE = (VAR & VAR_PIPE) != 0;
     static_assert(!PIPE || GLDS, "the pipelined tap loop reads the LDS-DMA weight image");
     constexpr int T = 64 * WM * WN;        // threads
@@ -108,13 +114,6 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
     int mt, nt;
     if (!decode_tile(blockIdx.x, p.mtiles, p.ntiles, mt, nt, blockIdx.y)) return;
     const int m0 = mt * TBM, n0 = p.n_begin + nt * BNT;
-    if (p.stagger_us > 0 && blockIdx.x < 256 && blockIdx.y == 0) {
-        // experiment: the first round's workgroups (one per CU) start up to 3 * stagger_us apart, so that the CUs of an XCD are not
-        // all in their epilogue (the only HBM-heavy phase of a tile) at the same moment; the offsets persist through later rounds
-        const long long ticks = (long long)((blockIdx.x >> 3) & 3) * p.stagger_us * 100;     // wall_clock64: 100 MHz
-        const long long t0 = wall_clock64();
-        while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-    }
     const int ld_row = tid >> 3, ld_col = (tid & 7) * 4;
     const float* zero = g_zero_page_halo;
 
@@ -125,7 +124,9 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
     const int ns = (p.NP * 8 + T - 1) / T;          // halo slots per thread actually used (uniform)
 
     // per-thread halo slots: pixel index in the image tensor (or -1: zero) -- fixed for the whole K loop
+    // (tiles of several small images, e.g. 8x8: also the slot's offset into the coefficient planes staged in LDS, see coef_stage)
     int h_pix[NS_MAX];
+    int h_cof[NS_MAX];
 #pragma unroll
     for (int j = 0; j < NS_MAX; ++j) {
         const int q = tid + j * T;
@@ -136,6 +137,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
         const int img = img0 + s, y = r0 + hr - 1, x = hc - 1;
         const bool ok = hp < p.NP && img < n_images && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
         h_pix[j] = ok ? (img * p.H + y) * p.W + x : -1;
+        h_cof[j] = s * 3 * (p.c0 + p.c1);
     }
     // per-lane A fragment bases inside the halo (two 32-row MFMA tiles per wave)
     int a_foff[2];
@@ -196,6 +198,20 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
         cga = *reinterpret_cast<const f32x4*>(cp + st);
         cbe = *reinterpret_cast<const f32x4*>(cp + 2 * st);
     };
+    // A tile of several images (8x8 layers: 2 or 4 images per tile) needs the coefficients of each slot's own image.  Loading them
+    // from global memory inside halo_store put an L2 latency plus an integer division per slot on the slab boundary (the 8x8 layers
+    // lost 11 % to it, profiles/r2_conv_ablations.txt v2); instead the {mu, A, B} planes of the tile's images are copied to LDS once,
+    // behind the halo, and halo_store reads them from there.
+    float* Cs = Ah + p.NP * LDSK;                   // [nimg][3][Ctot]
+    auto coef_stage = [&]() {
+        const int per = 3 * Ctot;
+        for (int i = tid * 4; i < p.nimg * per; i += T * 4) {
+            const int s = i / per;
+            f32x4 v = {0.f, 1.f, 0.f, 0.f};
+            if (img0 + s < n_images) v = *reinterpret_cast<const f32x4*>(p.norm + (size_t)img0 * per + i);
+            *reinterpret_cast<f32x4*>(Cs + i) = v;
+        }
+    };
     auto halo_store = [&](int chunk) {
         const bool do_norm = norm_on && chunk < nchunks && !(VAR & VAR_NO_NORM);
         const int cq = chunk * BK + ld_col;
@@ -207,7 +223,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
                 if (do_norm && h_pix[j] >= 0) {
                     f32x4 mu = cmu, ga = cga, be = cbe;
                     if (!one_img) {
-                        const float* cp = p.norm + (size_t)(h_pix[j] / p.HW) * 3 * Ctot + cq;
+                        const float* cp = (p.coef_lds ? Cs : p.norm + (size_t)img0 * 3 * Ctot) + h_cof[j] + cq;
                         mu = *reinterpret_cast<const f32x4*>(cp);
                         ga = *reinterpret_cast<const f32x4*>(cp + Ctot);
                         be = *reinterpret_cast<const f32x4*>(cp + 2 * Ctot);
@@ -284,6 +300,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b_addr(kt0, i));
     }
+    if (norm_on && !one_img && p.coef_lds) { coef_stage(); __syncthreads(); }
     halo_store(c_begin);
     if (!GLDS) b_store(kt0 & 1);
     if (PIPE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the first two weight tiles (see the note in the tap loop)
@@ -387,10 +404,15 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
             const float* as0 = Ah + a_foff[0] + toff;
             const float* as1 = Ah + a_foff[1] + toff;
             const float* bs = Bs + cur * BNT * BLD;
-            if (LEAN) b_dma_lean(nxt, cur ^ 1);
+            if (LEAN && !LATE) b_dma_lean(nxt, cur ^ 1);
             else if (GLDS && !(VAR & VAR_NO_DMA)) b_dma(nxt, cur ^ 1);   // buffer cur^1 was last read in tap kt-1 (barrier passed)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
+                if (LATE && ks == 2) {                          // buffer cur^1 was last read in tap kt-1 (barrier passed)
+                    __builtin_amdgcn_sched_barrier(0);
+                    b_dma_lean(nxt, cur ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 const f32x4 a0 = *reinterpret_cast<const f32x4*>(as0 + ks * 8);
                 const f32x4 a1 = *reinterpret_cast<const f32x4*>(as1 + ks * 8);
                 // register staging: the weight loads ride in the shadow of the MFMA groups
@@ -499,6 +521,11 @@ int launch_one(KParams p, const Geo& g, int n_begin, int ntiles, hipStream_t str
     p.ntiles = ntiles;
     p.n_begin = n_begin;
     int smem = B_BYTES + p.NP * LDSK * (int)sizeof(float);
+    // coefficient planes of a multi-image tile's images in LDS, where they fit without costing the 4-wave shape its second
+    // workgroup per CU (80 KB each) or the 8-wave shape the 128 KB it may ask for; otherwise halo_store reads them from global memory
+    const int coef_bytes = (p.norm && g.nimg > 1) ? g.nimg * 3 * (p.c0 + p.c1) * (int)sizeof(float) : 0;
+    p.coef_lds = coef_bytes > 0 && smem + coef_bytes <= (WM == 2 ? 80 : 128) * 1024 && !(g_variant & 512);     // 512: A/B switch
+    if (p.coef_lds) smem += coef_bytes;
     const int epi = 4 * 64 * EPI_LD * (int)sizeof(float);       // = 8 x 32 x EPI_LD for the 8-wave shape
     if (smem < epi) smem = epi;
     static bool attr_set = false;
@@ -525,7 +552,6 @@ int launch_wm(KParams& p, hipStream_t stream) {
         if (wide_n_tiles(p, g4)) {
             n256 = (p.N / 256) * 256;
             KParams q = p;
-            q.stagger_us = (g_variant >> 8) & 255;
             int rc;
 #ifdef DS_CONV_ABLATIONS
             if (g_variant & 0x10000) {                 // timing ablations of the 256 x 256 tile (wrong results on purpose)
@@ -540,12 +566,9 @@ int launch_wm(KParams& p, hipStream_t stream) {
             } else
 #endif
             {
-            switch (g_variant & (VAR_LEAN | VAR_NTEPI)) {
-                case VAR_LEAN: rc = launch_one<4, true, 2, VAR_LEAN, 4>(q, g4, 0, n256 / 256, stream); break;
-                case VAR_NTEPI: rc = launch_one<4, true, 2, VAR_NTEPI, 4>(q, g4, 0, n256 / 256, stream); break;
-                case VAR_LEAN | VAR_NTEPI: rc = launch_one<4, true, 2, VAR_LEAN | VAR_NTEPI, 4>(q, g4, 0, n256 / 256, stream); break;
-                default: rc = launch_one<4, true, 2, 0, 4>(q, g4, 0, n256 / 256, stream); break;
-            }
+            if (g_variant & 256) rc = launch_one<4, true, 2, 0, 4>(q, g4, 0, n256 / 256, stream);                  // plain (A/B)
+            else if (g_variant & VAR_LATE_DMA) rc = launch_one<4, true, 2, VAR_TILE_OPTS, 4>(q, g4, 0, n256 / 256, stream);
+            else rc = launch_one<4, true, 2, VAR_LEAN | VAR_NTEPI, 4>(q, g4, 0, n256 / 256, stream);
             if (rc) return rc;
             }
         }

@@ -386,6 +386,7 @@ extern "C" int ds_conv_kernel_id(const ds_conv_args* a) {
     p.c0 = a->c0; p.c1 = a->c1; p.ec0 = a->ec0; p.ec1 = a->ec1;
     if (a->workspace && a->workspace_floats > 0) { p.part = a->workspace; p.part_cap = a->workspace_floats; }
     p.stride = a->stride ? a->stride : 1; p.K = a->taps * (a->c0 + a->c1) + a->ec0 + a->ec1; p.norm = a->norm_coefs;
+    p.nrows_b = ((a->cout + BN - 1) / BN) * BN;                                     // weights are row-padded, as in ds_conv2d_nhwc
     if (a->wgt_f16) return a->wgt_f16 == 2 ? 2563 : (a->taps == 1 ? 2564 : 2562);
     if (g_force_generic) return 0;
     if (a->taps != 9 || a->stride > 1) return (g_use_dma8 && gemm_dma8_applicable(p)) ? 2561 : 0;

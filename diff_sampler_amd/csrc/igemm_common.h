@@ -25,6 +25,7 @@ struct KParams {
     int TH, nimg, HP, WP, NP;      // HP = TH + 2, WP = W + 2, NP = nimg * HP * WP halo pixels
     // fused input normalisation of the 3x3 sources: planes [n][3][c0+c1] = {mu, A, B}; in = act((x - mu) * A + B)
     const float* norm; int norm_act;
+    int coef_lds;                  // halo kernel, tiles of several images: the planes of the tile's images are staged in LDS (set by the launcher)
     // extra 1x1 sources appended along K after the 9*(c0+c1) columns (skip projection fused into the conv)
     const float* e0; const float* e1; int ec0, ec1, elda0, elda1;
     // epilogue
@@ -42,7 +43,6 @@ struct KParams {
     // split-K (small-M layers): blockIdx.y = split; each split contracts a contiguous range of K slabs / tiles and writes
     // its raw partial tile to part[split][M][N]; splitk_reduce_kernel sums them and applies the epilogue
     int splits; float* part; int vec_part; long long part_cap;     // part_cap: workspace capacity in floats (host side only)
-    int stagger_us;                                                // halo kernel, experiment: first-round workgroups start (b / 8 % 4) * stagger_us late
 };
 
 // Fused epilogue of one wave's 64x64 accumulator tile (2x2 MFMA 32x32 tiles).

@@ -1,0 +1,117 @@
+"""Zero-edit route into the reference: its own sanctioned extension point ``torch_utils.persistence.import_hook``.
+
+Reference: ``torch_utils/persistence.py:153-181`` (``import_hook(hook)``: every registered ``hook(meta) -> meta`` sees each
+persistent object while it is unpickled and may rewrite ``meta.module_src``, the pickled module source that is then
+``exec``'d, ``persistence.py:222-233``) and ``sample.py:83-87`` (``create_model`` unpickles ``['ema']`` -- an ``EDMPrecond`` --
+and moves it to the device).  SURVEY section 8(b) names this hook as the way an accelerated package substitutes the denoiser
+without editing ``sample.py``.
+
+    import torch_utils.persistence                     # the reference's module (diff-solvers-main / gits-main / amed-solver-main)
+    import diff_sampler_amd.persistence_hook as hook
+    hook.install()                                     # before the first pickle.load of an EDM snapshot
+
+After ``install()`` every ``EDMPrecond`` that is unpickled keeps its class, attributes, ``state_dict`` and module tree
+(``net.sigma_min``, ``net.label_dim``, ``net.model.enc[...]`` stay exactly what ``sample.py`` and the AMED code read), but a
+call ``net(x, sigma, class_labels)`` with ``x`` on the GPU is evaluated by ``engine.EDMDenoiser`` (the HIP plan, built lazily from
+the module's own weights on the first call and cached on the instance).  Nothing else changes: the samplers that call it are
+still the reference's ``solvers.py``; for the fused update kernels and the one-launch DPM-Solver++ step import
+``diff_sampler_amd.solvers`` instead of ``solvers``.
+
+What the route does NOT do, on purpose: it computes nothing itself.  Calls with CPU tensors or with ``augment_labels`` / other
+``model_kwargs`` go to the module's ORIGINAL ``forward`` -- the reference's own code, not a fallback of this package; a GPU call
+whose HIP library is missing (``_lib.DsError``) or whose module ``engine.spec_from_module`` does not recognise raises, like every
+other entry point.  Forward hooks on inner blocks (the AMED bottleneck tap,
+``solvers_amed.py:7-18``) do not fire under the route because the inner modules are not executed: AMED runs through
+``diff_sampler_amd.solvers_amed``, which takes the bottleneck from the plan.  Weights are packed when the engine is built;
+call ``invalidate(net)`` after changing them.
+"""
+from __future__ import annotations
+
+MARK = '# --- appended by diff_sampler_amd.persistence_hook ---'
+ROUTED_CLASSES = ('EDMPrecond',)
+
+_PATCH = '''
+
+%s
+def _ds_amd_route():
+    try:
+        import diff_sampler_amd.persistence_hook as _h
+    except ImportError:          # a snapshot re-saved under the route, loaded where the package is absent: plain reference
+        return
+    for _name in _h.ROUTED_CLASSES:
+        if _name in globals():
+            _h.route_class(globals()[_name])
+_ds_amd_route()
+del _ds_amd_route
+''' % MARK
+
+_ENGINES = '_ds_amd_engines'
+
+
+def hook(meta):
+    """``persistence.import_hook`` callback: append the routing stub to every pickled module source that defines a routed class
+    (the same patched source for the outer ``EDMPrecond`` and its inner ``SongUNet`` / ``DhariwalUNet`` objects, so that
+    ``_src_to_module`` still creates ONE module for them, persistence.py:222-233)."""
+    src = getattr(meta, 'module_src', None)
+    if getattr(meta, 'type', None) == 'class' and isinstance(src, str) and MARK not in src \
+            and any(f'class {name}' in src for name in ROUTED_CLASSES):
+        meta.module_src = src + _PATCH
+    return meta
+
+
+def install(persistence=None):
+    """Register ``hook`` with the reference's ``torch_utils.persistence`` (imported from ``sys.path`` unless given).  Idempotent.
+    Returns the persistence module."""
+    if persistence is None:
+        import importlib
+        persistence = importlib.import_module('torch_utils.persistence')
+    hooks = getattr(persistence, '_import_hooks')
+    if hook not in hooks:
+        persistence.import_hook(hook)
+    return persistence
+
+
+def uninstall(persistence=None):
+    if persistence is None:
+        import importlib
+        persistence = importlib.import_module('torch_utils.persistence')
+    hooks = getattr(persistence, '_import_hooks')
+    while hook in hooks:
+        hooks.remove(hook)
+
+
+def make_engine(net, device, use_fp16):
+    """The engine of one (module, device, precision): separate function so that tests can substitute it."""
+    from .engine import EDMDenoiser
+    return EDMDenoiser.from_reference_module(net, device=device, use_fp16=use_fp16)
+
+
+def invalidate(net):
+    """Drop the cached engines of ``net`` (after ``load_state_dict`` / weight edits); the next GPU call rebuilds them."""
+    net.__dict__.pop(_ENGINES, None)
+
+
+def route_class(cls):
+    """Wrap ``cls.forward`` (``EDMPrecond.forward``, networks_edm.py:482-496) so that GPU calls run on the HIP engine.  Same
+    signature, same return (denoised NCHW fp32).  Idempotent per class object."""
+    if cls.__dict__.get('_ds_amd_routed', False):
+        return cls
+    reference_forward = cls.forward
+
+    def forward(self, x, sigma, class_labels=None, force_fp32=False, **model_kwargs):
+        if not getattr(x, 'is_cuda', False) or model_kwargs:
+            return reference_forward(self, x, sigma, class_labels, force_fp32=force_fp32, **model_kwargs)
+        # networks_edm.py:486: fp16 body only when the module asks for it and the caller does not force fp32
+        use_fp16 = bool(getattr(self, 'use_fp16', False)) and not force_fp32
+        engines = self.__dict__.setdefault(_ENGINES, {})
+        key = (str(x.device), use_fp16)
+        eng = engines.get(key)
+        if eng is None:
+            eng = engines[key] = make_engine(self, x.device, use_fp16)
+        return eng(x, sigma, class_labels=class_labels)
+
+    forward.__doc__ = reference_forward.__doc__
+    forward.reference_forward = reference_forward
+    cls.forward = forward
+    cls._ds_amd_routed = True
+    return cls

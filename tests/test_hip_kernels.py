@@ -514,11 +514,20 @@ def test_conv_wide_n_tiles_match_aten(case):
     _run_halo_case(case, 6)
 
 
-@pytest.mark.parametrize('variant', [6 | 32, 6 | 128, 6 | 32 | 128, 6 | 32 | (2 << 8)])
+@pytest.mark.parametrize('variant', [6 | 256, 6 | 64])
 @pytest.mark.parametrize('case', [WIDE_N_CASES[1], WIDE_N_CASES[2], WIDE_N_CASES[3], WIDE_N_CASES[6]])
 def test_conv_wide_n_tile_options_match_aten(case, variant):
-    """Options of the 256 x 256 tile (conv3x3_halo.hip VAR_LEAN = scalar-addressed weight DMA, VAR_NTEPI = non-temporal epilogue,
-    bits 8.. = staggered first round): same results as the plain kernel."""
+    """The 256 x 256 tile's default kernel has VAR_LEAN | VAR_NTEPI (scalar-addressed weight DMA, non-temporal epilogue; covered by
+    the test above); here the plain kernel (variant bit 8, kept for A/B runs) and the late-DMA option (bit 6)."""
+    _run_halo_case(case, variant)
+
+
+@pytest.mark.parametrize('variant', [0, 512])
+@pytest.mark.parametrize('case', [(5, 8, 64, 64, 128, (64, 0), True, True), (3, 8, 96, 0, 192, (0, 0), True, False)])
+def test_conv_multi_image_tiles_coefficient_planes(case, variant):
+    """8x8 layers: a 256-pixel tile holds four images (the last tile here: one or three of them, the rest past the batch), each halo
+    slot normalises with its OWN image's {mu, A, B}.  Default: the planes of the tile's images staged in LDS; variant bit 9: read from
+    global memory per slot (the launcher's choice when they do not fit)."""
     _run_halo_case(case, variant)
 
 
