@@ -67,18 +67,18 @@ __device__ __forceinline__ unsigned lds_addr(const float* p) {
 // again, 16 = the epilogue stores nothing.
 constexpr int VAR_PIPE = 1, VAR_NO_NORM = 2, VAR_NO_HALO = 4, VAR_NO_DMA = 8, VAR_NO_EPI = 16;
 // Round-2 options of the 256 x 256 tile (NT = 4).  VAR_LEAN | VAR_NTEPI is the DEFAULT kernel of that tile (+1.3 % on the main
-// shapes, +1.1 % on the headline, profiles/r2_conv_tile_options.txt); ds_debug_conv_variant(256) selects the plain one (A/B runs),
-// bit 6 adds VAR_LATE_DMA:
+// shapes, +0.7 ... 1.1 % on the headline, profiles/r2_conv_tile_options.txt); ds_debug_conv_variant(256) selects the plain one (A/B runs):
 //   VAR_LEAN  the weight DMA of a tap is addressed as (uniform SGPR base of the tap and row group) + (ONE constant 32-bit per-lane
 //             offset) with the LDS destination computed on the scalar unit: the compiled loop otherwise spends 22 VALU instructions
 //             per tap on 64-bit pointer arithmetic, zero-page selects and v_readfirstlane of a wave-uniform value, and on this chip
 //             a VALU instruction costs ~3.3 cycles of fp32-matrix issue time (profiles/r2_probe_mfma_valu.txt).
 //   VAR_NTEPI residual loads / output stores of the epilogue carry the non-temporal hint.
-//   VAR_LATE_DMA the weight DMA of tap kt+1 is issued after the second K step of tap kt instead of at its top: right after the tap
-//             barrier all 8 waves request their first fragments (48-64 KB of LDS reads in one burst) and the 32 KB of DMA writes
-//             would land in the same window.
-constexpr int VAR_LEAN = 32, VAR_LATE_DMA = 64, VAR_NTEPI = 128;
-constexpr int VAR_TILE_OPTS = VAR_LEAN | VAR_LATE_DMA | VAR_NTEPI;
+// Measured and dropped (same file): issuing the weight DMA of tap kt+1 in the middle of tap kt instead of at its top (-2.3 %: an
+// LDS-DMA instruction between MFMA groups costs more issue time than one next to the tap's first fragment reads); starting the first
+// round's workgroups 2 ... 8 us apart so that the CUs are not all in their epilogue -- the tile's only HBM-heavy phase -- at once
+// (what the de-synchronised epilogues gain, the late finishers lose: +-0.1 %).
+constexpr int VAR_LEAN = 32, VAR_NTEPI = 128;
+constexpr int VAR_TILE_OPTS = VAR_LEAN | VAR_NTEPI;
 
 // GLDS = weight tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write).  The DMA
 // writes lane-linear (wave base + lane*16 B), so the LDS image is unpadded [row][32 floats] and the bank-conflict fix
@@ -93,9 +93,8 @@ constexpr int VAR_TILE_OPTS = VAR_LEAN | VAR_LATE_DMA | VAR_NTEPI;
 template <int WM, bool GLDS, int WN, int VAR = 0, int NT = 2>
 __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KParams p) {
     static_assert(NT == 2 || (NT == 4 && WM == 4 && WN == 2 && GLDS && (VAR & ~(VAR_TILE_OPTS | VAR_NO_NORM | VAR_NO_HALO | VAR_NO_DMA | VAR_NO_EPI)) == 0), "wide-N tiles: 8-wave LDS-DMA shape only");
-    static_assert(NT == 4 || (VAR & VAR_TILE_OPTS) == 0, "lean addressing / late DMA / non-temporal epilogue: 256 x 256 tiles only");
-    static_assert(!(VAR & VAR_LATE_DMA) || (VAR & VAR_LEAN), "the late DMA is issued by the lean addressing path");
-    constexpr bool LEAN = (VAR & VAR_LEAN) != 0, NTEPI = (VAR & VAR_NTEPI) != 0, LATE = (VAR & VAR_LATE_DMA) != 0;
+    static_assert(NT == 4 || (VAR & VAR_TILE_OPTS) == 0, "lean addressing / non-temporal epilogue: 256 x 256 tiles only");
+    constexpr bool LEAN = (VAR & VAR_LEAN) != 0, NTEPI = (VAR & VAR_NTEPI) != 0;
     constexpr bool PIPE = (VAR & VAR_PIPE) != 0;
     static_assert(!PIPE || GLDS, "the pipelined tap loop reads the LDS-DMA weight image");
     constexpr int T = 64 * WM * WN;        // threads
@@ -404,15 +403,10 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
             const float* as0 = Ah + a_foff[0] + toff;
             const float* as1 = Ah + a_foff[1] + toff;
             const float* bs = Bs + cur * BNT * BLD;
-            if (LEAN && !LATE) b_dma_lean(nxt, cur ^ 1);
+            if (LEAN) b_dma_lean(nxt, cur ^ 1);
             else if (GLDS && !(VAR & VAR_NO_DMA)) b_dma(nxt, cur ^ 1);   // buffer cur^1 was last read in tap kt-1 (barrier passed)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                if (LATE && ks == 2) {                          // buffer cur^1 was last read in tap kt-1 (barrier passed)
-                    __builtin_amdgcn_sched_barrier(0);
-                    b_dma_lean(nxt, cur ^ 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
                 const f32x4 a0 = *reinterpret_cast<const f32x4*>(as0 + ks * 8);
                 const f32x4 a1 = *reinterpret_cast<const f32x4*>(as1 + ks * 8);
                 // register staging: the weight loads ride in the shadow of the MFMA groups
@@ -567,8 +561,7 @@ int launch_wm(KParams& p, hipStream_t stream) {
 #endif
             {
             if (g_variant & 256) rc = launch_one<4, true, 2, 0, 4>(q, g4, 0, n256 / 256, stream);                  // plain (A/B)
-            else if (g_variant & VAR_LATE_DMA) rc = launch_one<4, true, 2, VAR_TILE_OPTS, 4>(q, g4, 0, n256 / 256, stream);
-            else rc = launch_one<4, true, 2, VAR_LEAN | VAR_NTEPI, 4>(q, g4, 0, n256 / 256, stream);
+            else rc = launch_one<4, true, 2, VAR_TILE_OPTS, 4>(q, g4, 0, n256 / 256, stream);
             if (rc) return rc;
             }
         }
