@@ -36,6 +36,7 @@ struct KParams {
     float scale; int act; int heads;
     float acc_scale;                                               // conv epilogue: accumulators are multiplied by this first (1; 2**-shift for pre-scaled split-fp16 weights)
     int vec_ok;                                                    // float4 epilogue allowed (alignment, ld % 4)
+    int nt_epi;                                                    // vector epilogue: non-temporal residual loads / output stores (large outputs)
     int out_planar;                                                // scalar epilogue writes out[(img * N + col) * HW + pixel]
     // optional per-(64-row block, column) sums of the OUTPUT for the consumer's GroupNorm: stats[(rb * 2 + {0: sum, 1: sum of
     // squares}) * N + col], rb = row / 64 (vector epilogue only: N % 64 == 0)
@@ -59,6 +60,7 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
     // HALF: the staging area holds 32 x EPI_LD floats per wave (8-wave blocks) and the two 32-row halves go one after
     // the other; otherwise 64 x EPI_LD and the whole tile is staged at once.
     const bool full_cols = (wn0 + 64 <= p.N);
+    const bool nts = NTS || p.nt_epi;
     if (p.vec_ok && full_cols) {
         const int c4 = (lane & 15) * 4;
         const int col = wn0 + c4;
@@ -80,7 +82,7 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
                 for (int pass = 0; pass < NP; ++pass) {
                     const int row = min(rbase + pass * 4 + (lane >> 4), p.M - 1);
                     const f32x4* rp = reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.res_ld + col);
-                    rv[pass] = NTS ? __builtin_nontemporal_load(rp) : *rp;
+                    rv[pass] = nts ? __builtin_nontemporal_load(rp) : *rp;
                 }
             }
             if (cb_uniform) {
@@ -116,7 +118,7 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = ds_silu(v[q]);
                 }
-                if (NTS) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col));
+                if (nts) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col));
                 else *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col) = v;
                 st_s += v; st_q += v * v;
             }
@@ -219,7 +221,7 @@ __device__ __forceinline__ KParams split_params(const KParams& p, int split) {
     KParams q = p;
     q.out = p.part + (size_t)split * p.M * p.N; q.ldo = p.N;
     q.colbias = nullptr; q.rowbias = nullptr; q.cbias = nullptr; q.res = nullptr; q.scale = 1.f; q.act = DS_ACT_NONE;
-    q.vec_ok = p.vec_part; q.out_planar = 0; q.stats = nullptr;
+    q.vec_ok = p.vec_part; q.out_planar = 0; q.stats = nullptr; q.nt_epi = 0;      // the partial planes are re-read at once by the reduce
     return q;
 }
 
@@ -239,6 +241,7 @@ inline double layer_cost_us(long long blocks, bool big_tile, int ktiles, int s, 
     return t;
 }
 extern int g_force_splits;      // benchmarks: > 0 overrides the heuristic (ds_debug_force_splits)
+extern int g_nt_epi;            // non-temporal epilogues for outputs of at least 32 MiB in every igemm-family kernel (ds_debug_conv_variant bit 10: A/B)
 // Best split count for a layer of `blocks` tiles whose K loop has `units` splittable units of `tiles_per_unit` K tiles.
 inline int choose_splits(long long blocks, bool big_tile, int units, int tiles_per_unit, long long part_capacity_floats,
                          long long mn, double* cost_out = nullptr) {
