@@ -24,6 +24,7 @@ Prints ONE JSON line on rank 0 with the driver's contract fields plus
   roofline_update_large_batch  the same kernel measured in-process at 16 384 images per launch, where it is bandwidth-bound
   kernels          time share of every kernel class in the instrumented step
   launch_modes     the same sampler call eager vs replayed from one captured hipGraph, at B=8 and at the benchmark batch
+  throughput_by_batch  (cifar10) the same call at 1024 images per call next to the benchmark batch (informational)
   cpu_baseline     the oracle (CPU restatement of the reference, ``oracle/``; the real reference when /root/reference is
                    importable) timed on this host's cores on a bounded sample of the same workload, at the best of a
                    thread-count sweep (cores = the thread count used)
@@ -76,6 +77,7 @@ def parse(argv=None):
     ap.add_argument('--cpu-calls', type=int, default=2)
     ap.add_argument('--cpu-threads', default='sweep', help="'sweep' (8,16,32; best reported) or a thread count")
     ap.add_argument('--no-launch-modes', action='store_true', help='skip the eager-vs-hipGraph comparison')
+    ap.add_argument('--no-batch-sweep', action='store_true', help='skip the extra throughput measurement at 1024 images per call')
     ap.add_argument('--stub', action='store_true', help=argparse.SUPPRESS)   # launcher self-test: gloo ranks on CPU, no kernels
     return ap.parse_args(argv)
 
@@ -492,11 +494,26 @@ def main(argv=None):
                           frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, launches_per_step=ul, avg_launch_ms=round(ums / ul, 4),
                           note='latency-bound at this batch (3 MB per operand); see DESIGN.md section 6 for the large-batch figure')
 
-    roof_ul = modes = None
+    roof_ul = modes = by_batch = None
     if rank == 0 and ldm is None and not stub:
         roof_ul = update_roofline_large_batch(dev)
         if not args.no_launch_modes and world == 1:
             modes = launch_modes(args, solvers, net_factory, spec, dev)
+        if not args.no_batch_sweep and world == 1 and args.config == 'cifar10' and not args.graph:
+            # the same sampler call at a larger batch (SURVEY 8d sweeps B for this config): per-launch fixed costs are amortised over more
+            # rounds of tiles.  Informational; `value` stays the batch named in config.workload.
+            by_batch = {str(B): round(B * args.steps / dt_local, 2)}
+            for b2 in (1024,):
+                if b2 == B:
+                    continue
+                lat2 = torch.randn(b2, spec.in_channels, spec.img_resolution, spec.img_resolution, device=dev)
+                sampler_call(solvers, args.solver, net, lat2, args.nfe); sync()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    sampler_call(solvers, args.solver, net, lat2, args.nfe)
+                sync()
+                by_batch[str(b2)] = round(2 * b2 / (time.perf_counter() - t1), 2)
+                del lat2
     if rank == 0:
         workload_name = {'cifar10': 'EDM CIFAR-10 32x32 SongUNet (55.7M params)', 'ffhq': 'EDM FFHQ-64 SongUNet (61.8M params)',
                          'afhqv2': 'EDM AFHQv2-64 SongUNet', 'imagenet64': 'EDM ImageNet-64 DhariwalUNet (295.9M params)',
@@ -515,7 +532,7 @@ def main(argv=None):
                        'images_per_step': B * world, 'sharding': 'independent image batches per rank, no collective',
                        'launch': 'hipGraph replay' if args.graph else 'eager'},
             'roofline': roof, 'roofline_update': roof_u, 'roofline_update_large_batch': roof_ul, 'kernels': kernels,
-            'launch_modes': modes, 'cpu_baseline': cpu, 'multi_gpu': multi,
+            'launch_modes': modes, 'throughput_by_batch': by_batch, 'cpu_baseline': cpu, 'multi_gpu': multi,
         }
         if stub:
             line['stub'] = True

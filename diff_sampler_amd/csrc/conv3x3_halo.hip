@@ -577,12 +577,9 @@ int launch_wm(KParams& p, hipStream_t stream) {
             KParams q = p;
             rc = launch_conv3x3_halo2(q, wide, 0, stream);
         } else if constexpr (GLDS) {
-            int var = g_variant & 31;
-            // One 4-wave workgroup per CU or fewer (the 8x8 layers at the benchmark batch): a SIMD holds ONE wave, nothing hides its
-            // exposed `ds_read -> wait -> MFMA` groups, and the software-pipelined fragment reads (VAR_PIPE) pay: +2.8 % on those layers
-            // (profiles/r2_conv_ablations.txt [6] v0 / v1); with two waves per SIMD they change nothing.  Bit 11 of the variant: off.
-            if (var == 0 && WM == 2 && !(g_variant & 2048) && (long long)((p.M + 127) / 128) * wide * p.splits <= 256) var = 1;
-            switch (var) {
+            // (routing the layers that leave a SIMD with ONE wave -- 8x8 layers at the benchmark batch -- to the software-pipelined
+            // VAR_PIPE kernel gains 2.8 % on those layers in isolation and nothing measurable on the network: not done)
+            switch (g_variant & 31) {
                 case 1: rc = launch_one<WM, GLDS, 2, 1>(p, g, n256, wide, stream); break;
 #ifdef DS_CONV_ABLATIONS
                 case 2: rc = launch_one<WM, GLDS, 2, 2>(p, g, 0, wide, stream); break;

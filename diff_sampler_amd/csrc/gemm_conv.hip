@@ -238,7 +238,6 @@ int g_force_generic = 0;
 }  // namespace
 
 int g_force_splits = 0;
-int g_nt_epi = 0;
 int g_use_dma8 = 1;
 
 namespace {
@@ -291,7 +290,6 @@ extern "C" int ds_debug_force_generic_conv(int v) {
 }
 
 extern "C" int ds_debug_conv_variant(int v) {
-    g_nt_epi = (v & 1024) ? 1 : 0;
     conv3x3_halo_set_variant(v);
     return DS_OK;
 }
@@ -336,7 +334,6 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     p.res = a->res; p.res_ld = a->res_ld;
     p.scale = a->out_scale; p.act = a->act; p.heads = 1; p.acc_scale = 1.0f;
     p.vec_ok = vec_epilogue_ok(p) ? 1 : 0;
-    p.nt_epi = (g_nt_epi && (long long)p.M * p.N * (long long)sizeof(float) >= (32LL << 20)) ? 1 : 0;
     p.stats = nullptr;
     if (a->stats_out) {
         if ((a->cout & 63) || !p.vec_ok || a->out_nchw || !ds_aligned16(a->stats_out)) return DS_E_ARG;

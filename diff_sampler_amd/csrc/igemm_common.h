@@ -36,7 +36,6 @@ struct KParams {
     float scale; int act; int heads;
     float acc_scale;                                               // conv epilogue: accumulators are multiplied by this first (1; 2**-shift for pre-scaled split-fp16 weights)
     int vec_ok;                                                    // float4 epilogue allowed (alignment, ld % 4)
-    int nt_epi;                                                    // vector epilogue: non-temporal residual loads / output stores (large outputs)
     int out_planar;                                                // scalar epilogue writes out[(img * N + col) * HW + pixel]
     // optional per-(64-row block, column) sums of the OUTPUT for the consumer's GroupNorm: stats[(rb * 2 + {0: sum, 1: sum of
     // squares}) * N + col], rb = row / 64 (vector epilogue only: N % 64 == 0)
@@ -53,14 +52,16 @@ struct KParams {
 // Vector path: the tile is transposed through LDS (`stage`, 64 x EPI_LD floats owned by this wave, free once every
 // wave of the block has passed the K loop's last barrier) so that bias / residual / output are accessed as float4
 // rows (16 B per lane, 256 B contiguous per 16 lanes) instead of 64 dword accesses per lane.
-// NTS: residual loads and output stores carry the non-temporal hint (read-once / write-once streams of a tile's epilogue).
+// NTS: residual loads and output stores carry the non-temporal hint (read-once / write-once streams of a tile's epilogue): +0.6 % on the
+// 256 x 256 conv tile; as a run-time option for every other kernel of the family (fp32 / fp16 GEMMs, fp16 convolutions; outputs of at
+// least 32 MiB) it changed nothing on the CIFAR-10, ImageNet-64 fp16 and SD-1.5 fp16 benches (profiles/r2_conv_tile_options.txt), so
+// only that kernel instantiates it.
 template <int MODE, bool HALF = false, bool NTS = false>
 __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2][2], float* stage, int lane, int wm0, int wn0,
                                          float* o_base) {
     // HALF: the staging area holds 32 x EPI_LD floats per wave (8-wave blocks) and the two 32-row halves go one after
     // the other; otherwise 64 x EPI_LD and the whole tile is staged at once.
     const bool full_cols = (wn0 + 64 <= p.N);
-    const bool nts = NTS || p.nt_epi;
     if (p.vec_ok && full_cols) {
         const int c4 = (lane & 15) * 4;
         const int col = wn0 + c4;
@@ -82,7 +83,7 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
                 for (int pass = 0; pass < NP; ++pass) {
                     const int row = min(rbase + pass * 4 + (lane >> 4), p.M - 1);
                     const f32x4* rp = reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.res_ld + col);
-                    rv[pass] = nts ? __builtin_nontemporal_load(rp) : *rp;
+                    rv[pass] = NTS ? __builtin_nontemporal_load(rp) : *rp;
                 }
             }
             if (cb_uniform) {
@@ -118,7 +119,7 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = ds_silu(v[q]);
                 }
-                if (nts) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col));
+                if (NTS) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col));
                 else *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col) = v;
                 st_s += v; st_q += v * v;
             }
@@ -221,7 +222,7 @@ __device__ __forceinline__ KParams split_params(const KParams& p, int split) {
     KParams q = p;
     q.out = p.part + (size_t)split * p.M * p.N; q.ldo = p.N;
     q.colbias = nullptr; q.rowbias = nullptr; q.cbias = nullptr; q.res = nullptr; q.scale = 1.f; q.act = DS_ACT_NONE;
-    q.vec_ok = p.vec_part; q.out_planar = 0; q.stats = nullptr; q.nt_epi = 0;      // the partial planes are re-read at once by the reduce
+    q.vec_ok = p.vec_part; q.out_planar = 0; q.stats = nullptr;
     return q;
 }
 
@@ -241,7 +242,6 @@ inline double layer_cost_us(long long blocks, bool big_tile, int ktiles, int s, 
     return t;
 }
 extern int g_force_splits;      // benchmarks: > 0 overrides the heuristic (ds_debug_force_splits)
-extern int g_nt_epi;            // non-temporal epilogues for outputs of at least 32 MiB in every igemm-family kernel (ds_debug_conv_variant bit 10: A/B)
 // Best split count for a layer of `blocks` tiles whose K loop has `units` splittable units of `tiles_per_unit` K tiles.
 inline int choose_splits(long long blocks, bool big_tile, int units, int tiles_per_unit, long long part_capacity_floats,
                          long long mn, double* cost_out = nullptr) {
