@@ -46,7 +46,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_FP16_MFMA_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md; measured 2495)
 PEAK_HBM_GBS = 8000.0
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r2_bench_pmc_hbm.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r2f_bench_pmc_hbm.json')
 KERNEL_NAMES = {0: 'igemm_f32_kernel<0> (generic gather conv / 1x1 / linear)', 128: 'conv3x3_halo_kernel<2> (128-pixel tiles)',
                 256: 'conv3x3_halo_kernel<4> (256-pixel tiles)', 2561: 'gemm_dma8_kernel (256x128 tiles, LDS-DMA, 1x1 / linear)',
                 2562: 'conv3x3_halo2_kernel<fp16 operands> (256-pixel tiles, v_mfma_f32_32x32x16_f16)',

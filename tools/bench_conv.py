@@ -32,6 +32,7 @@ ap.add_argument('--rounds', type=int, default=5)
 ap.add_argument('--split', action='store_true', help='split-fp16 fp32-emulated kernel (wgt_f16 = 2), 3x3 shapes only')
 ap.add_argument('--f16', action='store_true', help='fp16-operand kernel (ds_conv_args.wgt_f16), 3x3 shapes only')
 ap.add_argument('--extra', action='store_true', help='append the fused 1x1 skip projection (ec0 = c0 + c1 raw columns) as conv1 of a block with a skip conv has it')
+ap.add_argument('--ws', action='store_true', help='give the launcher a split-K workspace (256 MiB), as the engine plans do (the persistent schedule needs it)')
 ap.add_argument('--norm', action='store_true', help='fused GroupNorm affine + SiLU in the halo loader, as the network uses it')
 args = ap.parse_args()
 
@@ -78,6 +79,9 @@ for si, (res, c0, c1, cout, taps) in enumerate(SHAPES):
     if args.norm and taps == 9:
         coefs = torch.randn(B, 3, c0 + c1, device=dev) * 0.1 + torch.tensor([0., 1., 0.], device=dev).reshape(1, 3, 1)
         a.norm_coefs, a.norm_act = coefs.data_ptr(), 1
+    if args.ws:
+        scratch = torch.empty(64 << 20, device=dev)
+        a.workspace, a.workspace_floats = scratch.data_ptr(), scratch.numel()
     st = _lib.stream_ptr()
     if args.variants:
         import statistics
