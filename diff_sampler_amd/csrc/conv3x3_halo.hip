@@ -90,14 +90,8 @@ constexpr int VAR_TILE_OPTS = VAR_LEAN | VAR_NTEPI;
 // NT = 32-column MFMA tiles per wave: 2 = 64 x 64 per wave (the normal shape), 4 = 64 x 128 per wave, i.e. a 256-pixel x 256-channel
 // tile for the 8-wave shape: the halo of a slab is staged (normalised, SiLU'd) once for 256 output channels instead of twice, a K step
 // reads 6 fragments for 32 MFMAs instead of 4 for 16, and a tap has 128 MFMAs per wave between barriers (128 accumulator registers).
-// One tile = one call of conv_tile (the whole kernel for the ordinary launch, a loop body for the persistent one):
-//   b, rot      1-D tile id and XCD rotation (decode_tile)
-//   c_lo, c_hi  slab range to contract; c_hi < 0: derived from the split-K index `rot` (ordinary launch)
-//   part_st     != nullptr: the accumulators are parked there (register image, [32 quads][T threads] float4) instead of the epilogue
-//   part_ld     != nullptr: the accumulators start from that image instead of zero
-template <int WM, bool GLDS, int WN, int VAR, int NT>
-__device__ __forceinline__ void conv_tile(const KParams& p, float* smem, const int b, const int rot, const int c_lo, const int c_hi,
-                                          float* part_st, const float* part_ld) {
+template <int WM, bool GLDS, int WN, int VAR = 0, int NT = 2>
+__global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KParams p) {
     static_assert(NT == 2 || (NT == 4 && WM == 4 && WN == 2 && GLDS && (VAR & ~(VAR_TILE_OPTS | VAR_NO_NORM | VAR_NO_HALO | VAR_NO_DMA | VAR_NO_EPI)) == 0), "wide-N tiles: 8-wave LDS-DMA shape only");
     static_assert(NT == 4 || (VAR & VAR_TILE_OPTS) == 0, "lean addressing / non-temporal epilogue: 256 x 256 tiles only");
     constexpr bool LEAN = (VAR & VAR_LEAN) != 0, NTEPI = (VAR & VAR_NTEPI) != 0;
@@ -110,13 +104,14 @@ __device__ __forceinline__ void conv_tile(const KParams& p, float* smem, const i
     constexpr int BLD = GLDS ? 32 : LDSK;  // floats per weight row in LDS
     constexpr int NS_MAX = (NT == 4) ? 7 : ns_max(WN);      // wide-N tiles: one image per tile, at most 7 slots per thread (64-column images)
     constexpr int B_FLOATS = 2 * BNT * LDSK;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Bs = smem;                               // [2][BNT][LDSK]
     float* Ah = smem + B_FLOATS;                    // [NP][LDSK]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = (WN == 2) ? wave >> 1 : wave, wc = (WN == 2) ? wave & 1 : 0;
     int mt, nt;
-    if (!decode_tile(b, p.mtiles, p.ntiles, mt, nt, rot)) return;
+    if (!decode_tile(blockIdx.x, p.mtiles, p.ntiles, mt, nt, blockIdx.y)) return;
     const int m0 = mt * TBM, n0 = p.n_begin + nt * BNT;
     const int ld_row = tid >> 3, ld_col = (tid & 7) * 4;
     const float* zero = g_zero_page_halo;
@@ -283,26 +278,11 @@ __device__ __forceinline__ void conv_tile(const KParams& p, float* smem, const i
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acc_hi[i][j][r] = 0.f; }
-    if constexpr (NT == 4) {
-        if (part_ld) {                                   // second part of a K-split tile of the persistent schedule
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 lo = *reinterpret_cast<const f32x4*>(part_ld + ((size_t)(((i * 2 + j) * 4 + q) * T) + tid) * 4);
-                        const f32x4 hi = *reinterpret_cast<const f32x4*>(part_ld + ((size_t)((16 + (i * 2 + j) * 4 + q) * T) + tid) * 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { acc[i][j][q * 4 + e] = lo[e]; acc_hi[i][j][q * 4 + e] = hi[e]; }
-                    }
-        }
-    }
 
     const int NCH_all = nchunks + nextra;            // slabs: 3x3 ones (9 taps each) then 1x1 ones (centre tap only)
     // split-K: this block contracts slabs [c_begin, NCH) only (splits == 1: everything)
-    const int c_begin = c_hi >= 0 ? c_lo : (int)((long long)rot * NCH_all / p.splits);
-    const int NCH = c_hi >= 0 ? c_hi : (int)((long long)(rot + 1) * NCH_all / p.splits);
+    const int c_begin = (int)((long long)blockIdx.y * NCH_all / p.splits);
+    const int NCH = (int)((long long)(blockIdx.y + 1) * NCH_all / p.splits);
     auto kt_of = [&](int chunk) { return chunk < nchunks ? chunk * 9 : nchunks * 9 + (chunk - nchunks); };
     const int kt0 = kt_of(c_begin);
     const int KT = kt_of(NCH);
@@ -481,25 +461,8 @@ __device__ __forceinline__ void conv_tile(const KParams& p, float* smem, const i
             }
         return;
     }
-    if constexpr (NT == 4) {
-        if (part_st) {                                   // first part of a K-split tile: park the accumulators
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        f32x4 lo, hi;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { lo[e] = acc[i][j][q * 4 + e]; hi[e] = acc_hi[i][j][q * 4 + e]; }
-                        *reinterpret_cast<f32x4*>(part_st + ((size_t)(((i * 2 + j) * 4 + q) * T) + tid) * 4) = lo;
-                        *reinterpret_cast<f32x4*>(part_st + ((size_t)((16 + (i * 2 + j) * 4 + q) * T) + tid) * 4) = hi;
-                    }
-            return;
-        }
-    }
     if (p.splits > 1) {
-        const KParams q = split_params(p, rot);
+        const KParams q = split_params(p, blockIdx.y);
         epilogue<0, HALF>(q, acc, smem + wave * (HALF ? 32 : 64) * EPI_LD, lane, m0 + wr * 64, n0 + wc * 64, q.out);
         return;
     }
@@ -507,37 +470,6 @@ __device__ __forceinline__ void conv_tile(const KParams& p, float* smem, const i
     epilogue<0, HALF, NTEPI>(p, acc, smem + wave * (HALF ? 32 : 64) * EPI_LD, lane, m0 + wr * 64, n0 + wc * 32 * NT, p.out);
     if constexpr (NT == 4)
         epilogue<0, HALF, NTEPI>(p, acc_hi, smem + wave * (HALF ? 32 : 64) * EPI_LD, lane, m0 + wr * 64, n0 + wc * 32 * NT + 64, p.out);
-}
-
-template <int WM, bool GLDS, int WN, int VAR = 0, int NT = 2>
-__global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    conv_tile<WM, GLDS, WN, VAR, NT>(p, smem, (int)blockIdx.x, (int)blockIdx.y, 0, -1, nullptr, nullptr);
-}
-
-// Persistent, phase-shifted schedule of the 256 x 256 tile (one workgroup per CU, grid = number of CUs).  Every tile of a launch takes
-// the same time, so under the ordinary launch all CUs reach their epilogue -- the tile's only HBM-heavy phase, 134 MB per round --
-// together and it runs at the chip's burst rate.  Here workgroup w owns tiles w, w + G, w + 2G, ...
-// and starts its FIRST tile at slab `phase` (a quarter, half or three quarters of the K loop, by (w / 8) % 4): it contracts slabs
-// [phase, end) first and parks the accumulators in its 256 KiB of the split-K workspace, runs its other tiles normally, and finishes
-// the first tile (slabs [0, phase), accumulators reloaded) last.  Same work per CU, no idle tail, no cross-workgroup dependence, and
-// the epilogues of the four phase groups no longer coincide (all but each workgroup's last one).
-template <int VAR>
-__global__ void __launch_bounds__(512, 2) conv3x3_halo_persist_kernel(const KParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int G = (int)gridDim.x, w = (int)blockIdx.x;
-    const int total = (int)grid_1d(p.mtiles, p.ntiles);
-    const int ntl = (total - w + G - 1) / G;                              // tiles of this workgroup
-    const int nslab = (p.c0 + p.c1 + p.ec0 + p.ec1) / BK;
-    const int phase = ntl >= 2 ? ((w >> 3) & 3) * nslab / 4 : 0;
-    float* park = p.part + (size_t)w * (32 * 512 * 4);
-    const int nseg = ntl + (phase > 0 ? 1 : 0);
-    for (int seg = 0; seg < nseg; ++seg) {
-        if (seg > 0) __syncthreads();                                     // the previous epilogue's staging rows overlay the tile buffers
-        const bool head = seg == 0 && phase > 0, tail = seg == ntl;       // the two parts of the K-split first tile
-        conv_tile<4, true, 2, VAR, 4>(p, smem, w + (tail ? 0 : seg) * G, 0, head ? phase : 0, tail ? phase : nslab,
-                                      head ? park : nullptr, tail ? park : nullptr);
-    }
 }
 
 struct Geo { int TH, nimg, NP; bool ok; };
@@ -602,45 +534,6 @@ int launch_one(KParams p, const Geo& g, int n_begin, int ntiles, hipStream_t str
     return DS_OK;
 }
 
-int g_num_cus = 0;
-int launch_persist(KParams p, const Geo& g, int ntiles, hipStream_t stream) {
-    constexpr int B_BYTES = 2 * 32 * 4 * 2 * LDSK * (int)sizeof(float);
-    p.TH = g.TH; p.nimg = g.nimg; p.HP = g.TH + 2; p.WP = p.W + 2; p.NP = g.NP;
-    p.mtiles = (p.M + 255) / 256;
-    p.ntiles = ntiles;
-    p.n_begin = 0;
-    p.coef_lds = 0;
-    int smem = B_BYTES + p.NP * LDSK * (int)sizeof(float);
-    const int epi = 4 * 64 * EPI_LD * (int)sizeof(float);
-    if (smem < epi) smem = epi;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_persist_kernel<VAR_TILE_OPTS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    // (forced shape of the tests, variant 6: 32 workgroups, so that small layers exercise every phase and the ragged tile ids)
-    const int grid = (g_variant & 31) == 6 ? 32 : g_num_cus;
-    hipLaunchKernelGGL((conv3x3_halo_persist_kernel<VAR_TILE_OPTS>), dim3(grid), dim3(512), smem, stream, p);
-    DS_CHECK_LAUNCH();
-    return DS_OK;
-}
-
-// The persistent schedule applies where a layer has at least three rounds of 256 x 256 tiles on the chip's CUs (with fewer there is
-// nothing to de-synchronise) and the caller gave a split-K workspace that holds one parked tile per CU.
-bool persist_applies(const KParams& p, int n256) {
-    if (!(g_variant & 64) || !p.part || p.splits != 1) return false;
-    if (g_num_cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        g_num_cus = n;
-    }
-    const long long tiles = (long long)((p.M + 255) / 256) * (n256 / 256);
-    if (p.part_cap < (long long)g_num_cus * (32 * 512 * 4) || (g_num_cus % 8) != 0) return false;
-    return tiles >= 3LL * g_num_cus || (g_variant & 31) == 6;
-}
-
 // One layer = the full 128-column tiles (WN = 2) plus, when the channel count leaves 1..64 columns over, one launch of
 // 64-column tiles for them (WN = 1); the split-K partial planes are shared and reduced once.
 template <int WM, bool GLDS>
@@ -668,7 +561,6 @@ int launch_wm(KParams& p, hipStream_t stream) {
 #endif
             {
             if (g_variant & 256) rc = launch_one<4, true, 2, 0, 4>(q, g4, 0, n256 / 256, stream);                  // plain (A/B)
-            else if (persist_applies(q, n256)) rc = launch_persist(q, g4, n256 / 256, stream);
             else rc = launch_one<4, true, 2, VAR_TILE_OPTS, 4>(q, g4, 0, n256 / 256, stream);
             if (rc) return rc;
             }

@@ -212,7 +212,7 @@ __device__ __forceinline__ bool decode_tile(int b, int mtiles, int ntiles, int& 
     return mt < mtiles;
 }
 
-__device__ __host__ inline unsigned grid_1d(int mtiles, int ntiles) {
+inline unsigned grid_1d(int mtiles, int ntiles) {
     if (tile_order_swapped(mtiles, ntiles)) return (unsigned)(((ntiles + 7) / 8) * 8 * mtiles);
     return (unsigned)(((mtiles + 7) / 8) * 8 * ntiles);
 }

@@ -465,7 +465,7 @@ def _run_halo_case(case, variant, workspace=False):
                       coefs.data_ptr() if use_norm else None, 1 if act else 0,
                       e0.data_ptr() if ec0 else None, e1.data_ptr() if ec1 else None, ec0, ec1, ec0, ec1)
     a.stats_out = stats.data_ptr()
-    if workspace:                          # split-K scratch; also where the persistent schedule parks its K-split first tiles
+    if workspace:                          # split-K scratch
         scratch = torch.full((20 << 20,), float('nan'), device=dev)
         a.workspace, a.workspace_floats = scratch.data_ptr(), scratch.numel()
     before = lib.ds_debug_conv_halo2_launches()
@@ -523,21 +523,6 @@ def test_conv_wide_n_tile_options_match_aten(case, variant):
     """The 256 x 256 tile's default kernel has VAR_LEAN | VAR_NTEPI (scalar-addressed weight DMA, non-temporal epilogue; covered by
     the test above); here the plain kernel (variant bit 8, kept for A/B runs)."""
     _run_halo_case(case, variant)
-
-
-PERSIST_CASES = [
-    # B, H(=W), c0, c1, cout, (ec0, ec1), norm, act -- with the forced 32-workgroup grid: 64 tile ids, two per workgroup
-    (16, 32, 96, 32, 256, (32, 0), True, True),        # 5 slabs (one of them a fused 1x1 skip slab): phases 0 / 1 / 2 / 3 slabs
-    (15, 32, 64, 32, 256, (0, 0), True, False),        # 60 tiles: ids 60..63 are padding (workgroups 28..31 own one real tile)
-    (8, 32, 128, 0, 512, (0, 0), False, False),        # two column tiles: 64 ids of 32 row tiles x 2
-]
-
-
-@pytest.mark.parametrize('case', PERSIST_CASES)
-def test_conv_persistent_phase_shifted_schedule_matches_aten(case):
-    """conv3x3_halo_persist_kernel (variant bit 6): one workgroup per CU owns tiles w, w + G, ...; its first tile is split along K at a
-    per-workgroup phase, the accumulators of the first part parked in the workspace and reloaded for the second part at the end."""
-    _run_halo_case(case, 6 | 64, workspace=True)
 
 
 @pytest.mark.parametrize('variant', [0, 512])
