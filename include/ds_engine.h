@@ -164,10 +164,13 @@ int ds_debug_force_generic_conv(int v);
  * allows); 0 restores the heuristic. */
 int ds_debug_force_splits(int s);
 
-/* Benchmark switch: kernel variant of the LDS-halo 3x3 convolution's 128-column tiles.  0 = default (set by the library),
- * 1 = software-pipelined tap loop (LDS fragment reads of K step g+1 in flight under the MFMAs of step g), 3 = second-generation
- * kernel (conv3x3_halo2.hip: static tap schedule, double halo buffer) where it applies, other values = timing ablations compiled
- * only with -DDS_CONV_ABLATIONS (they compute wrong results on purpose). */
+/* Benchmark switch: kernel variant of the LDS-halo 3x3 convolution.  Low five bits: 0 = default (set by the library),
+ * 1 = software-pipelined tap loop of the 128-column tiles (LDS fragment reads of K step g+1 in flight under the MFMAs of step g),
+ * 3 = second-generation kernel (conv3x3_halo2.hip: static tap schedule, double halo buffer) where it applies, 6 / 7 = 256 x 256
+ * tiles forced (tests at small sizes) / switched off, other values = timing ablations compiled only with -DDS_CONV_ABLATIONS (they
+ * compute wrong results on purpose; + 0x10000: ablations of the 256 x 256 tile).  Bit 8 (256): the 256 x 256 tile's plain kernel
+ * instead of its default (scalar-addressed weight DMA + non-temporal epilogue); bit 9 (512): tiles of several images read their
+ * GroupNorm coefficient planes from global memory instead of LDS. */
 int ds_debug_conv_variant(int v);
 
 /* Number of convolution launches routed to the second-generation 256 x 128 halo kernel so far (tests assert the routing). */

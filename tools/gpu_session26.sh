@@ -4,8 +4,8 @@
 set -x
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/s26; mkdir -p $O
-for b in 16 32 64 128 256; do
-  timeout 100 python tools/bench_conv.py --batch $b --norm --only 0 --rounds 7 --iters 20 --variants 6 >> $O/tiles_vs_time.txt 2>&1
+for b in 8 16 32 64; do
+  DS_CONV=256 timeout 100 python tools/bench_conv.py --batch $b --norm --only 0 --rounds 7 --iters 20 --variants 6 >> $O/tiles_vs_time.txt 2>&1
 done
 grep "^\[" $O/tiles_vs_time.txt | cut -c1-200
 true
