@@ -2,7 +2,8 @@
 
   * the benchmarked configuration itself -- CIFAR-10 net, DPM-Solver++(2M) logSNR NFE=10 (the sampler bench.py times) at B=64,
     where the 32x32 layers dispatch to the 256-pixel-tile halo kernel (conv3x3_halo_kernel<4>, the dominant kernel of the
-    headline); the dispatch is asserted through ds_conv_kernel_id;
+    headline); the dispatch is asserted through ds_conv_kernel_id; and the same 64 golden samples embedded in a call at the BENCHMARK
+    batch of 256 images;
   * one full-size evaluation each of the FFHQ-64 SongUNet and the ImageNet-64 DhariwalUNet (BASELINE configs 4 / 3);
   * one full-size Stable-Diffusion-v1.5 config-5 trajectory (DPM-Solver++(2M) eps-prediction, discrete rho=1, CFG 7.5).
 
@@ -53,6 +54,27 @@ def test_headline_sampler_b64_matches_reference_and_uses_the_256_tile_kernel(dev
             if a.taps == 9 and a.h == 32 and a.cout % 128 == 0:
                 ids.append(lib.ds_conv_kernel_id(C.byref(a)))
     assert len(ids) >= 20 and all(i in (256, 2565) for i in ids) and sum(i == 2565 for i in ids) >= 20, ids
+
+
+def test_headline_sampler_at_the_benchmark_batch_b256_matches_reference(dev):
+    """The sampler call bench.py times, at ITS batch (256 images: four rounds of 256 x 256 tiles per 32x32 layer, one round per 16x16
+    layer -- tilings a 64-image call does not reach).  Samples are independent (per-image GroupNorm, per-sample thresholding), so the 64
+    latents of the real reference's golden run are scattered over the 256-image batch (every fourth slot, i.e. all four rounds and
+    every tile position of an image) and their outputs compared with that golden; the other 192 slots carry different latents and
+    must not leak into them."""
+    from diff_sampler_amd import solvers
+    from diff_sampler_amd.engine import EDMDenoiser
+    z = np.load(os.path.join(G, 'sampler_cifar10_dpmpp2m_nfe10_b64.npz'))
+    net = EDMDenoiser.from_config('cifar10', seed=int(z['seed']))
+    gold = torch.randn(64, 3, 32, 32, generator=torch.Generator().manual_seed(int(z['latent_seed'])))
+    latents = torch.randn(256, 3, 32, 32, generator=torch.Generator().manual_seed(99))
+    slots = torch.arange(64) * 4 + torch.arange(64) % 4            # 0, 5, 10, 15, 16, 21, ...: every residue mod 4, all four quarters
+    latents[slots] = gold
+    out = solvers.dpm_pp_sampler(net, latents.to(dev), num_steps=11, sigma_min=0.002, sigma_max=80., schedule_type='logsnr', schedule_rho=7,
+                                 max_order=2, predict_x0=True, lower_order_final=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    assert _rel(out.cpu()[slots], torch.from_numpy(z['out'])) < 5e-4
 
 
 @pytest.mark.parametrize('name', ['ffhq', 'imagenet64'])
