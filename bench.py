@@ -48,6 +48,7 @@ PEAK_FP16_MFMA_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak (MI355X_MICROARC
 PEAK_HBM_GBS = 8000.0
 PMC_FILE = os.path.join(ROOT, 'profiles', 'r2f_bench_pmc_hbm.json')
 KERNEL_NAMES = {0: 'igemm_f32_kernel<0> (generic gather conv / 1x1 / linear)', 128: 'conv3x3_halo_kernel<2> (128-pixel tiles)',
+                1284: 'conv3x3_halo_kernel<2, WN=4, NT=1> (128-pixel tiles on 8 waves of 64 x 32)',
                 256: 'conv3x3_halo_kernel<4> (256-pixel tiles)', 2561: 'gemm_dma8_kernel (256x128 tiles, LDS-DMA, 1x1 / linear)',
                 2562: 'conv3x3_halo2_kernel<fp16 operands> (256-pixel tiles, v_mfma_f32_32x32x16_f16)',
                 2563: 'conv3x3_halo2_kernel<split fp16 hi/lo operands, fp32-emulated> (256-pixel tiles, 3 x v_mfma_f32_32x32x16_f16 per product)',
@@ -55,7 +56,7 @@ KERNEL_NAMES = {0: 'igemm_f32_kernel<0> (generic gather conv / 1x1 / linear)', 1
                 2565: 'conv3x3_halo_kernel<4, NT=4> (256-pixel x 256-channel tiles, 64 x 128 per wave)'}
 # roofline peaks by kernel: the split mode issues three fp16 MFMAs per algorithmic multiply-add, so its ceiling in ALGORITHMIC FLOPs is a third
 KERNEL_PEAK = {2562: PEAK_FP16_MFMA_TFLOPS, 2563: PEAK_FP16_MFMA_TFLOPS / 3, 2564: PEAK_FP16_MFMA_TFLOPS}
-PMC_KEYS = {0: 'void igemm::igemm_f32_kernel<0>(igemm::KParams)', 128: 'void igemm::conv3x3_halo_kernel<2, true, 2, 0, 2>(igemm::KParams)',
+PMC_KEYS = {0: 'void igemm::igemm_f32_kernel<0>(igemm::KParams)', 1284: 'void igemm::conv3x3_halo_kernel<2, true, 4, 0, 1>(igemm::KParams)', 128: 'void igemm::conv3x3_halo_kernel<2, true, 2, 0, 2>(igemm::KParams)',
             256: 'void igemm::conv3x3_halo_kernel<4, true, 2, 0, 2>(igemm::KParams)', 2561: 'igemm::gemm_dma8_kernel(igemm::KParams)',
             2562: None, 2563: None, 2564: None, 2565: 'void igemm::conv3x3_halo_kernel<4, true, 2, 160, 4>(igemm::KParams)'}
 

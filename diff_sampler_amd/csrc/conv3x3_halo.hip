@@ -27,7 +27,7 @@
 namespace igemm {
 namespace {
 
-constexpr int ns_max(int wn) { return wn == 2 ? 10 : 18; }    // halo float4 slots per thread (upper bound per shape)
+constexpr int ns_max(int wn) { return wn == 4 ? 5 : (wn == 2 ? 10 : 18); }    // halo float4 slots per thread (upper bound per shape)
 
 __device__ float g_zero_page_halo[64];   // zero-initialised
 
@@ -61,6 +61,73 @@ __device__ __forceinline__ unsigned lds_addr(const float* p) {
     return (unsigned)(size_t)(lcptr_t)(p);
 }
 
+// Fused conv epilogue of a 64 x 32 wave tile (acc[i][0], i = the two 32-row MFMA blocks): the vector path of igemm_common.h's epilogue
+// re-laid for 32 columns -- 8 lanes x float4 cover a row segment, lane >> 3 picks one of 8 rows per pass, 4 passes per 32-row group.
+// The launcher only takes this kernel where the vector path is legal (p.vec_ok, whole 32-column tiles) and there is no GEGLU gate.
+//   out = act((acc * acc_scale + colbias + cbias[img] + res) * scale), column sums / sums of squares of the wave's 64 rows to p.stats
+template <bool HALF>
+__device__ __forceinline__ void epilogue32(const KParams& p, const f32x16 (&acc)[2][2], float* stage, int lane, int wm0, int wn0, float* o_base) {
+    static_assert(HALF, "8-wave tiles: 32 staging rows per wave, the two 32-row groups one after the other");
+    const int c4 = (lane & 7) * 4;
+    const int col = wn0 + c4;
+    f32x4 cb = {0.f, 0.f, 0.f, 0.f};
+    if (p.colbias) cb = *reinterpret_cast<const f32x4*>(p.colbias + col);
+    f32x4 st_s = {0.f, 0.f, 0.f, 0.f}, st_q = {0.f, 0.f, 0.f, 0.f};
+    constexpr int NP = 4;
+    const bool cb_uniform = p.cbias && (p.cbias_bcast || p.HW % 32 == 0);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int rbase = wm0 + half * 32;
+        f32x4 rv[NP], cvu = {0.f, 0.f, 0.f, 0.f};
+        if (p.res) {
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
+                const int row = min(rbase + pass * 8 + (lane >> 3), p.M - 1);
+                rv[pass] = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.res_ld + col);
+            }
+        }
+        if (cb_uniform) {
+            const int img = p.cbias_bcast ? 0 : __builtin_amdgcn_readfirstlane(min(rbase, p.M - 1)) / p.HW;
+            cvu = *reinterpret_cast<const f32x4*>(p.cbias + (size_t)img * p.cbias_ld + col);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_LD + (lane & 31)] = acc[half][0][r];
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {
+            const int rr = pass * 8 + (lane >> 3);
+            const int row = rbase + rr;
+            if (row >= p.M) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * EPI_LD + c4);
+            v *= p.acc_scale;
+            v += cb;
+            if (cb_uniform) v += cvu;
+            else if (p.cbias) v += *reinterpret_cast<const f32x4*>(p.cbias + (size_t)(row / p.HW) * p.cbias_ld + col);
+            if (p.res) v += rv[pass];
+            v *= p.scale;
+            if (p.act == DS_ACT_SILU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = ds_silu(v[q]);
+            }
+            *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col) = v;
+            st_s += v; st_q += v * v;
+        }
+    }
+    if (p.stats && wm0 < p.M) {
+        // column sums of this wave's 64 rows: the 8 lane groups (lane >> 3) hold disjoint rows of the same 4 columns
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            st_s[q] += __shfl_xor(st_s[q], 8); st_s[q] += __shfl_xor(st_s[q], 16); st_s[q] += __shfl_xor(st_s[q], 32);
+            st_q[q] += __shfl_xor(st_q[q], 8); st_q[q] += __shfl_xor(st_q[q], 16); st_q[q] += __shfl_xor(st_q[q], 32);
+        }
+        if (lane < 8) {
+            float* sp = p.stats + (size_t)(wm0 >> 6) * 2 * p.N + col;
+            *reinterpret_cast<f32x4*>(sp) = st_s;
+            *reinterpret_cast<f32x4*>(sp + p.N) = st_q;
+        }
+    }
+}
+
 // Kernel variants (template VAR, selected at run time by ds_debug_conv_variant; 0 = the round-1 kernel, 1 = PIPE).  The other
 // bits are TIMING ABLATIONS that produce wrong results on purpose (tools/bench_conv.py --variants): 2 = no GroupNorm/SiLU
 // arithmetic in the halo writer, 4 = the halo is staged once and never again, 8 = the weight DMA is issued once and never
@@ -87,12 +154,19 @@ constexpr int VAR_TILE_OPTS = VAR_LEAN | VAR_NTEPI;
 // WN = wave columns: 2 = 128 output channels per tile (the normal shape), 1 = 64 (launched only for the ragged last
 // column tile of layers whose channel count is not a multiple of 128 -- 192, 320, 576 ... -- and for the few-channel
 // output conv, instead of multiplying a half-empty 128-wide tile; it starts at column p.n_begin).
+// WN = 4 with NT = 1: the 128-pixel x 128-channel tile on EIGHT waves of 64 x 32 (2 wave rows x 4 wave columns).  A layer with at most
+// one 128 x 128 tile per CU (the 8x8 layers at the benchmark batch: 256 tiles) leaves every SIMD with ONE 64 x 64 wave: the fp32 matrix
+// pipe then issues at 91 % at best (profiles/r2_probe_mfma_valu.txt) and nothing hides that wave's LDS latency -- those layers ran at
+// 0.70 of the peak against 0.87 for the same kernel with two waves per SIMD.  Half-size wave tiles double the waves instead (3 fragment
+// reads per 8 MFMAs instead of 4 per 16).
 // NT = 32-column MFMA tiles per wave: 2 = 64 x 64 per wave (the normal shape), 4 = 64 x 128 per wave, i.e. a 256-pixel x 256-channel
 // tile for the 8-wave shape: the halo of a slab is staged (normalised, SiLU'd) once for 256 output channels instead of twice, a K step
 // reads 6 fragments for 32 MFMAs instead of 4 for 16, and a tap has 128 MFMAs per wave between barriers (128 accumulator registers).
 template <int WM, bool GLDS, int WN, int VAR = 0, int NT = 2>
-__global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KParams p) {
-    static_assert(NT == 2 || (NT == 4 && WM == 4 && WN == 2 && GLDS && (VAR & ~(VAR_TILE_OPTS | VAR_NO_NORM | VAR_NO_HALO | VAR_NO_DMA | VAR_NO_EPI)) == 0), "wide-N tiles: 8-wave LDS-DMA shape only");
+__global__ void __launch_bounds__(64 * WM * WN, WN == 4 ? 2 : WN) conv3x3_halo_kernel(const KParams p) {
+    static_assert(NT != 1 || (WM == 2 && WN == 4 && GLDS && VAR == 0), "half-size wave tiles: 128 x 128 tile on 8 waves, LDS-DMA weights");
+    static_assert(WN != 4 || NT == 1, "four wave columns: 32-column wave tiles only");
+    static_assert(NT == 1 || NT == 2 || (NT == 4 && WM == 4 && WN == 2 && GLDS && (VAR & ~(VAR_TILE_OPTS | VAR_NO_NORM | VAR_NO_HALO | VAR_NO_DMA | VAR_NO_EPI)) == 0), "wide-N tiles: 8-wave LDS-DMA shape only");
     static_assert(NT == 4 || (VAR & VAR_TILE_OPTS) == 0, "lean addressing / non-temporal epilogue: 256 x 256 tiles only");
     constexpr bool LEAN = (VAR & VAR_LEAN) != 0, NTEPI = (VAR & VAR_NTEPI) != 0;
     constexpr bool PIPE = (VAR & VAR_PIPE) != 0;
@@ -109,7 +183,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
     float* Ah = smem + B_FLOATS;                    // [NP][LDSK]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = (WN == 2) ? wave >> 1 : wave, wc = (WN == 2) ? wave & 1 : 0;
+    const int wr = wave / WN, wc = wave % WN;
     int mt, nt;
     if (!decode_tile(blockIdx.x, p.mtiles, p.ntiles, mt, nt, blockIdx.y)) return;
     const int m0 = mt * TBM, n0 = p.n_begin + nt * BNT;
@@ -414,7 +488,14 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
                     if (BROWS == 4) rb[ks] = *reinterpret_cast<const f32x4*>(b_addr(nxt, ks));
                     else if (ks < BROWS) rb[ks] = *reinterpret_cast<const f32x4*>(b_addr(nxt, ks));
                 }
-                {
+                if constexpr (NT == 1) {                        // 64 x 32 per wave: one column block
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bs + b_frag(ks));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[r], b0[r], acc[0][0], 0, 0, 0);
+                        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], b0[r], acc[1][0], 0, 0, 0);
+                    }
+                } else {
                     const f32x4 b0 = *reinterpret_cast<const f32x4*>(bs + b_frag(ks));
                     const f32x4 b1 = *reinterpret_cast<const f32x4*>(bs + 32 * BLD + b_frag(ks));
 #pragma unroll
@@ -459,6 +540,15 @@ __global__ void __launch_bounds__(64 * WM * WN, WN) conv3x3_halo_kernel(const KP
                 asm volatile("" :: "v"(acc[i][j]));
                 if constexpr (NT == 4) asm volatile("" :: "v"(acc_hi[i][j]));
             }
+        return;
+    }
+    if constexpr (NT == 1) {                         // 64 x 32 wave tiles (also the raw partial tile of a split)
+        if (p.splits > 1) {
+            const KParams q = split_params(p, blockIdx.y);
+            epilogue32<HALF>(q, acc, smem + wave * 32 * EPI_LD, lane, m0 + wr * 64, n0 + wc * 32, q.out);
+        } else {
+            epilogue32<HALF>(p, acc, smem + wave * 32 * EPI_LD, lane, m0 + wr * 64, n0 + wc * 32, p.out);
+        }
         return;
     }
     if (p.splits > 1) {
@@ -534,6 +624,17 @@ int launch_one(KParams p, const Geo& g, int n_begin, int ntiles, hipStream_t str
     return DS_OK;
 }
 
+// Half-size wave tiles (conv3x3_halo_kernel<2, true, 4, 0, 1>) for the `wide` full 128-column tiles of a layer on 128-pixel tiles: taken
+// where the whole launch is at most one workgroup per CU (with more, two 4-wave workgroups share a CU and every SIMD has its two waves
+// anyway), the float4 epilogue is legal and every one of those tiles is complete.  Variant bit 11: off (A/B runs).
+bool half_wave_tiles(const KParams& p, int n_begin, int wide) {
+    if ((g_variant & 31) != 0 || (g_variant & 2048) || !g_glds || wide < 1) return false;
+    if (!p.vec_ok || p.out_planar || p.act == DS_ACT_GEGLU || n_begin + wide * BN > p.N || p.nrows_b < n_begin + wide * BN) return false;
+    if (p.splits > 1 && !p.vec_part) return false;
+    if ((long long)((p.M + 127) / 128) * wide * p.splits > 256) return false;
+    return geometry(p, 128, 4).ok;
+}
+
 // One layer = the full 128-column tiles (WN = 2) plus, when the channel count leaves 1..64 columns over, one launch of
 // 64-column tiles for them (WN = 1); the split-K partial planes are shared and reduced once.
 template <int WM, bool GLDS>
@@ -576,6 +677,9 @@ int launch_wm(KParams& p, hipStream_t stream) {
         if (WM == 4 && GLDS && (g_variant & 31) == 3 && p.splits == 1 && n256 == 0 && conv3x3_halo2_applicable(p, wide, 0)) {
             KParams q = p;
             rc = launch_conv3x3_halo2(q, wide, 0, stream);
+        } else if (WM == 2 && GLDS && half_wave_tiles(p, n256, wide)) {
+            if constexpr (WM == 2 && GLDS) rc = launch_one<2, true, 4, 0, 1>(p, geometry(p, 128, 4), n256, wide, stream);
+            else rc = DS_E_ARG;
         } else if constexpr (GLDS) {
             // (routing the layers that leave a SIMD with ONE wave -- 8x8 layers at the benchmark batch -- to the software-pipelined
             // VAR_PIPE kernel gains 2.8 % on those layers in isolation and nothing measurable on the network: not done)
@@ -639,9 +743,16 @@ HaloPlan plan_halo(const KParams& p) {
     return hp;
 }
 
-// 0 = unsupported, 128 / 256 = M tile of the 128-column kernels, 2565 = the 256 x 256-tile kernel
+// 0 = unsupported, 128 / 256 = M tile of the 128-column kernels, 2565 = the 256 x 256-tile kernel, 1284 = 128-pixel tiles on 8 half-size waves
 int conv3x3_halo_choice(const KParams& p) {
     const HaloPlan hp = plan_halo(p);
+    if (hp.tile == 128 && g_glds) {
+        KParams q = p;
+        q.splits = hp.splits;
+        const int full = p.N / BN, rem = p.N - full * BN;
+        const bool tail64 = rem > 0 && rem <= 64 && geometry(p, 128, 1).ok && g_tail64;
+        if (half_wave_tiles(q, 0, tail64 ? full : (p.N + BN - 1) / BN)) return 1284;
+    }
     if (hp.tile == 256 && g_glds) {
         KParams q = p;
         q.splits = hp.splits;

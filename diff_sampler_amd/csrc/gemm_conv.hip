@@ -384,7 +384,13 @@ extern "C" int ds_conv_kernel_id(const ds_conv_args* a) {
     KParams p{};
     p.taps = a->taps; p.H = a->h; p.W = a->w; p.HW = a->h * a->w; p.M = a->n * a->h * a->w; p.N = a->cout;
     p.c0 = a->c0; p.c1 = a->c1; p.ec0 = a->ec0; p.ec1 = a->ec1;
-    if (a->workspace && a->workspace_floats > 0) { p.part = a->workspace; p.part_cap = a->workspace_floats; }
+    if (a->workspace && a->workspace_floats > 0 && ds_aligned16(a->workspace) && a->act != DS_ACT_GEGLU) {
+        p.part = a->workspace; p.part_cap = a->workspace_floats; p.vec_part = (p.N & 3) ? 0 : 1;
+    }
+    // the epilogue-related fields the tile choice looks at, as ds_conv2d_nhwc sets them
+    p.out = a->out; p.ldo = a->out_ld; p.colbias = a->bias; p.cbias = a->cbias; p.cbias_ld = a->cbias_ld; p.res = a->res; p.res_ld = a->res_ld;
+    p.act = a->act; p.out_planar = a->out_nchw ? 1 : 0;
+    p.vec_ok = (vec_epilogue_ok(p) && !a->out_nchw) ? 1 : 0;
     p.stride = a->stride ? a->stride : 1; p.K = a->taps * (a->c0 + a->c1) + a->ec0 + a->ec1; p.norm = a->norm_coefs;
     p.nrows_b = ((a->cout + BN - 1) / BN) * BN;                                     // weights are row-padded, as in ds_conv2d_nhwc
     if (a->wgt_f16) return a->wgt_f16 == 2 ? 2563 : (a->taps == 1 ? 2564 : 2562);

@@ -420,7 +420,7 @@ HALO2_CASES = [
 ]
 
 
-def _run_halo_case(case, variant, workspace=False):
+def _run_halo_case(case, variant, workspace=False, tile=256, want_kid=None):
     """One fused 3x3 layer (dual source, fused normalisation + SiLU, 1x1 skip columns, bias, per-image bias, residual, scale,
     epilogue statistics) through ds_conv2d_nhwc with the 256-pixel tile forced and the given kernel variant; checked against ATen."""
     import ctypes as C
@@ -469,7 +469,7 @@ def _run_halo_case(case, variant, workspace=False):
         scratch = torch.full((20 << 20,), float('nan'), device=dev)
         a.workspace, a.workspace_floats = scratch.data_ptr(), scratch.numel()
     before = lib.ds_debug_conv_halo2_launches()
-    lib.ds_debug_force_generic_conv(256)
+    lib.ds_debug_force_generic_conv(tile)
     lib.ds_debug_conv_variant(variant)
     try:
         kid = lib.ds_conv_kernel_id(C.byref(a))
@@ -481,6 +481,8 @@ def _run_halo_case(case, variant, workspace=False):
     assert rc == 0, lib.ds_error_string(rc)
     if variant == 3:
         assert lib.ds_debug_conv_halo2_launches() == before + 1, 'the layer was not routed to the second-generation kernel'
+    if want_kid is not None:
+        assert kid == want_kid, (kid, want_kid)
     if (variant & 31) == 6:
         assert kid == 2565, 'the layer was not routed to the 256 x 256-tile kernel'
     want = _nhwc(ref)
@@ -533,6 +535,24 @@ def test_conv_multi_image_tiles_coefficient_planes(case, variant):
     global memory per slot (the launcher's choice when they do not fit)."""
     _run_halo_case(case, variant)
 
+
+HALF_WAVE_CASES = [
+    # B, H(=W), c0, c1, cout, (ec0, ec1), norm, act
+    (16, 8, 64, 64, 256, (64, 0), True, True),         # 8x8: two images per 128-pixel tile, coefficient planes in LDS, skip-projection slab
+    (5, 8, 96, 0, 128, (0, 0), True, False),           # odd image count: the last tile's second image is past the batch
+    (2, 16, 64, 32, 256, (0, 0), True, True),          # 16x16, dual source
+    (1, 32, 64, 0, 384, (32, 0), False, False),        # 32x32 (4 halo slots), three column tiles
+    (1, 64, 32, 0, 128, (0, 0), True, True),           # W = 64: five halo slots per thread
+    (1, 8, 256, 256, 256, (256, 256), True, True),     # long K on one row tile: split-K partial tiles through the same epilogue
+]
+
+
+@pytest.mark.parametrize('variant', [0, 2048])
+@pytest.mark.parametrize('case', HALF_WAVE_CASES)
+def test_conv_half_wave_tiles_match_aten(case, variant):
+    """conv3x3_halo_kernel<2, true, 4, 0, 1>: a layer with at most one 128 x 128 tile per CU runs that tile on EIGHT waves of 64 x 32
+    (two per SIMD) instead of four of 64 x 64 (kernel id 1284; variant bit 11 switches back to the four-wave kernel, id 128)."""
+    _run_halo_case(case, variant, workspace=True, tile=128, want_kid=1284 if variant == 0 else 128)
 
 F16_CASES = [
     # B, H(=W), c0, c1, cout, (ec0, ec1), norm, act
