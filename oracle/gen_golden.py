@@ -24,6 +24,10 @@ Parts
             at B=64 (the bench.py headline sampler; final images); one full-size evaluation each of the FFHQ-64
             SongUNet and the ImageNet-64 DhariwalUNet (B=1, labels); one full-size SD-1.5 config-5 trajectory
             (DPM-Solver++(2M) eps-prediction, discrete rho=1, num_steps=6, CFG 7.5, B=1)
+  full3     BASELINE config 3 at full size through the reference sampler: ImageNet-64 DhariwalUNet (295.9M params, one-hot labels),
+            ipndm_sampler max_order=4 on the 11-point GITS-form schedule literal (t_steps), NFE=10, B=1: the whole trajectory
+  full4     BASELINE config 4 at full size through the reference sampler: FFHQ-64 SongUNet (61.8M params) + AMED_predictor
+            (num_steps=4, afs=True, time_uniform rho=1, scale_dir=0.01, scale_time=0; amed-solver-main/launch.sh:21-24), 5 NFE, B=2
 """
 import argparse
 import os
@@ -327,7 +331,44 @@ def part_full():
     print('full sd15 config-5 trajectory', tuple(tr.shape), float(tr[-1].abs().max()), flush=True)
 
 
-PARTS = dict(net=part_net, sched=part_sched, samplers=part_samplers, amed=part_amed, gits=part_gits, ldm=part_ldm, full=part_full)
+CONFIG3_TSTEPS = [80.0, 31.78, 14.51, 7.42, 3.88, 2.05, 1.06, 0.5666, 0.2531, 0.0631, 0.002]     # 11 points => NFE 10 (GITS form)
+
+
+def part_full3():
+    sys.path.insert(0, os.path.join(REF, 'diff-solvers-main'))
+    import solvers
+    torch.set_grad_enabled(False)
+    net, kw = _ref_net('imagenet64', 31)
+    g = torch.Generator().manual_seed(32)
+    latents = torch.randn(1, 3, 64, 64, generator=g)
+    labels = torch.eye(1000)[torch.randint(1000, (1,), generator=g)]
+    t_steps = torch.tensor(CONFIG3_TSTEPS)
+    tr = solvers.ipndm_sampler(net, latents, class_labels=labels, num_steps=11, sigma_min=0.002, sigma_max=80., max_order=4,
+                               t_steps=t_steps, return_inters=True)
+    np.savez_compressed(os.path.join(OUT, 'sampler_imagenet64_ipndm_gits_nfe10_b1.npz'), seed=31, input_seed=32, latents=latents.numpy(),
+                        labels=labels.numpy(), t_steps=t_steps.numpy(), traj=tr.numpy())
+    print('full3 imagenet64 ipndm-4 GITS-form schedule', tuple(tr.shape), float(tr[-1].abs().max()), flush=True)
+
+
+def part_full4():
+    sys.path.insert(0, os.path.join(REF, 'amed-solver-main'))
+    import solvers_amed
+    from training.networks import AMED_predictor
+    torch.set_grad_enabled(False)
+    net, kw = _ref_net('ffhq', 41)
+    latents = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(42))
+    pk = dict(scale_dir=0.01, scale_time=0)
+    pred = AMED_predictor(num_steps=4, sampler_stu='amed', sampler_tea='heun', M=1, schedule_type='time_uniform', schedule_rho=1,
+                          afs=True, **pk).eval()
+    pred.load_state_dict(amed_predictor_params(43, pk['scale_dir'], pk['scale_time']), strict=True)
+    tr = solvers_amed.amed_sampler(net, latents, num_steps=4, sigma_min=0.002, sigma_max=80., schedule_type='time_uniform',
+                                   schedule_rho=1, afs=True, return_inters=True, AMED_predictor=pred)
+    np.savez_compressed(os.path.join(OUT, 'sampler_ffhq_amed_nfe5_b2.npz'), seed=41, input_seed=42, predictor_seed=43,
+                        latents=latents.numpy(), traj=tr.numpy(), **pk)
+    print('full4 ffhq AMED-Solver nfe5', tuple(tr.shape), float(tr[-1].abs().max()), flush=True)
+
+
+PARTS = dict(full3=part_full3, full4=part_full4, net=part_net, sched=part_sched, samplers=part_samplers, amed=part_amed, gits=part_gits, ldm=part_ldm, full=part_full)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

@@ -5,6 +5,8 @@
     headline); the dispatch is asserted through ds_conv_kernel_id; and the same 64 golden samples embedded in a call at the BENCHMARK
     batch of 256 images;
   * one full-size evaluation each of the FFHQ-64 SongUNet and the ImageNet-64 DhariwalUNet (BASELINE configs 4 / 3);
+  * BASELINE configs 3 and 4 through the reference's own sampler calls at full size (ImageNet-64 iPNDM-4 on the GITS-form schedule,
+    FFHQ-64 AMED-Solver): whole trajectories;
   * one full-size Stable-Diffusion-v1.5 config-5 trajectory (DPM-Solver++(2M) eps-prediction, discrete rho=1, CFG 7.5).
 
 Tolerances (fp32 path): 2e-4 per evaluation, 5e-4 per EDM trajectory, 1e-3 for the 5-step SD trajectory."""
@@ -86,6 +88,39 @@ def test_full_size_64px_nets_match_reference(name, dev):
     out = net(torch.from_numpy(z['x']).to(dev), torch.from_numpy(z['sigma']).to(dev), class_labels=lab)
     torch.cuda.synchronize()
     assert _rel(out.cpu(), torch.from_numpy(z['out_vec'])) < 2e-4
+
+
+def test_config3_imagenet64_trajectory_matches_reference(dev):
+    """BASELINE config 3 at full size against the REAL reference's own sampler call (oracle/gen_golden.py --part full3): ImageNet-64
+    DhariwalUNet with a one-hot label, ipndm_sampler max_order 4 on the GITS-form schedule literal, NFE = 10, every intermediate."""
+    from diff_sampler_amd import solvers
+    from diff_sampler_amd.engine import EDMDenoiser
+    z = np.load(os.path.join(G, 'sampler_imagenet64_ipndm_gits_nfe10_b1.npz'))
+    net = EDMDenoiser.from_config('imagenet64', seed=int(z['seed']))
+    out = solvers.ipndm_sampler(net, torch.from_numpy(z['latents']).to(dev), class_labels=torch.from_numpy(z['labels']).to(dev), max_order=4,
+                                t_steps=torch.from_numpy(z['t_steps']).to(dev), num_steps=11, return_inters=True)
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == tuple(z['traj'].shape)
+    assert _rel(out.cpu(), torch.from_numpy(z['traj'])) < 5e-4
+
+
+def test_config4_ffhq64_amed_trajectory_matches_reference(dev):
+    """BASELINE config 4 at full size against the REAL reference's amed_sampler (oracle/gen_golden.py --part full4): FFHQ-64 SongUNet +
+    AMED_predictor(num_steps = 4, afs, time_uniform rho = 1, scale_dir 0.01), 5 NFE; tolerance 1e-3 (per-sample powf / expm1f on the device)."""
+    from diff_sampler_amd import solvers_amed
+    from diff_sampler_amd.engine import EDMDenoiser
+    from oracle import cases
+    z = np.load(os.path.join(G, 'sampler_ffhq_amed_nfe5_b2.npz'))
+    net = EDMDenoiser.from_config('ffhq', seed=int(z['seed']))
+    pk = dict(scale_dir=float(z['scale_dir']), scale_time=float(z['scale_time']))
+    pp = cases.amed_predictor_params(int(z['predictor_seed']), pk['scale_dir'], pk['scale_time'])
+    pred = solvers_amed.AMEDPredictor(pp, device=dev, num_steps=4, sampler_stu='amed', schedule_type='time_uniform', schedule_rho=1,
+                                      afs=True, **pk)
+    out = solvers_amed.amed_sampler(net, torch.from_numpy(z['latents']).to(dev), num_steps=4, sigma_min=0.002, sigma_max=80.,
+                                    schedule_type='time_uniform', schedule_rho=1, afs=True, return_inters=True, AMED_predictor=pred)
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == tuple(z['traj'].shape)
+    assert _rel(out.cpu(), torch.from_numpy(z['traj'])) < 1e-3
 
 
 def test_sd15_config5_trajectory_matches_reference(dev):
