@@ -122,7 +122,9 @@ int ds_conv2d_nhwc(const ds_conv_args* a, void* stream);
  * LDS-halo kernel with that M tile (conv3x3_halo_kernel<2> / <4>), 2561 = 8-wave LDS-DMA 1x1 / Linear kernel
  * (gemm_dma8_kernel), 2562 = fp16-operand halo kernel (conv3x3_halo2_kernel<W, 1>), 2563 = split-fp16 (fp32-emulated) halo kernel
  * (conv3x3_halo2_kernel<W, 2>), 2564 = fp16-operand 1x1 / Linear kernel (gemm_f16_kernel), 2565 = LDS-halo kernel <4> with
- * 256-pixel x 256-channel tiles (64 x 128 per wave; channel counts that are multiples of 256 on 16- and 32-column images).  Used by bench.py to attribute time per kernel. */
+ * 256-pixel x 256-channel tiles (64 x 128 per wave; channel counts that are multiples of 256 on 16-, 32- and 64-column images), 1284 =
+ * LDS-halo kernel with 128-pixel tiles on eight waves of 64 x 32 (layers with at most one tile per CU).  Used by bench.py to
+ * attribute time per kernel. */
 int ds_conv_kernel_id(const ds_conv_args* a);
 
 /* 1 if a 3x3 convolution on h x w images runs on the LDS-halo kernel (needed for norm_coefs), else 0. */
