@@ -88,3 +88,22 @@ def test_bench_without_gpu_fails_loudly():
         pytest.skip('a GPU is present')
     r = subprocess.run([sys.executable, BENCH, '--gpus', '1', '--steps', '1'], env=_clean_env(), capture_output=True, text=True, timeout=120)
     assert r.returncode == 2 and 'needs GPU' in r.stderr
+
+
+def test_committed_pmc_summary_names_the_dominant_kernel():
+    """bench.py reads `roofline.traffic` from the committed PMC summary by KERNEL NAME; a kernel whose template arguments change
+    (the 256 x 256 conv tile's did in round 2) would silently turn the field into null.  The summary under profiles/ must hold the
+    kernel bench.py attributes the dominant share to, and its HBM bytes per launch must be a plausible multiple of the algorithmic
+    bytes of the headline's 3x3 layers (about 503 MB per launch at B = 256)."""
+    import re
+    sys.path.insert(0, ROOT)
+    import bench
+    t = bench.pmc_traffic(2565)
+    assert t is not None, (bench.PMC_FILE, bench.PMC_KEYS[2565])
+    assert 0.9 * 503e6 < t < 1.5 * 503e6, t
+    # ... and the name is the one the in-tree source instantiates as the default 256 x 256 kernel
+    m = re.match(r'void igemm::conv3x3_halo_kernel<4, true, 2, (\d+), 4>', bench.PMC_KEYS[2565])
+    assert m, bench.PMC_KEYS[2565]
+    src = open(os.path.join(ROOT, 'diff_sampler_amd', 'csrc', 'conv3x3_halo.hip')).read()
+    lean, ntepi = (int(re.search(r'constexpr int VAR_LEAN = (\d+)', src).group(1)), int(re.search(r'VAR_NTEPI = (\d+)', src).group(1)))
+    assert int(m.group(1)) == (lean | ntepi) and 'launch_one<4, true, 2, VAR_TILE_OPTS, 4>' in src
