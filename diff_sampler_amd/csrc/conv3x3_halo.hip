@@ -20,6 +20,10 @@
 //   WM = 4: BM = 256, 8 waves, 1 workgroup per CU.  The weight tile is shared by twice as many pixels:
 //           (43.5 + 144) KB per 2x the FLOPs = 94 KB per 128x128-equivalent.  Used when the layer has enough 256-pixel
 //           tiles to fill the chip.
+// Round 2 added two wave-tile shapes on top of them (template WN = wave columns, NT = 32-column MFMA blocks per wave; see the kernel):
+//   WM = 4, WN = 2, NT = 4: 256 pixels x 256 channels, eight waves of 64 x 128 -- the dominant kernel of the headline (0.87-0.88 of the
+//           fp32 matrix peak), with scalar-addressed weight DMA and a non-temporal epilogue;
+//   WM = 2, WN = 4, NT = 1: the 128 x 128 tile on eight waves of 64 x 32, for layers with at most one tile per CU.
 // The halo for slab c+1 is loaded into registers while slab c is multiplied and written to LDS at the slab boundary
 // (one extra barrier per 576 MFMAs per wave).
 #include "igemm_common.h"

@@ -172,7 +172,8 @@ int ds_debug_force_splits(int s);
  * tiles forced (tests at small sizes) / switched off, other values = timing ablations compiled only with -DDS_CONV_ABLATIONS (they
  * compute wrong results on purpose; + 0x10000: ablations of the 256 x 256 tile).  Bit 8 (256): the 256 x 256 tile's plain kernel
  * instead of its default (scalar-addressed weight DMA + non-temporal epilogue); bit 9 (512): tiles of several images read their
- * GroupNorm coefficient planes from global memory instead of LDS. */
+ * GroupNorm coefficient planes from global memory instead of LDS; bit 11 (2048): the four-wave 128 x 128 tile also where the default
+ * is eight half-size waves. */
 int ds_debug_conv_variant(int v);
 
 /* Number of convolution launches routed to the second-generation 256 x 128 halo kernel so far (tests assert the routing). */

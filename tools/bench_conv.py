@@ -3,6 +3,8 @@
     python tools/bench_conv.py --batch 256 [--entry ds_conv2d_nhwc] [--check]
     python tools/bench_conv.py --batch 256 --only 0 1 --variants 0 1 28 29 --rounds 7    # interleaved A/B of kernel variants
                                                     (ds_debug_conv_variant; ablations need a -DDS_CONV_ABLATIONS build)
+    variant words: include/ds_engine.h (ds_debug_conv_variant); 256 = plain 256 x 256 kernel, 512 = coefficient planes from global memory,
+    2048 = four-wave 128 x 128 tiles where the default takes eight half-size waves; 65536 + {4, 16, 20, 28} = ablations of the 256 x 256 tile
 """
 import argparse
 import ctypes as C
