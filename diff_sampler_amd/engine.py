@@ -356,6 +356,7 @@ class EDMDenoiser:
         self.sigma_max = spec.sigma_max
         self.sigma_data = spec.sigma_data
         self.use_fp16 = bool(use_fp16)   # read-only after construction (weights are packed for the mode), like net.use_fp16 of the reference
+        self._last = None                # (plan, batch) of the last __call__ evaluation (block_output)
         self.bottleneck_name = None      # set by the AMED path: 'enc.8x8_block3' / 'enc.8x8_block2'
 
     @classmethod
@@ -427,6 +428,7 @@ class EDMDenoiser:
         x = x.to(torch.float32).contiguous()
         plan, emb_rows = self._prepare(x, sigma, class_labels)
         plan.run(_lib.stream_ptr())
+        self._last = (plan, B)
         out = torch.empty_like(x)
         # D = c_skip x + c_out F, evaluated by the update kernel with cx = 0, cm = 1, store_d = 0 (m = D)
         args = ops.make_update_args(plan.bufs['x'], plan.bufs['x'], plan.bufs['out'], B, Cc, H, W, None, raw=True, f_ld=0,
@@ -446,6 +448,17 @@ class EDMDenoiser:
         lib = self.engine.lib
         _lib.check(lib.ds_copy_rows(_ptr(plan.bufs['sigma']), 1, _ptr(cf[:, 6:]), 8, rows, 1, _lib.stream_ptr()), 'sigma->coefs')
         return cf
+
+    def block_output(self, name):
+        """Output of block ``name`` ('enc.8x8_block3', 'enc.16x16_block0', ...) of the LAST ``net(x, sigma, ...)`` evaluation, as the
+        NCHW tensor ``[B, C, h, w]`` a forward hook on that block of the reference module would see (solvers_amed.py:7-18 taps
+        ``net.model.enc['8x8_block3']``).  A copy: the plan's own buffer is overwritten by the next evaluation."""
+        plan, B = self._last
+        t = plan.bufs[name]
+        hw = t.shape[0] // B
+        h = int(round(hw ** 0.5))
+        assert h * h == hw, (name, tuple(t.shape), B)
+        return t.reshape(B, h, h, t.shape[1]).permute(0, 3, 1, 2).contiguous()
 
     def bottleneck_mean(self, plan, B, class_cond):
         """Channel mean of the AMED bottleneck tap, [B, 8, 8] (solvers_amed.py:16-17, :24-28)."""

@@ -20,10 +20,11 @@ still the reference's ``solvers.py``; for the fused update kernels and the one-l
 What the route does NOT do, on purpose: it computes nothing itself.  Calls with CPU tensors or with ``augment_labels`` / other
 ``model_kwargs`` go to the module's ORIGINAL ``forward`` -- the reference's own code, not a fallback of this package; a GPU call
 whose HIP library is missing (``_lib.DsError``) or whose module ``engine.spec_from_module`` does not recognise raises, like every
-other entry point.  Forward hooks on inner blocks (the AMED bottleneck tap,
-``solvers_amed.py:7-18``) do not fire under the route because the inner modules are not executed: AMED runs through
-``diff_sampler_amd.solvers_amed``, which takes the bottleneck from the plan.  Weights are packed when the engine is built;
-call ``invalidate(net)`` after changing them.
+other entry point.  The inner modules are not executed under the route; the one place the reference observes them -- the AMED
+bottleneck tap, a forward hook on ``net.model.enc['8x8_block2' | '8x8_block3']`` (``solvers_amed.py:7-18``) -- is honoured: hooks
+registered on those two blocks are called with the engine's output of the same block, so amed-solver-main's own ``solvers_amed.py``
+runs on a routed net (``diff_sampler_amd.solvers_amed`` does the same without hooks, taking the bottleneck from the plan).  Weights are
+packed when the engine is built; call ``invalidate(net)`` after changing them.
 """
 from __future__ import annotations
 
@@ -91,6 +92,26 @@ def invalidate(net):
     net.__dict__.pop(_ENGINES, None)
 
 
+AMED_TAPS = ('8x8_block2', '8x8_block3')          # solvers_amed.py:15-17: class-conditional / unconditional EDM nets
+
+
+def _fire_bottleneck_hooks(net, eng):
+    """The AMED code taps the U-Net bottleneck with a forward hook on ``net.model.enc['8x8_block2' | '8x8_block3']``
+    (amed-solver-main/solvers_amed.py:7-18).  Under the route that block's module does not execute, so its registered forward hooks are
+    called here with the engine's output of the same block (``EDMDenoiser.block_output``): the reference's ``solvers_amed.py`` then runs
+    unchanged on a routed net."""
+    enc = getattr(getattr(net, 'model', None), 'enc', None)
+    if enc is None:
+        return
+    for key in AMED_TAPS:
+        mod = enc[key] if key in enc else None
+        hooks = getattr(mod, '_forward_hooks', None) if mod is not None else None
+        if hooks:
+            out = eng.block_output('enc.' + key)
+            for fn in list(hooks.values()):
+                fn(mod, (), out)
+
+
 def route_class(cls):
     """Wrap ``cls.forward`` (``EDMPrecond.forward``, networks_edm.py:482-496) so that GPU calls run on the HIP engine.  Same
     signature, same return (denoised NCHW fp32).  Idempotent per class object."""
@@ -108,7 +129,9 @@ def route_class(cls):
         eng = engines.get(key)
         if eng is None:
             eng = engines[key] = make_engine(self, x.device, use_fp16)
-        return eng(x, sigma, class_labels=class_labels)
+        out = eng(x, sigma, class_labels=class_labels)
+        _fire_bottleneck_hooks(self, eng)
+        return out
 
     forward.__doc__ = reference_forward.__doc__
     forward.reference_forward = reference_forward

@@ -85,3 +85,29 @@ def test_amed_requires_hip_denoiser():
     with pytest.raises(RuntimeError, match='bottleneck tap'):
         solvers_amed.amed_sampler(lambda x, t, class_labels=None: x, torch.zeros(1, 3, 16, 16, device='cuda'), num_steps=3,
                                   AMED_predictor=pred)
+
+
+def test_block_output_is_the_bottleneck_a_forward_hook_would_see():
+    """`EDMDenoiser.block_output('enc.8x8_block3')` (what `persistence_hook` hands to the forward hooks of amed-solver-main's
+    `init_hook`, solvers_amed.py:7-18) against the oracle's tap of the same block, and its channel mean against `bottleneck_mean`
+    (the kernel the HIP AMED samplers use, solvers_amed.py:24-28)."""
+    import diff_sampler_amd.arch as arch
+    from diff_sampler_amd.engine import EDMDenoiser
+    from oracle.edm_net import OracleNet
+    dev = torch.device('cuda')
+    kw = dict(arch.NAMED_CONFIGS['tiny_song_amed'])
+    params = arch.init_params(arch.edm_precond_spec(**kw), seed=5)
+    net = EDMDenoiser(arch.edm_precond_spec(**kw), params)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(3, 3, 16, 16, generator=g) * 2.0
+    d = net(x.to(dev), 1.7)
+    tap = net.block_output('enc.8x8_block3')
+    assert tuple(tap.shape) == (3, 64, 8, 8) and tap.is_contiguous()
+    plan, B = net._last
+    assert _rel(tap.mean(1).cpu(), net.bottleneck_mean(plan, B, class_cond=False).cpu()) < 1e-5
+    ref_net = OracleNet(params, kw)
+    with torch.no_grad():
+        want_d = ref_net(x, torch.tensor(1.7))
+        want_tap = ref_net.last_bottleneck                # the oracle's tap of enc.8x8_block3 (no labels), NCHW
+    assert _rel(d.cpu(), want_d) < 2e-4
+    assert tuple(want_tap.shape) == tuple(tap.shape) and _rel(tap.cpu(), want_tap) < 2e-4

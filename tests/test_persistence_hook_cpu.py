@@ -106,6 +106,40 @@ def test_gpu_calls_go_to_the_engine_built_from_the_module(ref, monkeypatch):
         got(x, 1.0, augment_labels=None)
 
 
+def test_amed_bottleneck_hooks_fire_with_the_engines_block_output(ref, monkeypatch):
+    """amed-solver-main/solvers_amed.py:7-18 taps `net.model.enc['8x8_block3']` ('8x8_block2' with class labels) through a forward hook;
+    the routed forward calls the hooks registered there with `EDMDenoiser.block_output` of the same block."""
+    import diff_sampler_amd.persistence_hook as H
+    _, EDMPrecond = ref
+    for name, key in (('tiny_song_amed', '8x8_block3'), ('tiny_song_amed_cond', '8x8_block2')):
+        net, blob = _snapshot(EDMPrecond, name)
+        got = pickle.loads(blob)['ema']
+        asked = []
+
+        class FakeEngine:
+            def __call__(self, x, sigma, class_labels=None):
+                return 'D'
+
+            def block_output(self, block):
+                asked.append(block)
+                return torch.full((2, 64, 8, 8), 7.0)
+
+        monkeypatch.setattr(H, 'make_engine', lambda module, device, use_fp16: FakeEngine())
+
+        class OnGpu:
+            is_cuda, device = True, 'cuda:0'
+
+        assert got(OnGpu(), 1.0) == 'D' and asked == []                    # no hook registered: the tap is not even read
+        seen = []                                                            # init_hook of the reference, verbatim in behaviour
+        handle = got.model.enc[key].register_forward_hook(lambda module, inp, out: seen.append(out.detach()))
+        assert got(OnGpu(), 1.0) == 'D'
+        assert asked == ['enc.' + key] and len(seen) == 1 and tuple(seen[0].shape) == (2, 64, 8, 8)
+        assert torch.mean(seen[-1], dim=1).shape == (2, 8, 8)                # what get_amed_prediction does with it (solvers_amed.py:24-28)
+        handle.remove()
+        got(OnGpu(), 1.0)
+        assert len(seen) == 1
+
+
 def test_classes_without_a_routed_name_are_left_alone(ref):
     import diff_sampler_amd.persistence_hook as H
     persistence, _ = ref
