@@ -62,3 +62,34 @@ def test_split_mode_marks_the_3x3_convolutions_only():
     assert sum(1 for a in convs if a.taps == 9 and a.wgt_f16 == 2) >= 60
     assert all(a.wgt_f16 == 0 for a in convs if a.taps == 1)                   # 1x1 / Linear stay exact fp32
     assert all(a.wgt_shift >= 0 for a in convs)
+
+
+def test_headline_plan_kernel_routing_at_the_benchmark_batch():
+    """Which kernel every 3x3 convolution of the CIFAR-10 plan goes to at B = 256 (`ds_conv_kernel_id` is host logic: tile shape,
+    split-K and kernel choice of the launcher, no GPU): the 32x32 and 16x16 layers with 256 output channels on the 256 x 256 tile
+    (id 2565: 42 launches), the 8x8 layers on 128-pixel tiles -- eight half-size waves (1284) where the launch is at
+    most one workgroup per CU, four waves (128) where split-K already puts two on a CU -- and nothing on the generic gather kernel."""
+    import ctypes as C
+    from collections import Counter
+    lib = _lib.load()
+    spec, eng = _engine('cifar10')
+    P = eng.plan(256, 1)
+    by_res = {}
+    for op in P.ops:
+        if op.fn is lib.ds_conv2d_nhwc:
+            a = op.keep[0]
+            if a.taps == 9 and (a.stride or 1) == 1 and a.cout >= 128:
+                by_res.setdefault(a.h, Counter())[lib.ds_conv_kernel_id(C.byref(a))] += 1
+    assert set(by_res) == {32, 16, 8}
+    assert sum(by_res[32].values()) + sum(by_res[16].values()) - by_res[32][256] - by_res[16][256] == by_res[32][2565] + by_res[16][2565]
+    assert by_res[32][2565] + by_res[16][2565] == 42 and by_res[32][2565] >= 20 and by_res[16][2565] >= 15
+    assert set(by_res[8]) <= {128, 1284} and by_res[8][1284] >= 8 and sum(by_res[8].values()) == 24
+    # small batch: every layer has at most one tile per CU -> no four-wave 128 x 128 tiles without split-K left
+    P8 = eng.plan(8, 1)
+    ids = Counter()
+    for op in P8.ops:
+        if op.fn is lib.ds_conv2d_nhwc:
+            a = op.keep[0]
+            if a.taps == 9 and (a.stride or 1) == 1 and a.cout >= 128:
+                ids[lib.ds_conv_kernel_id(C.byref(a))] += 1
+    assert ids[1284] >= 30 and ids[0] == 0 and ids[2565] == 0, ids
