@@ -24,9 +24,8 @@ from typing import Dict, List
 import torch
 
 from . import _lib, arch
-from ._lib import (AttnArgs, ConvArgs, GemmArgs, GnFinalizeArgs, NormArgs, DS_ACT_NONE, DS_ACT_SILU, DS_RESAMPLE_NONE, DS_RESAMPLE_DOWN,
-                   DS_RESAMPLE_UP)
-from .ops import pack_conv_weight, pack_linear_weight, pack_linear_weight_f16, pack_stem_weight
+from ._lib import AttnArgs, DS_ACT_NONE, DS_ACT_SILU, DS_RESAMPLE_NONE, DS_RESAMPLE_DOWN, DS_RESAMPLE_UP
+from .ops import pack_conv_weight, pack_linear_weight, pack_stem_weight
 
 
 from .plan import Builder, Plan as _Plan, ptr as _ptr  # noqa: E402

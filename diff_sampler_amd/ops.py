@@ -11,8 +11,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import (ConvArgs, GemmArgs, NormArgs, UpdateArgs, DS_ACT_NONE, DS_ACT_SILU, DS_RESAMPLE_NONE,
-                   DS_RESAMPLE_DOWN, DS_RESAMPLE_UP)
+from ._lib import ConvArgs, GemmArgs, NormArgs, UpdateArgs, DS_ACT_NONE, DS_RESAMPLE_NONE
 
 
 def _p(t: Optional[torch.Tensor]):

@@ -12,7 +12,7 @@ Scope: inference (``train=False``) with an ``EDMDenoiser`` net -- the configurat
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List, Optional
+from typing import Dict
 
 import torch
 

@@ -1,7 +1,6 @@
 """ORACLE tooling (test infrastructure): case tables and deterministic input/weight generators shared by
 ``oracle/gen_golden.py`` (which runs the real reference on them) and the tests (which replay them through
 the oracle restatement and through the HIP path)."""
-import numpy as np
 import torch
 
 GITS_TSTEPS = [80, 10.9836, 3.8811, 1.584, 0.5666, 0.1698, 0.002]     # diff-solvers-main/launch.sh:122

@@ -26,7 +26,6 @@ import math
 import re
 from collections import OrderedDict
 
-import numpy as np
 import torch
 import torch.nn.functional as F
 

@@ -20,7 +20,6 @@ reference functions -- see ``oracle/gen_golden.py``).
 """
 from __future__ import annotations
 
-import math
 
 import numpy as np
 import torch
