@@ -44,6 +44,22 @@ SAMPLER_CASES = [
 ]
 
 
+# Full-size CIFAR-10 net, NFE = 10 for every solver family north_star names (oracle/gen_golden.py --part fullsolv): tag, solver fn,
+# schedule kind (None = the 11-point GITS-form literal), rho, num_steps, extra kwargs
+FULL_SOLVER_TSTEPS = [80.0, 31.78, 14.51, 7.42, 3.88, 2.05, 1.06, 0.5666, 0.2531, 0.0631, 0.002]
+FULL_SOLVER_CASES = [
+    ('heun', 'heun_sampler', 'polynomial', 7, 6, {}),
+    ('dpm2', 'dpm_2_sampler', 'polynomial', 7, 6, {}),
+    ('ipndm4', 'ipndm_sampler', 'polynomial', 7, 11, dict(max_order=4)),
+    ('ipndm4_gits', 'ipndm_sampler', None, None, 11, dict(max_order=4)),
+    ('ipndmv3_afs', 'ipndm_v_sampler', 'logsnr', 7, 11, dict(max_order=3, afs=True)),
+    ('deis_tab3', 'deis_sampler', 'time_uniform', 2, 11, dict(max_order=3, deis_mode='tab')),
+    ('dpmpp3m', 'dpm_pp_sampler', 'logsnr', 7, 11, dict(max_order=3, predict_x0=True, lower_order_final=True)),
+    ('dpmpp2m_eps', 'dpm_pp_sampler', 'logsnr', 7, 11, dict(max_order=2, predict_x0=False, lower_order_final=True)),
+    ('unipc3_bh2', 'unipc_sampler', 'logsnr', 7, 11, dict(max_order=3, predict_x0=True, lower_order_final=True, variant='bh2')),
+]
+
+
 AMED_CASES = [
     # tag, student sampler, num_steps, schedule, rho, afs, predictor kwargs, sampler kwargs
     ('amed', 'amed', 4, 'time_uniform', 1, True, dict(scale_dir=0.01, scale_time=0), {}),

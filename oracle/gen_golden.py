@@ -24,6 +24,9 @@ Parts
             at B=64 (the bench.py headline sampler; final images); one full-size evaluation each of the FFHQ-64
             SongUNet and the ImageNet-64 DhariwalUNet (B=1, labels); one full-size SD-1.5 config-5 trajectory
             (DPM-Solver++(2M) eps-prediction, discrete rho=1, num_steps=6, CFG 7.5, B=1)
+  fullsolv  every solver family north_star names on the FULL-size CIFAR-10 net at NFE = 10, B = 4 (Heun, DPM-Solver-2, iPNDM on a
+            polynomial and on the GITS-form schedule, iPNDM_v with AFS, DEIS tAB3 on time_uniform, DPM-Solver++(3M) and (2M, eps form),
+            UniPC bh2): final images
   full3     BASELINE config 3 at full size through the reference sampler: ImageNet-64 DhariwalUNet (295.9M params, one-hot labels),
             ipndm_sampler max_order=4 on the 11-point GITS-form schedule literal (t_steps), NFE=10, B=1: the whole trajectory
   full4     BASELINE config 4 at full size through the reference sampler: FFHQ-64 SongUNet (61.8M params) + AMED_predictor
@@ -41,7 +44,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = '/root/reference'
 OUT = os.path.join(ROOT, 'tests', 'golden')
 sys.path.insert(0, ROOT)
-from oracle.cases import (GITS_TSTEPS, SAMPLER_CASES, AMED_CASES, GITS_CASES, GITS_COMMON, make_inputs as _inputs,  # noqa: E402
+from oracle.cases import (FULL_SOLVER_CASES, FULL_SOLVER_TSTEPS, GITS_TSTEPS, SAMPLER_CASES, AMED_CASES, GITS_CASES, GITS_COMMON, make_inputs as _inputs,  # noqa: E402
                           amed_predictor_params, gits_warmup_latents)
 
 def _ref_net(name, seed):
@@ -368,7 +371,28 @@ def part_full4():
     print('full4 ffhq AMED-Solver nfe5', tuple(tr.shape), float(tr[-1].abs().max()), flush=True)
 
 
-PARTS = dict(full3=part_full3, full4=part_full4, net=part_net, sched=part_sched, samplers=part_samplers, amed=part_amed, gits=part_gits, ldm=part_ldm, full=part_full)
+def part_fullsolv():
+    sys.path.insert(0, os.path.join(REF, 'diff-solvers-main'))
+    import solvers
+    import solver_utils as su
+    torch.set_grad_enabled(False)
+    net, kw = _ref_net('cifar10', 31)
+    latents = torch.randn(4, 3, 32, 32, generator=torch.Generator().manual_seed(5))
+    d = dict(seed=31, latent_seed=5)
+    for tag, fn, kind, rho, n, extra in FULL_SOLVER_CASES:
+        extra = dict(extra)
+        ts = torch.tensor(FULL_SOLVER_TSTEPS) if kind is None else su.get_schedule(n, 0.002, 80., schedule_type=kind, schedule_rho=rho)
+        if fn == 'deis_sampler':
+            with torch.enable_grad():
+                extra['coeff_list'] = su.get_deis_coeff_list(ts, extra['max_order'], deis_mode=extra.pop('deis_mode'))
+        out = getattr(solvers, fn)(net, latents, num_steps=n, t_steps=ts, **extra)
+        d[f'{tag}_t'] = ts.numpy()
+        d[f'{tag}_out'] = out.numpy()
+        print('fullsolv', tag, float(out.abs().max()), flush=True)
+    np.savez_compressed(os.path.join(OUT, 'sampler_cifar10_solvers_nfe10_b4.npz'), **d)
+
+
+PARTS = dict(fullsolv=part_fullsolv, full3=part_full3, full4=part_full4, net=part_net, sched=part_sched, samplers=part_samplers, amed=part_amed, gits=part_gits, ldm=part_ldm, full=part_full)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

@@ -90,6 +90,26 @@ def test_full_size_64px_nets_match_reference(name, dev):
     assert _rel(out.cpu(), torch.from_numpy(z['out_vec'])) < 2e-4
 
 
+def test_every_solver_family_on_the_full_size_cifar10_net_matches_reference(dev):
+    """The real reference's solvers on the full-size CIFAR-10 net at NFE = 10, B = 4 (oracle/gen_golden.py --part fullsolv): every solver
+    family north_star names beyond the headline's DPM-Solver++(2M) -- Heun, DPM-Solver-2, iPNDM on a polynomial and on the GITS-form
+    schedule, iPNDM_v with AFS, DEIS tAB3 on time_uniform, DPM-Solver++(3M) / (2M, eps form), UniPC bh2 -- final images."""
+    from diff_sampler_amd import solvers, solver_utils
+    from diff_sampler_amd.engine import EDMDenoiser
+    from oracle import cases
+    z = np.load(os.path.join(G, 'sampler_cifar10_solvers_nfe10_b4.npz'))
+    net = EDMDenoiser.from_config('cifar10', seed=int(z['seed']))
+    latents = torch.randn(4, 3, 32, 32, generator=torch.Generator().manual_seed(int(z['latent_seed']))).to(dev)
+    for tag, fn, kind, rho, n, extra in cases.FULL_SOLVER_CASES:
+        extra = dict(extra)
+        ts = torch.from_numpy(z[f'{tag}_t']).to(dev)
+        if fn == 'deis_sampler':
+            extra['coeff_list'] = solver_utils.get_deis_coeff_list(ts, extra['max_order'], deis_mode=extra.pop('deis_mode'))
+        out = getattr(solvers, fn)(net, latents, num_steps=n, t_steps=ts, **extra)
+        torch.cuda.synchronize()
+        assert _rel(out.cpu(), torch.from_numpy(z[f'{tag}_out'])) < 5e-4, (tag, _rel(out.cpu(), torch.from_numpy(z[f'{tag}_out'])))
+
+
 def test_config3_imagenet64_trajectory_matches_reference(dev):
     """BASELINE config 3 at full size against the REAL reference's own sampler call (oracle/gen_golden.py --part full3): ImageNet-64
     DhariwalUNet with a one-hot label, ipndm_sampler max_order 4 on the GITS-form schedule literal, NFE = 10, every intermediate."""
