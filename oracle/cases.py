@@ -96,6 +96,9 @@ GITS_CASES = [
     ('l1_dpmpp', dict(num_steps=4, num_steps_tea=9, metric='l1', coeff=0.9, afs=False, solver='dpmpp', solver_tea='dpmpp', max_order=2,
                       schedule_type='time_uniform', schedule_rho=2, num_warmup=2, max_batch_size=2)),
 ]
+# the schedule search on the FULL-size CIFAR-10 net (oracle/gen_golden.py --part fullgits): 21-step iPNDM-4 teacher, 8 warm-up latents
+GITS_FULL_CASE = ('dev_ipndm4_cifar10', dict(num_steps=6, num_steps_tea=21, metric='dev', coeff=1.15, afs=False, solver='ipndm', solver_tea='ipndm',
+                                              max_order=4, schedule_type='polynomial', schedule_rho=7, num_warmup=8, max_batch_size=8))
 GITS_COMMON = dict(dataset_name='cifar10', sigma_min=0.002, sigma_max=80., model_source='edm', prompt=None, guidance_type=None,
                    guidance_rate=None, predict_x0=True, lower_order_final=True, deis_mode='tab', denoise_to_zero=False)
 

@@ -27,6 +27,7 @@ Parts
   fullsolv  every solver family north_star names on the FULL-size CIFAR-10 net at NFE = 10, B = 4 (Heun, DPM-Solver-2, iPNDM on a
             polynomial and on the GITS-form schedule, iPNDM_v with AFS, DEIS tAB3 on time_uniform, DPM-Solver++(3M) and (2M, eps form),
             UniPC bh2): final images
+  fullgits  gits-main get_dp_list on the FULL-size CIFAR-10 net (21-step iPNDM-4 teacher, 6-step student, 'dev' metric, 8 warm-up latents)
   full3     BASELINE config 3 at full size through the reference sampler: ImageNet-64 DhariwalUNet (295.9M params, one-hot labels),
             ipndm_sampler max_order=4 on the 11-point GITS-form schedule literal (t_steps), NFE=10, B=1: the whole trajectory
   full4     BASELINE config 4 at full size through the reference sampler: FFHQ-64 SongUNet (61.8M params) + AMED_predictor
@@ -44,7 +45,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = '/root/reference'
 OUT = os.path.join(ROOT, 'tests', 'golden')
 sys.path.insert(0, ROOT)
-from oracle.cases import (FULL_SOLVER_CASES, FULL_SOLVER_TSTEPS, GITS_TSTEPS, SAMPLER_CASES, AMED_CASES, GITS_CASES, GITS_COMMON, make_inputs as _inputs,  # noqa: E402
+from oracle.cases import (FULL_SOLVER_CASES, FULL_SOLVER_TSTEPS, GITS_TSTEPS, SAMPLER_CASES, AMED_CASES, GITS_CASES, GITS_COMMON, GITS_FULL_CASE, make_inputs as _inputs,  # noqa: E402
                           amed_predictor_params, gits_warmup_latents)
 
 def _ref_net(name, seed):
@@ -371,6 +372,23 @@ def part_full4():
     print('full4 ffhq AMED-Solver nfe5', tuple(tr.shape), float(tr[-1].abs().max()), flush=True)
 
 
+def part_fullgits():
+    sys.path.insert(0, os.path.join(REF, 'gits-main'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29572', RANK='0', WORLD_SIZE='1')
+    torch.distributed.init_process_group('gloo', rank=0, world_size=1)
+    import gits_utils
+    net, kw = _ref_net('cifar10', 31)
+    tag, gk = GITS_FULL_CASE
+    kwargs = dict(GITS_COMMON); kwargs.update(gk)
+    kwargs['solver_kwargs_seed'] = 2000 + len(tag)
+    torch.manual_seed(kwargs['solver_kwargs_seed'])
+    with torch.no_grad():
+        dp_list = gits_utils.get_dp_list(net, torch.device('cpu'), **kwargs)
+    np.savez_compressed(os.path.join(OUT, 'gits_cifar10.npz'), seed=31, warmup_seed=kwargs['solver_kwargs_seed'], dp_list=np.array(dp_list))
+    print('fullgits', tag, dp_list, flush=True)
+    torch.distributed.destroy_process_group()
+
+
 def part_fullsolv():
     sys.path.insert(0, os.path.join(REF, 'diff-solvers-main'))
     import solvers
@@ -392,7 +410,7 @@ def part_fullsolv():
     np.savez_compressed(os.path.join(OUT, 'sampler_cifar10_solvers_nfe10_b4.npz'), **d)
 
 
-PARTS = dict(fullsolv=part_fullsolv, full3=part_full3, full4=part_full4, net=part_net, sched=part_sched, samplers=part_samplers, amed=part_amed, gits=part_gits, ldm=part_ldm, full=part_full)
+PARTS = dict(fullgits=part_fullgits, fullsolv=part_fullsolv, full3=part_full3, full4=part_full4, net=part_net, sched=part_sched, samplers=part_samplers, amed=part_amed, gits=part_gits, ldm=part_ldm, full=part_full)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

@@ -41,3 +41,18 @@ def test_get_dp_list_matches_reference(tag):
     ts = solver_utils.get_schedule(kwargs['num_steps_tea'], 0.002, 80., device='cuda', schedule_type=kwargs['schedule_type'],
                                    schedule_rho=kwargs['schedule_rho'], dp_list=dp_list)
     assert ts.shape[0] == len(dp_list) and float(ts[0]) > float(ts[-1])
+
+
+def test_get_dp_list_on_the_full_size_cifar10_net_matches_reference():
+    """The schedule search itself (gits-main/gits_utils.py:42-255) on the FULL-size CIFAR-10 net against the real reference
+    (oracle/gen_golden.py --part fullgits): 21-step iPNDM-4 teacher on 8 warm-up latents, 'dev' cost, 6-step student."""
+    from diff_sampler_amd import gits_utils
+    from diff_sampler_amd.engine import EDMDenoiser
+    z = np.load(os.path.join(G, 'gits_cifar10.npz'))
+    net = EDMDenoiser.from_config('cifar10', seed=int(z['seed']))
+    tag, gk = cases.GITS_FULL_CASE
+    kwargs = dict(cases.GITS_COMMON); kwargs.update(gk)
+    rounds = kwargs['num_warmup'] // (kwargs['max_batch_size'] + 1) + 1
+    lat = cases.gits_warmup_latents(int(z['warmup_seed']), rounds, kwargs['max_batch_size'], (3, 32, 32))
+    dp_list = gits_utils.get_dp_list(net, torch.device('cuda'), warmup_latents=lat, **kwargs)
+    assert list(dp_list) == list(z['dp_list']), (dp_list, z['dp_list'])
