@@ -20,8 +20,10 @@ Prints ONE JSON line on rank 0 with the driver's contract fields plus
                    peak = 157.3 TFLOP/s (MI355X fp32 matrix pipe, MI355X_MICROARCH.md);
                    traffic = HBM bytes per launch from the PMC pass committed under profiles/ (FETCH_SIZE doubled per
                    the guide's gfx950 correction + WRITE_SIZE), or null when that file is absent
-  roofline_update  the fused solver-update kernel against HBM 8 TB/s at the benchmark's batch (latency-bound there), and
+  roofline_update  the headline solver's fused update kernel (ds_dpmpp_x0_step) against HBM 8 TB/s at the benchmark's batch
+                   (latency-bound there: 3 MB per operand), and
   roofline_update_large_batch  the same kernel measured in-process at 16 384 images per launch, where it is bandwidth-bound
+                   (roofline_update_large_batch_other_solver: the Adams-Bashforth family's ds_solver_update, iPNDM order 4)
   kernels          time share of every kernel class in the instrumented step
   launch_modes     the same sampler call eager vs replayed from one captured hipGraph, at B=8 and at the benchmark batch
   throughput_by_batch  (cifar10) the same call at 1024 images per call next to the benchmark batch (informational)
@@ -168,7 +170,7 @@ def instrumented_pass(net, solvers, solver, latents, nfe, ldm=None):
 
     cfg = ops.cfg_denoise
     x0s = ops.dpmpp_x0_step
-    ops.dpmpp_x0_step = timed_call('dpmpp_x0_step_kernel (D -> dynamic threshold -> multistep update, one launch)', x0s)
+    ops.dpmpp_x0_step = timed_call(X0_KIND, x0s)
     engine._Plan.run = timed_plan_run
     ops.solver_update = timed_call('solver_update_kernel', upd)
     ops.dynamic_threshold = timed_call('dynamic_threshold_kernel', thr)
@@ -185,31 +187,43 @@ def instrumented_pass(net, solvers, solver, latents, nfe, ldm=None):
     return rec
 
 
-def update_roofline_large_batch(dev, batch=16384):
-    """The fused solver-update kernel where it is bandwidth-bound: one iPNDM order-4 step (x, F, 3 history tensors read;
-    x' and d written = 7 passes of 12 288 B per CIFAR-10 image) on `batch` images, HIP-event timed."""
+X0_KIND = 'dpmpp_x0_step_kernel (D -> dynamic threshold -> multistep update, one launch)'
+
+
+def update_roofline_large_batch(dev, batch=16384, kind='ipndm'):
+    """The fused solver-update kernels where they are bandwidth-bound, HIP-event timed on `batch` CIFAR-10 images per launch.
+    kind 'ipndm': one iPNDM order-4 step of ds_solver_update (x, F, 3 history tensors read; x' and d written = 7 passes of 12 288 B
+    per image).  kind 'dpmpp': one DPM-Solver++(2M) data-prediction step of ds_dpmpp_x0_step -- the headline
+    solver's update: x, F and m1 read, m0 = thresh(D) and x' written = 5 passes (the fused launch touches every operand once; SURVEY 8d
+    prices the unfused sequence D pass + threshold + combination at 7)."""
     from diff_sampler_amd import ops
     C_, H = 3, 32
     x = torch.randn(batch, C_, H, H, device=dev)
     fr = torch.randn(batch, C_, H, H, device=dev)           # raw network output, channel-planar as the engine's output conv writes it
     hist = [torch.randn(batch, C_, H, H, device=dev) for _ in range(3)]
     xo, mo = torch.empty_like(x), torch.empty_like(x)
-    a = ops.make_update_args(x, x, fr, batch, C_, H, H, xo, raw=True, f_ld=0, hist=hist, hcoefs=[1, -.5, .1, .2, .3, 2., 2., 0], m_out=mo)
+    if kind == 'dpmpp':
+        a = ops.make_update_args(x, x, fr, batch, C_, H, H, xo, raw=True, f_ld=0, hist=hist[:1], hcoefs=[.5, .6, -.1, 0, 0, 2., 2., 0], m_out=mo,
+                                 store_d=False)
+        launch, passes, name = (lambda: ops.dpmpp_x0_step(a)), 5, 'dpmpp_x0_step_reg_kernel (DPM-Solver++(2M) data-prediction step: D, dynamic threshold, combination)'
+    else:
+        a = ops.make_update_args(x, x, fr, batch, C_, H, H, xo, raw=True, f_ld=0, hist=hist, hcoefs=[1, -.5, .1, .2, .3, 2., 2., 0], m_out=mo)
+        launch, passes, name = (lambda: ops.solver_update(a)), 7, 'solver_update_fast_kernel (iPNDM order-4 step)'
     for _ in range(3):
-        ops.solver_update(a)
+        launch()
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     n = 20
     e0.record()
     for _ in range(n):
-        ops.solver_update(a)
+        launch()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
-    byts = 7 * C_ * H * H * 4 * batch
+    byts = passes * C_ * H * H * 4 * batch
     gbs = byts / (ms * 1e-3) / 1e9
-    return dict(bound='hbm', kernel='solver_update_fast_kernel (iPNDM order-4 step)', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s',
+    return dict(bound='hbm', kernel=name, achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s',
                 frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, images_per_launch=batch, avg_launch_ms=round(ms, 4),
-                algorithmic_bytes_per_launch=byts,
+                algorithmic_bytes_per_launch=byts, passes_per_image=passes,
                 note='micro-benchmark inside bench.py at the batch where the update is bandwidth-bound (every operand is touched once)')
 
 
@@ -484,20 +498,31 @@ def main(argv=None):
                     traffic_unit='HBM bytes per launch (rocprofv3 PMC, %s)' % os.path.relpath(PMC_FILE, ROOT),
                     launches_per_step=launches, avg_launch_ms=round(ms / launches, 4), gflop_per_launch=round(fl / launches / 1e9, 2),
                     share_of_gpu_time=round(ms / total_ms, 4))
-        if 'solver_update_kernel' in rec and ldm is None:
+        per = spec.in_channels * spec.img_resolution ** 2 * 4
+        if X0_KIND in rec and ldm is None:
+            # the headline solver's update: ONE ds_dpmpp_x0_step launch per evaluation.  Algorithmic bytes of the fused launch: x, F read;
+            # m0, x' written; + one history tensor on the 2M steps (order 1 on the first and, with lower_order_final, the last step)
+            ums, ul, _ = rec[X0_KIND]
+            n2m = max(0, ul - 2)
+            byts = (4 * (ul - n2m) + 5 * n2m) * per * B
+            gbs = byts / (ums * 1e-3) / 1e9
+            roof_u = dict(bound='hbm', kernel=X0_KIND, achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s',
+                          frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, launches_per_step=ul, avg_launch_ms=round(ums / ul, 4),
+                          algorithmic_bytes_per_step=byts,
+                          note='latency-bound at this batch (3 MB per operand, one workgroup per image); roofline_update_large_batch has the same kernel at 16 384 images per launch')
+        elif 'solver_update_kernel' in rec and ldm is None:
             ums, ul, _ = rec['solver_update_kernel']
-            per = spec.in_channels * spec.img_resolution ** 2 * 4
-            # DPM-Solver++(2M), x0 form: D pass (x, F read; m written) + combine (x, m0, m1 read; x written) = 7 passes/image/step
             passes = {'dpmpp': 7, 'euler': 3, 'ipndm': 7, 'heun': 3.5}[args.solver]
             byts = passes * per * B * args.nfe
             gbs = byts / (ums * 1e-3) / 1e9
             roof_u = dict(bound='hbm', kernel='solver_update_kernel', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s',
                           frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, launches_per_step=ul, avg_launch_ms=round(ums / ul, 4),
-                          note='latency-bound at this batch (3 MB per operand); see DESIGN.md section 6 for the large-batch figure')
+                          note='latency-bound at this batch (3 MB per operand); see roofline_update_large_batch')
 
-    roof_ul = modes = by_batch = None
+    roof_ul = roof_ul_other = modes = by_batch = None
     if rank == 0 and ldm is None and not stub:
-        roof_ul = update_roofline_large_batch(dev)
+        roof_ul = update_roofline_large_batch(dev, kind=('dpmpp' if args.solver == 'dpmpp' else 'ipndm'))
+        roof_ul_other = update_roofline_large_batch(dev, kind=('ipndm' if args.solver == 'dpmpp' else 'dpmpp'))
         if not args.no_launch_modes and world == 1:
             modes = launch_modes(args, solvers, net_factory, spec, dev)
         if not args.no_batch_sweep and world == 1 and args.config == 'cifar10' and not args.graph:
@@ -532,7 +557,7 @@ def main(argv=None):
                         {'dpmpp': 'DPM-Solver++(2M) logSNR', 'euler': 'Euler', 'ipndm': 'iPNDM-4', 'heun': 'Heun'}[args.solver], args.nfe, B),
                        'images_per_step': B * world, 'sharding': 'independent image batches per rank, no collective',
                        'launch': 'hipGraph replay' if args.graph else 'eager'},
-            'roofline': roof, 'roofline_update': roof_u, 'roofline_update_large_batch': roof_ul, 'kernels': kernels,
+            'roofline': roof, 'roofline_update': roof_u, 'roofline_update_large_batch': roof_ul, 'roofline_update_large_batch_other_solver': roof_ul_other, 'kernels': kernels,
             'launch_modes': modes, 'throughput_by_batch': by_batch, 'cpu_baseline': cpu, 'multi_gpu': multi,
         }
         if stub:

@@ -78,6 +78,28 @@ class AmedCoefArgs(C.Structure):
                 ('order', C.c_int), ('predict_x0', C.c_int), ('thist', vp), ('coefs', vp), ('sigma2', vp), ('n', C.c_int)]
 
 
+class LayerNormArgs(C.Structure):
+    _fields_ = [('x', vp), ('ldx', C.c_int), ('gamma', vp), ('beta', vp), ('eps', C.c_float), ('y', vp), ('ldy', C.c_int),
+                ('rows', C.c_longlong), ('cols', C.c_int)]
+
+
+class GegluArgs(C.Structure):
+    _fields_ = [('x', vp), ('ldx', C.c_int), ('y', vp), ('ldy', C.c_int), ('rows', C.c_longlong), ('inner', C.c_int)]
+
+
+class NoiseEmbedArgs(C.Structure):
+    _fields_ = [('sigma', vp), ('bs', C.c_int), ('freqs', vp), ('nch', C.c_int), ('swap', C.c_int), ('out', vp), ('out_ld', C.c_int)]
+
+
+class StemIm2colArgs(C.Structure):
+    _fields_ = [('x', vp), ('sigma', vp), ('sigma_rows', C.c_int), ('sigma_data', C.c_float), ('n', C.c_int), ('c', C.c_int),
+                ('h', C.c_int), ('w', C.c_int), ('out', vp), ('kpad', C.c_int)]
+
+
+# ds_plan_add op codes (include/ds_engine.h)
+DS_OP_CONV2D, DS_OP_GEMM, DS_OP_GN_STATS, DS_OP_NORM_ACT, DS_OP_GN_FINALIZE, DS_OP_ATTENTION, DS_OP_ATTENTION_F16, DS_OP_LAYERNORM, \
+    DS_OP_GEGLU, DS_OP_NOISE_EMBED, DS_OP_STEM_IM2COL = range(1, 12)
+
 _SIGNATURES = {
     'ds_version': (C.c_int, []),
     'ds_error_string': (C.c_char_p, [C.c_int]),
@@ -107,6 +129,8 @@ _SIGNATURES = {
     'ds_stem_im2col': (C.c_int, [vp, vp, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     'ds_solver_update': (C.c_int, [C.POINTER(UpdateArgs), vp]),
     'ds_dpmpp_x0_step': (C.c_int, [C.POINTER(UpdateArgs), C.c_float, vp]),
+    'ds_dpmpp_x0_step_in_registers': (C.c_int, [C.c_longlong]),
+    'ds_debug_dpmpp_variant': (C.c_int, [C.c_int]),
     'ds_table_select': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp]),
     'ds_dynamic_threshold': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp]),
     'ds_scale': (C.c_int, [vp, C.c_float, vp, C.c_longlong, vp]),
@@ -121,6 +145,14 @@ _SIGNATURES = {
     'ds_debug_philox_probe': (C.c_int, [C.c_ulonglong, C.c_ulonglong, vp, C.c_int, C.c_int, vp]),
     'ds_philox_randint': (C.c_int, [vp, C.c_ulonglong, C.c_uint, vp, C.c_int, vp]),
     'ds_channel_mean': (C.c_int, [vp, C.c_int, C.c_int, C.c_longlong, vp, vp]),
+    'ds_plan_create': (C.c_int, [C.POINTER(vp)]),
+    'ds_plan_add': (C.c_int, [vp, C.c_int, vp, C.c_ulonglong]),
+    'ds_plan_size': (C.c_int, [vp]),
+    'ds_plan_run': (C.c_int, [vp, vp]),
+    'ds_plan_last_failed': (C.c_int, [vp]),
+    'ds_plan_graph_capture': (C.c_int, [vp, vp]),
+    'ds_plan_graph_launch': (C.c_int, [vp, vp]),
+    'ds_plan_destroy': (None, [vp]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

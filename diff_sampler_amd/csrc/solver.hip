@@ -1,5 +1,7 @@
 // Solver-side kernels: fused EDM-precondition + ODE update (HBM bound, one pass over every operand), dynamic
 // thresholding (exact torch.quantile semantics via LDS radix select), latent scaling, uint8 quantisation.
+#include <type_traits>
+
 #include "ds_common.h"
 
 namespace {
@@ -346,6 +348,147 @@ __global__ void __launch_bounds__(512) dpmpp_x0_step_kernel(const ds_update_args
     }
 }
 
+// The same step with the sample held in REGISTERS (samples of THREADS * VPT values: 3 x 32 x 32, 3 x 64 x 64, 4 x 64 x 64, tiny test
+// nets): every operand is read from HBM exactly once as non-temporal 16-B accesses (x, F, the one or two history tensors -- issued
+// before the select so that they are in flight under it) and x', m0 are written once: 3-4 R + 2 W passes per image against the
+// 5 R + 2 W of dpmpp_x0_step_kernel, whose dword loads and serial 256-bin histogram scans also make it latency-bound (52 us per
+// launch whatever the batch).  The order statistics come from a three-digit (11 + 10 + 10 bit) MSB-first radix select over the
+// register-resident |D| bit patterns: LDS histogram by atomics (the 11-bit first digit carries three mantissa bits, so the few
+// exponents a sample spans spread over 8x the bins), block-parallel prefix scan to find the digit.  Results are the exact order
+// statistics, hence bit-identical to the LDS kernel and to torch.quantile.  9 workgroups of 256 threads fit a CU (16.1 KB LDS each).
+template <int THREADS, int VPT>
+__global__ void __launch_bounds__(THREADS) dpmpp_x0_step_reg_kernel(const ds_update_args a, float p) {
+    constexpr int NV = VPT / 4, NW = THREADS / 64, per = THREADS * VPT;
+    __shared__ __attribute__((aligned(16))) unsigned hist[4096];        // digit 0: [0, 2048), digit 1: [2048, 3072), digit 2: [3072, 4096)
+    __shared__ unsigned s_wsum[16];
+    __shared__ unsigned s_sel[2];
+    __shared__ unsigned s_cnt, s_min;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int img = blockIdx.x;
+    const size_t base = (size_t)img * per;
+    const bool has_xb = a.xb != a.xe;
+    f32x4 xv[NV], dv[NV], h0[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const size_t off = base + (size_t)(j * THREADS + tid) * 4;
+        xv[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.xe + off));
+        if (!a.afs) dv[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.f + off));
+    }
+    // the newest history tensor (every 2M / 3M step) is requested now and lands under the select; a separate xb and the second history
+    // tensor (3M steps only) are read in the output loop, which keeps the kernel at <= 80 registers (6 workgroups of 256 per CU)
+    if (a.x_out && a.hist[0]) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            h0[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.hist[0] + base + (size_t)(j * THREADS + tid) * 4));
+    }
+    {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < 1024; i += THREADS) reinterpret_cast<f32x4*>(hist)[i] = z;
+        if (tid == 0) { s_cnt = 0; s_min = 0xffffffffu; }
+    }
+    const Coefs k = load_coefs(a, img);
+    float cskip = 0.f, cout_ = 0.f;
+    if (a.raw) { cskip = ds_c_skip(k.sig, a.sigma_data); cout_ = ds_c_out(k.sig, a.sigma_data); }
+    const float afs_div = sqrtf(1.0f + k.t * k.t);
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = xv[j][e];
+            float D;
+            if (a.afs) D = x - k.t * (x / afs_div);                        // solvers.py:77, :680
+            else { const float f = dv[j][e]; D = a.raw ? cskip * x + cout_ * f : f; }      // networks_edm.py:495
+            dv[j][e] = D;
+        }
+    auto key = [&](int i) -> unsigned { return __float_as_uint(dv[i >> 2][i & 3]) & 0x7fffffffu; };      // bit pattern of |D|
+    __syncthreads();
+    const float rank_f = p * (float)(per - 1);
+    const float lo_f = floorf(rank_f);
+    const float w = rank_f - lo_f;
+    const unsigned lo = (unsigned)lo_f;
+    const unsigned hi = (unsigned)ceilf(rank_f);
+
+    // block-parallel search of the bin that holds order statistic `rank` in a BINS-bin histogram: each thread owns BINS / THREADS
+    // consecutive bins; returns {bin, number of keys before it}
+    unsigned rank = lo, prefix = 0;
+    auto find_bin = [&](const unsigned* hp, auto binsc) {
+        constexpr int BINS = decltype(binsc)::value;
+        constexpr int BPT = BINS / THREADS;
+        static_assert(BPT >= 1, "bins per thread");
+        unsigned hv[BPT], sum = 0;
+#pragma unroll
+        for (int b = 0; b < BPT; ++b) { hv[b] = hp[tid * BPT + b]; sum += hv[b]; }
+        unsigned v = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(v, o); if (lane >= o) v += t; }
+        if (lane == 63) s_wsum[wave] = v;
+        __syncthreads();
+        unsigned excl = v - sum;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) if (q < wave) excl += s_wsum[q];
+        if (excl <= rank && rank < excl + sum) {                           // exactly one thread
+            unsigned cum = excl, digit = 0, before = excl;
+            bool found = false;
+#pragma unroll
+            for (int b = 0; b < BPT; ++b) {
+                if (!found && cum + hv[b] > rank) { digit = (unsigned)(tid * BPT + b); before = cum; found = true; }
+                cum += hv[b];
+            }
+            s_sel[0] = digit; s_sel[1] = before;
+        }
+        __syncthreads();
+        rank -= s_sel[1];
+        return s_sel[0];
+    };
+    // digit 0: key bits 30..20
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) atomicAdd(&hist[key(i) >> 20], 1u);
+    __syncthreads();
+    prefix = find_bin(hist, std::integral_constant<int, (2048 > THREADS ? 2048 : THREADS)>{});
+    // digit 1: bits 19..10 of the keys whose top digit matches
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) if ((key(i) >> 20) == prefix) atomicAdd(&hist[2048 + ((key(i) >> 10) & 1023u)], 1u);
+    __syncthreads();
+    prefix = (prefix << 10) | find_bin(hist + 2048, std::integral_constant<int, 1024>{});
+    // digit 2: bits 9..0
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) if ((key(i) >> 10) == prefix) atomicAdd(&hist[3072 + (key(i) & 1023u)], 1u);
+    __syncthreads();
+    const unsigned v_lo = (prefix << 10) | find_bin(hist + 3072, std::integral_constant<int, 1024>{});
+    unsigned v_hi = v_lo;
+    if (hi != lo) {
+        unsigned cnt = 0, mn = 0xffffffffu;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) { if (key(i) <= v_lo) ++cnt; else mn = min(mn, key(i)); }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { cnt += __shfl_xor(cnt, o); mn = min(mn, (unsigned)__shfl_xor(mn, o)); }
+        if (lane == 0) { atomicAdd(&s_cnt, cnt); atomicMin(&s_min, mn); }
+        __syncthreads();
+        v_hi = (s_cnt >= hi + 1) ? v_lo : s_min;
+    }
+    const float qa = __uint_as_float(v_lo), qb = __uint_as_float(v_hi);
+    float s = (w < 0.5f) ? qa + w * (qb - qa) : qb - (qb - qa) * (1.0f - w);       // at::lerp
+    s = fmaxf(s, 1.0f);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const size_t off = base + (size_t)(j * THREADS + tid) * 4;
+        f32x4 mv, xo, xb = xv[j], h1 = {0.f, 0.f, 0.f, 0.f};
+        if (a.x_out && has_xb) xb = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.xb + off));
+        if (a.x_out && a.hist[1]) h1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.hist[1] + off));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float m = fminf(fmaxf(dv[j][e], -s), s) / s;
+            mv[e] = m;
+            float acc = k.cx * xb[e] + k.cm * m;
+            if (a.hist[0]) acc += k.ch0 * h0[j][e];
+            if (a.hist[1]) acc += k.ch1 * h1[e];
+            xo[e] = acc;
+        }
+        if (a.m_out) __builtin_nontemporal_store(mv, reinterpret_cast<f32x4*>(a.m_out + off));
+        if (a.x_out) __builtin_nontemporal_store(xo, reinterpret_cast<f32x4*>(a.x_out + off));
+    }
+}
+
 // CFGPrecond epilogue: D = x - sigma * F, F = Fu + g (Fc - Fu) for a doubled evaluation.  Thread = one pixel (all channels):
 // the NHWC row of F is one 16-B load when f_ld == 4.
 __global__ void __launch_bounds__(256) cfg_denoise_kernel(const float* __restrict__ x, const float* __restrict__ f, int f_ld,
@@ -406,16 +549,20 @@ extern "C" int ds_dynamic_threshold(const float* x0, float* out, int n, int per,
     if (!x0 || !out || n <= 0 || per <= 1) return DS_E_ARG;
     const size_t smem = ((size_t)per + 256) * sizeof(unsigned);
     if (smem > 150 * 1024) return DS_E_SHAPE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dynamic_threshold_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dynamic_threshold_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);     // per device: set on every launch
+    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(dynamic_threshold_kernel, dim3(n), dim3(512), smem, (hipStream_t)stream, x0, out, per, p);
     DS_CHECK_LAUNCH();
     return DS_OK;
+}
+
+static int g_dpmpp_variant = 0;      // 0 = register kernel where the sample size has one, 1 = always the LDS kernel (tests compare the two)
+extern "C" int ds_debug_dpmpp_variant(int v) { const int o = g_dpmpp_variant; g_dpmpp_variant = v; return o; }
+
+// 1 when ds_dpmpp_x0_step runs a sample of `per` values on the register-resident kernel (given 16-B aligned tensors)
+extern "C" int ds_dpmpp_x0_step_in_registers(long long per) {
+    return (per == 64 * 12 || per == 256 * 12 || per == 512 * 24 || per == 1024 * 16) ? 1 : 0;
 }
 
 extern "C" int ds_dpmpp_x0_step(const ds_update_args* a, float p, void* stream) {
@@ -426,15 +573,23 @@ extern "C" int ds_dpmpp_x0_step(const ds_update_args* a, float p, void* stream) 
     if (a->raw && !a->afs && a->f_ld != 0) return DS_E_ARG;                  // the raw network output must be channel-planar here
     if (a->coefs && a->coef_rows != 1 && a->coef_rows != a->n) return DS_E_ARG;
     const long long per = (long long)a->c * a->h * a->w;
+    bool al = ds_aligned16(a->xe) && ds_aligned16(a->xb) && (a->afs || ds_aligned16(a->f)) && (!a->x_out || ds_aligned16(a->x_out)) &&
+              (!a->m_out || ds_aligned16(a->m_out)) && !a->hist[2];
+    for (int i = 0; i < 2; ++i) if (a->hist[i] && !ds_aligned16(a->hist[i])) al = false;
+    if (g_dpmpp_variant == 0 && al && ds_dpmpp_x0_step_in_registers(per)) {
+        const dim3 grid(a->n);
+        if (per == 64 * 12) hipLaunchKernelGGL((dpmpp_x0_step_reg_kernel<64, 12>), grid, dim3(64), 0, (hipStream_t)stream, *a, p);
+        else if (per == 256 * 12) hipLaunchKernelGGL((dpmpp_x0_step_reg_kernel<256, 12>), grid, dim3(256), 0, (hipStream_t)stream, *a, p);
+        else if (per == 512 * 24) hipLaunchKernelGGL((dpmpp_x0_step_reg_kernel<512, 24>), grid, dim3(512), 0, (hipStream_t)stream, *a, p);
+        else hipLaunchKernelGGL((dpmpp_x0_step_reg_kernel<1024, 16>), grid, dim3(1024), 0, (hipStream_t)stream, *a, p);
+        DS_CHECK_LAUNCH();
+        return DS_OK;
+    }
     const size_t smem = ((size_t)per + 256) * sizeof(unsigned);
     if (per <= 1 || smem > 150 * 1024) return DS_E_SHAPE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dpmpp_x0_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           150 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dpmpp_x0_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       150 * 1024);          // per device, cheap: set on every launch (a process may drive several GPUs)
+    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(dpmpp_x0_step_kernel, dim3(a->n), dim3(512), smem, (hipStream_t)stream, *a, p);
     DS_CHECK_LAUNCH();
     return DS_OK;

@@ -31,16 +31,81 @@ class Op:
 
 
 class Plan:
+    """The launches of one network evaluation.  ``run`` hands the whole list to the library in ONE call (``ds_plan_run`` walks a
+    native copy of the argument structs in C -- include/ds_engine.h "Native launch plans"); ``run_python`` issues the same launches
+    one ctypes call at a time (instrumented replays in bench.py, and the reference for the native walk in the tests)."""
+
     def __init__(self):
         self.ops: List[Op] = []
         self.bufs: Dict[str, torch.Tensor] = {}
         self.keep: List[torch.Tensor] = []      # every workspace tensor the launch arguments point into
+        self._native = None                     # (ds_plan*, number of ops it was built from)
 
-    def run(self, stream):
+    def run_python(self, stream):
         for op in self.ops:
             rc = op.fn(*op.args, stream)
             if rc:
                 _lib.check(rc, op.name)
+
+    def native(self):
+        """The ds_plan handle of this op list (built on first use, rebuilt if launches were appended since)."""
+        if self._native is None or self._native[1] != len(self.ops):
+            self.close()
+            self._native = (_native_plan(self.ops), len(self.ops))
+        return self._native[0]
+
+    def run(self, stream):
+        h = self.native()
+        lib = _lib.load()
+        rc = lib.ds_plan_run(h, stream)
+        if rc:
+            i = lib.ds_plan_last_failed(h)
+            _lib.check(rc, self.ops[i].name if 0 <= i < len(self.ops) else 'ds_plan_run')
+
+    def graph_capture(self, stream):
+        """Record one run into a hipGraph owned by the native plan (ds_plan_graph_capture; `stream` must not be the default stream)."""
+        _lib.check(_lib.load().ds_plan_graph_capture(self.native(), stream), 'ds_plan_graph_capture')
+
+    def graph_launch(self, stream):
+        _lib.check(_lib.load().ds_plan_graph_launch(self.native(), stream), 'ds_plan_graph_launch')
+
+    def close(self):
+        if self._native is not None:
+            _lib.load().ds_plan_destroy(self._native[0])
+            self._native = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _native_plan(ops):
+    """ds_plan_create + one ds_plan_add per launch (the library copies the argument structs)."""
+    lib = _lib.load()
+    by_ref = {id(lib.ds_conv2d_nhwc): _lib.DS_OP_CONV2D, id(lib.ds_gemm_nt_batched): _lib.DS_OP_GEMM, id(lib.ds_gn_stats): _lib.DS_OP_GN_STATS,
+              id(lib.ds_norm_act): _lib.DS_OP_NORM_ACT, id(lib.ds_gn_finalize): _lib.DS_OP_GN_FINALIZE,
+              id(lib.ds_attention): _lib.DS_OP_ATTENTION, id(lib.ds_attention_f16): _lib.DS_OP_ATTENTION_F16}
+    by_val = {id(lib.ds_layernorm_rows): (_lib.DS_OP_LAYERNORM, _lib.LayerNormArgs), id(lib.ds_geglu): (_lib.DS_OP_GEGLU, _lib.GegluArgs),
+              id(lib.ds_noise_embed): (_lib.DS_OP_NOISE_EMBED, _lib.NoiseEmbedArgs), id(lib.ds_stem_im2col): (_lib.DS_OP_STEM_IM2COL, _lib.StemIm2colArgs)}
+    h = C.c_void_p()
+    _lib.check(lib.ds_plan_create(C.byref(h)), 'ds_plan_create')
+    try:
+        for op in ops:
+            k = id(op.fn)
+            if k in by_ref:
+                code, st = by_ref[k], op.keep[0]              # the struct the launch passes by reference
+            elif k in by_val:
+                code, cls = by_val[k]
+                st = cls(*op.args)
+            else:
+                raise _lib.DsError(f'launch {op.name!r} has no ds_plan op code')
+            _lib.check(lib.ds_plan_add(h, code, C.byref(st), C.sizeof(st)), 'ds_plan_add ' + op.name)
+    except Exception:
+        lib.ds_plan_destroy(h)
+        raise
+    return h
 
 
 class Builder:

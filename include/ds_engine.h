@@ -330,8 +330,14 @@ int ds_solver_update(const ds_update_args* a, void* stream);
  *   m0 = clamp(D, -s, s) / s,  s = max(quantile_p(|D|), 1)      (dynamic thresholding; the same radix select as ds_dynamic_threshold)
  *   x' = hcoefs[0] * xb + hcoefs[1] * m0 + hcoefs[2] * hist[0] + hcoefs[3] * hist[1]
  * m_out receives m0 (the solver's history entry), x_out receives x'.  Replaces the three launches D pass -> threshold -> combination.
- * c * h * w <= ~38 000 elements per sample (LDS); f_ld must be 0 (channel-planar F). */
+ * c * h * w <= ~38 000 elements per sample (LDS); f_ld must be 0 (channel-planar F).
+ * Samples of 3x32x32, 3x64x64, 4x64x64 (and 3x16x16) values with 16-B aligned tensors and at most two history tensors run on the
+ * register-resident kernel (every operand touched once: 3-4 R + 2 W passes, HBM-bound from a few thousand images per launch);
+ * ds_dpmpp_x0_step_in_registers(c*h*w) tells which, ds_debug_dpmpp_variant(1) forces the LDS kernel (returns the previous setting).
+ * Both kernels return the exact order statistics, so their results are bit-identical. */
 int ds_dpmpp_x0_step(const ds_update_args* a, float p, void* stream);
+int ds_dpmpp_x0_step_in_registers(long long per_sample);
+int ds_debug_dpmpp_variant(int variant);
 
 /* dst[0..row_floats) = table[(*step) * row_floats ...]; then optionally (*step)++ when advance != 0.  The only
  * per-step state of a captured sampler step: every kernel of the step reads its scalars (sigma, coefficients) from
@@ -422,6 +428,54 @@ int ds_amed_coefs(const ds_amed_coef_args* a, void* stream);
 int ds_traj_moments(const float* traj, const float* eps, int n_pts, int batch, int per, double* out, void* stream);
 int ds_traj_pair_cost(const float* traj, const float* eps, const float* t_steps, int n_pts, int batch, int per, int p_norm,
                       double* cost, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Native launch plans (SURVEY.md section 8b "what a C-ABI engine should export": ds_unet_forward / ds_graph_capture_step).
+ *
+ * One network evaluation -- EDMPrecond.forward -> SongUNet / DhariwalUNet.forward (networks_edm.py:482-496, :312-355, :427-453) or
+ * CFGPrecond.forward -> UNetModel.forward (networks_edm.py:668-690, openaimodel.py:710-742) -- is a fixed sequence of the launches
+ * above over fixed workspaces (178 for the CIFAR-10 net, 361 for SD-1.5).  A ds_plan owns a COPY of every launch's argument
+ * struct, so a host in any language records the sequence once (ds_plan_add, in launch order) and then runs the whole forward with
+ * one call: ds_plan_run walks the list in C on `stream`; ds_plan_graph_capture records it into a hipGraph on a non-default
+ * stream (north_star: "each NFE step a hipGraph-captured sequence") and ds_plan_graph_launch replays it.  The device pointers
+ * inside the argument structs stay the caller's (the plan never allocates device memory); they must stay valid while the plan
+ * lives.  The inputs of an evaluation (x, sigma, labels / context) are written into the plan's input buffers by the caller
+ * before the run (ds_copy_rows / ds_fill on the same stream), the output is read from its output buffer after it.
+ * The entry points with scalar arguments get argument structs here so that they can be recorded. */
+typedef struct ds_layernorm_args { const float* x; int ldx; const float* gamma; const float* beta; float eps; float* y; int ldy;
+                                   long long rows; int cols; } ds_layernorm_args;                       /* ds_layernorm_rows */
+typedef struct ds_geglu_args { const float* x; int ldx; float* y; int ldy; long long rows; int inner; } ds_geglu_args;   /* ds_geglu */
+typedef struct ds_noise_embed_args { const float* sigma; int bs; const float* freqs; int nch; int swap; float* out; int out_ld;
+                                   } ds_noise_embed_args;                                              /* ds_noise_embed */
+typedef struct ds_stem_im2col_args { const float* x; const float* sigma; int sigma_rows; float sigma_data; int n, c, h, w;
+                                     float* out; int kpad; } ds_stem_im2col_args;                      /* ds_stem_im2col */
+
+enum { DS_OP_CONV2D = 1,        /* ds_conv_args        -> ds_conv2d_nhwc      */
+       DS_OP_GEMM = 2,          /* ds_gemm_args        -> ds_gemm_nt_batched  */
+       DS_OP_GN_STATS = 3,      /* ds_norm_args        -> ds_gn_stats         */
+       DS_OP_NORM_ACT = 4,      /* ds_norm_args        -> ds_norm_act         */
+       DS_OP_GN_FINALIZE = 5,   /* ds_gn_finalize_args -> ds_gn_finalize      */
+       DS_OP_ATTENTION = 6,     /* ds_attn_args        -> ds_attention        */
+       DS_OP_ATTENTION_F16 = 7, /* ds_attn_args        -> ds_attention_f16    */
+       DS_OP_LAYERNORM = 8,     /* ds_layernorm_args   -> ds_layernorm_rows   */
+       DS_OP_GEGLU = 9,         /* ds_geglu_args       -> ds_geglu            */
+       DS_OP_NOISE_EMBED = 10,  /* ds_noise_embed_args -> ds_noise_embed      */
+       DS_OP_STEM_IM2COL = 11   /* ds_stem_im2col_args -> ds_stem_im2col      */ };
+
+typedef struct ds_plan ds_plan;
+int ds_plan_create(ds_plan** out);
+/* Appends one launch; `args` (the struct named above for `op`, `args_bytes` = its sizeof, checked) is copied.  DS_E_ARG otherwise. */
+int ds_plan_add(ds_plan* plan, int op, const void* args, unsigned long long args_bytes);
+int ds_plan_size(const ds_plan* plan);
+/* Issues every launch of the plan on `stream`, in order.  Returns 0 or the first failing launch's code; ds_plan_last_failed then
+ * gives its index (-1 when the last run succeeded). */
+int ds_plan_run(ds_plan* plan, void* stream);
+int ds_plan_last_failed(const ds_plan* plan);
+/* Captures one run of the plan on `stream` (not the legacy default stream) into a hipGraph and instantiates it; a plan holds at most
+ * one graph (a second capture replaces it).  ds_plan_graph_launch replays it on `stream`. */
+int ds_plan_graph_capture(ds_plan* plan, void* stream);
+int ds_plan_graph_launch(ds_plan* plan, void* stream);
+void ds_plan_destroy(ds_plan* plan);
 
 #ifdef __cplusplus
 }

@@ -22,12 +22,36 @@ container by ``oracle/gen_golden.py``); ``tests/test_oracle_golden.py`` checks t
 """
 from __future__ import annotations
 
+import contextlib
 import math
 import re
 from collections import OrderedDict
 
 import torch
 import torch.nn.functional as F
+
+# Reduced-precision variant of the oracle (networks_edm.py:486 `use_fp16`, :79 `w.to(x.dtype)`): inside ``operands_f16(pred)`` the
+# multiplicands of every layer whose reference prefix satisfies ``pred`` ('model.enc.32x32_block0.conv0', '...skip', '...qkv',
+# '...proj', '...attention') are rounded to fp16 (round to nearest even, like ``.to(torch.float16)``) and multiplied / accumulated in
+# fp32 -- the arithmetic of the product's fp16-operand kernels, on the CPU.  Everything else (norms, SiLU, softmax, residuals,
+# embedding path, storage) stays fp32.  Outside the context manager the oracle is the pinned fp32 restatement.
+_F16_PRED = None
+
+
+@contextlib.contextmanager
+def operands_f16(pred):
+    global _F16_PRED
+    old, _F16_PRED = _F16_PRED, pred
+    try:
+        yield
+    finally:
+        _F16_PRED = old
+
+
+def _rnd(prefix, *ts):
+    if _F16_PRED is not None and _F16_PRED(prefix):
+        return tuple(t.to(torch.float16).to(torch.float32) for t in ts)
+    return ts
 
 
 def _silu(x):
@@ -63,6 +87,7 @@ def _conv(p, prefix, x, up=False, down=False):
     x = _resample(x, up, down)
     w = p.get(prefix + '.weight')
     if w is not None:
+        x, w = _rnd(prefix, x, w)
         x = F.conv2d(x, w, padding=w.shape[-1] // 2)       # networks_edm.py:79
         b = p.get(prefix + '.bias')
         if b is not None:
@@ -98,8 +123,9 @@ def _block(p, prefix, x, emb, *, up, down, adaptive, skip_scale, eps, heads, tap
     if heads:
         n, c = x.shape[0], x.shape[1]
         qkv = _conv(p, prefix + '.qkv', _gn(p, prefix + '.norm2', x, eps))
-        q, k, v = qkv.reshape(n * heads, c // heads, 3, -1).unbind(2)
+        q, k, v = _rnd(prefix + '.attention', *qkv.reshape(n * heads, c // heads, 3, -1).unbind(2))
         w = torch.einsum('ncq,nck->nqk', q, k / math.sqrt(k.shape[1])).softmax(dim=2)   # networks_edm.py:108
+        w, = _rnd(prefix + '.attention', w)
         a = torch.einsum('nqk,nck->ncq', w, v)
         x = (_conv(p, prefix + '.proj', a.reshape(*x.shape)) + x) * skip_scale
     return x

@@ -354,6 +354,20 @@ def part_full3():
     print('full3 imagenet64 ipndm-4 GITS-form schedule', tuple(tr.shape), float(tr[-1].abs().max()), flush=True)
 
 
+def part_fullffhq():
+    """The sampler call `bench.py --config ffhq` times (DPM-Solver++(2M), logSNR schedule, NFE = 10) on the full-size FFHQ-64 SongUNet at
+    B = 2 by the REAL reference: the GPU test scatters these two latents over the benchmark batch of 128."""
+    sys.path.insert(0, os.path.join(REF, 'diff-solvers-main'))
+    import solvers
+    torch.set_grad_enabled(False)
+    net, kw = _ref_net('ffhq', 61)
+    latents = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(7))
+    out = solvers.dpm_pp_sampler(net, latents, num_steps=11, sigma_min=0.002, sigma_max=80., schedule_type='logsnr', schedule_rho=7,
+                                 max_order=2, predict_x0=True, lower_order_final=True)
+    np.savez_compressed(os.path.join(OUT, 'sampler_ffhq_dpmpp2m_nfe10_b2.npz'), seed=61, latent_seed=7, latents=latents.numpy(), out=out.numpy())
+    print('fullffhq dpmpp2m nfe10 b2', float(out.abs().max()), flush=True)
+
+
 def part_full4():
     sys.path.insert(0, os.path.join(REF, 'amed-solver-main'))
     import solvers_amed
@@ -410,7 +424,7 @@ def part_fullsolv():
     np.savez_compressed(os.path.join(OUT, 'sampler_cifar10_solvers_nfe10_b4.npz'), **d)
 
 
-PARTS = dict(fullgits=part_fullgits, fullsolv=part_fullsolv, full3=part_full3, full4=part_full4, net=part_net, sched=part_sched, samplers=part_samplers, amed=part_amed, gits=part_gits, ldm=part_ldm, full=part_full)
+PARTS = dict(fullffhq=part_fullffhq, fullgits=part_fullgits, fullsolv=part_fullsolv, full3=part_full3, full4=part_full4, net=part_net, sched=part_sched, samplers=part_samplers, amed=part_amed, gits=part_gits, ldm=part_ldm, full=part_full)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

@@ -12,10 +12,32 @@ Follows, line by line, the reference modules it restates:
 The layer structure is discovered from the key names.  Pinned by tests/golden/ldm_*.npz, which oracle/gen_golden.py
 produced by running the real reference modules (part 'ldm').
 """
+import contextlib
 import math
 
 import torch
 import torch.nn.functional as F
+
+# Reduced-precision variant (the reference runs this U-Net under torch.autocast, sample.py:293-297): inside ``operands_f16(pred)`` the
+# multiplicands of every layer whose state_dict prefix satisfies ``pred`` are rounded to fp16 and multiplied / accumulated in fp32
+# (attention layers are named '<transformer block>.attn1' / '.attn2': q, k, v and the softmax weights are rounded).  See oracle/edm_net.py.
+_F16_PRED = None
+
+
+@contextlib.contextmanager
+def operands_f16(pred):
+    global _F16_PRED
+    old, _F16_PRED = _F16_PRED, pred
+    try:
+        yield
+    finally:
+        _F16_PRED = old
+
+
+def _rnd(prefix, *ts):
+    if _F16_PRED is not None and _F16_PRED(prefix):
+        return tuple(t.to(torch.float16).to(torch.float32) for t in ts)
+    return ts
 
 
 def _gn32(p, prefix, x, eps):
@@ -23,11 +45,12 @@ def _gn32(p, prefix, x, eps):
 
 
 def _lin(p, prefix, x):
-    return F.linear(x, p[prefix + '.weight'], p.get(prefix + '.bias'))
+    x, w = _rnd(prefix, x, p[prefix + '.weight'])
+    return F.linear(x, w, p.get(prefix + '.bias'))
 
 
 def _conv(p, prefix, x, stride=1):
-    w = p[prefix + '.weight']
+    x, w = _rnd(prefix, x, p[prefix + '.weight'])
     return F.conv2d(x, w, p[prefix + '.bias'], stride=stride, padding=w.shape[-1] // 2)
 
 
@@ -53,9 +76,10 @@ def _attn(p, prefix, x, context, heads):
     b, n, c = q.shape
     d = c // heads
     split = lambda t: t.reshape(b, t.shape[1], heads, d).permute(0, 2, 1, 3).reshape(b * heads, t.shape[1], d)
-    q, k, v = split(q), split(k), split(v)
+    q, k, v = _rnd(prefix, split(q), split(k), split(v))
     sim = torch.einsum('bid,bjd->bij', q, k) * (d ** -0.5)
-    out = torch.einsum('bij,bjd->bid', sim.softmax(dim=-1), v)
+    w, = _rnd(prefix, sim.softmax(dim=-1))
+    out = torch.einsum('bij,bjd->bid', w, v)
     out = out.reshape(b, heads, n, d).permute(0, 2, 1, 3).reshape(b, n, c)
     return _lin(p, prefix + '.to_out.0', out)
 

@@ -12,7 +12,7 @@ def test_library_builds_and_exports_header_symbols():
     build.build_lib(verbose=False)
     lib = _lib.load()
     header = open(os.path.join(ROOT, 'include', 'ds_engine.h')).read()
-    declared = set(re.findall(r'^(?:int|long long|const char\*)\s+(ds_\w+)\s*\(', header, flags=re.M))
+    declared = set(re.findall(r'^(?:int|long long|const char\*|void)\s+(ds_\w+)\s*\(', header, flags=re.M))
     assert declared, 'no declarations parsed'
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in ds_engine.h but not exported'
@@ -31,3 +31,26 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         assert 'no CPU fallback' in str(e)
     else:
         raise AssertionError('expected DsError')
+
+
+def test_native_plan_records_every_launch_and_checks_argument_sizes():
+    """ds_plan_* (include/ds_engine.h "Native launch plans"): host-side bookkeeping only -- no kernel runs without a GPU."""
+    import ctypes as C
+    import diff_sampler_amd.arch as arch
+    from diff_sampler_amd import _lib
+    from diff_sampler_amd.engine import UNetEngine
+    lib = _lib.load()
+    spec = arch.edm_precond_spec(**dict(arch.NAMED_CONFIGS['tiny_song']))
+    P = UNetEngine(spec, arch.init_params(spec, seed=1), device='cpu').plan(4, 1)
+    h = P.native()
+    assert lib.ds_plan_size(h) == len(P.ops) > 20
+    assert P.native().value == h.value                       # cached
+    assert lib.ds_plan_last_failed(h) == -1
+    a = _lib.ConvArgs()
+    assert lib.ds_plan_add(h, _lib.DS_OP_CONV2D, C.byref(a), C.sizeof(a) - 4) != 0      # wrong struct size
+    assert lib.ds_plan_add(h, 99, C.byref(a), C.sizeof(a)) != 0                         # unknown op code
+    assert lib.ds_plan_add(None, _lib.DS_OP_CONV2D, C.byref(a), C.sizeof(a)) != 0
+    assert lib.ds_plan_graph_launch(h, None) != 0                                       # nothing captured
+    assert lib.ds_plan_size(h) == len(P.ops)
+    P.close()
+    assert P._native is None

@@ -156,3 +156,89 @@ def test_sd15_config5_trajectory_matches_reference(dev):
     ref = torch.from_numpy(z['traj'])
     assert tr.shape == ref.shape
     assert _rel(tr.cpu(), ref) < 1e-3
+
+
+# ---- the OTHER benchmarked configurations at THEIR bench batches (bench.py --config imagenet64 --batch 64 / --config ffhq --batch 128),
+# ---- fp32 and the reference's fp16 mode: golden samples of the real reference scattered over the batch, kernel routing asserted --------
+def _conv_kernel_ids(net, B, emb_rows):
+    """{ds_conv_kernel_id: number of 3x3 launches} of the plan an evaluation at batch B runs."""
+    from diff_sampler_amd import _lib
+    lib = _lib.load()
+    ids = {}
+    for op in net.engine.plan(B, emb_rows).ops:
+        if op.fn is lib.ds_conv2d_nhwc and op.keep[0].taps == 9:
+            k = lib.ds_conv_kernel_id(C.byref(op.keep[0]))
+            ids[k] = ids.get(k, 0) + 1
+    return ids
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'fp16'])
+def test_config3_imagenet64_at_the_benchmark_batch_b64(mode, dev):
+    """`bench.py --config imagenet64 --batch 64 [--dtype fp16]`: the real reference's config-3 trajectory (B = 1, label, iPNDM-4 on the
+    GITS-form schedule, NFE = 10) occupies slots 0 / 21 / 42 / 63 of a 64-image call whose other slots carry different latents and labels;
+    every copy must reproduce the golden (samples are independent), on the tilings only this batch dispatches.  fp32: 5e-4 of the trajectory
+    scale.  use_fp16 (the checkpoint's own mode, networks_edm.py:486): 1e-2 over the 10-step trajectory against the FP32 reference, and
+    5e-3 for one evaluation at this batch (golden net_imagenet64.npz scattered the same way)."""
+    from diff_sampler_amd import solvers
+    from diff_sampler_amd.engine import EDMDenoiser
+    z = np.load(os.path.join(G, 'sampler_imagenet64_ipndm_gits_nfe10_b1.npz'))
+    f16 = mode == 'fp16'
+    net = EDMDenoiser.from_config('imagenet64', seed=int(z['seed']), use_fp16=f16)
+    B, slots = 64, [0, 21, 42, 63]
+    g = torch.Generator().manual_seed(991)
+    latents = torch.randn(B, 3, 64, 64, generator=g)
+    labels = torch.eye(1000)[torch.randint(1000, (B,), generator=g)]
+    latents[slots] = torch.from_numpy(z['latents'])
+    labels[slots] = torch.from_numpy(z['labels'])
+    out = solvers.ipndm_sampler(net, latents.to(dev), class_labels=labels.to(dev), max_order=4, t_steps=torch.from_numpy(z['t_steps']).to(dev),
+                                num_steps=11, return_inters=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    gold = torch.from_numpy(z['traj'])                       # [11, 1, 3, 64, 64]
+    tol = 1e-2 if f16 else 5e-4
+    for s in slots:
+        assert _rel(out[:, s:s + 1].cpu(), gold) < tol, (mode, s, _rel(out[:, s:s + 1].cpu(), gold))
+    ids = _conv_kernel_ids(net, B, B)
+    if f16:
+        assert ids.get(2562, 0) + ids.get(2566, 0) >= 60, ids       # fp16-operand 3x3 kernels (2562: 256 x 128 tiles, 2566: 256 x 256 tiles)
+    else:
+        assert ids.get(2565, 0) + ids.get(256, 0) + ids.get(128, 0) + ids.get(1284, 0) >= 60, ids     # the LDS-halo fp32 family
+        assert ids.get(2565, 0) >= 10, ids                   # 768-channel layers: 256 x 256 tiles
+    # one evaluation at this batch against the real reference's net_imagenet64.npz
+    zn = np.load(os.path.join(G, 'net_imagenet64.npz'))
+    netn = net if int(zn['seed']) == int(z['seed']) else EDMDenoiser.from_config('imagenet64', seed=int(zn['seed']), use_fp16=f16)
+    sig = torch.full((B,), 0.7)
+    x = torch.randn(B, 3, 64, 64, generator=g) * 0.7
+    x[slots], sig[slots], labels[slots] = torch.from_numpy(zn['x']), torch.from_numpy(zn['sigma']), torch.from_numpy(zn['labels'])
+    o = netn(x.to(dev), sig.to(dev), class_labels=labels.to(dev)).cpu()
+    for s in slots:
+        e = _rel(o[s:s + 1], torch.from_numpy(zn['out_vec']))
+        assert e < (5e-3 if f16 else 2e-4), (mode, s, e)
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'fp16'])
+def test_ffhq64_headline_solver_at_the_benchmark_batch_b128(mode, dev):
+    """`bench.py --config ffhq --batch 128 [--dtype fp16]`: the real reference's DPM-Solver++(2M) logSNR NFE = 10 call on the full-size
+    FFHQ-64 SongUNet (B = 2, oracle/gen_golden.py --part fullffhq) scattered over a 128-image call (each golden latent in two slots).
+    fp32: 5e-4; use_fp16: 1e-2 over the 10-evaluation trajectory against the FP32 reference."""
+    from diff_sampler_amd import solvers
+    from diff_sampler_amd.engine import EDMDenoiser
+    z = np.load(os.path.join(G, 'sampler_ffhq_dpmpp2m_nfe10_b2.npz'))
+    f16 = mode == 'fp16'
+    net = EDMDenoiser.from_config('ffhq', seed=int(z['seed']), use_fp16=f16)
+    B, slots = 128, [0, 77, 50, 127]                        # golden latent 0 in slots 0 and 50, latent 1 in slots 77 and 127
+    latents = torch.randn(B, 3, 64, 64, generator=torch.Generator().manual_seed(992))
+    gl = torch.from_numpy(z['latents'])
+    latents[slots] = torch.cat([gl, gl])
+    out = solvers.dpm_pp_sampler(net, latents.to(dev), num_steps=11, sigma_min=0.002, sigma_max=80., schedule_type='logsnr', schedule_rho=7,
+                                 max_order=2, predict_x0=True, lower_order_final=True).cpu()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    gold = torch.from_numpy(z['out'])
+    tol = 1e-2 if f16 else 5e-4
+    assert _rel(out[slots], torch.cat([gold, gold])) < tol, (mode, _rel(out[slots], torch.cat([gold, gold])))
+    ids = _conv_kernel_ids(net, B, 1)
+    if f16:
+        assert ids.get(2562, 0) + ids.get(2566, 0) >= 60, ids
+    else:
+        assert ids.get(2565, 0) >= 20 and ids.get(256, 0) >= 10, ids       # 256-channel layers on 256 x 256 tiles, 128-channel layers on 256 x 128

@@ -174,3 +174,70 @@ def test_cpu_latents_fail_loudly():
     from diff_sampler_amd import solvers
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         solvers.euler_sampler(lambda x, t, class_labels=None: x, torch.zeros(1, 3, 8, 8), num_steps=3)
+
+
+@pytest.mark.parametrize('shape', [(5, 3, 16, 16), (7, 3, 32, 32), (3, 3, 64, 64), (2, 4, 64, 64)])
+@pytest.mark.parametrize('mode', ['raw_2m', 'afs_1', 'denoised_3m', 'm_only'])
+def test_dpmpp_x0_step_register_kernel(shape, mode, dev):
+    """ds_dpmpp_x0_step on the register-resident kernel (three-digit radix select in registers) == the LDS kernel to the last bit
+    (both return the exact order statistics) and == the oracle's threshold + DPM-Solver++ combination (solver_utils.py:77-86,
+    :102-163) within fp32 re-association (1e-6 of the output scale; the thresholded m itself bit-exactly)."""
+    from diff_sampler_amd import _lib, ops
+    from oracle import solvers_ref
+    lib = _lib.load()
+    n, c, h, w = shape
+    assert lib.ds_dpmpp_x0_step_in_registers(c * h * w) == 1
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(*shape, generator=g) * 3).to(dev)
+    f = torch.randn(*shape, generator=g).to(dev)
+    hist = [torch.randn(*shape, generator=g).to(dev) for _ in range(2)]
+    sigma, t = 2.5, 2.5
+    hc = [0.37, 0.81, -0.23, 0.11, 0.0, t, sigma, 0.0]
+    kw = dict(raw_2m=dict(raw=True, hist=hist[:1]), afs_1=dict(afs=True, hist=[]), denoised_3m=dict(raw=False, hist=hist),
+              m_only=dict(raw=True, hist=[]))[mode]
+    outs = []
+    for variant in (0, 1):
+        xo = None if mode == 'm_only' else torch.empty_like(x)
+        mo = torch.empty_like(x)
+        a = ops.make_update_args(x, x, None if kw.get('afs') else f, n, c, h, w, xo, raw=kw.get('raw', False), f_ld=0, hist=kw['hist'],
+                                 hcoefs=hc, afs=kw.get('afs', False), sigma_data=0.5, m_out=mo, store_d=False)
+        prev = lib.ds_debug_dpmpp_variant(variant)
+        try:
+            ops.dpmpp_x0_step(a)
+            torch.cuda.synchronize()
+        finally:
+            lib.ds_debug_dpmpp_variant(prev)
+        outs.append((None if xo is None else xo.cpu(), mo.cpu()))
+    (xo_r, m_r), (xo_l, m_l) = outs
+    assert torch.equal(m_r, m_l)
+    if xo_r is not None:
+        assert torch.equal(xo_r, xo_l)
+    # oracle: D in the reference's fp32 operation order, torch.quantile thresholding
+    xc, fc = x.cpu(), f.cpu()
+    if kw.get('afs'):
+        D = xc - t * (xc / (1 + t * t) ** 0.5)
+    elif kw.get('raw'):
+        s2, sd2 = torch.tensor(sigma) ** 2, 0.25
+        D = (sd2 / (s2 + sd2)) * xc + (torch.tensor(sigma) * 0.5 / (s2 + sd2).sqrt()) * fc
+    else:
+        D = fc
+    m_ref = solvers_ref.threshold(D)
+    assert _rel(m_r, m_ref) < 1e-6
+    if xo_r is not None:
+        ref = hc[0] * xc + hc[1] * m_ref
+        for i, hh in enumerate(kw['hist']):
+            ref = ref + hc[2 + i] * hh.cpu()
+        assert _rel(xo_r, ref) < 1e-6
+
+
+def test_dpmpp_x0_step_register_kernel_ties(dev):
+    """Ties around the order statistics and a quantile below 1 (s clamps to 1), on the register kernel: bit-exact vs the oracle."""
+    from diff_sampler_amd import _lib, ops
+    from oracle import solvers_ref
+    x = torch.full((3, 3, 32, 32), 0.25, device=dev)
+    x[1, 0, 0, :20] = torch.tensor([5.0, -7.0, 7.0, 3.0] * 5, device=dev)           # > 0.5 % of the sample above 1, with ties
+    x[2].uniform_(-3, 3)
+    mo = torch.empty_like(x)
+    a = ops.make_update_args(x, x, x, 3, 3, 32, 32, None, raw=False, f_ld=0, hist=[], hcoefs=[0, 1, 0, 0, 0, 1, 1, 0], m_out=mo, store_d=False)
+    ops.dpmpp_x0_step(a)
+    assert torch.equal(mo.cpu(), solvers_ref.threshold(x.cpu()))
