@@ -477,7 +477,7 @@ def main(argv=None):
         dist.all_gather(per, torch.tensor([dt_local], dtype=torch.float64, device=dev))
         per_ms = [float(t.item()) / args.steps * 1e3 for t in per]
         multi = dict(per_rank_ms_per_step_min=round(min(per_ms), 3), per_rank_ms_per_step_max=round(max(per_ms), 3),
-                     per_rank_ms_per_step=[round(v, 3) for v in per_ms], backend='gloo' if stub else 'nccl (RCCL)',
+                     per_rank_ms_per_step=[round(v, 3) for v in per_ms], backend='gloo' if stub else 'nccl (RCCL)', communicator=dict(launch.COMM_INFO),
                      fid_moment_allreduce=fid_allreduce_timing(dist, dev, world))
     if not stub:
         assert torch.isfinite(out).all()

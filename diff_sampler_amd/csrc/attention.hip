@@ -211,13 +211,7 @@ int launch(const ds_attn_args* a, hipStream_t stream) {
     constexpr int DB = (D > 32 && (D % 32) == 8) ? D / 32 : (D + 31) / 32;
     constexpr int KT = (D <= 64 && !(D > 32 && (D % 32) == 8)) ? 64 : 32;
     constexpr int bytes = (KT * (D + 4) + KT * (DB * 32 + 8) + 32 + 4 * 32 * 33) * (int)sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_kernel<D>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    DS_ENSURE_DYN_LDS((&flash_attn_kernel<D>), bytes);
     dim3 grid((a->sq + 127) / 128, a->heads, a->batch);
     hipLaunchKernelGGL(flash_attn_kernel<D>, grid, dim3(256), bytes, stream, *a);
     DS_CHECK_LAUNCH();

@@ -241,13 +241,7 @@ int launch(const ds_attn_args* a, hipStream_t stream) {
     constexpr int DP = (D + 15) / 16 * 16, DB = (D + 31) / 32;
     constexpr int bytes = 2 * (64 * (DP + 8) * 2 + DB * 32 * 72 * 2) + 8 * 32 * 33 * (int)sizeof(float);
     static_assert(bytes <= 160 * 1024, "LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_f16_kernel<D>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    DS_ENSURE_DYN_LDS((&flash_attn_f16_kernel<D>), bytes);
     const int qblocks = (a->sq + 255) / 256, pairs = a->batch * a->heads;
     const long long blocks = (long long)qblocks * ((pairs + 7) / 8) * 8;
     if (blocks > 0x7fffffffLL) return DS_E_SHAPE;

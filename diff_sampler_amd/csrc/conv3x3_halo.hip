@@ -616,13 +616,7 @@ int launch_one(KParams p, const Geo& g, int n_begin, int ntiles, hipStream_t str
     if (p.coef_lds) smem += coef_bytes;
     const int epi = 4 * 64 * EPI_LD * (int)sizeof(float);       // = 8 x 32 x EPI_LD for the 8-wave shape
     if (smem < epi) smem = epi;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, GLDS, WN, VAR, NT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    DS_ENSURE_DYN_LDS((&conv3x3_halo_kernel<WM, GLDS, WN, VAR, NT>), 128 * 1024);
     hipLaunchKernelGGL((conv3x3_halo_kernel<WM, GLDS, WN, VAR, NT>), dim3(grid_1d(p.mtiles, p.ntiles), p.splits), dim3(64 * WM * WN), smem, stream, p);
     DS_CHECK_LAUNCH();
     return DS_OK;

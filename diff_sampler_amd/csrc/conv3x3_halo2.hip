@@ -498,12 +498,7 @@ int launch_halo2_w(KParams p, int wide, hipStream_t stream) {
     int smem = (int)G::SMEM;
     const int epi = 8 * 32 * EPI_LD * (int)sizeof(float);
     if (smem < epi) smem = epi;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo2_kernel<W, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    DS_ENSURE_DYN_LDS((&conv3x3_halo2_kernel<W, MODE>), 160 * 1024);
     hipLaunchKernelGGL((conv3x3_halo2_kernel<W, MODE>), dim3(grid_1d(p.mtiles, p.ntiles), 1), dim3(512), smem, stream, p);
     DS_CHECK_LAUNCH();
     return DS_OK;

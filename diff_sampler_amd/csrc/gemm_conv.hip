@@ -201,13 +201,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const KParams p) {
 
 template <int MODE>
 int launch(KParams& p, int batch, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f32_kernel<MODE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    DS_ENSURE_DYN_LDS((&igemm_f32_kernel<MODE>), SMEM_BYTES);
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = (p.N + BN - 1) / BN;
     dim3 grid;

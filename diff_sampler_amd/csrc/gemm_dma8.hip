@@ -107,12 +107,7 @@ bool gemm_dma8_applicable(const KParams& p) {
 }
 
 int launch_gemm_dma8(KParams& p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM8);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    DS_ENSURE_DYN_LDS((&gemm_dma8_kernel), SMEM8);
     p.mtiles = (p.M + TM8 - 1) / TM8;
     p.ntiles = (p.N + TN8 - 1) / TN8;
     p.splits = 1;

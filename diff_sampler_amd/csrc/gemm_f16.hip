@@ -176,12 +176,7 @@ bool gemm_f16_applicable(const KParams& p) {
 
 int launch_gemm_f16(KParams& p, hipStream_t stream) {
     constexpr int SMEM = 2 * 128 * 32 * 4 + 2 * 256 * 144;          // 106,496 B
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    DS_ENSURE_DYN_LDS((&gemm_f16_kernel), SMEM);
     p.mtiles = p.M / 256;
     p.ntiles = (p.N + 127) / 128;
     p.splits = 1;

@@ -549,9 +549,7 @@ extern "C" int ds_dynamic_threshold(const float* x0, float* out, int n, int per,
     if (!x0 || !out || n <= 0 || per <= 1) return DS_E_ARG;
     const size_t smem = ((size_t)per + 256) * sizeof(unsigned);
     if (smem > 150 * 1024) return DS_E_SHAPE;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dynamic_threshold_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);     // per device: set on every launch
-    if (e != hipSuccess) return (int)e;
+    DS_ENSURE_DYN_LDS((&dynamic_threshold_kernel), 150 * 1024);
     hipLaunchKernelGGL(dynamic_threshold_kernel, dim3(n), dim3(512), smem, (hipStream_t)stream, x0, out, per, p);
     DS_CHECK_LAUNCH();
     return DS_OK;
@@ -587,9 +585,7 @@ extern "C" int ds_dpmpp_x0_step(const ds_update_args* a, float p, void* stream) 
     }
     const size_t smem = ((size_t)per + 256) * sizeof(unsigned);
     if (per <= 1 || smem > 150 * 1024) return DS_E_SHAPE;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dpmpp_x0_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       150 * 1024);          // per device, cheap: set on every launch (a process may drive several GPUs)
-    if (e != hipSuccess) return (int)e;
+    DS_ENSURE_DYN_LDS((&dpmpp_x0_step_kernel), 150 * 1024);
     hipLaunchKernelGGL(dpmpp_x0_step_kernel, dim3(a->n), dim3(512), smem, (hipStream_t)stream, *a, p);
     DS_CHECK_LAUNCH();
     return DS_OK;

@@ -98,7 +98,8 @@ class UNetEngine:
                 from .ops import pack_conv_weight_f16
                 w[f'{b.name}.conv0.w16'] = (pack_conv_weight_f16(g(f'{p}.conv0.weight')), 0)
                 w[f'{b.name}.conv1.w16'] = (pack_conv_weight_f16(g(f'{p}.conv1.weight'), g(f'{p}.skip.weight') if b.skip_conv else None), 0)
-            elif self.conv_mode == 2:
+            elif self.conv_mode == 2 and b.cin % 32 == 0 and b.cout % 32 == 0:
+                # ineligible layers (channel counts that are not 32-multiples: tiny / custom nets) keep the exact fp32 kernel
                 from .ops import pack_conv_weight_split
                 w[f'{b.name}.conv0.w16'] = pack_conv_weight_split(g(f'{p}.conv0.weight'))
                 w[f'{b.name}.conv1.w16'] = pack_conv_weight_split(g(f'{p}.conv1.weight'), g(f'{p}.skip.weight') if b.skip_conv else None)
@@ -120,7 +121,7 @@ class UNetEngine:
                 w[f'{b.name}.proj.w'] = pack_conv_weight(g(f'{p}.proj.weight')); w[f'{b.name}.proj.b'] = g(f'{p}.proj.bias')
         w['out.g'] = g(f'{m}.{spec.out_norm}.weight'); w['out.b'] = g(f'{m}.{spec.out_norm}.bias')
         w['outc.w'] = pack_conv_weight(g(f'{m}.{spec.out_conv}.weight')); w['outc.b'] = g(f'{m}.{spec.out_conv}.bias')
-        if self.conv_mode == 2:
+        if self.conv_mode == 2 and g(f'{m}.{spec.out_conv}.weight').shape[1] % 32 == 0:
             from .ops import pack_conv_weight_split
             w['outc.w16'] = pack_conv_weight_split(g(f'{m}.{spec.out_conv}.weight'))
         self.w = w

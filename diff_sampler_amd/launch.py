@@ -25,6 +25,18 @@ class LaunchError(RuntimeError):
     pass
 
 
+COMM_INFO = {}      # filled by init_group: backend, world size from the communicator, RCCL's version line (NCCL_DEBUG=VERSION), IPC mode
+
+
+def ipc_default(env) -> None:
+    """Multi-process GPU work on the deployment pool needs dmabuf IPC: its host driver has no legacy IPC, and without
+    ``HSA_ENABLE_IPC_MODE_LEGACY=0`` RCCL / cross-process tensor sharing fail with ``hipIpcGetMemHandle: invalid argument`` (the pool's
+    images export the variable; a launcher that builds its own environment must keep it).  The value already in the environment
+    always wins; ``DS_KEEP_HSA_IPC_DEFAULT=1`` opts out of the default.  What a run used is reported in ``COMM_INFO``."""
+    if env.get('DS_KEEP_HSA_IPC_DEFAULT') != '1':
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+
 def free_port() -> int:
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(('127.0.0.1', 0))
@@ -62,10 +74,12 @@ def resolve(gpus: int, script: str, argv: Sequence[str], env=None, spawn=None) -
             return 0, 1, 0
         cmd = launch_command(gpus, script, argv)
         child_env = dict(os.environ if env is None else env)
-        child_env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC only on this pool (RCCL needs it)
+        ipc_default(child_env)
         rc = (spawn or subprocess.call)(cmd, env=child_env)
         raise SystemExit(rc)
     rank, world, local = ew
+    if env is None and world > 1:
+        ipc_default(os.environ)             # before the first HIP call of this rank (the HSA runtime reads it when it initialises)
     if world != gpus:
         raise LaunchError(f'--gpus {gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {gpus} (or drop the launcher and let '
                           f'`--gpus {gpus}` start the ranks itself)')
@@ -78,9 +92,19 @@ def init_group(rank: int, world: int, local: int, backend: str, device=None):
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
+    ver_file = None
     if backend == 'nccl':
         if torch.cuda.device_count() < world:
             raise LaunchError(f'{world} ranks need {world} GPUs on this node, {torch.cuda.device_count()} visible')
+        # make the first real multi-GPU run diagnosable: RCCL's NCCL_DEBUG=VERSION line goes to a per-rank file (stdout carries the
+        # one JSON line) and is reported back through COMM_INFO
+        if 'NCCL_DEBUG' not in os.environ and 'NCCL_DEBUG_FILE' not in os.environ:
+            import tempfile
+            ver_file = os.path.join(tempfile.gettempdir(), f'ds_rccl_version_{os.getpid()}.log')
+            os.environ['NCCL_DEBUG'], os.environ['NCCL_DEBUG_FILE'] = 'VERSION', ver_file
+        if 'HSA_ENABLE_IPC_MODE_LEGACY' not in os.environ and rank == 0:
+            print('launch: HSA_ENABLE_IPC_MODE_LEGACY is not set (DS_KEEP_HSA_IPC_DEFAULT=1); on hosts whose driver only supports dmabuf '
+                  'IPC RCCL fails with "hipIpcGetMemHandle: invalid argument"', file=sys.stderr)
     dist.init_process_group(backend=backend, init_method='env://', rank=rank, world_size=world)
     ones = torch.ones(1, dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
     dist.all_reduce(ones)
@@ -93,4 +117,15 @@ def init_group(rank: int, world: int, local: int, backend: str, device=None):
         got = sorted(int(t.item()) for t in ids)
         if got != list(range(world)):
             raise LaunchError(f'ranks do not own distinct devices: LOCAL_RANKs {got}')
+    COMM_INFO.clear()
+    COMM_INFO.update(backend=('nccl (RCCL)' if backend == 'nccl' else backend), world=n,
+                     HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'))
+    if ver_file is not None:
+        try:
+            with open(ver_file) as f:
+                lines = [l.strip() for l in f if 'version' in l.lower()]
+            COMM_INFO['rccl_version_line'] = lines[0] if lines else None
+            os.remove(ver_file)
+        except OSError:
+            COMM_INFO['rccl_version_line'] = None
     return dist, n

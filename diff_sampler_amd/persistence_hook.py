@@ -17,8 +17,10 @@ the module's own weights on the first call and cached on the instance).  Nothing
 still the reference's ``solvers.py``; for the fused update kernels and the one-launch DPM-Solver++ step import
 ``diff_sampler_amd.solvers`` instead of ``solvers``.
 
-What the route does NOT do, on purpose: it computes nothing itself.  Calls with CPU tensors or with ``augment_labels`` / other
-``model_kwargs`` go to the module's ORIGINAL ``forward`` -- the reference's own code, not a fallback of this package; a GPU call
+What the route does NOT do, on purpose: it computes nothing itself, and it is INFERENCE-ONLY.  Calls with CPU tensors, with
+``augment_labels`` / other ``model_kwargs``, or that autograd would record (grad mode on and an input or a parameter of the module
+requires grad: amed-solver-main's training path, ``solvers_amed.py:141-143`` with ``train=True``) go to the module's ORIGINAL
+``forward`` -- the reference's own code, not a fallback of this package -- so gradients are never silently dropped; a GPU call
 whose HIP library is missing (``_lib.DsError``) or whose module ``engine.spec_from_module`` does not recognise raises, like every
 other entry point.  The inner modules are not executed under the route; the one place the reference observes them -- the AMED
 bottleneck tap, a forward hook on ``net.model.enc['8x8_block2' | '8x8_block3']`` (``solvers_amed.py:7-18``) -- is honoured: hooks
@@ -27,6 +29,8 @@ runs on a routed net (``diff_sampler_amd.solvers_amed`` does the same without ho
 packed when the engine is built; call ``invalidate(net)`` after changing them.
 """
 from __future__ import annotations
+
+import torch
 
 MARK = '# --- appended by diff_sampler_amd.persistence_hook ---'
 ROUTED_CLASSES = ('EDMPrecond',)
@@ -112,6 +116,18 @@ def _fire_bottleneck_hooks(net, eng):
                 fn(mod, (), out)
 
 
+def _needs_autograd(net, *inputs):
+    """The route is INFERENCE-ONLY: the engine's output has no grad_fn.  A call that autograd would record -- grad mode on and an
+    input that requires grad (amed-solver-main/solvers_amed.py:141-143 with train=True differentiates through
+    net(x_mid(r), scale_time * t_mid(r)); training_loop.py:205 backward) or a trainable parameter of the module itself -- goes to the
+    reference forward, so gradients are never silently dropped."""
+    if not torch.is_grad_enabled():
+        return False
+    if any(isinstance(t, torch.Tensor) and t.requires_grad for t in inputs):
+        return True
+    return any(p.requires_grad for p in net.parameters())
+
+
 def route_class(cls):
     """Wrap ``cls.forward`` (``EDMPrecond.forward``, networks_edm.py:482-496) so that GPU calls run on the HIP engine.  Same
     signature, same return (denoised NCHW fp32).  Idempotent per class object."""
@@ -120,7 +136,7 @@ def route_class(cls):
     reference_forward = cls.forward
 
     def forward(self, x, sigma, class_labels=None, force_fp32=False, **model_kwargs):
-        if not getattr(x, 'is_cuda', False) or model_kwargs:
+        if not getattr(x, 'is_cuda', False) or model_kwargs or _needs_autograd(self, x, sigma, class_labels):
             return reference_forward(self, x, sigma, class_labels, force_fp32=force_fp32, **model_kwargs)
         # networks_edm.py:486: fp16 body only when the module asks for it and the caller does not force fp32
         use_fp16 = bool(getattr(self, 'use_fp16', False)) and not force_fp32

@@ -59,9 +59,42 @@ class StackedRandomGenerator:
                     g.set_offset(self.offset)
         return self._generators
 
+    _fast_ok = {}            # device index -> did ds_philox_randn reproduce torch's own generators on this torch build / device?
+
+    @classmethod
+    def fast_path_verified(cls, device) -> bool:
+        """The batched Philox kernel's Box-Muller is pinned to the device math of ONE torch / ROCm build (csrc/rng.hip); on another build
+        latents could differ from the reference's per-generator ``randn`` by an ulp and seeds would silently stop reproducing.  So the
+        first use on a device draws a small sample both ways -- at offset 0 and at a non-zero offset -- and the fast path is used only
+        if they are bit-identical; otherwise real per-seed generators are (the reference's own path), with a one-line notice."""
+        device = torch.device(device)
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        ok = cls._fast_ok.get(key)
+        if ok is None:
+            from . import ops
+            ok = True
+            try:
+                seeds, n = [3, 4000000007 % (1 << 32)], 1500
+                sd = torch.tensor(seeds, dtype=torch.int64, device=device)
+                for off in (0, 24):
+                    got = torch.empty(len(seeds), n, dtype=torch.float32, device=device)
+                    ops.philox_randn(sd, off, got, n)
+                    for i, sv in enumerate(seeds):
+                        g = torch.Generator(device).manual_seed(sv)
+                        g.set_offset(off)
+                        ok = ok and torch.equal(got[i], torch.randn(n, generator=g, device=device))
+            except Exception as e:                                       # a missing library is reported by the samplers, not here
+                print(f'StackedRandomGenerator: batched Philox check failed ({e}); using per-seed generators')
+                ok = False
+            if not ok:
+                print('StackedRandomGenerator: ds_philox_randn does not reproduce torch.randn bit-for-bit on this torch build / device; '
+                      'using per-seed torch generators (slower, reference-identical)')
+            cls._fast_ok[key] = ok
+        return ok
+
     def _fast(self, device, dtype):
         return (self._generators is None and self.device.type == 'cuda' and torch.device(device if device is not None else self.device).type == 'cuda'
-                and dtype in (None, torch.float32))
+                and dtype in (None, torch.float32) and self.fast_path_verified(self.device))
 
     def _dev_seeds(self):
         if self._seeds_dev is None:
@@ -112,9 +145,11 @@ def shard_seeds(seeds, max_batch_size: int, rank: int, world: int):
     return all_batches[rank::world]
 
 
-def compute_nfe(solver, num_steps, afs, denoise_to_zero, dataset_name, dp=False):
+def compute_nfe(solver, num_steps, afs, denoise_to_zero, dataset_name, dp=False, guidance_rate=None):
     """sample.py:211-219; with a searched GITS schedule (``dp``) AFS INSERTS a step into the schedule instead of replacing
-    one (gits-main/sample.py:231-241): free for the 1-NFE solvers, one extra evaluation for dpm / heun."""
+    one (gits-main/sample.py:231-241): free for the 1-NFE solvers, one extra evaluation for dpm / heun.  Classifier-free guidance
+    doubles the count for ms_coco -- unconditionally in diff-solvers-main (:218), only for guidance rates outside {0, 1} in gits-main
+    (:240-242; pass ``guidance_rate`` to get that rule)."""
     if solver in ('dpm', 'heun'):
         nfe = 2 * (num_steps - 1)
         if afs:
@@ -125,7 +160,9 @@ def compute_nfe(solver, num_steps, afs, denoise_to_zero, dataset_name, dp=False)
             nfe = nfe if dp else nfe - 1
     if denoise_to_zero:
         nfe += 1
-    return 2 * nfe if dataset_name in ['ms_coco'] else nfe
+    if dataset_name in ['ms_coco'] and (guidance_rate is None or guidance_rate not in (0., 1.)):
+        nfe = 2 * nfe
+    return nfe
 
 
 AMED_SOLVER_FNS = dict(amed='amed_sampler', euler='euler_sampler', dpm='dpm_2_sampler', ipndm='ipndm_sampler', dpmpp='dpm_pp_sampler')
@@ -144,6 +181,8 @@ def find_predictor(predictor_path, exps_dir='./exps'):
                 idx = int(ck.split('-')[-1].split('.')[0])
                 if idx > best_idx:
                     best, best_idx = ck, idx
+            if best is None:
+                raise FileNotFoundError(f'experiment directory {os.path.join(exps_dir, name)!r} holds no predictor snapshot (*.pkl)')
             return os.path.join(exps_dir, name, best)
     return predictor_path
 
@@ -313,8 +352,15 @@ def run(dataset_name=None, max_batch_size=64, seeds='0-63', grid=False, outdir=N
     from . import solvers, solver_utils
     seeds = parse_int_list(seeds)
     dist, rank, world = _dist()
-    device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0))) if device is None else torch.device(device)
-    torch.cuda.set_device(device)
+    # Launcher self-test (tests/test_launch_cpu.py, hidden --stub): gloo ranks on the CPU, NO kernels and no arithmetic -- every
+    # "image" is a flat colour that encodes its seed, written through the real sharding / per-batch barriers / PNG sink / output tree.
+    # It exists so that the N > 1 host path is exercised where there is no GPU; it is not a CPU mode of the sampler.
+    stub = bool(solver_kwargs.pop('stub', False))
+    if stub:
+        device = torch.device('cpu')
+    else:
+        device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0))) if device is None else torch.device(device)
+        torch.cuda.set_device(device)
     rank_batches = shard_seeds(seeds, max_batch_size, rank, world)
     log = print if rank == 0 else (lambda *a, **k: None)
 
@@ -339,10 +385,15 @@ def run(dataset_name=None, max_batch_size=64, seeds='0-63', grid=False, outdir=N
         t_steps = None
     if dataset_name is None:
         raise ValueError('--dataset_name is required (or --predictor_path, which carries it)')
-    net, solver_kwargs['model_source'] = create_model(dataset_name, model_path, random_init, device,
-                                                      guidance_type=solver_kwargs.get('guidance_type'),
-                                                      guidance_rate=solver_kwargs.get('guidance_rate'),
-                                                      use_fp16=solver_kwargs.get('use_fp16', False))
+    if stub:
+        import types
+        net = types.SimpleNamespace(img_channels=3, img_resolution=8, label_dim=0, sigma_min=0.002, sigma_max=80.)
+        solver_kwargs['model_source'] = 'stub'
+    else:
+        net, solver_kwargs['model_source'] = create_model(dataset_name, model_path, random_init, device,
+                                                          guidance_type=solver_kwargs.get('guidance_type'),
+                                                          guidance_rate=solver_kwargs.get('guidance_rate'),
+                                                          use_fp16=solver_kwargs.get('use_fp16', False))
     ldm = solver_kwargs['model_source'] == 'ldm'
     cond_table = None
     if ldm and solver_kwargs.get('condition_path'):
@@ -358,6 +409,7 @@ def run(dataset_name=None, max_batch_size=64, seeds='0-63', grid=False, outdir=N
         solver_kwargs.setdefault(k, v)
     solver_kwargs['sigma_min'], solver_kwargs['sigma_max'] = net.sigma_min, net.sigma_max
     dp = bool(solver_kwargs.get('dp'))
+    gits_cli = 'dp' in solver_kwargs         # the option only exists in gits-main/sample.py: its NFE rule for guided sampling applies (:240-242)
     if predictor is not None:
         # amed-solver-main/sample.py:196-199: two evaluations per step (the first one free under AFS); the samplers build
         # their own schedule from the predictor's schedule_type / rho
@@ -398,7 +450,8 @@ def run(dataset_name=None, max_batch_size=64, seeds='0-63', grid=False, outdir=N
             log('Pre-specified t_steps:', t_list)
         solver_kwargs['t_steps'] = t_steps
         solver = solver_kwargs['solver']
-        nfe = compute_nfe(solver, solver_kwargs['num_steps'], solver_kwargs['afs'], solver_kwargs['denoise_to_zero'], dataset_name, dp=dp)
+        nfe = compute_nfe(solver, solver_kwargs['num_steps'], solver_kwargs['afs'], solver_kwargs['denoise_to_zero'], dataset_name, dp=dp,
+                          guidance_rate=((7.5 if solver_kwargs['guidance_rate'] is None else solver_kwargs['guidance_rate']) if gits_cli else None))
         solver_kwargs['nfe'] = nfe
         sampler_fn = getattr(solvers, SOLVER_FNS[solver])
         if solver == 'deis':
@@ -415,6 +468,12 @@ def run(dataset_name=None, max_batch_size=64, seeds='0-63', grid=False, outdir=N
             dist.barrier()                                          # per-batch barrier, as the reference (sample.py:268)
         B = len(batch_seeds)
         if B == 0:
+            continue
+        if stub:
+            import numpy as np
+            arr = np.stack([np.full((8, 8, 3), int(sd) % 251, dtype=np.uint8) for sd in batch_seeds])
+            sink.submit(arr, batch_seeds, outdir, subdirs)
+            n_done += B
             continue
         rnd = StackedRandomGenerator(device, batch_seeds)
         latents = rnd.randn([B, net.img_channels, net.img_resolution, net.img_resolution], device=device)
@@ -496,6 +555,7 @@ if click is not None:
     @click.option('--num_warmup', help='Number of warm-up trajectories', type=click.IntRange(min=1), default=256)
     @click.option('--solver_tea', help='Teacher solver', type=click.Choice(['euler', 'ipndm', 'ipndm_v', 'heun', 'dpm', 'dpmpp', 'deis']), default='ipndm', show_default=True)
     @click.option('--num_steps_tea', help='Number of timestamps for teacher', type=click.IntRange(min=1), default=21, show_default=True)
+    @click.option('--stub', help='launcher self-test: gloo ranks on the CPU, no kernels (tests/test_launch_cpu.py)', type=bool, default=False, hidden=True)
     def main(**kw):
         run(**kw)
 

@@ -76,10 +76,18 @@ def _attn(p, prefix, x, context, heads):
     b, n, c = q.shape
     d = c // heads
     split = lambda t: t.reshape(b, t.shape[1], heads, d).permute(0, 2, 1, 3).reshape(b * heads, t.shape[1], d)
-    q, k, v = _rnd(prefix, split(q), split(k), split(v))
-    sim = torch.einsum('bid,bjd->bij', q, k) * (d ** -0.5)
-    w, = _rnd(prefix, sim.softmax(dim=-1))
-    out = torch.einsum('bij,bjd->bid', w, v)
+    q, k, v = split(q), split(k), split(v)
+    if _F16_PRED is not None and _F16_PRED(prefix):
+        # the fp16-operand attention kernel's arithmetic: q pre-multiplied by d^-1/2 * log2(e) and THEN rounded, k and v rounded,
+        # fp32 scores, un-normalised exp2 weights rounded for the P V product, fp32 row sums of the unrounded weights.  (Where the
+        # roundings sit matters: on SD-1.5 two placements differ by 3.5e-3 of the output -- as much as either differs from fp32.)
+        q, k, v = _rnd(prefix, q * (d ** -0.5 * math.log2(math.e)), k, v)
+        sim = torch.einsum('bid,bjd->bij', q, k)
+        pw = torch.exp2(sim - sim.max(dim=-1, keepdim=True).values)
+        out = torch.einsum('bij,bjd->bid', _rnd(prefix, pw)[0], v) / pw.sum(-1, keepdim=True)
+    else:
+        sim = torch.einsum('bid,bjd->bij', q, k) * (d ** -0.5)
+        out = torch.einsum('bij,bjd->bid', sim.softmax(dim=-1), v)
     out = out.reshape(b, heads, n, d).permute(0, 2, 1, 3).reshape(b, n, c)
     return _lin(p, prefix + '.to_out.0', out)
 

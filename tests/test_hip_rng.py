@@ -64,3 +64,30 @@ def test_large_tensor_uses_several_values_per_thread():
     a, b = StackedRandomGenerator(dev, seeds), ReferenceStack(dev, seeds)
     assert torch.equal(a.randn([2, n], device=dev), b.randn([2, n], device=dev))
     assert torch.equal(a.randn([2, 100], device=dev), b.randn([2, 100], device=dev))       # offsets advanced identically
+
+
+def test_fast_path_is_self_checked_and_falls_back_on_mismatch(monkeypatch):
+    """First use per device compares the batched kernel with torch's own generators (offset 0 and a non-zero offset); a build where
+    they differ by one ulp must fall back to real per-seed generators instead of silently changing the latents."""
+    from diff_sampler_amd import ops
+    from diff_sampler_amd.sample import StackedRandomGenerator
+    dev = torch.device('cuda')
+    StackedRandomGenerator._fast_ok.clear()
+    assert StackedRandomGenerator.fast_path_verified(dev) is True            # this build: bit-identical
+    seeds = [5, 6, 7]
+    ref = ReferenceStack(dev, seeds).randn([3, 3, 32, 32], device=dev)
+    # a "different torch build": the kernel's values are off by one ulp
+    real = ops.philox_randn
+
+    def off_by_an_ulp(seeds_, offset, out, n):
+        step = real(seeds_, offset, out, n)
+        out.copy_(torch.nextafter(out, torch.full_like(out, 10.0)))
+        return step
+    monkeypatch.setattr(ops, 'philox_randn', off_by_an_ulp)
+    StackedRandomGenerator._fast_ok.clear()
+    assert StackedRandomGenerator.fast_path_verified(dev) is False
+    got = StackedRandomGenerator(dev, seeds).randn([3, 3, 32, 32], device=dev)  # per-seed generators: still the reference's numbers
+    assert torch.equal(got, ref)
+    monkeypatch.undo()
+    StackedRandomGenerator._fast_ok.clear()
+    assert StackedRandomGenerator.fast_path_verified(dev) is True

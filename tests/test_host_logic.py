@@ -50,6 +50,10 @@ def test_cli_helpers():
     assert S.compute_nfe('heun', 6, True, False, 'cifar10') == 9
     assert S.compute_nfe('dpm', 6, False, True, 'cifar10') == 11
     assert S.compute_nfe('ipndm', 6, True, False, 'ms_coco') == 8
+    # gits-main/sample.py:240-242 doubles only for guidance rates outside {0, 1}; diff-solvers-main/sample.py:218 always
+    assert S.compute_nfe('ipndm', 6, False, False, 'ms_coco', guidance_rate=1.0) == 5
+    assert S.compute_nfe('ipndm', 6, False, False, 'ms_coco', guidance_rate=7.5) == 10
+    assert S.compute_nfe('ipndm', 6, False, False, 'ms_coco') == 10
     assert set(S.SOLVER_FNS) == {'euler', 'ipndm', 'ipndm_v', 'heun', 'dpm', 'dpmpp', 'deis', 'unipc'}
 
 
@@ -329,6 +333,9 @@ def test_amed_predictor_loading_rules(tmp_path):
         (exp / f'network-snapshot-{idx:06d}.pkl').write_bytes(b'')
     assert sample.find_predictor('12', str(tmp_path / 'exps')).endswith('network-snapshot-000100.pkl')
     assert sample.find_predictor('a/b.pkl', str(tmp_path / 'exps')) == 'a/b.pkl'
+    os.makedirs(tmp_path / 'exps' / '00013-empty')
+    with pytest.raises(FileNotFoundError):                   # a matched experiment directory without snapshots: a clear error
+        sample.find_predictor('13', str(tmp_path / 'exps'))
     pp = cases.amed_predictor_params(43, 0.01, 0)
     path = str(tmp_path / 'p.pt')
     torch.save(dict(state_dict=pp, dataset_name='cifar10', num_steps=4, sampler_stu='amed', schedule_type='time_uniform', schedule_rho=1,

@@ -107,3 +107,40 @@ def test_committed_pmc_summary_names_the_dominant_kernel():
     src = open(os.path.join(ROOT, 'diff_sampler_amd', 'csrc', 'conv3x3_halo.hip')).read()
     lean, ntepi = (int(re.search(r'constexpr int VAR_LEAN = (\d+)', src).group(1)), int(re.search(r'VAR_NTEPI = (\d+)', src).group(1)))
     assert int(m.group(1)) == (lean | ntepi) and 'launch_one<4, true, 2, VAR_TILE_OPTS, 4>' in src
+
+
+def test_sample_cli_under_two_gloo_ranks_writes_every_seed_exactly_once(tmp_path):
+    """`python -m diff_sampler_amd.sample` as the reference launches it (torchrun, one process per device; sample.py:164-169, :268,
+    torch_utils/distributed.py:14-31) under 2 gloo ranks on the CPU, in the CLI's launcher self-test mode (--stub: the real seed
+    sharding, rank-0-first model barrier, per-batch barriers, PNG sink and output tree; no kernels, every image is a flat colour that
+    encodes its seed).  The union of the PNGs must be the seed list, each seed written exactly once, by the rank the reference's
+    partition assigns it to, in the reference's directory layout."""
+    import numpy as np
+    import PIL.Image
+    from diff_sampler_amd import sample
+    out = tmp_path / 'out'
+    seeds = '0-20,1003,2500-2504'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(launch.free_port()), '-m', 'diff_sampler_amd.sample', '--stub', 'true', '--dataset_name', 'cifar10',
+           '--solver', 'ipndm', '--num_steps', '6', '--batch', '4', '--seeds', seeds, '--outdir', str(out)]
+    env = _clean_env()
+    env['PYTHONPATH'] = ROOT + os.pathsep + env.get('PYTHONPATH', '')
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.count('Done.') == 1                              # only rank 0 talks (dist.print0)
+    want = sample.parse_int_list(seeds)
+    found = {}
+    for d, _, files in os.walk(out):
+        for f in files:
+            assert f.endswith('.png')
+            sd = int(f[:-4])
+            assert sd not in found, f'seed {sd} written twice'
+            assert os.path.basename(d) == f'{sd - sd % 1000:06d}'     # samples/.../<seed - seed % 1000>/<seed>.png (sample.py:313-316)
+            found[sd] = os.path.join(d, f)
+    assert sorted(found) == want
+    for sd, path in found.items():
+        img = np.asarray(PIL.Image.open(path))
+        assert img.shape == (8, 8, 3) and (img == sd % 251).all()
+    # both ranks had work, by the reference's partition
+    parts = [sorted(int(s) for b in sample.shard_seeds(want, 4, r_, 2) for s in b) for r_ in range(2)]
+    assert parts[0] and parts[1] and sorted(parts[0] + parts[1]) == want and not set(parts[0]) & set(parts[1])

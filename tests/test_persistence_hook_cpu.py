@@ -92,18 +92,53 @@ def test_gpu_calls_go_to_the_engine_built_from_the_module(ref, monkeypatch):
         is_cuda, device = True, 'cuda:0'
 
     x = OnGpu()
-    assert got(x, 2.0, class_labels='L') == 'from-engine' and got(x, 1.0) == 'from-engine'
-    assert len(built) == 1 and built[0][0] is got and built[0][1:] == ('cuda:0', False)      # built once, cached on the instance
-    assert calls[0] == (x, 2.0, 'L') and calls[1] == (x, 1.0, None)
-    got.use_fp16 = True                                      # networks_edm.py:486: fp16 body unless force_fp32
-    got(x, 1.0); got(x, 1.0, force_fp32=True)
-    assert [b[2] for b in built] == [False, True] and len(calls) == 4
-    H.invalidate(got)
-    got(x, 1.0)
-    assert len(built) == 3
-    # model_kwargs (augment_labels) are not an engine input: the reference's own forward gets them
-    with pytest.raises(AttributeError):                      # ... and fails on the stand-in exactly where real code would run
-        got(x, 1.0, augment_labels=None)
+    with torch.no_grad():                                    # the samplers' own context (solvers.py decorators, sample.py:294)
+        assert got(x, 2.0, class_labels='L') == 'from-engine' and got(x, 1.0) == 'from-engine'
+        assert len(built) == 1 and built[0][0] is got and built[0][1:] == ('cuda:0', False)      # built once, cached on the instance
+        assert calls[0] == (x, 2.0, 'L') and calls[1] == (x, 1.0, None)
+        got.use_fp16 = True                                      # networks_edm.py:486: fp16 body unless force_fp32
+        got(x, 1.0); got(x, 1.0, force_fp32=True)
+        assert [b[2] for b in built] == [False, True] and len(calls) == 4
+        H.invalidate(got)
+        got(x, 1.0)
+        assert len(built) == 3
+        # model_kwargs (augment_labels) are not an engine input: the reference's own forward gets them
+        with pytest.raises(AttributeError):                      # ... and fails on the stand-in exactly where real code would run
+            got(x, 1.0, augment_labels=None)
+
+
+def test_calls_that_autograd_would_record_go_to_the_reference_forward(ref, monkeypatch):
+    """The route is inference-only (the engine's output has no grad_fn): amed-solver-main's training path differentiates through
+    net(x_mid(r), scale_time * t_mid(r)) (solvers_amed.py:141-143 with train=True, training_loop.py:205), so a call with grad mode on and
+    an input -- or a parameter of the module -- that requires grad must run the module's ORIGINAL forward, never the engine."""
+    import diff_sampler_amd.persistence_hook as H
+    _, EDMPrecond = ref
+    net, blob = _snapshot(EDMPrecond, 'tiny_song')
+    got = pickle.loads(blob)['ema']
+    monkeypatch.setattr(H, 'make_engine', lambda *a, **k: (_ for _ in ()).throw(AssertionError('engine must not be built')))
+    seen = []
+    ref_fwd = type(got).forward.reference_forward
+    monkeypatch.setattr(type(got).forward, 'reference_forward', ref_fwd, raising=False)
+
+    class GpuTensor(torch.Tensor):                            # a real (CPU) tensor that claims to live on the GPU
+        @property
+        def is_cuda(self):
+            return True
+
+    x = torch.randn(2, net.img_channels, net.img_resolution, net.img_resolution).as_subclass(GpuTensor)
+    got.requires_grad_(False)
+    assert H._needs_autograd(got, x, torch.tensor(1.0), None) is False
+    with torch.no_grad():
+        assert H._needs_autograd(got, x.clone().requires_grad_(True), torch.tensor(1.0), None) is False     # nothing is recorded
+    sig = torch.tensor([0.7, 3.0], requires_grad=True)       # the AMED training case: sigma = scale_time * t_mid(r) carries the graph
+    assert H._needs_autograd(got, x, sig, None) is True
+    out = got(x, sig)                                        # reference forward: differentiable
+    assert out.grad_fn is not None
+    out.sum().backward()
+    assert sig.grad is not None and torch.isfinite(sig.grad).all()
+    got.requires_grad_(True)                                 # trainable module in grad mode: also the reference forward
+    assert H._needs_autograd(got, x, torch.tensor(1.0), None) is True
+    assert got(x, torch.tensor([0.7, 3.0])).grad_fn is not None
 
 
 def test_amed_bottleneck_hooks_fire_with_the_engines_block_output(ref, monkeypatch):
@@ -129,15 +164,16 @@ def test_amed_bottleneck_hooks_fire_with_the_engines_block_output(ref, monkeypat
         class OnGpu:
             is_cuda, device = True, 'cuda:0'
 
-        assert got(OnGpu(), 1.0) == 'D' and asked == []                    # no hook registered: the tap is not even read
-        seen = []                                                            # init_hook of the reference, verbatim in behaviour
-        handle = got.model.enc[key].register_forward_hook(lambda module, inp, out: seen.append(out.detach()))
-        assert got(OnGpu(), 1.0) == 'D'
-        assert asked == ['enc.' + key] and len(seen) == 1 and tuple(seen[0].shape) == (2, 64, 8, 8)
-        assert torch.mean(seen[-1], dim=1).shape == (2, 8, 8)                # what get_amed_prediction does with it (solvers_amed.py:24-28)
-        handle.remove()
-        got(OnGpu(), 1.0)
-        assert len(seen) == 1
+        with torch.no_grad():                                                # the sampler's context (solvers_amed.py decorators)
+            assert got(OnGpu(), 1.0) == 'D' and asked == []                # no hook registered: the tap is not even read
+            seen = []                                                        # init_hook of the reference, verbatim in behaviour
+            handle = got.model.enc[key].register_forward_hook(lambda module, inp, out: seen.append(out.detach()))
+            assert got(OnGpu(), 1.0) == 'D'
+            assert asked == ['enc.' + key] and len(seen) == 1 and tuple(seen[0].shape) == (2, 64, 8, 8)
+            assert torch.mean(seen[-1], dim=1).shape == (2, 8, 8)            # what get_amed_prediction does with it (solvers_amed.py:24-28)
+            handle.remove()
+            got(OnGpu(), 1.0)
+            assert len(seen) == 1
 
 
 def test_classes_without_a_routed_name_are_left_alone(ref):
