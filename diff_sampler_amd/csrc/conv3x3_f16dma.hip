@@ -1,0 +1,342 @@
+// 3x3 convolution on fp16 ACTIVATIONS, third generation of the LDS-halo implicit GEMM (gfx950, v_mfma_f32_32x32x16_f16):
+// a pure matrix kernel.  Both operands reach LDS by LDS-DMA (global_load_lds_dwordx4) -- no VGPR round trip, no conversion, no
+// ds_write -- and the tile is 256 pixels x (NB * 64) channels, NB = 1 .. 4 (64 x (NB * 32) per wave, eight waves).
+//
+// Why (round 3, profiles/r3_fp16_conv_counters.json): conv3x3_halo2_kernel<., 1> -- fp32 activations, GroupNorm affine + SiLU + RNE
+// rounding done by the halo loader -- issues 6 - 8 non-MFMA VALU instructions per MFMA (two transcendentals per input element, repeated
+// for every 128-column tile and for the 25 - 55 % halo overlap), keeps the fp16 matrix pipe busy 30 % of the time (ImageNet-64, 64x64
+// layers) and throws a quarter of that away on the ragged second tile of 192-channel layers.  Here the normalised, activated tensor
+// is an fp16 NHWC tensor in HBM (written once per element by ds_norm_act with out_f16 -- the reference's own storage type in this
+// mode, networks_edm.py:486) and the convolution only multiplies:
+//
+//   * halo of a 64-channel slab: NP pixels x 128 B, pixel-major, the 16-B chunk index XOR-swizzled by (pixel >> 1) & 7 (same
+//     involution on the DMA source address and on the fragment read: 16 consecutive pixels of one chunk hit 16 different bank
+//     quads); out-of-image pixels fetch a zero page.  Two halo buffers: slab s+1 streams in (one 8-KB DMA round per tap) while slab s
+//     is multiplied;
+//   * weights of a tap: NB * 64 rows x 128 B, swizzled the same way, double-buffered, one tap ahead;
+//   * per tap: one barrier; the A-fragment addresses of the 9 taps are 18 precomputed registers, a K step is `base ^ (ks << 5)`;
+//   * 192-channel layers (ADM: 192 / 384 / 576 / 768) get 192-column tiles (NB = 3), 256-multiples NB = 4 where two halo
+//     buffers + 64 KB of weights fit the 160 KB LDS (images of at most 32 columns), tails NB = 2 / 1;
+//   * the fused epilogue of the family (bias, per-image embedding bias, residual, scale, SiLU, GroupNorm column sums) is unchanged:
+//     outputs, norms and the residual stream stay fp32.
+// Scope: taps == 9, stride 1, ONE fp16 source [M][c0] (c0 % 64 == 0; the decoder's concatenation is materialised by the norm pass),
+// optional fused 1x1 skip projection on ONE fp16 source [M][ec0], square power-of-two images W in {8, 16, 32, 64} with 256-pixel
+// tiles (one image per tile, or four 8x8 images), cout % 64 == 0, no split-K.
+#include "pipe_common.h"
+
+namespace igemm {
+namespace {
+
+__device__ __attribute__((aligned(128))) _Float16 g_zero_halfs[64];        // zero-initialised: the 128-B row of an out-of-image pixel
+
+template <int W>
+struct GeoD {
+    static constexpr int NIMG = (W * W >= 256) ? 1 : 256 / (W * W);        // image slots per tile (8x8 images: 4)
+    static constexpr int TH = 256 / (W * NIMG), WP = W + 2, HP = TH + 2, NP = NIMG * HP * WP;
+    static constexpr int NDMA = (NP * 8 + 511) / 512;                      // DMA rounds per halo (512 threads x 16 B = 8 KB each)
+    static constexpr unsigned HALO_B = NDMA * 8192u;
+};
+
+template <int W, int NB>
+constexpr unsigned f16dma_smem() { return 2u * NB * 8192u + 2u * GeoD<W>::HALO_B; }
+
+template <int W, int NB>
+__global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p) {
+    using G = GeoD<W>;
+    constexpr int WP = G::WP, HP = G::HP, TH = G::TH, NIMG = G::NIMG, NP = G::NP, NDMA = G::NDMA;
+    constexpr unsigned WB = NB * 8192u, HB = G::HALO_B;
+    static_assert(f16dma_smem<W, NB>() <= 160u * 1024u, "LDS");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* lds = reinterpret_cast<char*>(smem);                 // [weights 0 | weights 1 | halo 0 | halo 1]
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    int mt, nt;
+    if (!decode_tile(blockIdx.x, p.mtiles, p.ntiles, mt, nt, 0)) return;
+    const int m0 = mt * 256, n0 = p.n_begin + nt * (NB * 64);
+    const _Float16* a0 = reinterpret_cast<const _Float16*>(p.a0);
+    const _Float16* e0 = reinterpret_cast<const _Float16*>(p.e0);
+    const _Float16* wgt = reinterpret_cast<const _Float16*>(p.b);
+    const size_t ldbh = (size_t)p.ldb * 2;                     // weight row pitch in halfs
+
+    const int img0 = m0 / p.HW;
+    const int r0 = NIMG == 1 ? (m0 - img0 * p.HW) / W : 0;
+
+    // ---- halo DMA: thread tid owns 16-B unit j * 512 + tid of round j: pixel (unit >> 3), LDS chunk slot tid & 7 -----------------
+    int hpix[NDMA];                                            // source pixel (-1: zero page)
+    // source channel offset (halfs): chunk slot ^ ((pixel >> 1) & 7); pixel = j * 64 + (tid >> 3), so the same for every round j
+    const int hch = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) {
+        const int hp = j * 64 + (tid >> 3);
+        const int sl = hp / (HP * WP), rem = hp - sl * (HP * WP);
+        const int hr = rem / WP, hc = rem - hr * WP;
+        const int y = r0 + hr - 1, x = hc - 1;
+        const bool ok = hp < NP && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)W;
+        hpix[j] = ok ? ((img0 + sl) * p.H + y) * W + x : -1;
+    }
+    const int nchunks = p.c0 / 64;                             // 3x3 slabs (9 taps each)
+    const int nextra = p.ec0 / 64;                             // appended 1x1 slabs (centre tap only)
+    const int NCH = nchunks + nextra;
+    const int KT = nchunks * 9 + nextra;
+    auto halo_dma = [&](int chunk, int hbuf, auto jc) {          // DMA round j of slab `chunk` into halo buffer hbuf
+        constexpr int j = decltype(jc)::value;
+        const bool extra = chunk >= nchunks;
+        const _Float16* base = extra ? e0 + (size_t)(chunk - nchunks) * 64 : a0 + (size_t)chunk * 64;
+        const int ld = extra ? p.elda0 : p.lda0;
+        const _Float16* g = hpix[j] >= 0 ? base + (size_t)hpix[j] * ld + hch : g_zero_halfs;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + 2 * WB + hbuf * HB + (j * 512 + wave * 64) * 16), 16, 0, 0);
+    };
+    // ---- weight DMA of K tile (tap) kt: rows i * 64 + (tid >> 3), i < NB; the source chunk is pre-swizzled -----------------------
+    const _Float16* wsrc = wgt + (size_t)(n0 + (tid >> 3)) * ldbh + (((tid & 7) ^ ((tid >> 4) & 7)) * 8);
+    auto w_dma = [&](int kt, int wbuf) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (size_t)i * 64 * ldbh + (size_t)kt * 64),
+                                             (lptr_t)(lds + wbuf * WB + (i * 64 + wave * 8) * 128), 16, 0, 0);
+    };
+
+    // ---- fragment addresses (LDS byte addresses relative to a halo buffer / a weight buffer) ------------------------------------------
+    // A fragments: row block i covers 32 consecutive output pixels; tap (ty, tx) reads halo pixel hp0[i] + ty * WP + tx, chunk
+    // (2 ks + g) ^ ((hp >> 1) & 7).  Only hp0 is kept; the 5 VALU per (tap, block) that rebuild the address are noise next to 16 NB MFMAs.
+    int hp0[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = wr * 64 + i * 32 + (lane & 31);
+        const int sl = m / (TH * W), rem = m - sl * (TH * W);
+        const int r = rem / W, c = rem - r * W;
+        hp0[i] = (sl * HP + r) * WP + c;
+    }
+    const unsigned gsel = (unsigned)(lane >> 5);
+    auto a_addr = [&](int i, int tt) -> unsigned {             // byte offset inside a halo buffer, K step 0
+        const unsigned hp = (unsigned)(hp0[i] + (tt / 3) * WP + (tt % 3));
+        return hp * 128u + 16u * (((hp >> 1) & 7u) ^ gsel);
+    };
+    const int brow = wc * (NB * 32) + (lane & 31);
+    const unsigned lds0 = lds_addr2(smem);
+    const unsigned bbase = lds0 + (unsigned)brow * 128u + 16u * (unsigned)(((brow >> 1) & 7) ^ (lane >> 5));
+
+    f32x16 accA[2][2], accB[2][2];                             // output columns [0, 64) and [64, 128) of the wave tile
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accA[i][j][r] = 0.f; accB[i][j][r] = 0.f; }
+
+    // Fragment sets of one K step (16 channels): two A blocks (32 pixels each), NB weight blocks.  Reads are volatile asm in program
+    // order; the wait names the set it releases ("+v"), so no use can move above it (cdna_hip_programming.md 5.7, form (ii)).
+    struct Frag { f32x4 a0, a1, b0, b1, b2, b3; };
+    auto frag_read = [&](Frag& f, unsigned va0, unsigned va1, unsigned vb) {
+        f.a0 = lds_rd<0>(va0);
+        f.a1 = lds_rd<0>(va1);
+        f.b0 = lds_rd<0>(vb);
+        if constexpr (NB > 1) f.b1 = lds_rd<4096>(vb);
+        if constexpr (NB > 2) f.b2 = lds_rd<8192>(vb);
+        if constexpr (NB > 3) f.b3 = lds_rd<12288>(vb);
+    };
+    auto frag_wait = [&](Frag& f, auto nc) {                   // wait until at most N younger LDS operations are outstanding
+        constexpr int N = decltype(nc)::value;
+        if constexpr (NB == 1) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(f.a0), "+v"(f.a1), "+v"(f.b0) : "n"(N));
+        if constexpr (NB == 2) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f.a0), "+v"(f.a1), "+v"(f.b0), "+v"(f.b1) : "n"(N));
+        if constexpr (NB == 3) asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(f.a0), "+v"(f.a1), "+v"(f.b0), "+v"(f.b1), "+v"(f.b2) : "n"(N));
+        if constexpr (NB == 4)
+            asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f.a0), "+v"(f.a1), "+v"(f.b0), "+v"(f.b1), "+v"(f.b2), "+v"(f.b3) : "n"(N));
+    };
+#define DSD_MM(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a_), __builtin_bit_cast(h8, b_), acc_, 0, 0, 0)
+    auto mfma_group = [&](Frag& f) {                           // consecutive MFMAs never touch the same accumulator
+        DSD_MM(accA[0][0], f.a0, f.b0); DSD_MM(accA[1][0], f.a1, f.b0);
+        if constexpr (NB > 1) { DSD_MM(accA[0][1], f.a0, f.b1); DSD_MM(accA[1][1], f.a1, f.b1); }
+        if constexpr (NB > 2) { DSD_MM(accB[0][0], f.a0, f.b2); DSD_MM(accB[1][0], f.a1, f.b2); }
+        if constexpr (NB > 3) { DSD_MM(accB[0][1], f.a0, f.b3); DSD_MM(accB[1][1], f.a1, f.b3); }
+    };
+    constexpr int NR = 2 + NB;                                 // LDS reads per fragment set
+    const unsigned halo0 = lds0 + 2 * WB;
+
+    // ---- prologue: halo of slab 0, the part of slab 1's halo that is due (see the tap), weights of taps 0 and 1 -------------------
+    static_for<NDMA>([&](auto jc) { halo_dma(0, 0, jc); });
+    if (NCH > 1) {
+        if (nchunks == 0) static_for<NDMA>([&](auto jc) { halo_dma(1, 1, jc); });      // slab 0 is a one-tap slab
+        else halo_dma(1, 1, IC<0>{});
+    }
+    w_dma(0, 0);
+    if (KT > 1) w_dma(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    Frag P_, Q_;
+    {
+        const unsigned ctr = nchunks > 0 ? 0u : 4u;            // first tap: (0, 0) of a 3x3 slab, or the centre tap of a 1x1 slab
+        frag_read(P_, halo0 + a_addr(0, (int)ctr), halo0 + a_addr(1, (int)ctr), bbase);
+    }
+
+    int kt = 0;
+    // One tap: T9 = tap of a 3x3 slab (0..8) or 9 = the centre tap of an appended 1x1 slab.  P holds the fragments of its K step 0
+    // (read after the previous tap's barrier).
+    //   K steps 0..2 : reads of step k+1 in flight under the MFMAs of step k
+    //   then         : all reads of this tap done, own DMAs landed (vmcnt(0)), barrier: buffer kt & 1 -- and, at a slab end, the
+    //                  halo buffer -- are free and the operands of tap kt+1 are in LDS
+    //   K step 3     : its MFMAs run behind the barrier, under the DMA issue of tap kt+2's weights and of the next halo piece and
+    //                  the first fragment reads of tap kt+1
+    // Halo schedule: slab s+1 lives in buffer (s+1) & 1, free once slab s-1 is done; its DMA rounds are issued one per barrier from the
+    // last tap of slab s-1 on (all of them at once when slab s is a one-tap slab).
+    auto tap = [&](auto t9c, int chunk) {
+        Frag &P = P_, &Q = Q_;
+        constexpr int T9 = decltype(t9c)::value;
+        constexpr bool X = (T9 == 9);
+        constexpr int TT = X ? 4 : T9;
+        constexpr bool SLAB_END = X || T9 == 8;
+        const unsigned hoff = halo0 + (unsigned)(chunk & 1) * HB;
+        const unsigned woff = (unsigned)(kt & 1) * WB;
+        const unsigned a_0 = a_addr(0, TT) + hoff, a_1 = a_addr(1, TT) + hoff;
+        const unsigned vb = bbase + woff;
+        frag_read(Q, a_0 ^ 32u, a_1 ^ 32u, vb ^ 32u);
+        frag_wait(P, IC<NR>{});
+        DS2_FENCE(); mfma_group(P); DS2_FENCE();
+        frag_read(P, a_0 ^ 64u, a_1 ^ 64u, vb ^ 64u);
+        frag_wait(Q, IC<NR>{});
+        DS2_FENCE(); mfma_group(Q); DS2_FENCE();
+        frag_read(Q, a_0 ^ 96u, a_1 ^ 96u, vb ^ 96u);
+        frag_wait(P, IC<NR>{});
+        DS2_FENCE(); mfma_group(P); DS2_FENCE();
+        frag_wait(Q, IC<0>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        DS2_FENCE();
+        // ---- behind the barrier ---------------------------------------------------------------------------------------------------
+        if (kt + 2 < KT) w_dma(kt + 2, kt & 1);
+        if constexpr (SLAB_END) {
+            if (chunk + 2 < NCH) {
+                if (chunk + 1 >= nchunks) static_for<NDMA>([&](auto jc) { halo_dma(chunk + 2, chunk & 1, jc); });   // next slab has one tap
+                else halo_dma(chunk + 2, chunk & 1, IC<0>{});
+            }
+        } else if constexpr (T9 + 1 < NDMA) {
+            if (chunk + 1 < NCH) halo_dma(chunk + 1, (chunk + 1) & 1, IC<T9 + 1>{});
+        }
+        if (kt + 1 < KT) {
+            const unsigned nwoff = (unsigned)((kt + 1) & 1) * WB;
+            if constexpr (SLAB_END) {
+                const unsigned nh = halo0 + (unsigned)((chunk + 1) & 1) * HB;
+                const int nt9 = chunk + 1 >= nchunks ? 4 : 0;
+                frag_read(P, nh + a_addr(0, nt9), nh + a_addr(1, nt9), bbase + nwoff);
+            } else {
+                frag_read(P, a_addr(0, T9 + 1) + hoff, a_addr(1, T9 + 1) + hoff, bbase + nwoff);
+            }
+        }
+        DS2_FENCE(); mfma_group(Q); DS2_FENCE();
+        ++kt;
+    };
+    int chunk = 0;
+    for (; chunk < nchunks; ++chunk) {
+        tap(IC<0>{}, chunk); tap(IC<1>{}, chunk); tap(IC<2>{}, chunk);
+        tap(IC<3>{}, chunk); tap(IC<4>{}, chunk); tap(IC<5>{}, chunk);
+        tap(IC<6>{}, chunk); tap(IC<7>{}, chunk); tap(IC<8>{}, chunk);
+    }
+    for (; chunk < NCH; ++chunk) tap(IC<9>{}, chunk);
+#undef DSD_MM
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (no fragment read is pending after the last tap; cheap insurance)
+
+    float* stage = smem + wave * 32 * EPI_LD;
+    const int wn0 = n0 + wc * (NB * 32);
+    if constexpr (NB == 1) {
+        epilogue32<true>(p, accA, stage, lane, m0 + wr * 64, wn0, p.out);
+    } else {
+        epilogue<0, true>(p, accA, stage, lane, m0 + wr * 64, wn0, p.out);
+        if constexpr (NB == 3) epilogue32<true>(p, accB, stage, lane, m0 + wr * 64, wn0 + 64, p.out);
+        if constexpr (NB == 4) epilogue<0, true>(p, accB, stage, lane, m0 + wr * 64, wn0 + 64, p.out);
+    }
+}
+
+template <int W, int NB>
+int launch_w_nb(KParams p, int n_begin, int ntiles, hipStream_t stream) {
+    p.mtiles = p.M / 256;
+    p.ntiles = ntiles;
+    p.n_begin = n_begin;
+    p.splits = 1;
+    int smem = (int)f16dma_smem<W, NB>();
+    const int epi = 8 * 32 * EPI_LD * (int)sizeof(float);
+    if (smem < epi) smem = epi;
+    DS_ENSURE_DYN_LDS((&conv3x3_f16dma_kernel<W, NB>), 160 * 1024);
+    hipLaunchKernelGGL((conv3x3_f16dma_kernel<W, NB>), dim3(grid_1d(p.mtiles, p.ntiles), 1), dim3(512), smem, stream, p);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+template <int W>
+int launch_w(const KParams& p, int nb, int n_begin, int ntiles, hipStream_t stream) {
+    switch (nb) {
+        case 1: return launch_w_nb<W, 1>(p, n_begin, ntiles, stream);
+        case 2: return launch_w_nb<W, 2>(p, n_begin, ntiles, stream);
+        case 3: return launch_w_nb<W, 3>(p, n_begin, ntiles, stream);
+        default:
+            if constexpr (f16dma_smem<W, 4>() <= 160u * 1024u) return launch_w_nb<W, 4>(p, n_begin, ntiles, stream);
+            else return DS_E_SHAPE;
+    }
+}
+
+}  // namespace
+
+int g_f16dma_nb = 0;            // benchmarks / tests: > 0 forces the column-tile width of the main launch (64 * nb columns)
+
+// widest column tile the LDS holds next to two halo buffers
+static int max_nb(int W) { return (W == 16 || W == 32) ? 4 : 3; }
+
+bool conv3x3_f16dma_applicable(const KParams& p) {
+    if (p.taps != 9 || p.stride > 1 || p.norm != nullptr) return false;
+    if (!(p.W == 8 || p.W == 16 || p.W == 32 || p.W == 64) || p.H != p.W) return false;
+    if (p.HW != p.H * p.W || p.M % 256) return false;
+    if (p.c0 <= 0 || p.c0 % 64 || p.c1 != 0 || p.ec0 % 64 || p.ec1 != 0) return false;
+    if (p.N % 64 || !p.vec_ok || p.nrows_b < p.N) return false;
+    return true;
+}
+
+// Column tiling of a layer: a list of (first column, tiles, NB), widest tiles first (e.g. 320 = 192 + 128, 640 = 2 x 256 + 128).
+// The starting width is chosen by a small cost model: a launch of t workgroups takes ceil(t / 256) rounds of tiles, and a tile of
+// 64 * nb columns costs about 1 + nb (the halo stream, the A-fragment reads, prologue and epilogue do not shrink with the width), so
+// a layer with few pixel tiles takes narrower column tiles to cover the 256 CUs.
+static int tiling(const KParams& p, int nb0, int (*out)[3], int* cost) {
+    const int mtiles = p.M / 256;
+    int n = 0, col = 0, c = 0;
+    for (int w = nb0; w >= 1 && col < p.N; --w) {
+        const int t = (p.N - col) / (64 * w);
+        if (t > 0) {
+            out[n][0] = col; out[n][1] = t; out[n][2] = w; ++n;
+            col += t * 64 * w;
+            c += (int)(((long long)mtiles * t + 255) / 256) * (1 + w);
+        }
+    }
+    *cost = c;
+    return n;
+}
+
+int conv3x3_f16dma_plan(const KParams& p, int (*out)[3]) {
+    const int cap = max_nb(p.W);
+    int cost;
+    if (g_f16dma_nb > 0) return tiling(p, g_f16dma_nb < cap ? g_f16dma_nb : cap, out, &cost);
+    int best_nb = cap, best_cost = 0x7fffffff, best_n = 99;
+    for (int nb = cap; nb >= 1; --nb) {
+        int tmp[4][3];
+        const int n = tiling(p, nb, tmp, &cost);
+        if (cost < best_cost || (cost == best_cost && n < best_n)) { best_cost = cost; best_n = n; best_nb = nb; }
+    }
+    return tiling(p, best_nb, out, &cost);
+}
+
+int launch_conv3x3_f16dma(KParams& p, hipStream_t stream) {
+    int plan[4][3];
+    const int n = conv3x3_f16dma_plan(p, plan);
+    for (int i = 0; i < n; ++i) {
+        int rc;
+        switch (p.W) {
+            case 8: rc = launch_w<8>(p, plan[i][2], plan[i][0], plan[i][1], stream); break;
+            case 16: rc = launch_w<16>(p, plan[i][2], plan[i][0], plan[i][1], stream); break;
+            case 32: rc = launch_w<32>(p, plan[i][2], plan[i][0], plan[i][1], stream); break;
+            default: rc = launch_w<64>(p, plan[i][2], plan[i][0], plan[i][1], stream); break;
+        }
+        if (rc) return rc;
+    }
+    return DS_OK;
+}
+
+}  // namespace igemm

@@ -301,6 +301,10 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     if (a->taps != 1 && a->taps != 9) return DS_E_ARG;
     if (a->c0 <= 0 || a->c0 % 32 || a->c1 < 0 || a->c1 % 32) return DS_E_SHAPE;
     if (a->c1 && !a->x1) return DS_E_ARG;
+    if (a->in_f16) {          // fp16 activations: pure matrix kernel (conv3x3_f16dma.hip); ld in halfs, 16-byte chunks
+        if (a->wgt_f16 != 1 || a->taps != 9 || a->c1 || a->ec1 || a->norm_coefs || a->out_nchw || (a->stride && a->stride != 1)) return DS_E_ARG;
+        if ((a->ld0 & 7) || (a->ec0 && ((a->eld0 & 7) || !a->e0 || !ds_aligned16(a->e0)))) return DS_E_ALIGN;
+    }
     if ((a->ld0 & 3) || (a->c1 && (a->ld1 & 3))) return DS_E_ALIGN;
     if (!ds_aligned16(a->x0) || (a->c1 && !ds_aligned16(a->x1)) || !ds_aligned16(a->wgt)) return DS_E_ALIGN;
     if (a->n <= 0 || a->h <= 0 || a->w <= 0 || a->cout <= 0) return DS_E_ARG;
@@ -359,6 +363,12 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
         }
         if (a->taps != 9 || stride != 1 || (a->wgt_f16 != 1 && a->wgt_f16 != 2)) return DS_E_ARG;
         if (a->wgt_shift < 0 || a->wgt_shift > 24 || (a->wgt_f16 == 1 && a->wgt_shift)) return DS_E_ARG;
+        if (a->in_f16) {
+            p.ldb = p.K / 2;
+            p.part = nullptr; p.part_cap = 0; p.splits = 1;
+            if (!conv3x3_f16dma_applicable(p)) return DS_E_SHAPE;
+            return launch_conv3x3_f16dma(p, (hipStream_t)stream);
+        }
         const int wide = (p.N + BN - 1) / BN;
         // row pitch of the fp16 weight matrix in float units: fp16 = K halfs per row, split = 2 K halfs (hi and lo)
         p.ldb = a->wgt_f16 == 1 ? p.K / 2 : p.K;
@@ -387,6 +397,7 @@ extern "C" int ds_conv_kernel_id(const ds_conv_args* a) {
     p.vec_ok = (vec_epilogue_ok(p) && !a->out_nchw) ? 1 : 0;
     p.stride = a->stride ? a->stride : 1; p.K = a->taps * (a->c0 + a->c1) + a->ec0 + a->ec1; p.norm = a->norm_coefs;
     p.nrows_b = ((a->cout + BN - 1) / BN) * BN;                                     // weights are row-padded, as in ds_conv2d_nhwc
+    if (a->wgt_f16 == 1 && a->in_f16) return 2566;
     if (a->wgt_f16) return a->wgt_f16 == 2 ? 2563 : (a->taps == 1 ? 2564 : 2562);
     if (g_force_generic) return 0;
     if (a->taps != 9 || a->stride > 1) return (g_use_dma8 && gemm_dma8_applicable(p)) ? 2561 : 0;
@@ -401,6 +412,13 @@ static int reduced_supported(int mode, int n, int h, int w, int c0, int c1, int 
     return w >= 16 ? 2 : 1;                      // 8x8: four images per tile, the per-image normalisation planes are not fused
 }
 extern "C" int ds_conv_f16_supported(int n, int h, int w, int c0, int c1, int ec0, int ec1) { return reduced_supported(1, n, h, w, c0, c1, ec0, ec1); }
+extern "C" int ds_conv_f16dma_supported(int n, int h, int w, int c0, int ec0, int cout) {
+    KParams p{};
+    p.taps = 9; p.stride = 1; p.H = h; p.W = w; p.HW = h * w; p.M = n * h * w; p.N = cout; p.c0 = c0; p.ec0 = ec0;
+    p.vec_ok = 1; p.nrows_b = ((cout + BN - 1) / BN) * BN;
+    return conv3x3_f16dma_applicable(p) ? 1 : 0;
+}
+extern "C" int ds_debug_f16dma_nb(int nb) { const int o = g_f16dma_nb; g_f16dma_nb = nb; return o; }
 extern "C" int ds_gemm_f16_supported(long long rows, int c0, int c1) {
     KParams p{};
     if (rows > 0x7fffffffLL) return 0;

@@ -188,6 +188,73 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
     }
 }
 
+// Fused conv epilogue of a 64 x 32 wave tile (acc[i][0], i = the two 32-row MFMA blocks): the vector path of igemm_common.h's epilogue
+// re-laid for 32 columns -- 8 lanes x float4 cover a row segment, lane >> 3 picks one of 8 rows per pass, 4 passes per 32-row group.
+// The launcher only takes this kernel where the vector path is legal (p.vec_ok, whole 32-column tiles) and there is no GEGLU gate.
+//   out = act((acc * acc_scale + colbias + cbias[img] + res) * scale), column sums / sums of squares of the wave's 64 rows to p.stats
+template <bool HALF>
+__device__ __forceinline__ void epilogue32(const KParams& p, const f32x16 (&acc)[2][2], float* stage, int lane, int wm0, int wn0, float* o_base) {
+    static_assert(HALF, "8-wave tiles: 32 staging rows per wave, the two 32-row groups one after the other");
+    const int c4 = (lane & 7) * 4;
+    const int col = wn0 + c4;
+    f32x4 cb = {0.f, 0.f, 0.f, 0.f};
+    if (p.colbias) cb = *reinterpret_cast<const f32x4*>(p.colbias + col);
+    f32x4 st_s = {0.f, 0.f, 0.f, 0.f}, st_q = {0.f, 0.f, 0.f, 0.f};
+    constexpr int NP = 4;
+    const bool cb_uniform = p.cbias && (p.cbias_bcast || p.HW % 32 == 0);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int rbase = wm0 + half * 32;
+        f32x4 rv[NP], cvu = {0.f, 0.f, 0.f, 0.f};
+        if (p.res) {
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
+                const int row = min(rbase + pass * 8 + (lane >> 3), p.M - 1);
+                rv[pass] = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.res_ld + col);
+            }
+        }
+        if (cb_uniform) {
+            const int img = p.cbias_bcast ? 0 : __builtin_amdgcn_readfirstlane(min(rbase, p.M - 1)) / p.HW;
+            cvu = *reinterpret_cast<const f32x4*>(p.cbias + (size_t)img * p.cbias_ld + col);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_LD + (lane & 31)] = acc[half][0][r];
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {
+            const int rr = pass * 8 + (lane >> 3);
+            const int row = rbase + rr;
+            if (row >= p.M) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * EPI_LD + c4);
+            v *= p.acc_scale;
+            v += cb;
+            if (cb_uniform) v += cvu;
+            else if (p.cbias) v += *reinterpret_cast<const f32x4*>(p.cbias + (size_t)(row / p.HW) * p.cbias_ld + col);
+            if (p.res) v += rv[pass];
+            v *= p.scale;
+            if (p.act == DS_ACT_SILU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = ds_silu(v[q]);
+            }
+            *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col) = v;
+            st_s += v; st_q += v * v;
+        }
+    }
+    if (p.stats && wm0 < p.M) {
+        // column sums of this wave's 64 rows: the 8 lane groups (lane >> 3) hold disjoint rows of the same 4 columns
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            st_s[q] += __shfl_xor(st_s[q], 8); st_s[q] += __shfl_xor(st_s[q], 16); st_s[q] += __shfl_xor(st_s[q], 32);
+            st_q[q] += __shfl_xor(st_q[q], 8); st_q[q] += __shfl_xor(st_q[q], 16); st_q[q] += __shfl_xor(st_q[q], 32);
+        }
+        if (lane < 8) {
+            float* sp = p.stats + (size_t)(wm0 >> 6) * 2 * p.N + col;
+            *reinterpret_cast<f32x4*>(sp) = st_s;
+            *reinterpret_cast<f32x4*>(sp + p.N) = st_q;
+        }
+    }
+}
+
 // XCD-aware decode of a 1-D workgroup id into (m tile, n tile): the dispatcher places workgroup b on XCD b % 8, so
 // within each group of 8*NT ids the NT column tiles that share an A slab get the SAME b % 8 (same L2) and are
 // dispatched back to back.  With fewer than 8 row tiles (small batch: the weights are the traffic) the roles swap: the
@@ -286,6 +353,11 @@ void conv3x3_halo_set_tail64(int on);     // 64-column tiles for the ragged last
 bool conv3x3_halo2_applicable(const KParams& p, int wide, int mode);   // mode 0 fp32 / 1 fp16 / 2 split-fp16
 int launch_conv3x3_halo2(KParams& p, int wide, int mode, hipStream_t stream);
 extern long long g_halo2_launches;
+
+// conv3x3_f16dma.hip: 3x3 on fp16 activations, both operands by LDS-DMA, 256-pixel x 64/128/192/256-channel tiles
+bool conv3x3_f16dma_applicable(const KParams& p);
+int launch_conv3x3_f16dma(KParams& p, hipStream_t stream);
+extern int g_f16dma_nb;
 
 // gemm_f16.hip: 1x1 / Linear with fp16 operands (A rounded while staged, W packed fp16)
 bool gemm_f16_applicable(const KParams& p);

@@ -138,6 +138,8 @@ __global__ void __launch_bounds__(1024) norm_act_kernel(const ds_norm_args a, in
         mu[j] = m; A[j] = r * gm * sc1; Bc[j] = bt * sc1 + sh;
     }
     const bool identity = !a.mean && !a.gamma && !a.scale;
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    auto to_h4 = [](const f32x4 v) { h4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]}; return o; };   // RNE, like .to(float16)
     auto xf = [&](const f32x4 v) {
         f32x4 o;
 #pragma unroll
@@ -151,26 +153,37 @@ __global__ void __launch_bounds__(1024) norm_act_kernel(const ds_norm_args a, in
     const int OH = (a.resample == DS_RESAMPLE_DOWN) ? H / 2 : (a.resample == DS_RESAMPLE_UP ? H * 2 : H);
     const int OW = (a.resample == DS_RESAMPLE_DOWN) ? W / 2 : (a.resample == DS_RESAMPLE_UP ? W * 2 : W);
     float* dst = a.out + (size_t)n * OH * OW * a.out_ld + c;
+    _Float16* dst16 = reinterpret_cast<_Float16*>(a.out) + (size_t)n * OH * OW * a.out_ld + c;
+    _Float16* raw16 = a.raw_out ? reinterpret_cast<_Float16*>(a.raw_out) + (size_t)n * OH * OW * a.raw_ld + c : nullptr;
     const int p_begin = blockIdx.x * chunk;
     const int p_end = min(p_begin + chunk, OH * OW);
     for (int p = p_begin + pl; p < p_end; p += PL) {
-        f32x4 o;
+        f32x4 o, raw;
         if (a.resample == DS_RESAMPLE_NONE) {
-            o = xf(*reinterpret_cast<const f32x4*>(src + (size_t)p * ld));
+            raw = *reinterpret_cast<const f32x4*>(src + (size_t)p * ld);
+            o = xf(raw);
         } else if (a.resample == DS_RESAMPLE_UP) {
             const int oh = p / OW, ow = p - oh * OW;
-            o = xf(*reinterpret_cast<const f32x4*>(src + (size_t)((oh >> 1) * W + (ow >> 1)) * ld));
+            raw = *reinterpret_cast<const f32x4*>(src + (size_t)((oh >> 1) * W + (ow >> 1)) * ld);
+            o = xf(raw);
         } else {
             const int oh = p / OW, ow = p - oh * OW;
             const float* s0 = src + (size_t)((2 * oh) * W + 2 * ow) * ld;
-            const f32x4 v00 = xf(*reinterpret_cast<const f32x4*>(s0));
-            const f32x4 v01 = xf(*reinterpret_cast<const f32x4*>(s0 + ld));
-            const f32x4 v10 = xf(*reinterpret_cast<const f32x4*>(s0 + (size_t)W * ld));
-            const f32x4 v11 = xf(*reinterpret_cast<const f32x4*>(s0 + (size_t)W * ld + ld));
+            const f32x4 r00 = *reinterpret_cast<const f32x4*>(s0), r01 = *reinterpret_cast<const f32x4*>(s0 + ld);
+            const f32x4 r10 = *reinterpret_cast<const f32x4*>(s0 + (size_t)W * ld), r11 = *reinterpret_cast<const f32x4*>(s0 + (size_t)W * ld + ld);
+            const f32x4 v00 = xf(r00), v01 = xf(r01), v10 = xf(r10), v11 = xf(r11);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = ((v00[j] + v01[j]) + (v10[j] + v11[j])) * 0.25f;
+            for (int j = 0; j < 4; ++j) {
+                o[j] = ((v00[j] + v01[j]) + (v10[j] + v11[j])) * 0.25f;
+                raw[j] = ((r00[j] + r01[j]) + (r10[j] + r11[j])) * 0.25f;      // the same box filter on the raw input (the skip path's resample)
+            }
         }
-        *reinterpret_cast<f32x4*>(dst + (size_t)p * a.out_ld) = o;
+        if (a.out_f16) {
+            *reinterpret_cast<h4*>(dst16 + (size_t)p * a.out_ld) = to_h4(o);
+            if (raw16) *reinterpret_cast<h4*>(raw16 + (size_t)p * a.raw_ld) = to_h4(raw);
+        } else {
+            *reinterpret_cast<f32x4*>(dst + (size_t)p * a.out_ld) = o;
+        }
     }
 }
 
@@ -408,6 +421,8 @@ extern "C" int ds_norm_act(const ds_norm_args* a, void* stream) {
     if ((a->mean == nullptr) != (a->rstd == nullptr)) return DS_E_ARG;
     if ((a->scale == nullptr) != (a->shift == nullptr)) return DS_E_ARG;
     if ((a->ld0 & 3) || (a->c1 && (a->ld1 & 3)) || (a->out_ld & 3)) return DS_E_ALIGN;
+    if (a->raw_out && (!a->out_f16 || (a->raw_ld & 3) || (reinterpret_cast<uintptr_t>(a->raw_out) & 7u))) return DS_E_ARG;
+    if (a->out_f16 && (reinterpret_cast<uintptr_t>(a->out) & 7u)) return DS_E_ALIGN;
     if (a->resample == DS_RESAMPLE_DOWN && ((a->h | a->w) & 1)) return DS_E_SHAPE;
     int CQ, PL;
     int rc = norm_geometry(a, &CQ, &PL);

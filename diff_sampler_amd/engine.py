@@ -170,6 +170,8 @@ class UNetEngine:
         sres = new(B * max_h)            # resampled skip-path input
         sproj = new(B * max_h)           # projected skip
         ncoef = new(B * 3 * max(max(b.cin, b.cout) for b in spec.blocks))      # {mu, A, B} planes of the fused GroupNorm
+        if self.conv_mode == 1:          # fp16 activated tensors: norm0 output, norm1 output, raw copy for the fused skip projection
+            a16_buf, b16_buf, r16_buf = bd.new16(B * max_act), bd.new16(B * max_act), bd.new16(B * max_act)
         if max_attn:
             n2 = new(B * max_attn // 2); qk = new(B * max_attn // 2 * 3); ao = new(B * max_attn // 2)
         bufs.update(act=act, hbuf=hbuf, sres=sres, sproj=sproj)
@@ -240,8 +242,40 @@ class UNetEngine:
                 fuse = False        # fp16 operands without the fused normalisation (8x8: four images per tile): normalise in a pass
             aoff = self.aff_off[nm]
             cb = dict(cbias=aff[:, aoff:], cbias_ld=self.aff_total, cbias_rows=Bs) if not b.adaptive_scale else {}
+            # fp16 mode, the reference's storage (networks_edm.py:486 runs the body on x.to(float16)): norm + SiLU (+ resample, + the
+            # decoder's concatenation) are ONE pass that writes the activated tensor in fp16, and the convolution is a pure matrix
+            # kernel on fp16 activations (csrc/conv3x3_f16dma.hip).  Outputs, norms and the residual stream stay fp32.
+            dma16 = (w16_0 is not None and w16_1 is not None and self.conv_mode == 1
+                     and lib.ds_conv_f16dma_supported(n, Ho, Ho, cin, 0, cout)
+                     and lib.ds_conv_f16dma_supported(n, Ho, Ho, cout, cin if b.skip_conv else 0, cout))
+            if dma16:
+                a16, b16 = a16_buf[:M * cin].view(M, cin), b16_buf[:M * cout].view(M, cout)
+                r16 = r16_buf[:M * cin].view(M, cin) if b.skip_conv else None
+                norm('stats', x0, c0, c0, n, Hin, Hin, nm + '.norm0.stats', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps)
+                norm('apply', x0, c0, c0, n, Hin, Hin, nm + '.norm0', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps,
+                     gamma=w[f'{nm}.norm0.g'], beta=w[f'{nm}.norm0.b'], act_=DS_ACT_SILU, resample=rs, out=a16, out_ld=cin,
+                     out_f16=True, raw_out=r16, raw_ld=cin)
+                conv(a16, cin, cin, n, Ho, Ho, w[f'{nm}.conv0.w'], cout, hbuf, cout, 9, nm + '.conv0', bias=w[f'{nm}.conv0.b'], stats=True,
+                     w16=w16_0, in_f16=True, **cb)
+                ss = dict(scale=aff[:, aoff:], shift=aff[:, aoff + cout:], ss_ld=self.aff_total, ss_rows=Bs) if b.adaptive_scale else {}
+                norm('stats', hbuf, cout, cout, n, Ho, Ho, nm + '.norm1.stats', groups=G_out, eps=b.eps)
+                norm('apply', hbuf, cout, cout, n, Ho, Ho, nm + '.norm1', groups=G_out, eps=b.eps, gamma=w[f'{nm}.norm1.g'],
+                     beta=w[f'{nm}.norm1.b'], act_=DS_ACT_SILU, out=b16, out_ld=cout, out_f16=True, **ss)
+                if b.skip_conv:          # 1x1 skip projection fused into conv1 as extra K columns on the raw (resampled) fp16 input
+                    c1_w, c1_b = w[f'{nm}.conv1s.w'], w[f'{nm}.conv1s.b']
+                    c1_skip = dict(e0=r16, ec0=cin)
+                else:
+                    s0 = x0
+                    if rs != DS_RESAMPLE_NONE:
+                        norm('apply', x0, c0, c0, n, Hin, Hin, nm + '.skip.resample', x1=x1, c1=c1, ld1=c1, use_stats=False,
+                             resample=rs, out=sres, out_ld=cin)
+                        s0 = sres
+                    assert x1 is None and c0 == cout
+                    c1_w, c1_b = w[f'{nm}.conv1.w'], w[f'{nm}.conv1.b']
+                    c1_skip = dict(res=s0, res_ld=cout)
+                c1_in, c1_norm = b16, dict(in_f16=True)
             # norm0 + silu (+resample) -> conv0 (+bias, + per-image embedding for the non-adaptive variant)
-            if fuse and rs == DS_RESAMPLE_NONE:
+            elif fuse and rs == DS_RESAMPLE_NONE:
                 norm('stats', x0, c0, c0, n, Hin, Hin, nm + '.norm0.stats', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps,
                      gamma=w[f'{nm}.norm0.g'], beta=w[f'{nm}.norm0.b'], coefs=ncoef)
                 conv(x0, c0, c0, n, Ho, Ho, w[f'{nm}.conv0.w'], cout, hbuf, cout, 9, nm + '.conv0', x1=x1, c1=c1, ld1=c1,
@@ -254,7 +288,9 @@ class UNetEngine:
                      w16=w16_0, **cb)
             # norm1 (+adaptive scale/shift) + silu
             ss = dict(scale=aff[:, aoff:], shift=aff[:, aoff + cout:], ss_ld=self.aff_total, ss_rows=Bs) if b.adaptive_scale else {}
-            if fuse:
+            if dma16:
+                pass
+            elif fuse:
                 norm('stats', hbuf, cout, cout, n, Ho, Ho, nm + '.norm1.stats', groups=G_out, eps=b.eps, gamma=w[f'{nm}.norm1.g'],
                      beta=w[f'{nm}.norm1.b'], coefs=ncoef, **ss)
                 c1_in, c1_norm = hbuf, dict(norm_coefs=ncoef, norm_act=DS_ACT_SILU)
@@ -265,11 +301,15 @@ class UNetEngine:
                 c1_in, c1_norm = act, {}
             # skip path: raw (resampled) input, projected by a 1x1 that is fused into conv1 as extra K columns
             s0, sc0, s1, sc1 = x0, c0, x1, c1
-            if rs != DS_RESAMPLE_NONE:
+            if dma16:
+                pass
+            elif rs != DS_RESAMPLE_NONE:
                 norm('apply', x0, c0, c0, n, Hin, Hin, nm + '.skip.resample', x1=x1, c1=c1, ld1=c1, use_stats=False,
                      resample=rs, out=sres, out_ld=cin)
                 s0, sc0, s1, sc1 = sres, cin, None, 0
-            if b.skip_conv:
+            if dma16:
+                pass
+            elif b.skip_conv:
                 c1_w, c1_b = w[f'{nm}.conv1s.w'], w[f'{nm}.conv1s.b']
                 c1_skip = dict(e0=s0, ec0=sc0, e1=s1, ec1=sc1)
             else:

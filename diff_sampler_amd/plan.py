@@ -122,6 +122,12 @@ class Builder:
         self.stats_of: Dict[int, tuple] = {}   # data_ptr of an activation tensor -> (epilogue column-sum buffer, channels)
         self.ws = None                      # split-K scratch shared by every convolution of the plan (launches are serial)
 
+    def new16(self, *shape):
+        """fp16 workspace (activated tensors of the fp16-activation convolutions), owned by the plan like every other buffer."""
+        t = torch.empty(*shape, dtype=torch.float16, device=self.dev)
+        self.P.keep.append(t)
+        return t
+
     def new(self, *shape, zero=False):
         # The argument structs hold raw pointers: the plan must own every tensor they point into, otherwise the
         # caching allocator would hand the memory to the next torch.empty() while the plan still uses it.
@@ -134,12 +140,16 @@ class Builder:
 
     def conv(self, x0, c0, ld0, n, h, w, wgt, cout, out, out_ld, taps, name, x1=None, c1=0, ld1=0, bias=None, cbias=None,
              cbias_ld=0, cbias_rows=1, res=None, res_ld=0, scale=1.0, act=DS_ACT_NONE, norm_coefs=None, norm_act=DS_ACT_NONE,
-             e0=None, ec0=0, e1=None, ec1=0, stride=1, stats=False, w16=None, out_nchw=0):
+             e0=None, ec0=0, e1=None, ec1=0, stride=1, stats=False, w16=None, out_nchw=0, in_f16=False):
         """stats=True: the epilogue also leaves the output's per-(64-row block, channel) sums for the consumer's GroupNorm
         (honoured when cout % 64 == 0; otherwise the consumer falls back to a ds_gn_stats pass).
         w16: fp16 weights of the same layer (ops.pack_conv_weight_f16); used -- with the fp16-operand kernel -- when the
-        geometry supports it (f16_level), else the fp32 weights `wgt` are."""
-        f16 = w16 is not None and taps == 9 and stride == 1 and self.f16_level(n, h, w, c0, c1, ec0, ec1) >= (2 if norm_coefs is not None else 1)
+        geometry supports it (f16_level), else the fp32 weights `wgt` are.
+        in_f16: x0 (and e0) are fp16 NHWC tensors (leading dimensions in halfs) written by ``norm(..., out_f16=True)``: the
+        fp16-activation kernel (csrc/conv3x3_f16dma.hip); needs w16."""
+        if in_f16:
+            assert w16 is not None and taps == 9 and stride == 1 and x1 is None and e1 is None and norm_coefs is None and not out_nchw
+        f16 = in_f16 or w16 is not None and taps == 9 and stride == 1 and self.f16_level(n, h, w, c0, c1, ec0, ec1) >= (2 if norm_coefs is not None else 1)
         shift = 0
         if f16:
             wgt, shift = w16
@@ -153,6 +163,7 @@ class Builder:
         a.workspace, a.workspace_floats = ptr(self.ws), self.ws.numel()
         a.out_nchw = out_nchw               # network output written channel-planar (NCHW) by the epilogue
         a.wgt_f16, a.wgt_shift = (self.conv_mode, shift) if f16 else (0, 0)
+        a.in_f16 = 1 if in_f16 else 0
         self.stats_of.pop(out.data_ptr(), None)
         if stats and cout % 64 == 0 and out_ld == cout:
             sb = self.new(-(-(n * h * w) // 64) * 2 * cout)
@@ -185,7 +196,7 @@ class Builder:
 
     def norm(self, kind, x0, c0, ld0, n, h, w, name, x1=None, c1=0, ld1=0, groups=1, eps=1e-5, use_stats=True, gamma=None,
              beta=None, scale=None, shift=None, ss_ld=0, ss_rows=1, act=DS_ACT_NONE, resample=DS_RESAMPLE_NONE, out=None,
-             out_ld=0, coefs=None):
+             out_ld=0, coefs=None, out_f16=False, raw_out=None, raw_ld=0):
         if use_stats and (self.mean is None or self.mean.numel() < n * 64):
             self.mean, self.rstd = self.new(n * 64), self.new(n * 64)
         if kind == 'stats':
@@ -200,6 +211,9 @@ class Builder:
         a = NormArgs(ptr(x0), ptr(x1), c0, c1, ld0, ld1, n, h, w, groups, eps, ptr(self.mean) if use_stats else None,
                      ptr(self.rstd) if use_stats else None, ptr(gamma), ptr(beta), ptr(scale), ptr(shift), ss_ld, ss_rows, act,
                      resample, ptr(out), out_ld, ptr(coefs))
+        if out_f16:
+            assert kind == 'apply' and out.dtype == torch.float16 and (raw_out is None or raw_out.dtype == torch.float16)
+            a.out_f16, a.raw_out, a.raw_ld = 1, ptr(raw_out), raw_ld
         if kind == 'stats' and n < 256:
             if self.gn_partial is None or self.gn_counters.numel() < n:
                 self.gn_partial = torch.empty(n * _lib.DS_GN_MAX_CHUNKS * 128, dtype=torch.float64, device=self.dev)

@@ -114,6 +114,12 @@ typedef struct ds_conv_args {
      * (keeps hi and lo in fp16's normal range); the epilogue multiplies the accumulators by 2**-wgt_shift.  Available where
      * ds_conv_split_supported() says so, else DS_E_SHAPE. */
     int wgt_shift;
+    /* 1 (with wgt_f16 == 1, taps == 9): THE INPUT IS fp16 -- x0 (and e0) point to fp16 NHWC tensors [M][ld0] (ld0 / eld0 in halfs,
+     * multiples of 8; c0 % 64 == 0, c1 == ec1 == 0), already normalised / activated by ds_norm_act(out_f16) -- the reference's storage
+     * type in this mode (networks_edm.py:486 runs the U-Net body on x.to(float16)).  The convolution is then a pure matrix kernel
+     * (csrc/conv3x3_f16dma.hip: both operands staged by LDS-DMA, 256-pixel x 64/128/192/256-channel tiles).  norm_coefs must be NULL.
+     * Bias / residual / output stay fp32.  Availability: ds_conv_f16dma_supported(); otherwise DS_E_SHAPE. */
+    int in_f16;
 } ds_conv_args;
 
 int ds_conv2d_nhwc(const ds_conv_args* a, void* stream);
@@ -134,6 +140,10 @@ int ds_conv3x3_halo_supported(int h, int w);
  * and the fused input normalisation (norm_coefs) too.  n, h, w: images and size; cin = c0 + c1 and ecin = ec0 + ec1 with every
  * source a multiple of 64 channels. */
 int ds_conv_f16_supported(int n, int h, int w, int c0, int c1, int ec0, int ec1);
+/* 1 when a 3x3 layer of this geometry runs on the fp16-activation kernel (ds_conv_args.in_f16). */
+int ds_conv_f16dma_supported(int n, int h, int w, int c0, int ec0, int cout);
+/* benchmarks / tests: force the column-tile width (64 * nb columns, nb = 1..4; 0 = cost model) of the fp16-activation kernel; returns the previous value */
+int ds_debug_f16dma_nb(int nb);
 
 /* 1x1 convolution / Linear with fp16 operands (wgt_f16 == 1 and taps == 1: `wgt` = [cout_pad][K] halfs in plain K order; the fp32
  * input rows are rounded to fp16 while they are staged): 1 if rows % 256 == 0 and every source is a multiple of 64 channels. */
@@ -220,6 +230,11 @@ typedef struct ds_norm_args {
      * partial: [n][DS_GN_MAX_CHUNKS][128] doubles (scratch).  counters: reserved, may be NULL.  partial == NULL = one
      * workgroup per image. */
     double* partial; int* counters;
+    /* ds_norm_act only.  out_f16 = 1: `out` is an fp16 NHWC tensor [rows][out_ld] (out_ld in halfs, % 4 == 0) -- the activated tensor as
+     * the reference's fp16 mode stores it (networks_edm.py:486), read by ds_conv2d_nhwc(in_f16).  raw_out (optional, with out_f16):
+     * a second fp16 tensor [rows][raw_ld] that receives the UN-normalised (but resampled, concatenated) input -- the operand of a
+     * block's 1x1 skip projection (networks_edm.py:170) when that projection is fused into conv1 as extra K columns. */
+    int out_f16; void* raw_out; int raw_ld;
 } ds_norm_args;
 
 #define DS_GN_MAX_CHUNKS 32

@@ -842,3 +842,90 @@ def test_attention_f16_rejects_uncovered_head_sizes():
     x = torch.zeros(64, 3 * 256, device='cuda'); o = torch.zeros(64, 256, device='cuda')
     a = _lib.AttnArgs(x.data_ptr(), x.data_ptr(), x.data_ptr(), o.data_ptr(), 768, 768, 768, 256, 0, 0, 0, 0, 1, 1, 64, 64, 256, 1.0)
     assert lib.ds_attention_f16(C.byref(a), _lib.stream_ptr()) == -3
+
+
+F16DMA_CASES = [
+    # B, H(=W), cin, cout, ec0, forced nb (0 = cost model), with stats
+    (1, 16, 64, 64, 0, 0, False),            # one slab, NB = 1
+    (1, 16, 128, 128, 0, 2, True),
+    (2, 32, 64, 192, 0, 3, True),            # 192-column tiles (ADM channel counts)
+    (1, 32, 192, 256, 64, 4, True),          # 256-column tiles + one appended 1x1 slab
+    (1, 32, 128, 320, 128, 0, False),        # 320 = 256 + 64 / 192 + 128: mixed column tiling, two 1x1 slabs
+    (1, 64, 192, 192, 192, 3, True),         # W = 64: seven DMA rounds per halo, three 1x1 slabs back to back
+    (1, 64, 64, 128, 0, 1, False),
+    (4, 8, 128, 192, 0, 3, True),            # 8x8: four images per tile
+    (8, 8, 64, 64, 64, 0, False),
+    (1, 16, 576, 576, 0, 0, True),           # nine slabs; few pixel tiles -> the cost model narrows the column tiles
+    (2, 16, 64, 256, 0, 4, False),
+]
+
+
+@pytest.mark.parametrize('case', F16DMA_CASES)
+def test_conv_f16_activations_dma_kernel(case):
+    """ds_conv2d_nhwc with in_f16 (csrc/conv3x3_f16dma.hip): the input is an fp16 NHWC tensor, both operands go to LDS by DMA, column tiles
+    of 64 / 128 / 192 / 256 channels.  Reference = the same arithmetic on the CPU (fp16 operands, products summed in fp64): 2e-5 of the
+    output scale -- only the fp32 accumulation order differs; the GroupNorm column sums the epilogue leaves are checked too."""
+    import ctypes as C
+    from diff_sampler_amd import _lib, ops
+    B, H, cin, cout, ec0, nb, with_stats = case
+    lib = _lib.load()
+    assert lib.ds_conv_f16dma_supported(B, H, H, cin, ec0, cout) == 1
+    g = torch.Generator().manual_seed(sum(case[:5]) + 5)
+    x = torch.randn(B, cin, H, H, generator=g).to(torch.float16)
+    e = torch.randn(B, ec0, H, H, generator=g).to(torch.float16) if ec0 else None
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    we = torch.randn(cout, ec0, 1, 1, generator=g) / ec0 ** 0.5 if ec0 else None
+    bias = torch.randn(cout, generator=g)
+    cb = torch.randn(B, cout, generator=g)
+    res = torch.randn(B, cout, H, H, generator=g)
+    h16 = lambda t: t.to(torch.float16).to(torch.float64)
+    ref = F.conv2d(x.double(), h16(w), padding=1)
+    if ec0:
+        ref = ref + F.conv2d(e.double(), h16(we))
+    ref = ((ref + (bias[None, :, None, None] + cb[:, :, None, None] + res).double()) * 0.7071).float()
+    dev = 'cuda'
+    xn = x.permute(0, 2, 3, 1).reshape(-1, cin).contiguous().to(dev)
+    en = e.permute(0, 2, 3, 1).reshape(-1, ec0).contiguous().to(dev) if ec0 else None
+    wp = ops.pack_conv_weight_f16(w.to(dev), we.to(dev) if ec0 else None)
+    M = B * H * H
+    out = torch.full((M, cout), float('nan'), device=dev)
+    stats = torch.full((-(-M // 64) * 2 * cout,), float('nan'), device=dev) if with_stats else None
+    biasd, cbd, resd = bias.to(dev), cb.to(dev), _nhwc(res).to(dev)
+    a = _lib.ConvArgs(xn.data_ptr(), None, cin, 0, cin, 0, B, H, H, 9, wp.data_ptr(), cout, biasd.data_ptr(), cbd.data_ptr(), cout, B,
+                      resd.data_ptr(), cout, 0.7071, 0, out.data_ptr(), cout, None, 0, en.data_ptr() if ec0 else None, None, ec0, 0, ec0, 0)
+    a.wgt_f16, a.in_f16 = 1, 1
+    if with_stats:
+        a.stats_out = stats.data_ptr()
+    assert lib.ds_conv_kernel_id(C.byref(a)) == 2566
+    prev = lib.ds_debug_f16dma_nb(nb)
+    try:
+        rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
+        torch.cuda.synchronize()
+    finally:
+        lib.ds_debug_f16dma_nb(prev)
+    assert rc == 0, lib.ds_error_string(rc)
+    got = out.cpu()
+    assert torch.isfinite(got).all()
+    assert _rel(got, _nhwc(ref)) < 2e-5
+    if with_stats:
+        st = stats.cpu().reshape(-1, 2, cout)
+        blocks = got.reshape(-1, 64, cout)
+        assert _rel(st[:, 0], blocks.sum(1)) < 1e-5 and _rel(st[:, 1], (blocks * blocks).sum(1)) < 1e-5
+
+
+def test_conv_f16_activations_rejects_what_it_does_not_cover():
+    import ctypes as C
+    from diff_sampler_amd import _lib
+    lib = _lib.load()
+    assert lib.ds_conv_f16dma_supported(1, 16, 16, 96, 0, 64) == 0          # channels not a multiple of 64
+    assert lib.ds_conv_f16dma_supported(1, 16, 16, 64, 0, 96) == 0
+    assert lib.ds_conv_f16dma_supported(3, 8, 8, 64, 0, 64) == 0            # 8x8 needs whole tiles of four images
+    assert lib.ds_conv_f16dma_supported(1, 4, 4, 64, 0, 64) == 0
+    x = torch.zeros(256, 64, dtype=torch.float16, device='cuda')
+    w = torch.zeros(128, 9 * 64 // 2, device='cuda')
+    out = torch.zeros(256, 64, device='cuda')
+    a = _lib.ConvArgs(x.data_ptr(), None, 64, 0, 64, 0, 1, 16, 16, 9, w.data_ptr(), 64, None, None, 0, 1, None, 0, 1.0, 0, out.data_ptr(), 64)
+    a.in_f16 = 1                                                             # fp16 input without fp16 weights
+    assert lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr()) == -1
+    a.wgt_f16, a.ld0 = 1, 68                                                 # leading dimension not a multiple of 8 halfs
+    assert lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr()) == -2

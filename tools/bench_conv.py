@@ -42,6 +42,8 @@ ap.add_argument('--variants', type=int, nargs='*', default=None)
 ap.add_argument('--rounds', type=int, default=5)
 ap.add_argument('--split', action='store_true', help='split-fp16 fp32-emulated kernel (wgt_f16 = 2), 3x3 shapes only')
 ap.add_argument('--f16', action='store_true', help='fp16-operand kernel (ds_conv_args.wgt_f16), 3x3 shapes only')
+ap.add_argument('--dma16', action='store_true', help='with --f16: fp16 ACTIVATIONS (ds_conv_args.in_f16, csrc/conv3x3_f16dma.hip); single source (c0 + c1 channels), no --norm')
+ap.add_argument('--nb', type=int, default=0, help='with --dma16: force the column-tile width (64 * nb)')
 ap.add_argument('--extra', action='store_true', help='append the fused 1x1 skip projection (ec0 = c0 + c1 raw columns) as conv1 of a block with a skip conv has it')
 ap.add_argument('--ws', action='store_true', help='give the launcher a split-K workspace (256 MiB), as the engine plans do (the persistent schedule needs it)')
 ap.add_argument('--norm', action='store_true', help='fused GroupNorm affine + SiLU in the halo loader, as the network uses it')
@@ -88,6 +90,14 @@ for si, (res, c0, c1, cout, taps) in enumerate(SHAPES):
         a.wgt = wp.data_ptr()
     if args.f16 or args.split:
         a.wgt_f16 = 2 if args.split else 1
+    if args.dma16:
+        assert args.f16 and not args.norm
+        x16 = torch.randn(M, c0 + c1, device=dev).to(torch.float16)
+        a.x0, a.x1, a.c0, a.c1, a.ld0, a.ld1, a.in_f16 = x16.data_ptr(), None, c0 + c1, 0, c0 + c1, 0, 1
+        if args.extra and taps == 9:
+            e16 = torch.randn(M, c0 + c1, device=dev).to(torch.float16)
+            a.e0, a.ec0, a.eld0 = e16.data_ptr(), c0 + c1, c0 + c1
+        lib.ds_debug_f16dma_nb(args.nb)
     if args.norm and taps == 9:
         coefs = torch.randn(B, 3, c0 + c1, device=dev) * 0.1 + torch.tensor([0., 1., 0.], device=dev).reshape(1, 3, 1)
         a.norm_coefs, a.norm_act = coefs.data_ptr(), 1
