@@ -27,7 +27,7 @@ class ConvArgs(C.Structure):
                 ('norm_coefs', vp), ('norm_act', C.c_int),
                 ('e0', vp), ('e1', vp), ('ec0', C.c_int), ('ec1', C.c_int), ('eld0', C.c_int), ('eld1', C.c_int),
                 ('stride', C.c_int), ('workspace', vp), ('workspace_floats', C.c_longlong),
-                ('out_nchw', C.c_int), ('stats_out', vp), ('wgt_f16', C.c_int), ('wgt_shift', C.c_int), ('in_f16', C.c_int)]
+                ('out_nchw', C.c_int), ('stats_out', vp), ('wgt_f16', C.c_int), ('wgt_shift', C.c_int), ('in_f16', C.c_int), ('out_f16', C.c_int)]
 
 
 class GemmArgs(C.Structure):
@@ -43,7 +43,7 @@ class NormArgs(C.Structure):
                 ('n', C.c_int), ('h', C.c_int), ('w', C.c_int), ('groups', C.c_int), ('eps', C.c_float),
                 ('mean', vp), ('rstd', vp), ('gamma', vp), ('beta', vp), ('scale', vp), ('shift', vp),
                 ('ss_ld', C.c_int), ('ss_rows', C.c_int), ('act', C.c_int), ('resample', C.c_int), ('out', vp),
-                ('out_ld', C.c_int), ('coefs', vp), ('partial', vp), ('counters', vp), ('out_f16', C.c_int), ('raw_out', vp), ('raw_ld', C.c_int)]
+                ('out_ld', C.c_int), ('coefs', vp), ('partial', vp), ('counters', vp), ('out_f16', C.c_int), ('raw_out', vp), ('raw_ld', C.c_int), ('in_f16', C.c_int)]
 
 
 class AttnArgs(C.Structure):
@@ -113,6 +113,7 @@ _SIGNATURES = {
     'ds_conv_f16_supported': (C.c_int, [C.c_int] * 7),
     'ds_conv_f16dma_supported': (C.c_int, [C.c_int] * 6),
     'ds_debug_f16dma_nb': (C.c_int, [C.c_int]),
+    'ds_debug_f16dma_ablate': (C.c_int, [C.c_int]),
     'ds_conv_split_supported': (C.c_int, [C.c_int] * 7),
     'ds_gemm_f16_supported': (C.c_int, [C.c_longlong, C.c_int, C.c_int]),
     'ds_gemm_nt_batched': (C.c_int, [C.POINTER(GemmArgs), vp]),

@@ -301,6 +301,7 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     if (a->taps != 1 && a->taps != 9) return DS_E_ARG;
     if (a->c0 <= 0 || a->c0 % 32 || a->c1 < 0 || a->c1 % 32) return DS_E_SHAPE;
     if (a->c1 && !a->x1) return DS_E_ARG;
+    if (a->out_f16 && (!a->in_f16 || (a->cout & 63) || (a->out_ld & 3) || a->act == DS_ACT_GEGLU)) return DS_E_ARG;   // fp16 output: the fp16-activation kernel only
     if (a->in_f16) {          // fp16 activations: pure matrix kernel (conv3x3_f16dma.hip); ld in halfs, 16-byte chunks
         if (a->wgt_f16 != 1 || a->taps != 9 || a->c1 || a->ec1 || a->norm_coefs || a->out_nchw || (a->stride && a->stride != 1)) return DS_E_ARG;
         if ((a->ld0 & 7) || (a->ec0 && ((a->eld0 & 7) || !a->e0 || !ds_aligned16(a->e0)))) return DS_E_ALIGN;
@@ -365,6 +366,7 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
         if (a->wgt_shift < 0 || a->wgt_shift > 24 || (a->wgt_f16 == 1 && a->wgt_shift)) return DS_E_ARG;
         if (a->in_f16) {
             p.ldb = p.K / 2;
+            p.out_f16 = a->out_f16 ? 1 : 0;
             p.part = nullptr; p.part_cap = 0; p.splits = 1;
             if (!conv3x3_f16dma_applicable(p)) return DS_E_SHAPE;
             return launch_conv3x3_f16dma(p, (hipStream_t)stream);
@@ -419,6 +421,7 @@ extern "C" int ds_conv_f16dma_supported(int n, int h, int w, int c0, int ec0, in
     return conv3x3_f16dma_applicable(p) ? 1 : 0;
 }
 extern "C" int ds_debug_f16dma_nb(int nb) { const int o = g_f16dma_nb; g_f16dma_nb = nb; return o; }
+extern "C" int ds_debug_f16dma_ablate(int mask) { const int o = g_f16dma_ablate; g_f16dma_ablate = mask; return o; }
 extern "C" int ds_gemm_f16_supported(long long rows, int c0, int c1) {
     KParams p{};
     if (rows > 0x7fffffffLL) return 0;

@@ -37,6 +37,7 @@ struct KParams {
     float acc_scale;                                               // conv epilogue: accumulators are multiplied by this first (1; 2**-shift for pre-scaled split-fp16 weights)
     int vec_ok;                                                    // float4 epilogue allowed (alignment, ld % 4)
     int out_planar;                                                // scalar epilogue writes out[(img * N + col) * HW + pixel]
+    int out_f16;                                                   // vector epilogue stores fp16 rows [M][ldo halfs] (ds_conv_args.out_f16)
     // optional per-(64-row block, column) sums of the OUTPUT for the consumer's GroupNorm: stats[(rb * 2 + {0: sum, 1: sum of
     // squares}) * N + col], rb = row / 64 (vector epilogue only: N % 64 == 0)
     float* stats;
@@ -119,7 +120,11 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = ds_silu(v[q]);
                 }
-                if (NTS) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col));
+                if (p.out_f16) {
+                    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+                    const h4_t hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                    *reinterpret_cast<h4_t*>(reinterpret_cast<_Float16*>(o_base) + (size_t)row * p.ldo + col) = hv;
+                } else if (NTS) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col));
                 else *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col) = v;
                 st_s += v; st_q += v * v;
             }
@@ -236,7 +241,11 @@ __device__ __forceinline__ void epilogue32(const KParams& p, const f32x16 (&acc)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = ds_silu(v[q]);
             }
-            *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col) = v;
+            if (p.out_f16) {
+                typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+                const h4_t hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                *reinterpret_cast<h4_t*>(reinterpret_cast<_Float16*>(o_base) + (size_t)row * p.ldo + col) = hv;
+            } else *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col) = v;
             st_s += v; st_q += v * v;
         }
     }
@@ -357,7 +366,7 @@ extern long long g_halo2_launches;
 // conv3x3_f16dma.hip: 3x3 on fp16 activations, both operands by LDS-DMA, 256-pixel x 64/128/192/256-channel tiles
 bool conv3x3_f16dma_applicable(const KParams& p);
 int launch_conv3x3_f16dma(KParams& p, hipStream_t stream);
-extern int g_f16dma_nb;
+extern int g_f16dma_nb, g_f16dma_ablate;
 
 // gemm_f16.hip: 1x1 / Linear with fp16 operands (A rounded while staged, W packed fp16)
 bool gemm_f16_applicable(const KParams& p);

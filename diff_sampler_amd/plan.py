@@ -140,7 +140,7 @@ class Builder:
 
     def conv(self, x0, c0, ld0, n, h, w, wgt, cout, out, out_ld, taps, name, x1=None, c1=0, ld1=0, bias=None, cbias=None,
              cbias_ld=0, cbias_rows=1, res=None, res_ld=0, scale=1.0, act=DS_ACT_NONE, norm_coefs=None, norm_act=DS_ACT_NONE,
-             e0=None, ec0=0, e1=None, ec1=0, stride=1, stats=False, w16=None, out_nchw=0, in_f16=False):
+             e0=None, ec0=0, e1=None, ec1=0, stride=1, stats=False, w16=None, out_nchw=0, in_f16=False, out_f16=False):
         """stats=True: the epilogue also leaves the output's per-(64-row block, channel) sums for the consumer's GroupNorm
         (honoured when cout % 64 == 0; otherwise the consumer falls back to a ds_gn_stats pass).
         w16: fp16 weights of the same layer (ops.pack_conv_weight_f16); used -- with the fp16-operand kernel -- when the
@@ -164,6 +164,9 @@ class Builder:
         a.out_nchw = out_nchw               # network output written channel-planar (NCHW) by the epilogue
         a.wgt_f16, a.wgt_shift = (self.conv_mode, shift) if f16 else (0, 0)
         a.in_f16 = 1 if in_f16 else 0
+        if out_f16:          # fp16 output rows (a tensor that only feeds a normalisation pass): the fp16-activation kernel's epilogue
+            assert in_f16 and out.dtype == torch.float16 and cout % 64 == 0
+            a.out_f16 = 1
         self.stats_of.pop(out.data_ptr(), None)
         if stats and cout % 64 == 0 and out_ld == cout:
             sb = self.new(-(-(n * h * w) // 64) * 2 * cout)
@@ -196,7 +199,7 @@ class Builder:
 
     def norm(self, kind, x0, c0, ld0, n, h, w, name, x1=None, c1=0, ld1=0, groups=1, eps=1e-5, use_stats=True, gamma=None,
              beta=None, scale=None, shift=None, ss_ld=0, ss_rows=1, act=DS_ACT_NONE, resample=DS_RESAMPLE_NONE, out=None,
-             out_ld=0, coefs=None, out_f16=False, raw_out=None, raw_ld=0):
+             out_ld=0, coefs=None, out_f16=False, raw_out=None, raw_ld=0, in_f16=False):
         if use_stats and (self.mean is None or self.mean.numel() < n * 64):
             self.mean, self.rstd = self.new(n * 64), self.new(n * 64)
         if kind == 'stats':
@@ -211,6 +214,9 @@ class Builder:
         a = NormArgs(ptr(x0), ptr(x1), c0, c1, ld0, ld1, n, h, w, groups, eps, ptr(self.mean) if use_stats else None,
                      ptr(self.rstd) if use_stats else None, ptr(gamma), ptr(beta), ptr(scale), ptr(shift), ss_ld, ss_rows, act,
                      resample, ptr(out), out_ld, ptr(coefs))
+        if in_f16:
+            assert kind == 'apply' and x0.dtype == torch.float16 and x1 is None
+            a.in_f16 = 1
         if out_f16:
             assert kind == 'apply' and out.dtype == torch.float16 and (raw_out is None or raw_out.dtype == torch.float16)
             a.out_f16, a.raw_out, a.raw_ld = 1, ptr(raw_out), raw_ld

@@ -120,6 +120,11 @@ typedef struct ds_conv_args {
      * (csrc/conv3x3_f16dma.hip: both operands staged by LDS-DMA, 256-pixel x 64/128/192/256-channel tiles).  norm_coefs must be NULL.
      * Bias / residual / output stay fp32.  Availability: ds_conv_f16dma_supported(); otherwise DS_E_SHAPE. */
     int in_f16;
+    /* 1: the OUTPUT is written as fp16 NHWC rows [M][out_ld halfs] (rounded to nearest even from the fp32 epilogue value; the GroupNorm
+     * column sums of stats_out are taken before rounding).  For tensors that only feed a normalisation pass (the conv0 output of a
+     * block in fp16 mode: read back by ds_norm_act with in_f16).  Requires the aligned vector epilogue (cout % 64 == 0), no out_nchw,
+     * no GEGLU. */
+    int out_f16;
 } ds_conv_args;
 
 int ds_conv2d_nhwc(const ds_conv_args* a, void* stream);
@@ -144,6 +149,9 @@ int ds_conv_f16_supported(int n, int h, int w, int c0, int c1, int ec0, int ec1)
 int ds_conv_f16dma_supported(int n, int h, int w, int c0, int ec0, int cout);
 /* benchmarks / tests: force the column-tile width (64 * nb columns, nb = 1..4; 0 = cost model) of the fp16-activation kernel; returns the previous value */
 int ds_debug_f16dma_nb(int nb);
+/* benchmarks only (results are WRONG when set): timing ablations of the fp16-activation kernel -- bit 0: no weight DMA after the
+ * prologue, bit 1: no halo DMA after the first slab, bit 2: no epilogue; returns the previous mask */
+int ds_debug_f16dma_ablate(int mask);
 
 /* 1x1 convolution / Linear with fp16 operands (wgt_f16 == 1 and taps == 1: `wgt` = [cout_pad][K] halfs in plain K order; the fp32
  * input rows are rounded to fp16 while they are staged): 1 if rows % 256 == 0 and every source is a multiple of 64 channels. */
@@ -235,6 +243,9 @@ typedef struct ds_norm_args {
      * a second fp16 tensor [rows][raw_ld] that receives the UN-normalised (but resampled, concatenated) input -- the operand of a
      * block's 1x1 skip projection (networks_edm.py:170) when that projection is fused into conv1 as extra K columns. */
     int out_f16; void* raw_out; int raw_ld;
+    /* ds_norm_act only.  in_f16 = 1: x0 is an fp16 tensor [rows][ld0 halfs] (c1 must be 0) -- a convolution output written with
+     * ds_conv_args.out_f16. */
+    int in_f16;
 } ds_norm_args;
 
 #define DS_GN_MAX_CHUNKS 32

@@ -929,3 +929,57 @@ def test_conv_f16_activations_rejects_what_it_does_not_cover():
     assert lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr()) == -1
     a.wgt_f16, a.ld0 = 1, 68                                                 # leading dimension not a multiple of 8 halfs
     assert lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr()) == -2
+
+
+def test_conv_f16_output_rows_and_norm_pass_on_fp16_tensors():
+    """The fp16-mode chain of one block: ds_norm_act(out_f16 [+ raw copy]) -> ds_conv2d_nhwc(in_f16, out_f16) -> ds_norm_act(in_f16, out_f16).
+    fp16 tensors must equal the fp32 results rounded to nearest even (the conv output within the accumulation-order tolerance)."""
+    import ctypes as C
+    from diff_sampler_amd import _lib, ops
+    lib = _lib.load()
+    dev = 'cuda'
+    B, H, cin, cout = 2, 16, 128, 192
+    M = B * H * H
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(M, cin, generator=g).to(dev)
+    mean, rstd = (torch.randn(B * 32, generator=g) * 0.1).to(dev), (1 + 0.1 * torch.rand(B * 32, generator=g)).to(dev)
+    gamma, beta = (1 + 0.1 * torch.randn(cin, generator=g)).to(dev), (0.1 * torch.randn(cin, generator=g)).to(dev)
+    a16 = torch.zeros(M, cin, dtype=torch.float16, device=dev)
+    r16 = torch.zeros(M, cin, dtype=torch.float16, device=dev)
+    na = ops._norm_args(x, cin, cin, B, H, H, groups=32, eps=1e-5, mean=mean, rstd=rstd, gamma=gamma, beta=beta, act=1, out=a16, out_ld=cin)
+    na.out = C.c_void_p(a16.data_ptr())
+    na.out_f16, na.raw_out, na.raw_ld = 1, C.c_void_p(r16.data_ptr()), cin
+    assert lib.ds_norm_act(C.byref(na), _lib.stream_ptr()) == 0
+    xr = x.reshape(B, H * H, 32, cin // 32)
+    y = (xr - mean.reshape(B, 1, 32, 1)) * rstd.reshape(B, 1, 32, 1)
+    y = F.silu(y.reshape(M, cin) * gamma + beta)
+    torch.cuda.synchronize()
+    assert torch.equal(r16, x.to(torch.float16))
+    assert _rel(a16.float().cpu(), y.to(torch.float16).float().cpu()) < 1e-3       # device exp differs by an ulp here and there
+    # conv on the fp16 tensor, fp16 output rows
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    wp = ops.pack_conv_weight_f16(w.to(dev))
+    bias = torch.randn(cout, generator=g).to(dev)
+    h16 = torch.zeros(M, cout, dtype=torch.float16, device=dev)
+    stats = torch.zeros(-(-M // 64) * 2 * cout, device=dev)
+    ca = _lib.ConvArgs(a16.data_ptr(), None, cin, 0, cin, 0, B, H, H, 9, wp.data_ptr(), cout, bias.data_ptr(), None, 0, 1, None, 0, 1.0, 0,
+                       h16.data_ptr(), cout)
+    ca.wgt_f16, ca.in_f16, ca.out_f16, ca.stats_out = 1, 1, 1, stats.data_ptr()
+    assert lib.ds_conv2d_nhwc(C.byref(ca), _lib.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    xin = a16.double().cpu().reshape(B, H, H, cin).permute(0, 3, 1, 2)
+    ref = F.conv2d(xin, w.to(torch.float16).double(), padding=1) + bias.double().cpu()[None, :, None, None]
+    ref = ref.permute(0, 2, 3, 1).reshape(M, cout).float()
+    assert _rel(h16.float().cpu(), ref.to(torch.float16).float()) < 1.5e-3          # one fp16 ulp where the fp32 sums straddle a rounding boundary
+    st = stats.cpu().reshape(-1, 2, cout)
+    assert _rel(st[:, 0], ref.reshape(-1, 64, cout).sum(1)) < 1e-5                 # column sums are taken BEFORE rounding
+    # second norm pass reads the fp16 tensor
+    b16 = torch.zeros(M, cout, dtype=torch.float16, device=dev)
+    nb = ops._norm_args(x, cout, cout, B, H, H, groups=32, eps=1e-5, mean=mean, rstd=rstd, act=1, out=b16, out_ld=cout)
+    nb.x0, nb.out = C.c_void_p(h16.data_ptr()), C.c_void_p(b16.data_ptr())
+    nb.in_f16, nb.out_f16 = 1, 1
+    assert lib.ds_norm_act(C.byref(nb), _lib.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    hr = h16.float().reshape(B, H * H, 32, cout // 32)
+    y2 = F.silu(((hr - mean.reshape(B, 1, 32, 1)) * rstd.reshape(B, 1, 32, 1)).reshape(M, cout))
+    assert _rel(b16.float().cpu(), y2.to(torch.float16).float().cpu()) < 1e-3

@@ -44,6 +44,8 @@ ap.add_argument('--split', action='store_true', help='split-fp16 fp32-emulated k
 ap.add_argument('--f16', action='store_true', help='fp16-operand kernel (ds_conv_args.wgt_f16), 3x3 shapes only')
 ap.add_argument('--dma16', action='store_true', help='with --f16: fp16 ACTIVATIONS (ds_conv_args.in_f16, csrc/conv3x3_f16dma.hip); single source (c0 + c1 channels), no --norm')
 ap.add_argument('--nb', type=int, default=0, help='with --dma16: force the column-tile width (64 * nb)')
+ap.add_argument('--ablate', type=int, default=0, help='with --dma16: ds_debug_f16dma_ablate mask (timing only)')
+ap.add_argument('--no-res', action='store_true', help='no residual operand in the epilogue')
 ap.add_argument('--extra', action='store_true', help='append the fused 1x1 skip projection (ec0 = c0 + c1 raw columns) as conv1 of a block with a skip conv has it')
 ap.add_argument('--ws', action='store_true', help='give the launcher a split-K workspace (256 MiB), as the engine plans do (the persistent schedule needs it)')
 ap.add_argument('--norm', action='store_true', help='fused GroupNorm affine + SiLU in the halo loader, as the network uses it')
@@ -71,6 +73,8 @@ for si, (res, c0, c1, cout, taps) in enumerate(SHAPES):
     out = torch.zeros(M, old, device=dev)
     a = ConvArgs(x0.data_ptr(), x1.data_ptr() if c1 else None, c0, c1, c0, c1, B, res, res, taps, wp.data_ptr(), cout, bias.data_ptr(),
                  None, 0, 1, res_t.data_ptr() if cout >= 4 else None, cout, 0.70710678, 0, out.data_ptr(), old)
+    if args.no_res:
+        a.res = None
     if (args.f16 or args.split) and (taps != 9 or cout < 64 or (args.norm and res < 16)):
         continue
     if args.extra and taps == 9:
@@ -98,6 +102,7 @@ for si, (res, c0, c1, cout, taps) in enumerate(SHAPES):
             e16 = torch.randn(M, c0 + c1, device=dev).to(torch.float16)
             a.e0, a.ec0, a.eld0 = e16.data_ptr(), c0 + c1, c0 + c1
         lib.ds_debug_f16dma_nb(args.nb)
+        lib.ds_debug_f16dma_ablate(args.ablate)
     if args.norm and taps == 9:
         coefs = torch.randn(B, 3, c0 + c1, device=dev) * 0.1 + torch.tensor([0., 1., 0.], device=dev).reshape(1, 3, 1)
         a.norm_coefs, a.norm_act = coefs.data_ptr(), 1
