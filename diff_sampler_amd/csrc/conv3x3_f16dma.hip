@@ -133,6 +133,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
     // order; the wait names the set it releases ("+v"), so no use can move above it (cdna_hip_programming.md 5.7, form (ii)).
     struct Frag { f32x4 a0, a1, b0, b1, b2, b3; };
     auto frag_read = [&](Frag& f, unsigned va0, unsigned va1, unsigned vb) {
+        if (abl & 32) return;                                  // (timing ablation: no fragment reads)
         f.a0 = lds_rd<0>(va0);
         f.a1 = lds_rd<0>(va1);
         f.b0 = lds_rd<0>(vb);
@@ -205,7 +206,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
         DS2_FENCE(); mfma_group(P); DS2_FENCE();
         frag_wait(Q, IC<0>{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!(abl & 16)) __builtin_amdgcn_s_barrier();         // (timing ablation: no per-tap barrier)
         DS2_FENCE();
         // ---- behind the barrier: first the fragment reads of tap kt+1 and the last K step's MFMAs, THEN the DMA issue (address
         // arithmetic, M0 writes, NB + 1 LDS-DMA instructions: ~150-300 cycles per wave) in the shadow of those MFMAs -------------------
@@ -219,7 +220,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
                 frag_read(P, a_addr(0, T9 + 1) + hoff, a_addr(1, T9 + 1) + hoff, bbase + nwoff);
             }
         }
-        DS2_FENCE(); mfma_group(Q); DS2_FENCE();
+        if (abl & 8) { DS2_FENCE(); mfma_group(Q); DS2_FENCE(); }         // (A/B: MFMAs first, DMA issue in their shadow -- measured slower)
         if (kt + 2 < KT) w_dma(kt + 2, kt & 1);
         if constexpr (SLAB_END) {
             if (chunk + 2 < NCH) {
@@ -230,6 +231,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
             if (chunk + 1 < NCH) halo_dma(chunk + 1, (chunk + 1) & 1, IC<T9 + 1>{});
         }
         DS2_FENCE();
+        if (!(abl & 8)) { mfma_group(Q); DS2_FENCE(); }
         ++kt;
     };
     int chunk = 0;
@@ -258,7 +260,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
 }
 
 }  // namespace
-int g_f16dma_ablate = 0;        // benchmarks only: bit 0 = no weight DMA after the prologue, 1 = no halo DMA after slab 0, 2 = no epilogue
+int g_f16dma_ablate = 0;        // benchmarks only: bit 0 = no weight DMA after the prologue, 1 = no halo DMA after slab 0, 2 = no epilogue,
+                                // 3 = last K step's MFMAs before the DMA issue, 4 = no per-tap barrier, 5 = no fragment reads
 namespace {
 
 template <int W, int NB>

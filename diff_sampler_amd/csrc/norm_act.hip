@@ -123,6 +123,13 @@ __global__ void __launch_bounds__(1024) norm_act_kernel(const ds_norm_args a, in
 
     float mu[4], A[4], Bc[4];
     const int cpg = a.mean ? C / a.groups : 1;
+    const bool planes = a.coefs != nullptr && a.out_f16;      // {mu, A, B} planes [n][3][C] written by ds_gn_finalize / ds_gn_stats: three
+    if (planes) {                                             // independent 16-B loads instead of 24 dependent scalar ones
+        const float* cp = a.coefs + (size_t)n * 3 * C + c;
+        const f32x4 m4 = *reinterpret_cast<const f32x4*>(cp), a4 = *reinterpret_cast<const f32x4*>(cp + C), b4 = *reinterpret_cast<const f32x4*>(cp + 2 * C);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { mu[j] = m4[j]; A[j] = a4[j]; Bc[j] = b4[j]; }
+    } else
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float m = 0.f, r = 1.f;
@@ -137,7 +144,7 @@ __global__ void __launch_bounds__(1024) norm_act_kernel(const ds_norm_args a, in
         }
         mu[j] = m; A[j] = r * gm * sc1; Bc[j] = bt * sc1 + sh;
     }
-    const bool identity = !a.mean && !a.gamma && !a.scale;
+    const bool identity = !planes && !a.mean && !a.gamma && !a.scale;
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     auto to_h4 = [](const f32x4 v) { h4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]}; return o; };   // RNE, like .to(float16)
     auto xf = [&](const f32x4 v) {
@@ -453,11 +460,23 @@ extern "C" int ds_norm_act(const ds_norm_args* a, void* stream) {
     if (rc) return rc;
     const int OH = (a->resample == DS_RESAMPLE_DOWN) ? a->h / 2 : (a->resample == DS_RESAMPLE_UP ? a->h * 2 : a->h);
     const int OW = (a->resample == DS_RESAMPLE_DOWN) ? a->w / 2 : (a->resample == DS_RESAMPLE_UP ? a->w * 2 : a->w);
+    if (a->coefs && a->out_f16 && !ds_aligned16(a->coefs)) return DS_E_ALIGN;
+    if (a->out_f16) {
+        // the fp16-mode pass streams whole tensors (it runs twice per block): 256-thread workgroups, and few enough of them that a thread
+        // walks >= 16 pixels with four loads in flight -- the 1024-thread / 2048-workgroup geometry below left ~6 pixels per thread behind
+        // a 2-us coefficient prologue and ran at 2.1 TB/s
+        PL = 256 / CQ;
+        if (PL < 1) PL = 1;
+    }
     if (PL > OH * OW) PL = OH * OW;
     int threads = ((CQ * PL + 63) / 64) * 64;
     // enough blocks per image to cover the chip even at small batch: aim for >= 2048 blocks in total
     int chunks = (2048 + a->n - 1) / a->n;
-    const int max_chunks = (OH * OW + PL - 1) / PL;
+    int max_chunks = (OH * OW + PL - 1) / PL;
+    if (a->out_f16) {
+        const int by_work = (OH * OW + 16 * PL - 1) / (16 * PL);      // at least 16 pixels per thread
+        if (max_chunks > by_work) max_chunks = by_work;
+    }
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;
     int chunk = (OH * OW + chunks - 1) / chunks;

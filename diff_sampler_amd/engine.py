@@ -252,16 +252,17 @@ class UNetEngine:
                 a16, b16 = a16_buf[:M * cin].view(M, cin), b16_buf[:M * cout].view(M, cout)
                 h16 = h16_buf[:M * cout].view(M, cout)       # conv0 output: only read by norm1 -> stored in fp16 (networks_edm.py:486)
                 r16 = r16_buf[:M * cin].view(M, cin) if b.skip_conv else None
-                norm('stats', x0, c0, c0, n, Hin, Hin, nm + '.norm0.stats', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps)
-                norm('apply', x0, c0, c0, n, Hin, Hin, nm + '.norm0', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps,
-                     gamma=w[f'{nm}.norm0.g'], beta=w[f'{nm}.norm0.b'], act_=DS_ACT_SILU, resample=rs, out=a16, out_ld=cin,
-                     out_f16=True, raw_out=r16, raw_ld=cin)
+                norm('stats', x0, c0, c0, n, Hin, Hin, nm + '.norm0.stats', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps,
+                     gamma=w[f'{nm}.norm0.g'], beta=w[f'{nm}.norm0.b'], coefs=ncoef)
+                norm('apply', x0, c0, c0, n, Hin, Hin, nm + '.norm0', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps, use_stats=False,
+                     act_=DS_ACT_SILU, resample=rs, out=a16, out_ld=cin, out_f16=True, raw_out=r16, raw_ld=cin, coefs=ncoef)
                 conv(a16, cin, cin, n, Ho, Ho, w[f'{nm}.conv0.w'], cout, h16, cout, 9, nm + '.conv0', bias=w[f'{nm}.conv0.b'], stats=True,
                      w16=w16_0, in_f16=True, out_f16=True, **cb)
                 ss = dict(scale=aff[:, aoff:], shift=aff[:, aoff + cout:], ss_ld=self.aff_total, ss_rows=Bs) if b.adaptive_scale else {}
-                norm('stats', h16, cout, cout, n, Ho, Ho, nm + '.norm1.stats', groups=G_out, eps=b.eps)      # from conv0's epilogue sums (fp32)
-                norm('apply', h16, cout, cout, n, Ho, Ho, nm + '.norm1', groups=G_out, eps=b.eps, gamma=w[f'{nm}.norm1.g'],
-                     beta=w[f'{nm}.norm1.b'], act_=DS_ACT_SILU, out=b16, out_ld=cout, out_f16=True, in_f16=True, **ss)
+                norm('stats', h16, cout, cout, n, Ho, Ho, nm + '.norm1.stats', groups=G_out, eps=b.eps, gamma=w[f'{nm}.norm1.g'],
+                     beta=w[f'{nm}.norm1.b'], coefs=ncoef, **ss)             # from conv0's epilogue sums (fp32), incl. the adaptive scale / shift
+                norm('apply', h16, cout, cout, n, Ho, Ho, nm + '.norm1', groups=G_out, eps=b.eps, use_stats=False, act_=DS_ACT_SILU,
+                     out=b16, out_ld=cout, out_f16=True, in_f16=True, coefs=ncoef)
                 if b.skip_conv:          # 1x1 skip projection fused into conv1 as extra K columns on the raw (resampled) fp16 input
                     c1_w, c1_b = w[f'{nm}.conv1s.w'], w[f'{nm}.conv1s.b']
                     c1_skip = dict(e0=r16, ec0=cin)

@@ -142,11 +142,26 @@ class LDMUNetEngine:
         bd.linear(e0, E, emb_rows, w['te2.w'], E, emb, 'time_embed.2', bias=w['te2.b'], act=DS_ACT_SILU)   # SiLU of emb_layers[0]
         bd.linear(emb, E, emb_rows, w['aff.w'], self.aff_total, aff, 'emb_layers_all', bias=w['aff.b'])
 
-        def gn_conv(x0, c0, x1, c1, side, gk, bk, eps, wgt, bias, cout, out, out_ld, name, w16=None, **kw):
+        def gn_conv(x0, c0, x1, c1, side, gk, bk, eps, wgt, bias, cout, out, out_ld, name, w16=None, dma16=False, raw16=None, e16=None, **kw):
             """GroupNorm(32) + SiLU + 3x3 conv over the concatenation [x0 | x1]; the normalisation rides in the conv's loader
             when the LDS-halo kernel takes the shape, otherwise it is a separate pass (also when the fp16-operand kernel is
             available for the normalised tensor but not with the fused normalisation: 8x8 images)."""
             cin = c0 + c1
+            if dma16:
+                # fp16 mode (the reference runs this U-Net under autocast, sample.py:293-297): one pass writes GroupNorm + SiLU of the
+                # concatenation as an fp16 tensor (and, for a block with a skip_connection, the raw fp16 copy `raw16` that projection
+                # reads), the convolution is the fp16-activation matrix kernel (csrc/conv3x3_f16dma.hip).  `e16` = (raw fp16 tensor,
+                # channels) of a fused skip_connection; an fp16 `out` (a tensor that only feeds the next normalisation) is stored as such
+                a16 = bd.new16(N * side * side, cin)
+                bd.norm('stats', x0, c0, c0, N, side, side, name + '.gn.stats', x1=x1, c1=c1, ld1=c1, groups=32, eps=eps, gamma=gk,
+                        beta=bk, coefs=ncoef)
+                bd.norm('apply', x0, c0, c0, N, side, side, name + '.gn', x1=x1, c1=c1, ld1=c1, groups=32, eps=eps, use_stats=False,
+                        act=DS_ACT_SILU, out=a16, out_ld=cin, out_f16=True, raw_out=raw16, raw_ld=cin, coefs=ncoef,
+                        in_f16=(x0.dtype == torch.float16))
+                ex = dict(e0=e16[0], ec0=e16[1]) if e16 is not None else {}
+                bd.conv(a16, cin, cin, N, side, side, wgt, cout, out, out_ld, 9, name, bias=bias, stats=True, w16=w16, in_f16=True,
+                        out_f16=(out.dtype == torch.float16), **ex, **kw)
+                return
             unfused_f16 = w16 is not None and bd.f16_level(N, side, side, cin, 0, kw.get('ec0', 0), kw.get('ec1', 0)) == 1
             if lib.ds_conv3x3_halo_supported(side, side) and not unfused_f16:
                 bd.norm('stats', x0, c0, c0, N, side, side, name + '.gn.stats', x1=x1, c1=c1, ld1=c1, groups=32, eps=eps, gamma=gk,
@@ -163,8 +178,25 @@ class LDMUNetEngine:
         def res_layer(l, x0, c0, x1, c1):
             p, res, cout = l.key, l.res_out, l.cout
             M = N * res * res
-            h1, out = new(M, cout), new(M, cout)
             ao = self.aff_off[p]
+            cin = c0 + c1
+            w16_0, w16_1 = w.get(f'{p}.c0.w16'), w.get(f'{p}.c1.w16')
+            dma16 = bool(w16_0 is not None and w16_1 is not None and bd.conv_mode == 1
+                         and lib.ds_conv_f16dma_supported(N, res, res, cin, 0, cout)
+                         and lib.ds_conv_f16dma_supported(N, res, res, cout, cin if l.skip_conv else 0, cout))
+            out = new(M, cout)
+            if dma16:
+                h1 = bd.new16(M, cout)                       # in_layers output: only read by the out_layers normalisation
+                r16 = bd.new16(M, cin) if l.skip_conv else None
+                gn_conv(x0, c0, x1, c1, res, w[f'{p}.n0.g'], w[f'{p}.n0.b'], 1e-5, w[f'{p}.c0.w'], w[f'{p}.c0.b'], cout, h1, cout,
+                        p + '.in_layers', w16=w16_0, dma16=True, raw16=r16, cbias=aff[:, ao:], cbias_ld=self.aff_total, cbias_rows=emb_rows)
+                skip = dict(e16=(r16, cin)) if l.skip_conv else dict(res=x0, res_ld=cout)
+                if not l.skip_conv:
+                    assert x1 is None and c0 == cout
+                gn_conv(h1, cout, None, 0, res, w[f'{p}.n1.g'], w[f'{p}.n1.b'], 1e-5, w[f'{p}.c1.w'], w[f'{p}.c1.b'], cout, out, cout,
+                        p + '.out_layers', w16=w16_1, dma16=True, **skip)
+                return out, cout
+            h1 = new(M, cout)
             gn_conv(x0, c0, x1, c1, res, w[f'{p}.n0.g'], w[f'{p}.n0.b'], 1e-5, w[f'{p}.c0.w'], w[f'{p}.c0.b'], cout, h1, cout,
                     p + '.in_layers', w16=w.get(f'{p}.c0.w16'), cbias=aff[:, ao:], cbias_ld=self.aff_total, cbias_rows=emb_rows)
             if l.skip_conv:
@@ -239,12 +271,19 @@ class LDMUNetEngine:
                             bias=w[f'{p}.b'], stride=2, stats=True)
                     cur = (out, l.cout)
                 elif l.kind == 'up':
-                    up = new(N * l.res_out ** 2, l.cin)
-                    bd.norm('apply', cur[0], l.cin, l.cin, N, l.res_in, l.res_in, p + '.nearest', use_stats=False,
-                            resample=DS_RESAMPLE_UP, out=up, out_ld=l.cin)
                     out = new(N * l.res_out ** 2, l.cout)
-                    bd.conv(up, l.cin, l.cin, N, l.res_out, l.res_out, w[f'{p}.w'], l.cout, out, l.cout, 9, p + '.conv', bias=w[f'{p}.b'],
-                            stats=True, w16=w.get(f'{p}.w16'))
+                    if w.get(f'{p}.w16') is not None and bd.conv_mode == 1 and lib.ds_conv_f16dma_supported(N, l.res_out, l.res_out, l.cin, 0, l.cout):
+                        up = bd.new16(N * l.res_out ** 2, l.cin)     # nearest x2 of the raw tensor, stored in fp16 for the matrix kernel
+                        bd.norm('apply', cur[0], l.cin, l.cin, N, l.res_in, l.res_in, p + '.nearest', use_stats=False,
+                                resample=DS_RESAMPLE_UP, out=up, out_ld=l.cin, out_f16=True)
+                        bd.conv(up, l.cin, l.cin, N, l.res_out, l.res_out, w[f'{p}.w'], l.cout, out, l.cout, 9, p + '.conv', bias=w[f'{p}.b'],
+                                stats=True, w16=w.get(f'{p}.w16'), in_f16=True)
+                    else:
+                        up = new(N * l.res_out ** 2, l.cin)
+                        bd.norm('apply', cur[0], l.cin, l.cin, N, l.res_in, l.res_in, p + '.nearest', use_stats=False,
+                                resample=DS_RESAMPLE_UP, out=up, out_ld=l.cin)
+                        bd.conv(up, l.cin, l.cin, N, l.res_out, l.res_out, w[f'{p}.w'], l.cout, out, l.cout, 9, p + '.conv', bias=w[f'{p}.b'],
+                                stats=True, w16=w.get(f'{p}.w16'))
                     cur = (out, l.cout)
                 bufs[p] = cur[0]
             if b.pushes_skip:
@@ -252,6 +291,14 @@ class LDMUNetEngine:
         assert not skips
         gn_conv(cur[0], cur[1], None, 0, R, w['out.g'], w['out.b'], 1e-5, w['outc.w'], w['outc.b'], spec.out_channels, bufs['out'], 4,
                 'out')
+        # The cross-attention key / value projections (ldm/modules/attention.py:168-176: to_k(context), to_v(context)) depend on the text
+        # context only -- not on x or sigma -- so they form their own small plan that CFGDenoiser runs once per context, not once per
+        # network evaluation (16 launches of 361 at SD-1.5 size)
+        from .plan import Plan
+        P.ctx = Plan()
+        P.ctx.ops = [op for op in P.ops if op.name.endswith('.attn2.kv')]
+        P.ops = [op for op in P.ops if not op.name.endswith('.attn2.kv')]
+        P.ctx_key = None
         self._plans[key] = P
         return P
 
@@ -314,6 +361,7 @@ class CFGDenoiser(CFGSchedule):
         self.img_resolution, self.img_channels, self.label_dim = spec.img_resolution, spec.in_channels, True
         CFGSchedule.__init__(self, spec)                                    # host tables (networks_edm.py:654-658)
         self.use_fp16 = bool(use_fp16)      # the reference's autocast mode (sample.py:296); fixed at construction
+        self.cache_context = True           # cross-attention K / V projections once per context tensor, not once per evaluation
 
     @classmethod
     def from_config(cls, name_or_kwargs, seed=0, device='cuda', **kw):
@@ -361,13 +409,22 @@ class CFGDenoiser(CFGSchedule):
             bufs['c_noise'].copy_(cn)
         cd = self.spec.context_dim
         parts = [unconditional_condition, cond] if doubled else [cond]
-        for i, c_ in enumerate(parts):
-            c_ = c_.to(device=self.device, dtype=torch.float32)
-            if c_.shape[0] == 1 and B > 1:
-                c_ = c_.expand(B, -1, -1)
-            c_ = c_.contiguous()
-            assert c_.shape == (B, L, cd), (c_.shape, (B, L, cd))
-            _lib.check(lib.ds_copy_rows(ptr(c_), cd, ptr(bufs['context'][i * B * L:]), cd, B * L, cd, st), 'copy context')
+        # context -> plan buffer and its key / value projections: once per context.  The cache key holds the caller's tensor OBJECTS
+        # (so their storage cannot be recycled under it) and their in-place-modification counters.
+        key = tuple((t, t._version) for t in parts)
+        old_key = plan.ctx_key
+        same = (self.cache_context and old_key is not None and len(old_key) == len(key)
+                and all(a[0] is b[0] and a[1] == b[1] for a, b in zip(old_key, key)))
+        if not same:
+            for i, c_ in enumerate(parts):
+                c_ = c_.to(device=self.device, dtype=torch.float32)
+                if c_.shape[0] == 1 and B > 1:
+                    c_ = c_.expand(B, -1, -1)
+                c_ = c_.contiguous()
+                assert c_.shape == (B, L, cd), (c_.shape, (B, L, cd))
+                _lib.check(lib.ds_copy_rows(ptr(c_), cd, ptr(bufs['context'][i * B * L:]), cd, B * L, cd, st), 'copy context')
+            plan.ctx.run(st)
+            plan.ctx_key = key
         plan.run(st)
         return bufs['out'], plan, doubled
 

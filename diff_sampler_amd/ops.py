@@ -17,7 +17,7 @@ from ._lib import ConvArgs, GemmArgs, NormArgs, UpdateArgs, DS_ACT_NONE, DS_RESA
 def _p(t: Optional[torch.Tensor]):
     if t is None:
         return None
-    assert t.is_cuda and t.dtype in (torch.float32, torch.uint8, torch.int32, torch.int64), (t.device, t.dtype)
+    assert t.is_cuda and t.dtype in (torch.float32, torch.float16, torch.uint8, torch.int32, torch.int64), (t.device, t.dtype)
     return C.c_void_p(t.data_ptr())
 
 

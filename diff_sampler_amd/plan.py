@@ -211,6 +211,7 @@ class Builder:
                                    ptr(scale), ptr(shift), ss_ld, ss_rows, ptr(self.mean), ptr(self.rstd), ptr(coefs))
                 self.add(self.lib.ds_gn_finalize, (C.byref(f),), name + '.finalize', keep=(f,))
                 return
+        assert not (kind == 'stats' and x0.dtype == torch.float16), 'statistics of an fp16 tensor come from its producer (ds_gn_finalize)'
         a = NormArgs(ptr(x0), ptr(x1), c0, c1, ld0, ld1, n, h, w, groups, eps, ptr(self.mean) if use_stats else None,
                      ptr(self.rstd) if use_stats else None, ptr(gamma), ptr(beta), ptr(scale), ptr(shift), ss_ld, ss_rows, act,
                      resample, ptr(out), out_ld, ptr(coefs))

@@ -241,7 +241,9 @@ typedef struct ds_norm_args {
     /* ds_norm_act only.  out_f16 = 1: `out` is an fp16 NHWC tensor [rows][out_ld] (out_ld in halfs, % 4 == 0) -- the activated tensor as
      * the reference's fp16 mode stores it (networks_edm.py:486), read by ds_conv2d_nhwc(in_f16).  raw_out (optional, with out_f16):
      * a second fp16 tensor [rows][raw_ld] that receives the UN-normalised (but resampled, concatenated) input -- the operand of a
-     * block's 1x1 skip projection (networks_edm.py:170) when that projection is fused into conv1 as extra K columns. */
+     * block's 1x1 skip projection (networks_edm.py:170) when that projection is fused into conv1 as extra K columns.
+     * With out_f16, a non-NULL `coefs` is an INPUT: the {mu, A, B} planes [n][3][c0+c1] a preceding ds_gn_finalize / ds_gn_stats wrote
+     * (mean / rstd / gamma / beta / scale / shift are then ignored). */
     int out_f16; void* raw_out; int raw_ld;
     /* ds_norm_act only.  in_f16 = 1: x0 is an fp16 tensor [rows][ld0 halfs] (c1 must be 0) -- a convolution output written with
      * ds_conv_args.out_f16. */

@@ -96,3 +96,34 @@ def test_ldm_samplers_match_golden(name, dev):
         ref = torch.from_numpy(z[f'traj_{tag}'])
         assert tr.shape == ref.shape
         assert _rel(tr.cpu(), ref) < 1e-3, tag
+
+
+def test_cross_attention_kv_projections_are_cached_per_context(dev):
+    """to_k(context) / to_v(context) (ldm/modules/attention.py:168-176) do not depend on x or sigma: they run once per context TENSOR, not
+    once per network evaluation.  Same results; a new tensor object, or an in-place change of the cached one, recomputes them."""
+    from diff_sampler_amd.ldm_engine import CFGDenoiser
+    z = np.load(os.path.join(G, 'ldm_tiny_ldm.npz'))
+    net = CFGDenoiser.from_config('tiny_ldm', seed=int(z['seed']), guidance_rate=7.5)
+    x, cond, uncond = (torch.from_numpy(z[k]).to(dev) for k in ('x', 'cond', 'uncond'))
+    f, plan, _ = net.raw(x, 1.9, cond, uncond)
+    assert len(plan.ctx.ops) > 0 and all(op.name.endswith('.attn2.kv') for op in plan.ctx.ops)
+    assert not any(op.name.endswith('.attn2.kv') for op in plan.ops)
+    a = net(x, 1.9, condition=cond, unconditional_condition=uncond).clone()
+    runs = []
+    real = plan.ctx.run
+    plan.ctx.run = lambda st: (runs.append(1), real(st))[1]
+    b = net(x, 1.9, condition=cond, unconditional_condition=uncond).clone()          # same tensors: projections reused
+    assert runs == [] and torch.equal(a, b)
+    net.cache_context = False
+    c = net(x, 1.9, condition=cond, unconditional_condition=uncond).clone()
+    assert runs == [1] and torch.equal(a, c)
+    net.cache_context = True
+    cond2 = cond.clone()                                                                # a different tensor object: recomputed
+    d = net(x, 1.9, condition=cond2, unconditional_condition=uncond).clone()
+    assert runs == [1, 1] and torch.equal(a, d)
+    cond2.mul_(0.5)                                                                     # in-place change of the cached tensor: recomputed
+    e = net(x, 1.9, condition=cond2, unconditional_condition=uncond).clone()
+    assert runs == [1, 1, 1] and not torch.equal(a, e)
+    ref = CFGDenoiser.from_config('tiny_ldm', seed=int(z['seed']), guidance_rate=7.5)
+    ref.cache_context = False
+    assert torch.equal(e, ref(x, 1.9, condition=cond2, unconditional_condition=uncond))
