@@ -50,7 +50,7 @@ class AttnArgs(C.Structure):
     _fields_ = [('q', vp), ('k', vp), ('v', vp), ('out', vp), ('ldq', C.c_int), ('ldk', C.c_int), ('ldv', C.c_int),
                 ('ldo', C.c_int), ('q_bs', C.c_longlong), ('k_bs', C.c_longlong), ('v_bs', C.c_longlong),
                 ('o_bs', C.c_longlong), ('batch', C.c_int), ('heads', C.c_int), ('sq', C.c_int), ('skv', C.c_int),
-                ('d', C.c_int), ('scale', C.c_float)]
+                ('d', C.c_int), ('scale', C.c_float), ('out_f16', C.c_int)]
 
 
 class GnFinalizeArgs(C.Structure):
@@ -98,7 +98,7 @@ class StemIm2colArgs(C.Structure):
 
 # ds_plan_add op codes (include/ds_engine.h)
 DS_OP_CONV2D, DS_OP_GEMM, DS_OP_GN_STATS, DS_OP_NORM_ACT, DS_OP_GN_FINALIZE, DS_OP_ATTENTION, DS_OP_ATTENTION_F16, DS_OP_LAYERNORM, \
-    DS_OP_GEGLU, DS_OP_NOISE_EMBED, DS_OP_STEM_IM2COL = range(1, 12)
+    DS_OP_GEGLU, DS_OP_NOISE_EMBED, DS_OP_STEM_IM2COL, DS_OP_LAYERNORM_F16 = range(1, 13)
 
 _SIGNATURES = {
     'ds_version': (C.c_int, []),
@@ -112,6 +112,7 @@ _SIGNATURES = {
     'ds_conv3x3_halo_supported': (C.c_int, [C.c_int, C.c_int]),
     'ds_conv_f16_supported': (C.c_int, [C.c_int] * 7),
     'ds_conv_f16dma_supported': (C.c_int, [C.c_int] * 6),
+    'ds_gemm_f16dma_supported': (C.c_int, [C.c_longlong, C.c_int, C.c_int]),
     'ds_debug_f16dma_nb': (C.c_int, [C.c_int]),
     'ds_debug_f16dma_ablate': (C.c_int, [C.c_int]),
     'ds_conv_split_supported': (C.c_int, [C.c_int] * 7),
@@ -126,6 +127,7 @@ _SIGNATURES = {
     'ds_attention_f16': (C.c_int, [C.POINTER(AttnArgs), vp]),
     'ds_attention_f16_supported': (C.c_int, [C.c_int]),
     'ds_layernorm_rows': (C.c_int, [vp, C.c_int, vp, vp, C.c_float, vp, C.c_int, C.c_longlong, C.c_int, vp]),
+    'ds_layernorm_rows_f16': (C.c_int, [vp, C.c_int, vp, vp, C.c_float, vp, C.c_int, C.c_longlong, C.c_int, vp]),
     'ds_geglu': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_longlong, C.c_int, vp]),
     'ds_cfg_denoise': (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     'ds_noise_embed': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp]),

@@ -229,8 +229,14 @@ __global__ void __launch_bounds__(512) flash_attn_f16_kernel(const ds_attn_args 
             f32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = patch[q * 33 + c4 + j];
-            if (q0 + q < a.sq && i * 32 + c4 < D)
+            if (q0 + q < a.sq && i * 32 + c4 < D) {
+                if (a.out_f16) {
+                    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+                    const h4_t hv = {(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+                    *reinterpret_cast<h4_t*>(reinterpret_cast<_Float16*>(a.out) + (size_t)b * a.o_bs + h * D + (size_t)(q0 + q) * a.ldo + i * 32 + c4) = hv;
+                } else
                 *reinterpret_cast<f32x4*>(op + (size_t)(q0 + q) * a.ldo + i * 32 + c4) = o;
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }

@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
                 frag_read(P, a_addr(0, T9 + 1) + hoff, a_addr(1, T9 + 1) + hoff, bbase + nwoff);
             }
         }
-        if (abl & 8) { DS2_FENCE(); mfma_group(Q); DS2_FENCE(); }         // (A/B: MFMAs first, DMA issue in their shadow -- measured slower)
+        DS2_FENCE(); mfma_group(Q); DS2_FENCE();      // (A/B in one session, profiles/r3_conv_f16dma_ablations.txt: +2 % over issuing the DMA first)
         if (kt + 2 < KT) w_dma(kt + 2, kt & 1);
         if constexpr (SLAB_END) {
             if (chunk + 2 < NCH) {
@@ -231,7 +231,6 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
             if (chunk + 1 < NCH) halo_dma(chunk + 1, (chunk + 1) & 1, IC<T9 + 1>{});
         }
         DS2_FENCE();
-        if (!(abl & 8)) { mfma_group(Q); DS2_FENCE(); }
         ++kt;
     };
     int chunk = 0;
@@ -261,7 +260,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
 
 }  // namespace
 int g_f16dma_ablate = 0;        // benchmarks only: bit 0 = no weight DMA after the prologue, 1 = no halo DMA after slab 0, 2 = no epilogue,
-                                // 3 = last K step's MFMAs before the DMA issue, 4 = no per-tap barrier, 5 = no fragment reads
+                                // 4 = no per-tap barrier, 5 = no fragment reads
 namespace {
 
 template <int W, int NB>

@@ -301,9 +301,10 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     if (a->taps != 1 && a->taps != 9) return DS_E_ARG;
     if (a->c0 <= 0 || a->c0 % 32 || a->c1 < 0 || a->c1 % 32) return DS_E_SHAPE;
     if (a->c1 && !a->x1) return DS_E_ARG;
-    if (a->out_f16 && (!a->in_f16 || (a->cout & 63) || (a->out_ld & 3) || a->act == DS_ACT_GEGLU)) return DS_E_ARG;   // fp16 output: the fp16-activation kernel only
-    if (a->in_f16) {          // fp16 activations: pure matrix kernel (conv3x3_f16dma.hip); ld in halfs, 16-byte chunks
-        if (a->wgt_f16 != 1 || a->taps != 9 || a->c1 || a->ec1 || a->norm_coefs || a->out_nchw || (a->stride && a->stride != 1)) return DS_E_ARG;
+    if (a->out_f16 && (!a->in_f16 || (a->cout & 63) || (a->out_ld & 3))) return DS_E_ARG;   // fp16 output rows: the fp16-activation kernels only
+    if (a->in_f16) {          // fp16 activations: pure matrix kernels (conv3x3_f16dma.hip / gemm_f16dma.hip); ld in halfs, 16-byte chunks
+        if (a->wgt_f16 != 1 || a->c1 || a->ec1 || a->norm_coefs || a->out_nchw || (a->stride && a->stride != 1)) return DS_E_ARG;
+        if (a->taps == 1 && a->ec0) return DS_E_ARG;
         if ((a->ld0 & 7) || (a->ec0 && ((a->eld0 & 7) || !a->e0 || !ds_aligned16(a->e0)))) return DS_E_ALIGN;
     }
     if ((a->ld0 & 3) || (a->c1 && (a->ld1 & 3))) return DS_E_ALIGN;
@@ -359,6 +360,11 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
             if (a->wgt_shift) return DS_E_ARG;
             p.ldb = p.K / 2;
             p.part = nullptr; p.part_cap = 0; p.splits = 1;
+            if (a->in_f16) {            // fp16 activations: both operands by LDS-DMA
+                p.out_f16 = a->out_f16 ? 1 : 0;
+                if (!gemm_f16dma_applicable(p)) return DS_E_SHAPE;
+                return launch_gemm_f16dma(p, (hipStream_t)stream);
+            }
             if (!gemm_f16_applicable(p)) return DS_E_SHAPE;
             return launch_gemm_f16(p, (hipStream_t)stream);
         }
@@ -399,7 +405,7 @@ extern "C" int ds_conv_kernel_id(const ds_conv_args* a) {
     p.vec_ok = (vec_epilogue_ok(p) && !a->out_nchw) ? 1 : 0;
     p.stride = a->stride ? a->stride : 1; p.K = a->taps * (a->c0 + a->c1) + a->ec0 + a->ec1; p.norm = a->norm_coefs;
     p.nrows_b = ((a->cout + BN - 1) / BN) * BN;                                     // weights are row-padded, as in ds_conv2d_nhwc
-    if (a->wgt_f16 == 1 && a->in_f16) return 2566;
+    if (a->wgt_f16 == 1 && a->in_f16) return a->taps == 1 ? 2567 : 2566;
     if (a->wgt_f16) return a->wgt_f16 == 2 ? 2563 : (a->taps == 1 ? 2564 : 2562);
     if (g_force_generic) return 0;
     if (a->taps != 9 || a->stride > 1) return (g_use_dma8 && gemm_dma8_applicable(p)) ? 2561 : 0;
@@ -419,6 +425,12 @@ extern "C" int ds_conv_f16dma_supported(int n, int h, int w, int c0, int ec0, in
     p.taps = 9; p.stride = 1; p.H = h; p.W = w; p.HW = h * w; p.M = n * h * w; p.N = cout; p.c0 = c0; p.ec0 = ec0;
     p.vec_ok = 1; p.nrows_b = ((cout + BN - 1) / BN) * BN;
     return conv3x3_f16dma_applicable(p) ? 1 : 0;
+}
+extern "C" int ds_gemm_f16dma_supported(long long rows, int k, int cout) {
+    KParams p{};
+    if (rows > 0x7fffffffLL || rows < 1) return 0;
+    p.taps = 1; p.stride = 1; p.M = (int)rows; p.N = cout; p.K = k; p.c0 = k; p.vec_ok = 1; p.nrows_b = ((cout + BN - 1) / BN) * BN;
+    return gemm_f16dma_applicable(p) ? 1 : 0;
 }
 extern "C" int ds_debug_f16dma_nb(int nb) { const int o = g_f16dma_nb; g_f16dma_nb = nb; return o; }
 extern "C" int ds_debug_f16dma_ablate(int mask) { const int o = g_f16dma_ablate; g_f16dma_ablate = mask; return o; }

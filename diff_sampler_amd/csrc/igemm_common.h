@@ -112,6 +112,11 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
                         const f32x4 gt = *reinterpret_cast<const f32x4*>(stage + rr * EPI_LD + c4 + 32) + cbg;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[q] *= 0.5f * gt[q] * (1.0f + erff(gt[q] * 0.70710678118654752440f));
+                        if (p.out_f16) {
+                            typedef _Float16 h4g_t __attribute__((ext_vector_type(4)));
+                            const h4g_t hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                            *reinterpret_cast<h4g_t*>(reinterpret_cast<_Float16*>(o_base) + (size_t)row * p.ldo + (wn0 >> 1) + c4) = hv;
+                        } else
                         *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + (wn0 >> 1) + c4) = v;
                     }
                     continue;
@@ -367,6 +372,10 @@ extern long long g_halo2_launches;
 bool conv3x3_f16dma_applicable(const KParams& p);
 int launch_conv3x3_f16dma(KParams& p, hipStream_t stream);
 extern int g_f16dma_nb, g_f16dma_ablate;
+
+// gemm_f16dma.hip: 1x1 / Linear on fp16 activations (both operands by LDS-DMA)
+bool gemm_f16dma_applicable(const KParams& p);
+int launch_gemm_f16dma(KParams& p, hipStream_t stream);
 
 // gemm_f16.hip: 1x1 / Linear with fp16 operands (A rounded while staged, W packed fp16)
 bool gemm_f16_applicable(const KParams& p);

@@ -290,6 +290,7 @@ __global__ void channel_mean_kernel(const float* __restrict__ x, int ld, int c, 
 // --------------------------------------------------------------------------------------------------------------
 // LayerNorm over the channel dimension of token rows: one wave per row, the row lives in registers (<= 8 float4 per
 // lane), two-pass mean / variance like ATen's row-wise moments.
+template <bool OUT16>
 __global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps, float* __restrict__ y, int ldy,
                                                              long long rows, int cols) {
@@ -330,6 +331,11 @@ __global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __rest
             f32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+            if (OUT16) {
+                typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+                const h4_t hv = {(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+                *reinterpret_cast<h4_t*>(reinterpret_cast<_Float16*>(y) + row * ldy + idx * 4) = hv;
+            } else
             *reinterpret_cast<f32x4*>(yr + idx * 4) = o;
         }
     }
@@ -537,8 +543,22 @@ extern "C" int ds_layernorm_rows(const float* x, int ldx, const float* gamma, co
     if ((ldx & 3) || (ldy & 3) || !ds_aligned16(x) || !ds_aligned16(y) || !ds_aligned16(gamma) || !ds_aligned16(beta)) return DS_E_ALIGN;
     const long long blocks = (rows + 3) / 4;
     if (blocks > 0x7fffffffLL) return DS_E_SHAPE;
-    hipLaunchKernelGGL(layernorm_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, eps, y,
+    hipLaunchKernelGGL(layernorm_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, eps, y,
                        ldy, rows, cols);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+extern "C" int ds_layernorm_rows_f16(const float* x, int ldx, const float* gamma, const float* beta, float eps, void* y16, int ldy,
+                                     long long rows, int cols, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !gamma || !beta || !y16 || rows <= 0 || cols <= 0) return DS_E_ARG;
+    if ((cols & 3) || cols > 2048) return DS_E_SHAPE;
+    if ((ldx & 3) || (ldy & 3) || !ds_aligned16(x) || (reinterpret_cast<uintptr_t>(y16) & 7u) || !ds_aligned16(gamma) || !ds_aligned16(beta)) return DS_E_ALIGN;
+    const long long blocks = (rows + 3) / 4;
+    if (blocks > 0x7fffffffLL) return DS_E_SHAPE;
+    hipLaunchKernelGGL(layernorm_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, eps,
+                       reinterpret_cast<float*>(y16), ldy, rows, cols);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }

@@ -174,6 +174,8 @@ class UNetEngine:
             a16_buf, b16_buf, r16_buf, h16_buf = (bd.new16(B * max_act) for _ in range(4))
         if max_attn:
             n2 = new(B * max_attn // 2); qk = new(B * max_attn // 2 * 3); ao = new(B * max_attn // 2)
+            if self.conv_mode == 1:
+                n2_16, ao_16 = bd.new16(B * max_attn // 2), bd.new16(B * max_attn // 2)
         bufs.update(act=act, hbuf=hbuf, sres=sres, sproj=sproj)
         # ---- launch emitters: plan.Builder (shared with ldm_engine); thin adapters keep this file's argument names --------------
         f16_level = bd.f16_level
@@ -335,14 +337,19 @@ class UNetEngine:
                 S = Ho * Ho
                 hd = b.heads
                 ch = cout // hd
+                f16_attn = self.conv_mode == 1 and lib.ds_attention_f16_supported(ch)     # networks_edm.py:98-110 with fp16 q / k / v
+                # fp16 mode: the GroupNorm output and the attention output are only operands of the qkv / proj 1x1s -> fp16 rows,
+                # streamed by the fp16-activation GEMM (csrc/gemm_f16dma.hip)
+                a16 = bool(f16_attn and lib.ds_gemm_f16dma_supported(M, cout, 3 * cout) and lib.ds_gemm_f16dma_supported(M, cout, cout))
+                n2_, ao_ = (n2_16[:M * cout].view(M, cout), ao_16[:M * cout].view(M, cout)) if a16 else (n2, ao)
                 norm('stats', out, cout, cout, n, Ho, Ho, nm + '.norm2.stats', groups=G_out, eps=b.eps)
                 norm('apply', out, cout, cout, n, Ho, Ho, nm + '.norm2', groups=G_out, eps=b.eps, gamma=w[f'{nm}.norm2.g'],
-                     beta=w[f'{nm}.norm2.b'], out=n2, out_ld=cout)
-                conv(n2, cout, cout, n, Ho, Ho, w[f'{nm}.qkv.w'], 3 * cout, qk, 3 * cout, 1, nm + '.qkv', bias=w[f'{nm}.qkv.b'])
+                     beta=w[f'{nm}.norm2.b'], out=n2_, out_ld=cout, out_f16=a16)
+                conv(n2_, cout, cout, n, Ho, Ho, w[f'{nm}.qkv.w'], 3 * cout, qk, 3 * cout, 1, nm + '.qkv', bias=w[f'{nm}.qkv.b'])
                 # softmax(Q K^T / sqrt(ch)) V per (image, head), scores kept on chip (networks_edm.py:171-176)
-                at = AttnArgs(_ptr(qk), _ptr(qk[cout:]), _ptr(qk[2 * cout:]), _ptr(ao), 3 * cout, 3 * cout, 3 * cout, cout,
+                at = AttnArgs(_ptr(qk), _ptr(qk[cout:]), _ptr(qk[2 * cout:]), _ptr(ao_), 3 * cout, 3 * cout, 3 * cout, cout,
                               S * 3 * cout, S * 3 * cout, S * 3 * cout, S * cout, B, hd, S, S, ch, 1.0 / math.sqrt(ch))
-                f16_attn = self.conv_mode == 1 and lib.ds_attention_f16_supported(ch)     # networks_edm.py:98-110 with fp16 q / k / v
+                at.out_f16 = 1 if a16 else 0
                 add(lib.ds_attention_f16 if f16_attn else lib.ds_attention, (C.byref(at),), nm + '.attention', keep=(at,))
                 if b.pushes_skip:
                     out2 = new(M, cout)
@@ -351,7 +358,7 @@ class UNetEngine:
                         dec_pp[dec_i] = new(B * max_h)
                     out2 = dec_pp[dec_i]
                     dec_i ^= 1
-                conv(ao, cout, cout, n, Ho, Ho, w[f'{nm}.proj.w'], cout, out2, cout, 1, nm + '.proj', bias=w[f'{nm}.proj.b'],
+                conv(ao_, cout, cout, n, Ho, Ho, w[f'{nm}.proj.w'], cout, out2, cout, 1, nm + '.proj', bias=w[f'{nm}.proj.b'],
                      res=out, res_ld=cout, scale=b.skip_scale, stats=True)
                 out = out2
             x_cur = (out, cout)

@@ -214,10 +214,17 @@ class LDMUNetEngine:
             M = N * S
             d = c // hd
             L = ctx_len
-            n2, t0, ln, ao = new(M, c), new(M, c), new(M, c), new(M, c)
+            # fp16 mode: tensors that are only the operand of the next projection -- the GroupNorm output, the three LayerNorm outputs,
+            # both attention outputs, the GEGLU product -- are stored as fp16 rows and streamed by the fp16-activation GEMM
+            # (csrc/gemm_f16dma.hip); the residual stream t0 .. t3 and q / k / v stay fp32
+            h16 = bool(bd.conv_mode == 1 and lib.ds_attention_f16_supported(d) and lib.ds_gemm_f16dma_supported(M, c, c)
+                       and lib.ds_gemm_f16dma_supported(M, c, 3 * c) and lib.ds_gemm_f16dma_supported(M, c, 8 * c)
+                       and lib.ds_gemm_f16dma_supported(M, 4 * c, c))
+            mk = bd.new16 if h16 else new
+            n2, t0, ln, ao = mk(M, c), new(M, c), mk(M, c), mk(M, c)
             bd.norm('stats', x_in, c, c, N, res, res, p + '.norm.stats', groups=32, eps=1e-6)
             bd.norm('apply', x_in, c, c, N, res, res, p + '.norm', groups=32, eps=1e-6, gamma=w[f'{p}.n.g'], beta=w[f'{p}.n.b'],
-                    out=n2, out_ld=c)
+                    out=n2, out_ld=c, out_f16=h16)
             bd.conv(n2, c, c, N, res, res, w[f'{p}.pi.w'], c, t0, c, 1, p + '.proj_in', bias=w[f'{p}.pi.b'])
             # self-attention
             qkv, t1 = new(M, 3 * c), new(M, c)
@@ -235,7 +242,7 @@ class LDMUNetEngine:
                          q_bs=S * c, k_bs=L * 2 * c, v_bs=L * 2 * c, o_bs=S * c, scale=d ** -0.5)
             bd.linear(ao, c, M, w[f'{p}.attn2.o.w'], c, t2, p + '.attn2.to_out', bias=w[f'{p}.attn2.o.b'], res=t1, res_ld=c)
             # GEGLU feed-forward
-            gg, t3 = new(M, 4 * c), new(M, c)
+            gg, t3 = mk(M, 4 * c), new(M, c)
             bd.layernorm(t2, c, w[f'{p}.norm3.g'], w[f'{p}.norm3.b'], 1e-5, ln, c, M, c, p + '.norm3')
             bd.linear(ln, c, M, w[f'{p}.ff0.w'], 8 * c, gg, p + '.ff.proj_geglu', out_ld=4 * c, bias=w[f'{p}.ff0.b'], act=DS_ACT_GEGLU)
             bd.linear(gg, 4 * c, M, w[f'{p}.ff2.w'], c, t3, p + '.ff.out', bias=w[f'{p}.ff2.b'], res=t2, res_ld=c)

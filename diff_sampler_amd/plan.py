@@ -88,7 +88,8 @@ def _native_plan(ops):
               id(lib.ds_norm_act): _lib.DS_OP_NORM_ACT, id(lib.ds_gn_finalize): _lib.DS_OP_GN_FINALIZE,
               id(lib.ds_attention): _lib.DS_OP_ATTENTION, id(lib.ds_attention_f16): _lib.DS_OP_ATTENTION_F16}
     by_val = {id(lib.ds_layernorm_rows): (_lib.DS_OP_LAYERNORM, _lib.LayerNormArgs), id(lib.ds_geglu): (_lib.DS_OP_GEGLU, _lib.GegluArgs),
-              id(lib.ds_noise_embed): (_lib.DS_OP_NOISE_EMBED, _lib.NoiseEmbedArgs), id(lib.ds_stem_im2col): (_lib.DS_OP_STEM_IM2COL, _lib.StemIm2colArgs)}
+              id(lib.ds_noise_embed): (_lib.DS_OP_NOISE_EMBED, _lib.NoiseEmbedArgs), id(lib.ds_stem_im2col): (_lib.DS_OP_STEM_IM2COL, _lib.StemIm2colArgs),
+              id(lib.ds_layernorm_rows_f16): (_lib.DS_OP_LAYERNORM_F16, _lib.LayerNormArgs)}
     h = C.c_void_p()
     _lib.check(lib.ds_plan_create(C.byref(h)), 'ds_plan_create')
     try:
@@ -147,7 +148,13 @@ class Builder:
         geometry supports it (f16_level), else the fp32 weights `wgt` are.
         in_f16: x0 (and e0) are fp16 NHWC tensors (leading dimensions in halfs) written by ``norm(..., out_f16=True)``: the
         fp16-activation kernel (csrc/conv3x3_f16dma.hip); needs w16."""
-        if in_f16:
+        if taps == 1 and x0.dtype == torch.float16:
+            # 1x1 / Linear on an fp16 tensor (LayerNorm / GroupNorm pass / attention / GEGLU output in fp16 mode): csrc/gemm_f16dma.hip
+            assert x1 is None and not ec0 and norm_coefs is None and not out_nchw and stride == 1
+            wgt, ok = self.linear_w16(wgt, n * h * w, c0, 0, dma=True, cout=cout)
+            assert ok, (name, 'no fp16-activation GEMM for this shape')
+            w16, in_f16 = (wgt, 0), True
+        elif in_f16:
             assert w16 is not None and taps == 9 and stride == 1 and x1 is None and e1 is None and norm_coefs is None and not out_nchw
         f16 = in_f16 or w16 is not None and taps == 9 and stride == 1 and self.f16_level(n, h, w, c0, c1, ec0, ec1) >= (2 if norm_coefs is not None else 1)
         shift = 0
@@ -164,7 +171,7 @@ class Builder:
         a.out_nchw = out_nchw               # network output written channel-planar (NCHW) by the epilogue
         a.wgt_f16, a.wgt_shift = (self.conv_mode, shift) if f16 else (0, 0)
         a.in_f16 = 1 if in_f16 else 0
-        if out_f16:          # fp16 output rows (a tensor that only feeds a normalisation pass): the fp16-activation kernel's epilogue
+        if out_f16 or out.dtype == torch.float16:          # fp16 output rows (a tensor that only feeds a normalisation pass or a projection)
             assert in_f16 and out.dtype == torch.float16 and cout % 64 == 0
             a.out_f16 = 1
         self.stats_of.pop(out.data_ptr(), None)
@@ -174,11 +181,11 @@ class Builder:
             self.stats_of[out.data_ptr()] = (sb, cout)
         self.add(self.lib.ds_conv2d_nhwc, (C.byref(a),), name, keep=(a,))
 
-    def linear_w16(self, wgt, rows, c0, c1):
+    def linear_w16(self, wgt, rows, c0, c1, dma=False, cout=0):
         """(weights, use the fp16-operand GEMM?) of a 1x1 / Linear layer in fp16 mode: the fp16 packing of `wgt` (cached per weight
         tensor) where gemm_f16_kernel covers the shape, else the fp32 weights unchanged."""
-        if wgt.dtype != torch.float32 or wgt.dim() != 2 or wgt.shape[0] % 128 or wgt.shape[1] != c0 + c1 \
-                or not self.lib.ds_gemm_f16_supported(rows, c0, c1):
+        ok = self.lib.ds_gemm_f16dma_supported(rows, c0, cout) if dma else self.lib.ds_gemm_f16_supported(rows, c0, c1)
+        if wgt.dtype != torch.float32 or wgt.dim() != 2 or wgt.shape[0] % 128 or wgt.shape[1] != c0 + c1 or not ok:
             return wgt, False
         key = wgt.data_ptr()
         if key not in self.w16_cache:
@@ -238,10 +245,14 @@ class Builder:
     def attention(self, q, k, v, out, name, *, batch, heads, sq, skv, d, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, scale):
         a = AttnArgs(ptr(q), ptr(k), ptr(v), ptr(out), ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, batch, heads, sq, skv, d, scale)
         f16 = self.conv_mode == 1 and self.lib.ds_attention_f16_supported(d)      # fp16 mode: fp16-operand kernel where it covers the head size
+        if out.dtype == torch.float16:
+            assert f16, 'fp16 attention output needs the fp16-operand kernel'
+            a.out_f16 = 1
         self.add(self.lib.ds_attention_f16 if f16 else self.lib.ds_attention, (C.byref(a),), name, keep=(a,))
 
     def layernorm(self, x, ldx, gamma, beta, eps, y, ldy, rows, cols, name):
-        self.add(self.lib.ds_layernorm_rows, (ptr(x), ldx, ptr(gamma), ptr(beta), eps, ptr(y), ldy, rows, cols), name)
+        fn = self.lib.ds_layernorm_rows_f16 if y.dtype == torch.float16 else self.lib.ds_layernorm_rows
+        self.add(fn, (ptr(x), ldx, ptr(gamma), ptr(beta), eps, ptr(y), ldy, rows, cols), name)
 
     def geglu(self, x, ldx, y, ldy, rows, inner, name):
         self.add(self.lib.ds_geglu, (ptr(x), ldx, ptr(y), ldy, rows, inner), name)

@@ -114,7 +114,7 @@ typedef struct ds_conv_args {
      * (keeps hi and lo in fp16's normal range); the epilogue multiplies the accumulators by 2**-wgt_shift.  Available where
      * ds_conv_split_supported() says so, else DS_E_SHAPE. */
     int wgt_shift;
-    /* 1 (with wgt_f16 == 1, taps == 9): THE INPUT IS fp16 -- x0 (and e0) point to fp16 NHWC tensors [M][ld0] (ld0 / eld0 in halfs,
+    /* 1 (with wgt_f16 == 1; taps == 9, or taps == 1 = csrc/gemm_f16dma.hip with the plain-K fp16 weights of the Linear layers): THE INPUT IS fp16 -- x0 (and e0) point to fp16 NHWC tensors [M][ld0] (ld0 / eld0 in halfs,
      * multiples of 8; c0 % 64 == 0, c1 == ec1 == 0), already normalised / activated by ds_norm_act(out_f16) -- the reference's storage
      * type in this mode (networks_edm.py:486 runs the U-Net body on x.to(float16)).  The convolution is then a pure matrix kernel
      * (csrc/conv3x3_f16dma.hip: both operands staged by LDS-DMA, 256-pixel x 64/128/192/256-channel tiles).  norm_coefs must be NULL.
@@ -147,10 +147,13 @@ int ds_conv3x3_halo_supported(int h, int w);
 int ds_conv_f16_supported(int n, int h, int w, int c0, int c1, int ec0, int ec1);
 /* 1 when a 3x3 layer of this geometry runs on the fp16-activation kernel (ds_conv_args.in_f16). */
 int ds_conv_f16dma_supported(int n, int h, int w, int c0, int ec0, int cout);
+/* 1 when a 1x1 / Linear layer [rows][k] -> [rows][cout] runs on the fp16-activation GEMM (in_f16 with taps == 1, csrc/gemm_f16dma.hip). */
+int ds_gemm_f16dma_supported(long long rows, int k, int cout);
 /* benchmarks / tests: force the column-tile width (64 * nb columns, nb = 1..4; 0 = cost model) of the fp16-activation kernel; returns the previous value */
 int ds_debug_f16dma_nb(int nb);
 /* benchmarks only (results are WRONG when set): timing ablations of the fp16-activation kernel -- bit 0: no weight DMA after the
- * prologue, bit 1: no halo DMA after the first slab, bit 2: no epilogue; returns the previous mask */
+ * prologue, bit 1: no halo DMA after the first slab, bit 2: no epilogue, bit 4: no per-tap barrier, bit 5: no LDS fragment reads;
+ * returns the previous mask */
 int ds_debug_f16dma_ablate(int mask);
 
 /* 1x1 convolution / Linear with fp16 operands (wgt_f16 == 1 and taps == 1: `wgt` = [cout_pad][K] halfs in plain K order; the fp32
@@ -283,6 +286,7 @@ typedef struct ds_attn_args {
     long long q_bs, k_bs, v_bs, o_bs;
     int batch, heads, sq, skv, d;
     float scale;
+    int out_f16;     /* ds_attention_f16 only: `out` is an fp16 tensor (ldo / o_bs in halfs): the operand of the output projection in fp16 mode */
 } ds_attn_args;
 
 int ds_attention(const ds_attn_args* a, void* stream);
@@ -300,6 +304,10 @@ int ds_attention_f16_supported(int d);
  * * gamma + beta, cols % 4 == 0, cols <= 2048. */
 int ds_layernorm_rows(const float* x, int ldx, const float* gamma, const float* beta, float eps, float* y, int ldy,
                       long long rows, int cols, void* stream);
+/* The same with an fp16 output tensor y16[rows][ldy halfs] (rounded to nearest even): in fp16 / autocast mode the LayerNorm output is only
+ * the operand of the following projection (torch.autocast casts nn.Linear inputs to fp16). */
+int ds_layernorm_rows_f16(const float* x, int ldx, const float* gamma, const float* beta, float eps, void* y16, int ldy,
+                          long long rows, int cols, void* stream);
 
 /* GEGLU gate (ldm/modules/attention.py:45-52): y[r, c] = x[r, c] * gelu(x[r, inner + c]) with the exact (erf) GELU. */
 int ds_geglu(const float* x, int ldx, float* y, int ldy, long long rows, int inner, void* stream);
@@ -488,7 +496,8 @@ enum { DS_OP_CONV2D = 1,        /* ds_conv_args        -> ds_conv2d_nhwc      */
        DS_OP_LAYERNORM = 8,     /* ds_layernorm_args   -> ds_layernorm_rows   */
        DS_OP_GEGLU = 9,         /* ds_geglu_args       -> ds_geglu            */
        DS_OP_NOISE_EMBED = 10,  /* ds_noise_embed_args -> ds_noise_embed      */
-       DS_OP_STEM_IM2COL = 11   /* ds_stem_im2col_args -> ds_stem_im2col      */ };
+       DS_OP_STEM_IM2COL = 11,  /* ds_stem_im2col_args -> ds_stem_im2col      */
+       DS_OP_LAYERNORM_F16 = 12 /* ds_layernorm_args   -> ds_layernorm_rows_f16 (y = fp16 rows) */ };
 
 typedef struct ds_plan ds_plan;
 int ds_plan_create(ds_plan** out);

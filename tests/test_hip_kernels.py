@@ -983,3 +983,104 @@ def test_conv_f16_output_rows_and_norm_pass_on_fp16_tensors():
     hr = h16.float().reshape(B, H * H, 32, cout // 32)
     y2 = F.silu(((hr - mean.reshape(B, 1, 32, 1)) * rstd.reshape(B, 1, 32, 1)).reshape(M, cout))
     assert _rel(b16.float().cpu(), y2.to(torch.float16).float().cpu()) < 1e-3
+
+
+GEMM_F16DMA_CASES = [
+    # rows, k, cout, forced nb, epilogue ('plain' | 'res' | 'geglu' | 'f16out' | 'stats')
+    (256, 64, 64, 0, 'plain'),
+    (1000, 320, 960, 0, 'plain'),            # ragged row count, 960 = 3 x 256 + 192 / 5 x 192
+    (512, 320, 320, 3, 'res'),
+    (4096, 640, 640, 4, 'stats'),
+    (300, 1280, 1280, 2, 'res'),
+    (2048, 320, 2560, 4, 'geglu'),           # SD-1.5 ff.net.0.proj with the gate in the epilogue
+    (1024, 320, 2560, 2, 'geglu_f16out'),
+    (777, 384, 1152, 0, 'f16out'),
+    (128, 768, 768, 1, 'res'),
+]
+
+
+@pytest.mark.parametrize('case', GEMM_F16DMA_CASES)
+def test_gemm_f16_activations_dma_kernel(case):
+    """1x1 / Linear on an fp16 tensor (ds_conv_args.in_f16 with taps == 1, csrc/gemm_f16dma.hip) against the same arithmetic on the CPU
+    (fp16 operands, fp64 sums): 2e-5 of the output scale; fp16 output rows equal the rounded fp32 result up to one fp16 ulp."""
+    import ctypes as C
+    from diff_sampler_amd import _lib, ops
+    rows, k, cout, nb, mode = case
+    lib = _lib.load()
+    assert lib.ds_gemm_f16dma_supported(rows, k, cout) == 1
+    g = torch.Generator().manual_seed(rows + k + cout)
+    x = torch.randn(rows, k, generator=g).to(torch.float16)
+    wt = torch.randn(cout, k, generator=g) / k ** 0.5
+    bias = torch.randn(cout, generator=g)
+    res = torch.randn(rows, cout, generator=g)
+    dev = 'cuda'
+    geglu, f16out = mode.startswith('geglu'), mode.endswith('f16out')
+    h16 = lambda t: t.to(torch.float16).to(torch.float64)
+    y = x.double() @ h16(wt).t() + bias.double()
+    if geglu:
+        inner = cout // 2
+        val = torch.arange(inner).reshape(-1, 32)
+        perm = torch.stack([val, val + inner], 1).reshape(-1)                              # [32 values | their 32 gates] per 64-row block
+        wp = ops.pack_linear_weight_f16(ops.pack_linear_weight(wt[perm].to(dev)))
+        bp = bias[perm].contiguous()
+        ref = (y[:, :inner] * F.gelu(y[:, inner:])).float()
+        ocols = inner
+    else:
+        wp = ops.pack_linear_weight_f16(ops.pack_linear_weight(wt.to(dev)))
+        bp = bias
+        ref = ((y + res.double()) * 0.7071).float() if mode == 'res' else y.float()
+        ocols = cout
+    out = torch.full((rows, ocols), float('nan'), dtype=torch.float16 if f16out else torch.float32, device=dev)
+    xd, bd_, resd = x.to(dev), bp.to(dev), res.to(dev)
+    stats = torch.full((-(-rows // 64) * 2 * cout,), float('nan'), device=dev) if mode == 'stats' else None
+    a = _lib.ConvArgs(xd.data_ptr(), None, k, 0, k, 0, rows, 1, 1, 1, wp.data_ptr(), cout, bd_.data_ptr(), None, 0, 1,
+                      resd.data_ptr() if mode == 'res' else None, cout, 0.7071 if mode == 'res' else 1.0, 2 if geglu else 0, out.data_ptr(), ocols)
+    a.wgt_f16, a.in_f16, a.out_f16 = 1, 1, int(f16out)
+    if stats is not None:
+        a.stats_out = stats.data_ptr()
+    assert lib.ds_conv_kernel_id(C.byref(a)) == 2567
+    prev = lib.ds_debug_f16dma_nb(nb)
+    try:
+        rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
+        torch.cuda.synchronize()
+    finally:
+        lib.ds_debug_f16dma_nb(prev)
+    assert rc == 0, lib.ds_error_string(rc)
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    if f16out:
+        assert _rel(got, ref.to(torch.float16).float()) < 1.5e-3
+    else:
+        assert _rel(got, ref) < 2e-5
+    if stats is not None and rows % 64 == 0:
+        st = stats.cpu().reshape(-1, 2, cout)
+        assert _rel(st[:, 0], got.reshape(-1, 64, cout).sum(1)) < 1e-5
+
+
+def test_layernorm_and_attention_fp16_outputs():
+    """ds_layernorm_rows_f16 and ds_attention_f16 with out_f16: the fp32 results rounded to nearest even."""
+    import ctypes as C
+    from diff_sampler_amd import _lib, ops
+    lib = _lib.load()
+    dev = 'cuda'
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(300, 320, generator=g).to(dev)
+    gm, bt = (1 + 0.1 * torch.randn(320, generator=g)).to(dev), (0.1 * torch.randn(320, generator=g)).to(dev)
+    y32, y16 = torch.empty(300, 320, device=dev), torch.empty(300, 320, dtype=torch.float16, device=dev)
+    ops.layernorm_rows(x, 320, gm, bt, 1e-5, y32, 320, 300, 320)
+    rc = lib.ds_layernorm_rows_f16(x.data_ptr(), 320, gm.data_ptr(), bt.data_ptr(), 1e-5, y16.data_ptr(), 320, 300, 320, _lib.stream_ptr())
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.equal(y16, y32.to(torch.float16))
+    B, S, hd, d = 2, 256, 4, 40
+    c = hd * d
+    qkv = torch.randn(B * S, 3 * c, generator=g).to(dev)
+    o32, o16 = torch.empty(B * S, c, device=dev), torch.empty(B * S, c, dtype=torch.float16, device=dev)
+    kw = dict(batch=B, heads=hd, sq=S, skv=S, d=d, ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c, q_bs=S * 3 * c, k_bs=S * 3 * c, v_bs=S * 3 * c,
+              o_bs=S * c, scale=d ** -0.5)
+    ops.attention(qkv, qkv[:, c:], qkv[:, 2 * c:], o32, f16=True, **kw)
+    a = _lib.AttnArgs(qkv.data_ptr(), qkv[:, c:].data_ptr(), qkv[:, 2 * c:].data_ptr(), o16.data_ptr(), 3 * c, 3 * c, 3 * c, c, S * 3 * c, S * 3 * c,
+                      S * 3 * c, S * c, B, hd, S, S, d, d ** -0.5)
+    a.out_f16 = 1
+    assert lib.ds_attention_f16(C.byref(a), _lib.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(o16, o32.to(torch.float16))
