@@ -105,7 +105,8 @@ __global__ void __launch_bounds__(64 * WM * WN, WN == 4 ? 2 : WN) conv3x3_halo_k
     static_assert(NT != 1 || (WM == 2 && WN == 4 && GLDS && VAR == 0), "half-size wave tiles: 128 x 128 tile on 8 waves, LDS-DMA weights");
     static_assert(WN != 4 || NT == 1, "four wave columns: 32-column wave tiles only");
     static_assert(NT == 1 || NT == 2 || (NT == 4 && WM == 4 && WN == 2 && GLDS && (VAR & ~(VAR_TILE_OPTS | VAR_NO_NORM | VAR_NO_HALO | VAR_NO_DMA | VAR_NO_EPI)) == 0), "wide-N tiles: 8-wave LDS-DMA shape only");
-    static_assert(NT == 4 || (VAR & VAR_TILE_OPTS) == 0, "lean addressing / non-temporal epilogue: 256 x 256 tiles only");
+    static_assert(NT == 4 || (VAR & VAR_TILE_OPTS) == 0 || (NT == 2 && WN == 2 && GLDS),
+                  "lean addressing / non-temporal epilogue: the 256 x 256 tile, and (round 3) the 128-column LDS-DMA tiles");
     constexpr bool LEAN = (VAR & VAR_LEAN) != 0, NTEPI = (VAR & VAR_NTEPI) != 0;
     constexpr bool PIPE = (VAR & VAR_PIPE) != 0;
     static_assert(!PIPE || GLDS, "the pipelined tap loop reads the LDS-DMA weight image");
@@ -627,7 +628,14 @@ int launch_wm(KParams& p, hipStream_t stream) {
                 case 17: rc = launch_one<WM, GLDS, 2, 17>(p, g, 0, wide, stream); break;
                 case 29: rc = launch_one<WM, GLDS, 2, 29>(p, g, 0, wide, stream); break;
 #endif
-                default: rc = launch_one<WM, GLDS, 2, 0>(p, g, n256, wide, stream); break;
+                default:
+                    // round 3: the 128-column tiles take the 256 x 256 tile's scalar-addressed weight DMA and non-temporal epilogue
+                    // (every weight row of a full tile exists: rows are padded to 128); variant bit 12 switches it off (A/B runs)
+                    if (p.splits == 1 && !(g_variant & 4096) && n256 + wide * BN <= p.nrows_b)
+                        rc = launch_one<WM, GLDS, 2, VAR_LEAN | VAR_NTEPI>(p, g, n256, wide, stream);
+                    else
+                        rc = launch_one<WM, GLDS, 2, 0>(p, g, n256, wide, stream);
+                    break;
             }
         } else {
             rc = launch_one<WM, GLDS, 2>(p, g, n256, wide, stream);

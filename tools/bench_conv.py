@@ -27,12 +27,15 @@ SHAPES_IMAGENET64 = [  # ADM ImageNet-64 (192 / 384 / 576 / 768 channels): bench
     (64, 192, 0, 192, 9), (64, 192, 192, 192, 9), (32, 384, 0, 384, 9), (32, 384, 384, 384, 9),
     (16, 576, 0, 576, 9), (16, 576, 576, 576, 9), (8, 768, 0, 768, 9), (32, 192, 0, 384, 9),
 ]
+SHAPES_FFHQ = [  # FFHQ-64 SongUNet (128 / 256 channels at 64 / 32 / 16 / 8): bench with --batch 128; the 128-channel layers run 128-column tiles
+    (64, 128, 0, 128, 9), (64, 128, 128, 128, 9), (64, 256, 128, 128, 9), (32, 128, 0, 256, 9), (8, 256, 0, 256, 9),
+]
 SHAPES_SD15 = [  # SD-1.5 latent U-Net 3x3 convs (320 / 640 / 1280 channels at 64 / 32 / 16 / 8): bench with --batch 32
     (64, 320, 0, 320, 9), (64, 320, 320, 320, 9), (32, 640, 0, 640, 9), (32, 640, 640, 640, 9), (16, 1280, 0, 1280, 9), (16, 1280, 1280, 1280, 9),
 ]
 
 ap = argparse.ArgumentParser()
-ap.add_argument('--shapes', default='cifar10', choices=['cifar10', 'imagenet64', 'sd15'])
+ap.add_argument('--shapes', default='cifar10', choices=['cifar10', 'imagenet64', 'sd15', 'ffhq'])
 ap.add_argument('--batch', type=int, default=256)
 ap.add_argument('--entry', default='ds_conv2d_nhwc')
 ap.add_argument('--iters', type=int, default=10)
@@ -50,7 +53,7 @@ ap.add_argument('--extra', action='store_true', help='append the fused 1x1 skip 
 ap.add_argument('--ws', action='store_true', help='give the launcher a split-K workspace (256 MiB), as the engine plans do (the persistent schedule needs it)')
 ap.add_argument('--norm', action='store_true', help='fused GroupNorm affine + SiLU in the halo loader, as the network uses it')
 args = ap.parse_args()
-SHAPES = {'cifar10': SHAPES, 'imagenet64': SHAPES_IMAGENET64, 'sd15': SHAPES_SD15}[args.shapes]
+SHAPES = {'cifar10': SHAPES, 'imagenet64': SHAPES_IMAGENET64, 'sd15': SHAPES_SD15, 'ffhq': SHAPES_FFHQ}[args.shapes]
 
 lib = _lib.load()
 lib.ds_debug_force_generic_conv(int(os.environ.get("DS_CONV", "0")))
