@@ -48,7 +48,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_FP16_MFMA_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md; measured 2495)
 PEAK_HBM_GBS = 8000.0
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r2f_bench_pmc_hbm.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r3_bench_pmc_hbm.json')
 KERNEL_NAMES = {0: 'igemm_f32_kernel<0> (generic gather conv / 1x1 / linear)', 128: 'conv3x3_halo_kernel<2> (128-pixel tiles)',
                 1284: 'conv3x3_halo_kernel<2, WN=4, NT=1> (128-pixel tiles on 8 waves of 64 x 32)',
                 256: 'conv3x3_halo_kernel<4> (256-pixel tiles)', 2561: 'gemm_dma8_kernel (256x128 tiles, LDS-DMA, 1x1 / linear)',
@@ -189,7 +189,7 @@ def instrumented_pass(net, solvers, solver, latents, nfe, ldm=None):
     return rec
 
 
-X0_KIND = 'dpmpp_x0_step_kernel (D -> dynamic threshold -> multistep update, one launch)'
+X0_KIND = 'dpmpp_x0_step_reg_kernel (D -> dynamic threshold -> multistep update in one launch, sample held in registers)'
 
 
 def update_roofline_large_batch(dev, batch=16384, kind='ipndm'):
