@@ -81,6 +81,22 @@ def _cost_matrix_round(traj, eps, t_host, metric):
     raise NotImplementedError(f"Unknown metric: {metric}")
 
 
+def _load_captions(prompt_path):
+    """MS-COCO captions for the FID-30k protocol (gits_utils.py:63-73: the csv's 'text' column)."""
+    import csv
+    if not prompt_path:
+        raise FileNotFoundError("GITS on ms_coco without --prompt needs the caption csv (solver_kwargs['prompt_path'])")
+    with open(prompt_path, 'r') as f:
+        return [row['text'] for row in csv.DictReader(f)]
+
+
+def _mean_l2(a, b):
+    """mean over the batch of || a_n - b_n ||_2 (gits_utils.py:171) from the trajectory-moment kernel: R of the two-point "trajectory"
+    (a, b) is |b - a|^2 per sample -- no ATen arithmetic."""
+    m = trajectory_moments(torch.stack([a, b], dim=0))              # [2, B, 6]; index 2 = R = |c - x_i|^2 with c = last point
+    return torch.tensor(float(np.sqrt(np.maximum(m[0, :, 2], 0.0)).mean()), dtype=torch.float32, device=a.device)
+
+
 def dp(cost_mat, num_steps, num_steps_tea, coeff, multiple_coeff=False, desc=None, t_steps=None):
     """Dynamic programme of gits_utils.py:185-203: V[j][k] = min_i cost[j][i] + coeff * V[i][k-1]; the path is read
     back with the reference's rule (first j that attains the minimum)."""
@@ -105,11 +121,44 @@ def dp(cost_mat, num_steps, num_steps_tea, coeff, multiple_coeff=False, desc=Non
     return phi
 
 
-def get_dp_list(net, device, warmup_latents=None, **solver_kwargs):
-    """Search the ``num_steps``-point sub-schedule of the ``num_steps_tea``-point teacher schedule (gits_utils.py:42-180).
+def _warmup_conditioning(net, device, batch, model_source, dataset_name, solver_kwargs, sample_captions):
+    """Labels / text conditions of one warm-up round, by model source (gits_utils.py:86-102).
+      'adm'            integer class indices ``randint(label_dim, (B,))`` (the ADM wrapper takes indices, not one-hot rows)
+      'ldm' + ms_coco  text conditions: with a reference-style net (``net.model.get_learned_conditioning``) the prompts are encoded as
+                       the reference does -- the given ``prompt`` for every sample, or ``random.sample`` of the caption list; an engine
+                       net (``CFGDenoiser``: the text encoder is not on the sampling path) gets seeded N(0, 1) states of the CLIP shape
+                       ``[B, 77, context_dim]`` and one fixed unconditional row, the convention of ``sample.py`` (BASELINE config 5)
+      otherwise        one-hot rows ``eye(label_dim)[randint]`` (EDM nets)
+    Returns (class_labels, condition, unconditional_condition)."""
+    if not net.label_dim:
+        return None, None, None
+    if model_source == 'adm':
+        return torch.randint(net.label_dim, size=(batch,), device=device), None, None
+    if model_source == 'ldm' and dataset_name == 'ms_coco':
+        guided = solver_kwargs.get('guidance_rate') != 1.0
+        model = getattr(net, 'model', None)
+        if model is not None and hasattr(model, 'get_learned_conditioning'):
+            if solver_kwargs.get('prompt') is None:
+                import random
+                prompts = random.sample(sample_captions, batch)
+            else:
+                prompts = [solver_kwargs['prompt'] for _ in range(batch)]
+            uc = model.get_learned_conditioning(batch * [""]) if guided else None
+            return None, model.get_learned_conditioning(list(prompts)), uc
+        cd = net.spec.context_dim
+        c = torch.randn(batch, 77, cd, device=device)
+        uc = torch.randn(1, 77, cd, generator=torch.Generator().manual_seed(0)).to(device).expand(batch, -1, -1) if guided else None
+        return None, c, uc
+    return torch.eye(net.label_dim, device=device)[torch.randint(net.label_dim, size=[batch], device=device)], None, None
 
-    warmup_latents (extension, for reproducible tests): list of latent tensors, one per accumulation round; by default
-    every round draws ``torch.randn`` on ``device`` like the reference."""
+
+def get_dp_list(net, device, warmup_latents=None, warmup_conditions=None, **solver_kwargs):
+    """Search the ``num_steps``-point sub-schedule of the ``num_steps_tea``-point teacher schedule (gits_utils.py:42-180), for every
+    model source the reference's search handles: 'edm' (one-hot labels), 'adm' (integer labels), 'ldm' (text conditions; classifier-free
+    guidance doubles the evaluation inside the denoiser) -- gits_utils.py:86-108.
+
+    warmup_latents / warmup_conditions (extensions, for reproducible tests): per accumulation round a latent tensor and a
+    ``(class_labels, condition, unconditional_condition)`` triple; by default every round draws them on ``device`` like the reference."""
     kwargs = copy.copy(solver_kwargs)
     num_warmup, max_batch_size = kwargs['num_warmup'], kwargs['max_batch_size']
     sigma_min, sigma_max = kwargs['sigma_min'], kwargs['sigma_max']
@@ -131,16 +180,36 @@ def get_dp_list(net, device, warmup_latents=None, **solver_kwargs):
     rounds = num_warmup // (max_batch_size + 1) + 1
     batch_gpu = max_batch_size // world
     cost = np.zeros((num_steps_tea, num_steps_tea))
-    latents = class_labels = teacher_traj = None
+    model_source, dataset_name = kwargs.get('model_source'), kwargs.get('dataset_name')
+    sample_captions = None
+    if dataset_name == 'ms_coco' and model_source == 'ldm' and kwargs.get('prompt') is None and hasattr(getattr(net, 'model', None), 'get_learned_conditioning'):
+        sample_captions = _load_captions(kwargs.get('prompt_path'))               # gits_utils.py:63-73
+    for k in ('condition', 'unconditional_condition', 'class_labels'):           # the search supplies its own
+        kwargs.pop(k, None)
+
+    def run_sampler(fn, lat, cond3, kw):
+        """The teacher / student call of one round; 'ldm': under autocast + ema_scope when the net is a reference-style module
+        (gits_utils.py:104-108) -- an engine net carries its precision mode itself."""
+        cl, c, uc = cond3
+        if model_source == 'ldm':
+            model = getattr(net, 'model', None)
+            if model is not None and hasattr(model, 'ema_scope'):
+                with torch.autocast('cuda'), model.ema_scope():
+                    return fn(net, lat, condition=c, unconditional_condition=uc, **kw)
+            return fn(net, lat, condition=c, unconditional_condition=uc, **kw)
+        return fn(net, lat, class_labels=cl, **kw)
+
+    latents = cond3 = teacher_traj = None
     for r in range(rounds):
         if warmup_latents is not None:
             latents = warmup_latents[r].to(device)
         else:
             latents = torch.randn([batch_gpu, net.img_channels, net.img_resolution, net.img_resolution], device=device)
-        class_labels = None
-        if net.label_dim:
-            class_labels = torch.eye(net.label_dim, device=device)[torch.randint(net.label_dim, size=[latents.shape[0]], device=device)]
-        teacher_traj, eps_traj = sampler_fn_tea(net, latents, class_labels=class_labels, **kwargs)
+        if warmup_conditions is not None:
+            cond3 = tuple(None if t is None else t.to(device) for t in warmup_conditions[r])
+        else:
+            cond3 = _warmup_conditioning(net, device, latents.shape[0], model_source, dataset_name, kwargs, sample_captions)
+        teacher_traj, eps_traj = run_sampler(sampler_fn_tea, latents, cond3, kwargs)
         cost += _cost_matrix_round(teacher_traj, eps_traj, t_host, metric)
     cost_t = torch.from_numpy(cost).to(torch.float32).to(device)
     if dist:
@@ -159,8 +228,8 @@ def get_dp_list(net, device, warmup_latents=None, **solver_kwargs):
             sampler_fn, kwargs['coeff_list'] = get_sampler_fn(device=device, dp_list=cand, net=net, **{**kwargs, 'coeff_list': None})
             kwargs['t_steps'] = solver_utils.get_schedule(num_steps_tea, sigma_min, sigma_max, device='cpu', schedule_type=schedule_type,
                                                           schedule_rho=schedule_rho, net=net, dp_list=cand)
-            images_afs = sampler_fn(net, latents, class_labels=class_labels, **kwargs)
-            d = torch.norm(images_afs - teacher_traj[-1], p=2, dim=(1, 2, 3)).mean()
+            images_afs = run_sampler(sampler_fn, latents, cond3, kwargs)
+            d = _mean_l2(images_afs, teacher_traj[-1])
             if dist:
                 dist.all_reduce(d)
                 d = d / world

@@ -108,3 +108,23 @@ def gits_warmup_latents(seed, rounds, batch, shape):
     torch.manual_seed(seed): one [batch, *shape] tensor per accumulation round."""
     torch.manual_seed(seed)
     return [torch.randn([batch] + list(shape)) for _ in range(rounds)]
+
+
+# GITS schedule search on a latent-diffusion denoiser (gits-main/gits_utils.py:86-108, model_source == 'ldm'): tiny LDM U-Net under
+# classifier-free guidance; the text encoder is a shim whose k-th call returns seeded N(0, 1) states (oracle/gen_golden.py --part gitsldm)
+GITS_LDM_CASE = ('dev_dpmpp_tiny_ldm', dict(num_steps=4, num_steps_tea=9, metric='dev', coeff=1.1, afs=False, solver='dpmpp', solver_tea='dpmpp',
+                                             max_order=2, schedule_type='discrete', schedule_rho=1, num_warmup=3, max_batch_size=2,
+                                             dataset_name='ms_coco', model_source='ldm', prompt='a photo', guidance_type='cfg', guidance_rate=7.5,
+                                             predict_x0=False))
+
+
+def gits_ldm_conditions(seed, rounds, batch, ctx_dim):
+    """What the shimmed get_learned_conditioning returns, in the reference's call order per round: unconditional first, then the prompts
+    (gits_utils.py:97-101)."""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(rounds):
+        uc = torch.randn(batch, 77, ctx_dim, generator=g)
+        c = torch.randn(batch, 77, ctx_dim, generator=g)
+        out.append((None, c, uc))
+    return out

@@ -45,6 +45,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = '/root/reference'
 OUT = os.path.join(ROOT, 'tests', 'golden')
 sys.path.insert(0, ROOT)
+from oracle import cases  # noqa: E402
 from oracle.cases import (FULL_SOLVER_CASES, FULL_SOLVER_TSTEPS, GITS_TSTEPS, SAMPLER_CASES, AMED_CASES, GITS_CASES, GITS_COMMON, GITS_FULL_CASE, make_inputs as _inputs,  # noqa: E402
                           amed_predictor_params, gits_warmup_latents)
 
@@ -252,6 +253,38 @@ def _ref_cfg_net(name, seed, guidance_rate=7.5):
     return net, unet, kw, spec
 
 
+def part_gitsldm():
+    """gits-main/gits_utils.py:get_dp_list with model_source == 'ldm' on the tiny latent-diffusion net (real reference code path:
+    autocast + ema_scope + get_learned_conditioning), text encoder and EMA scope shimmed."""
+    import contextlib
+    sys.path.insert(0, os.path.join(REF, 'gits-main'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29573', RANK='0', WORLD_SIZE='1')
+    torch.distributed.init_process_group('gloo', rank=0, world_size=1)
+    import gits_utils
+    torch.set_grad_enabled(False)
+    net, unet, kw, spec = _ref_cfg_net('tiny_ldm', 52)
+    tag, gk = cases.GITS_LDM_CASE
+    kwargs = dict(cases.GITS_COMMON); kwargs.update(gk)
+    kwargs['sigma_min'], kwargs['sigma_max'] = net.sigma_min, net.sigma_max
+    rounds = kwargs['num_warmup'] // (kwargs['max_batch_size'] + 1) + 1
+    conds = cases.gits_ldm_conditions(77, rounds, kwargs['max_batch_size'], kw['context_dim'])
+    calls = []
+
+    def get_learned_conditioning(prompts):
+        r, which = divmod(len(calls), 2)
+        calls.append(list(prompts))
+        return conds[r][2] if which == 0 else conds[r][1]       # unconditional first, then the prompts (gits_utils.py:97-101)
+    net.model.get_learned_conditioning = get_learned_conditioning
+    net.model.ema_scope = contextlib.nullcontext
+    torch.manual_seed(4321)
+    dp_list = gits_utils.get_dp_list(net, torch.device('cpu'), **kwargs)
+    assert len(calls) == 2 * rounds and calls[0] == [''] * kwargs['max_batch_size'] and calls[1] == ['a photo'] * kwargs['max_batch_size']
+    np.savez_compressed(os.path.join(OUT, 'gits_ldm.npz'), seed=52, warmup_seed=4321, cond_seed=77, dp_list=np.array(dp_list),
+                        sigma_min=net.sigma_min, sigma_max=net.sigma_max)
+    print('gitsldm', tag, dp_list, flush=True)
+    torch.distributed.destroy_process_group()
+
+
 def part_ldm():
     sys.path.insert(0, os.path.join(REF, 'diff-solvers-main'))
     import solvers
@@ -424,7 +457,7 @@ def part_fullsolv():
     np.savez_compressed(os.path.join(OUT, 'sampler_cifar10_solvers_nfe10_b4.npz'), **d)
 
 
-PARTS = dict(fullffhq=part_fullffhq, fullgits=part_fullgits, fullsolv=part_fullsolv, full3=part_full3, full4=part_full4, net=part_net, sched=part_sched, samplers=part_samplers, amed=part_amed, gits=part_gits, ldm=part_ldm, full=part_full)
+PARTS = dict(gitsldm=part_gitsldm, fullffhq=part_fullffhq, fullgits=part_fullgits, fullsolv=part_fullsolv, full3=part_full3, full4=part_full4, net=part_net, sched=part_sched, samplers=part_samplers, amed=part_amed, gits=part_gits, ldm=part_ldm, full=part_full)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

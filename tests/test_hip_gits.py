@@ -56,3 +56,27 @@ def test_get_dp_list_on_the_full_size_cifar10_net_matches_reference():
     lat = cases.gits_warmup_latents(int(z['warmup_seed']), rounds, kwargs['max_batch_size'], (3, 32, 32))
     dp_list = gits_utils.get_dp_list(net, torch.device('cuda'), warmup_latents=lat, **kwargs)
     assert list(dp_list) == list(z['dp_list']), (dp_list, z['dp_list'])
+
+
+def test_get_dp_list_on_a_latent_diffusion_denoiser_matches_reference():
+    """model_source == 'ldm' (gits-main/gits_utils.py:86-108): text conditions instead of labels, classifier-free guidance inside the
+    denoiser, 'discrete' schedule from the net's own sigma(t).  Golden = the REAL reference's get_dp_list on the tiny LDM U-Net with a
+    shimmed text encoder (oracle/gen_golden.py --part gitsldm); here the same latents and conditions go through the HIP CFGDenoiser."""
+    from diff_sampler_amd import gits_utils
+    from diff_sampler_amd.ldm_engine import CFGDenoiser
+    import diff_sampler_amd.ldm_arch as la
+    z = np.load(os.path.join(G, 'gits_ldm.npz'))
+    net = CFGDenoiser.from_config('tiny_ldm', seed=int(z['seed']), guidance_rate=7.5)
+    assert abs(net.sigma_min - float(z['sigma_min'])) < 1e-6 and abs(net.sigma_max - float(z['sigma_max'])) < 1e-4
+    tag, gk = cases.GITS_LDM_CASE
+    kwargs = dict(cases.GITS_COMMON); kwargs.update(gk)
+    kwargs['sigma_min'], kwargs['sigma_max'] = net.sigma_min, net.sigma_max
+    kw = la.NAMED_LDM_CONFIGS['tiny_ldm']
+    rounds = kwargs['num_warmup'] // (kwargs['max_batch_size'] + 1) + 1
+    lat = cases.gits_warmup_latents(int(z['warmup_seed']), rounds, kwargs['max_batch_size'], (kw['in_channels'], kw['img_resolution'], kw['img_resolution']))
+    conds = cases.gits_ldm_conditions(int(z['cond_seed']), rounds, kwargs['max_batch_size'], kw['context_dim'])
+    dp_list = gits_utils.get_dp_list(net, torch.device('cuda'), warmup_latents=lat, warmup_conditions=conds, **kwargs)
+    assert list(dp_list) == list(z['dp_list']), (dp_list, z['dp_list'])
+    # without the test hooks the search draws its own conditions (seeded N(0,1) CLIP-shaped states for an engine net) and still returns a path
+    dp2 = gits_utils.get_dp_list(net, torch.device('cuda'), **kwargs)
+    assert dp2[0] == 0 and dp2[-1] == kwargs['num_steps_tea'] - 1 and len(dp2) == kwargs['num_steps']

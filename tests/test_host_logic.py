@@ -393,3 +393,28 @@ def test_fid_cli_ref_then_calc_matches_numpy(tmp_path):
     r = CliRunner().invoke(F.main, ['calc', '--images', str(tmp_path / 'imgs'), '--ref', str(tmp_path / 'ref.npz'), '--num', '40',
                                     '--detector', det, '--device', 'cpu'])
     assert r.exit_code != 0            # fewer images than --num
+
+
+def test_gits_warmup_conditioning_by_model_source():
+    """gits-main/gits_utils.py:86-102: integer class indices for 'adm', text conditions for 'ldm' on ms_coco (reference-style net: its own
+    get_learned_conditioning, unconditional first; engine net: seeded N(0,1) CLIP-shaped states), one-hot rows otherwise."""
+    import types
+    from diff_sampler_amd import gits_utils
+    dev = torch.device('cpu')
+    edm = types.SimpleNamespace(label_dim=10)
+    cl, c, uc = gits_utils._warmup_conditioning(edm, dev, 5, 'edm', 'cifar10', {}, None)
+    assert cl.shape == (5, 10) and torch.equal(cl.sum(1), torch.ones(5)) and c is None and uc is None
+    cl, c, uc = gits_utils._warmup_conditioning(edm, dev, 5, 'adm', 'imagenet64', {}, None)
+    assert cl.dtype == torch.int64 and cl.shape == (5,) and int(cl.max()) < 10 and c is None
+    assert gits_utils._warmup_conditioning(types.SimpleNamespace(label_dim=0), dev, 5, 'edm', 'cifar10', {}, None) == (None, None, None)
+    calls = []
+    model = types.SimpleNamespace(get_learned_conditioning=lambda p: (calls.append(list(p)), torch.zeros(len(p), 77, 8))[1])
+    ref_net = types.SimpleNamespace(label_dim=True, model=model)
+    cl, c, uc = gits_utils._warmup_conditioning(ref_net, dev, 3, 'ldm', 'ms_coco', dict(prompt='a cat', guidance_rate=7.5), None)
+    assert cl is None and c.shape == (3, 77, 8) and uc.shape == (3, 77, 8) and calls == [[''] * 3, ['a cat'] * 3]
+    calls.clear()
+    cl, c, uc = gits_utils._warmup_conditioning(ref_net, dev, 2, 'ldm', 'ms_coco', dict(prompt=None, guidance_rate=1.0), ['x', 'y', 'z'])
+    assert uc is None and len(calls) == 1 and set(calls[0]) <= {'x', 'y', 'z'} and len(calls[0]) == 2
+    eng_net = types.SimpleNamespace(label_dim=True, spec=types.SimpleNamespace(context_dim=16))
+    cl, c, uc = gits_utils._warmup_conditioning(eng_net, dev, 4, 'ldm', 'ms_coco', dict(prompt=None, guidance_rate=7.5), None)
+    assert c.shape == (4, 77, 16) and uc.shape == (4, 77, 16) and torch.equal(uc[0], uc[3])
