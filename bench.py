@@ -47,6 +47,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_FP16_MFMA_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md; measured 2495)
+# What the matrix pipes SUSTAIN on random operands (the part lowers its clock under data toggling; tools/probes/mfma32_data.hip,
+# mfma16_pattern.hip; profiles/r3_probe_*): informational, `roofline.peak` stays the nominal figure
+SUSTAINED_RANDOM_FP32_TFLOPS, SUSTAINED_RANDOM_FP16_TFLOPS = 145.5, 1720.0
 PEAK_HBM_GBS = 8000.0
 PMC_FILE = os.path.join(ROOT, 'profiles', 'r3_bench_pmc_hbm.json')
 KERNEL_NAMES = {0: 'igemm_f32_kernel<0> (generic gather conv / 1x1 / linear)', 128: 'conv3x3_halo_kernel<2> (128-pixel tiles)',
@@ -499,7 +502,8 @@ def main(argv=None):
                     frac=round(ach / peak, 4), traffic=(round(traffic) if traffic else None),
                     traffic_unit='HBM bytes per launch (rocprofv3 PMC, %s)' % os.path.relpath(PMC_FILE, ROOT),
                     launches_per_step=launches, avg_launch_ms=round(ms / launches, 4), gflop_per_launch=round(fl / launches / 1e9, 2),
-                    share_of_gpu_time=round(ms / total_ms, 4))
+                    share_of_gpu_time=round(ms / total_ms, 4),
+                    frac_of_rate_sustained_on_random_operands=round(ach / (SUSTAINED_RANDOM_FP32_TFLOPS if peak == PEAK_FP32_MFMA_TFLOPS else SUSTAINED_RANDOM_FP16_TFLOPS * peak / PEAK_FP16_MFMA_TFLOPS), 4))
         per = spec.in_channels * spec.img_resolution ** 2 * 4
         if X0_KIND in rec and ldm is None:
             # the headline solver's update: ONE ds_dpmpp_x0_step launch per evaluation.  Algorithmic bytes of the fused launch: x, F read;
