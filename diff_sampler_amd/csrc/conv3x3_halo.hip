@@ -104,8 +104,8 @@ template <int WM, bool GLDS, int WN, int VAR = 0, int NT = 2>
 __global__ void __launch_bounds__(64 * WM * WN, WN == 4 ? 2 : WN) conv3x3_halo_kernel(const KParams p) {
     static_assert(NT != 1 || (WM == 2 && WN == 4 && GLDS && VAR == 0), "half-size wave tiles: 128 x 128 tile on 8 waves, LDS-DMA weights");
     static_assert(WN != 4 || NT == 1, "four wave columns: 32-column wave tiles only");
-    static_assert(NT == 1 || NT == 2 || (NT == 4 && WM == 4 && WN == 2 && GLDS && (VAR & ~(VAR_TILE_OPTS | VAR_NO_NORM | VAR_NO_HALO | VAR_NO_DMA | VAR_NO_EPI)) == 0), "wide-N tiles: 8-wave LDS-DMA shape only");
-    static_assert(NT == 4 || (VAR & VAR_TILE_OPTS) == 0 || (NT == 2 && WN == 2 && GLDS),
+    static_assert(NT == 1 || NT == 2 || ((NT == 4 || NT == 3) && WM == 4 && WN == 2 && GLDS && (VAR & ~(VAR_TILE_OPTS | VAR_NO_NORM | VAR_NO_HALO | VAR_NO_DMA | VAR_NO_EPI)) == 0), "wide-N tiles: 8-wave LDS-DMA shape only");
+    static_assert(NT >= 3 || (VAR & VAR_TILE_OPTS) == 0 || (NT == 2 && WN == 2 && GLDS),
                   "lean addressing / non-temporal epilogue: the 256 x 256 tile, and (round 3) the 128-column LDS-DMA tiles");
     constexpr bool LEAN = (VAR & VAR_LEAN) != 0, NTEPI = (VAR & VAR_NTEPI) != 0;
     constexpr bool PIPE = (VAR & VAR_PIPE) != 0;
@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WN == 4 ? 2 : WN) conv3x3_halo_k
     constexpr int BNT = 32 * NT * WN;      // output channels per tile
     constexpr int BROWS = BNT * 8 / T;     // weight float4 per thread per tap (4 or 2)
     constexpr int BLD = GLDS ? 32 : LDSK;  // floats per weight row in LDS
-    constexpr int NS_MAX = (NT == 4) ? 7 : ns_max(WN);      // wide-N tiles: one image per tile, at most 7 slots per thread (64-column images)
+    constexpr int NS_MAX = (NT >= 3) ? 7 : ns_max(WN);      // wide-N tiles: one image per tile, at most 7 slots per thread (64-column images)
     constexpr int B_FLOATS = 2 * BNT * LDSK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Bs = smem;                               // [2][BNT][LDSK]
@@ -445,6 +445,14 @@ __global__ void __launch_bounds__(64 * WM * WN, WN == 4 ? 2 : WN) conv3x3_halo_k
                         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], b1[r], acc[1][1], 0, 0, 0);
                     }
                 }
+                if constexpr (NT == 3) {                        // 64 x 96 per wave (192-column tiles, round 3): one more 32-column block
+                    const f32x4 b2 = *reinterpret_cast<const f32x4*>(bs + 64 * BLD + b_frag(ks));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc_hi[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[r], b2[r], acc_hi[0][0], 0, 0, 0);
+                        acc_hi[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], b2[r], acc_hi[1][0], 0, 0, 0);
+                    }
+                }
                 if constexpr (NT == 4) {                        // second 64-column half: 2 + 2 fragments live at a time
                     const f32x4 b2 = *reinterpret_cast<const f32x4*>(bs + 64 * BLD + b_frag(ks));
                     const f32x4 b3 = *reinterpret_cast<const f32x4*>(bs + 96 * BLD + b_frag(ks));
@@ -477,7 +485,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WN == 4 ? 2 : WN) conv3x3_halo_k
 #pragma unroll
             for (int j = 0; j < 2; ++j) {                                         // keep the accumulators (and the K loop) alive
                 asm volatile("" :: "v"(acc[i][j]));
-                if constexpr (NT == 4) asm volatile("" :: "v"(acc_hi[i][j]));
+                if constexpr (NT >= 3) asm volatile("" :: "v"(acc_hi[i][j]));
             }
         return;
     }
@@ -499,6 +507,8 @@ __global__ void __launch_bounds__(64 * WM * WN, WN == 4 ? 2 : WN) conv3x3_halo_k
     epilogue<0, HALF, NTEPI>(p, acc, smem + wave * (HALF ? 32 : 64) * EPI_LD, lane, m0 + wr * 64, n0 + wc * 32 * NT, p.out);
     if constexpr (NT == 4)
         epilogue<0, HALF, NTEPI>(p, acc_hi, smem + wave * (HALF ? 32 : 64) * EPI_LD, lane, m0 + wr * 64, n0 + wc * 32 * NT + 64, p.out);
+    if constexpr (NT == 3)
+        epilogue32<HALF>(p, acc_hi, smem + wave * 32 * EPI_LD, lane, m0 + wr * 64, n0 + wc * 32 * NT + 64, p.out);
 }
 
 struct Geo { int TH, nimg, NP; bool ok; };
@@ -533,6 +543,12 @@ bool wide_n_tiles(const KParams& p, const Geo& g) {
     if (p.splits != 1 || p.N < 256 || g.NP * 8 > 7 * 512 || g.nimg != 1 || p.nrows_b < (p.N / 256) * 256) return false;
     const long long blocks = (long long)((p.M + 255) / 256) * (p.N / 256);       // the 256-column tiles (a remainder keeps 128 / 64-column tiles)
     return v == 6 || blocks >= 256;
+}
+
+bool wide192_tiles(const KParams& p, const Geo& g) {
+    if ((g_variant & 31) != 0 || (g_variant & 8192)) return false;
+    if (p.splits != 1 || p.N % 192 || p.N % 256 == 0 || g.NP * 8 > 7 * 512 || g.nimg != 1 || p.nrows_b < p.N || !p.vec_ok || p.out_planar) return false;
+    return (g_variant & 16384) || (long long)((p.M + 255) / 256) * (p.N / 192) >= 256;          // the tiles still cover the 256 CUs (bit 14: forced, tests)
 }
 
 template <int WM, bool GLDS, int WN, int VAR = 0, int NT = 2>
@@ -577,6 +593,14 @@ int launch_wm(KParams& p, hipStream_t stream) {
     int n256 = 0;
     if constexpr (WM == 4 && GLDS) {
         const Geo g4 = geometry(p, 256, 2);
+        // round 3: channel counts that are multiples of 192 but not of 256 (ADM: 192 / 384 / 576) take 192-column tiles (64 x 96 per wave)
+        // for ALL their columns instead of 256 / 128-column tiles plus a 64-column tail; variant bit 13 switches it off (A/B runs)
+        if (wide192_tiles(p, g4)) {
+            KParams q = p;
+            const int rc = launch_one<4, true, 2, VAR_TILE_OPTS, 3>(q, g4, 0, p.N / 192, stream);
+            if (rc) return rc;
+            return DS_OK;
+        }
         if (wide_n_tiles(p, g4)) {
             n256 = (p.N / 256) * 256;
             KParams q = p;
@@ -679,7 +703,7 @@ HaloPlan plan_halo(const KParams& p) {
         const int s256 = choose_splits(blocks256, true, units, 9, cap, mn, &c256);
         if (g_tile_override == 256 || 0.97 * c256 < c128) { hp.tile = 256; hp.splits = s256; }
     }
-    if ((g_variant & 31) == 6 && hp.tile == 256) hp.splits = 1;      // forced 256 x 256 tiles (tests at small sizes): no split-K
+    if (((g_variant & 31) == 6 || (g_variant & 16384)) && hp.tile == 256) hp.splits = 1;      // forced wide tiles (tests at small sizes): no split-K
     return hp;
 }
 
@@ -696,6 +720,7 @@ int conv3x3_halo_choice(const KParams& p) {
     if (hp.tile == 256 && g_glds) {
         KParams q = p;
         q.splits = hp.splits;
+        if (wide192_tiles(q, geometry(p, 256, 2))) return 2568;        // 192-column tiles for every column (ADM channel counts)
         if (wide_n_tiles(q, geometry(p, 256, 2))) return 2565;         // (its first N / 256 column tiles; a remainder stays on 128 / 64 columns)
     }
     return hp.tile;

@@ -194,7 +194,8 @@ int ds_debug_force_splits(int s);
  * compute wrong results on purpose; + 0x10000: ablations of the 256 x 256 tile).  Bit 8 (256): the 256 x 256 tile's plain kernel
  * instead of its default (scalar-addressed weight DMA + non-temporal epilogue); bit 9 (512): tiles of several images read their
  * GroupNorm coefficient planes from global memory instead of LDS; bit 11 (2048): the four-wave 128 x 128 tile also where the default
- * is eight half-size waves. */
+ * is eight half-size waves; bit 12 (4096): the 128-column tiles without the scalar-addressed weight DMA / non-temporal epilogue; bit 13
+ * (8192): no 256 x 192 tiles for the 192-multiples (ADM channel counts); bit 14 (16384): force them regardless of the tile count (tests). */
 int ds_debug_conv_variant(int v);
 
 /* Number of convolution launches routed to the second-generation 256 x 128 halo kernel so far (tests assert the routing). */

@@ -485,6 +485,8 @@ def _run_halo_case(case, variant, workspace=False, tile=256, want_kid=None):
         assert kid == want_kid, (kid, want_kid)
     if (variant & 31) == 6:
         assert kid == 2565, 'the layer was not routed to the 256 x 256-tile kernel'
+    if variant & 16384:
+        assert kid == 2568, 'the layer was not routed to the 256 x 192-tile kernel'
     want = _nhwc(ref)
     assert _rel(out.cpu(), want) < TOL
     if cout % 64 == 0:       # the epilogue's per-(64-row block, channel) sums feed the consumer's GroupNorm
@@ -517,6 +519,23 @@ def test_conv_wide_n_tiles_match_aten(case):
     """conv3x3_halo_kernel<4, NT = 4>: 256-pixel x 256-channel tiles (64 x 128 per wave) for the 256-multiples of the channel
     count, the remainder on 128- / 64-column tiles of the same layer (ds_debug_conv_variant(6) forces the shape at test sizes)."""
     _run_halo_case(case, 6)
+
+
+WIDE192_CASES = [
+    # B, H(=W), c0, c1, cout, (ec0, ec1), norm, act          -- ADM channel counts: 192-multiples that are not 256-multiples
+    (1, 32, 32, 0, 192, (0, 0), False, False),
+    (2, 16, 64, 32, 384, (0, 0), True, True),          # two 192-column tiles, dual source, fused normalisation
+    (1, 64, 32, 32, 192, (32, 0), True, True),         # W = 64 (7 halo slots per thread), fused 1x1 skip columns
+    (3, 16, 288, 0, 576, (0, 0), False, False),        # three 192-column tiles, nine slabs
+]
+
+
+@pytest.mark.parametrize('case', WIDE192_CASES)
+def test_conv_192_column_tiles_match_aten(case):
+    """conv3x3_halo_kernel<4, NT = 3>: 256-pixel x 192-channel tiles (64 x 96 per wave) for channel counts that are multiples of 192 but not
+    of 256 (ADM: 192 / 384 / 576) -- all columns of the layer in one launch instead of 256- / 128-column tiles plus a 64-column tail
+    (ds_debug_conv_variant bit 14 forces the shape at test sizes)."""
+    _run_halo_case(case, 16384)
 
 
 @pytest.mark.parametrize('variant', [6 | 256])
