@@ -21,7 +21,7 @@ for step in "$@"; do
   n=$((n+1)); kind=${step%%:*}; arg=""; [ "$kind" != "$step" ] && arg=${step#*:}
   case $kind in
     suite) timeout 900 python -m pytest tests -x -q -m gpu > $O/pytest_all.txt 2>&1; tail -4 $O/pytest_all.txt ;;
-    tests) timeout 900 python -m pytest $arg -q -m gpu > $O/pytest_$n.txt 2>&1; tail -15 $O/pytest_$n.txt ;;
+    tests) eval "timeout 900 python -m pytest $arg -q -m gpu" > $O/pytest_$n.txt 2>&1; tail -15 $O/pytest_$n.txt ;;   # eval: -k 'a or b' stays one argument
     smoke) timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt ;;
     bench) timeout 600 python bench.py $arg > $O/bench_$n.json 2> $O/bench_$n.err; tail -1 $O/bench_$n.json | cut -c1-300; tail -2 $O/bench_$n.err ;;
     prof)  timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_$n -o bench -- python bench.py $QUICK $arg > $O/bench_under_rocprof_$n.json 2> $O/prof_$n.err
