@@ -27,7 +27,7 @@ class ConvArgs(C.Structure):
                 ('norm_coefs', vp), ('norm_act', C.c_int),
                 ('e0', vp), ('e1', vp), ('ec0', C.c_int), ('ec1', C.c_int), ('eld0', C.c_int), ('eld1', C.c_int),
                 ('stride', C.c_int), ('workspace', vp), ('workspace_floats', C.c_longlong),
-                ('out_nchw', C.c_int), ('stats_out', vp), ('wgt_f16', C.c_int), ('wgt_shift', C.c_int), ('in_f16', C.c_int), ('out_f16', C.c_int)]
+                ('out_nchw', C.c_int), ('stats_out', vp), ('wgt_f16', C.c_int), ('wgt_shift', C.c_int), ('in_f16', C.c_int), ('out_f16', C.c_int), ('res_f16', C.c_int)]
 
 
 class GemmArgs(C.Structure):

@@ -302,6 +302,7 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     if (a->c0 <= 0 || a->c0 % 32 || a->c1 < 0 || a->c1 % 32) return DS_E_SHAPE;
     if (a->c1 && !a->x1) return DS_E_ARG;
     if (a->out_f16 && (!a->in_f16 || (a->cout & 63) || (a->out_ld & 3))) return DS_E_ARG;   // fp16 output rows: the fp16-activation kernels only
+    if (a->res_f16 && (!a->in_f16 || !a->res || (a->res_ld & 3))) return DS_E_ARG;          // fp16 residual rows: the same kernels
     if (a->in_f16) {          // fp16 activations: pure matrix kernels (conv3x3_f16dma.hip / gemm_f16dma.hip); ld in halfs, 16-byte chunks
         if (a->wgt_f16 != 1 || a->c1 || a->ec1 || a->norm_coefs || a->out_nchw || (a->stride && a->stride != 1)) return DS_E_ARG;
         if (a->taps == 1 && a->ec0) return DS_E_ARG;
@@ -361,7 +362,7 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
             p.ldb = p.K / 2;
             p.part = nullptr; p.part_cap = 0; p.splits = 1;
             if (a->in_f16) {            // fp16 activations: both operands by LDS-DMA
-                p.out_f16 = a->out_f16 ? 1 : 0;
+                p.out_f16 = a->out_f16 ? 1 : 0; p.res_f16 = a->res_f16 ? 1 : 0;
                 if (!gemm_f16dma_applicable(p)) return DS_E_SHAPE;
                 return launch_gemm_f16dma(p, (hipStream_t)stream);
             }
@@ -372,7 +373,7 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
         if (a->wgt_shift < 0 || a->wgt_shift > 24 || (a->wgt_f16 == 1 && a->wgt_shift)) return DS_E_ARG;
         if (a->in_f16) {
             p.ldb = p.K / 2;
-            p.out_f16 = a->out_f16 ? 1 : 0;
+            p.out_f16 = a->out_f16 ? 1 : 0; p.res_f16 = a->res_f16 ? 1 : 0;
             p.part = nullptr; p.part_cap = 0; p.splits = 1;
             if (!conv3x3_f16dma_applicable(p)) return DS_E_SHAPE;
             return launch_conv3x3_f16dma(p, (hipStream_t)stream);

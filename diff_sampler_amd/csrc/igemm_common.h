@@ -38,6 +38,7 @@ struct KParams {
     int vec_ok;                                                    // float4 epilogue allowed (alignment, ld % 4)
     int out_planar;                                                // scalar epilogue writes out[(img * N + col) * HW + pixel]
     int out_f16;                                                   // vector epilogue stores fp16 rows [M][ldo halfs] (ds_conv_args.out_f16)
+    int res_f16;                                                   // `res` is an fp16 tensor [M][res_ld halfs] (ds_conv_args.res_f16): the fp16 residual stream
     // optional per-(64-row block, column) sums of the OUTPUT for the consumer's GroupNorm: stats[(rb * 2 + {0: sum, 1: sum of
     // squares}) * N + col], rb = row / 64 (vector epilogue only: N % 64 == 0)
     float* stats;
@@ -57,7 +58,9 @@ struct KParams {
 // 256 x 256 conv tile; as a run-time option for every other kernel of the family (fp32 / fp16 GEMMs, fp16 convolutions; outputs of at
 // least 32 MiB) it changed nothing on the CIFAR-10, ImageNet-64 fp16 and SD-1.5 fp16 benches (profiles/r2_conv_tile_options.txt), so
 // only that kernel instantiates it.
-template <int MODE, bool HALF = false, bool NTS = false>
+// H16: fp16 output rows / fp16 residual rows (p.out_f16, p.res_f16) -- compiled into the fp16-activation kernels only; the column sums
+// left for the consumer's GroupNorm are then those of the ROUNDED values, i.e. of the tensor that is actually stored.
+template <int MODE, bool HALF = false, bool NTS = false, bool H16 = false>
 __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2][2], float* stage, int lane, int wm0, int wn0,
                                          float* o_base) {
     // HALF: the staging area holds 32 x EPI_LD floats per wave (8-wave blocks) and the two 32-row halves go one after
@@ -83,6 +86,12 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
 #pragma unroll
                 for (int pass = 0; pass < NP; ++pass) {
                     const int row = min(rbase + pass * 4 + (lane >> 4), p.M - 1);
+                    if (H16 && p.res_f16) {
+                        typedef _Float16 h4r_t __attribute__((ext_vector_type(4)));
+                        const h4r_t hv = __builtin_nontemporal_load(reinterpret_cast<const h4r_t*>(reinterpret_cast<const _Float16*>(p.res) + (size_t)row * p.res_ld + col));
+                        rv[pass] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+                        continue;
+                    }
                     const f32x4* rp = reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.res_ld + col);
                     rv[pass] = NTS ? __builtin_nontemporal_load(rp) : *rp;
                 }
@@ -112,7 +121,7 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
                         const f32x4 gt = *reinterpret_cast<const f32x4*>(stage + rr * EPI_LD + c4 + 32) + cbg;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[q] *= 0.5f * gt[q] * (1.0f + erff(gt[q] * 0.70710678118654752440f));
-                        if (p.out_f16) {
+                        if (H16 && p.out_f16) {
                             typedef _Float16 h4g_t __attribute__((ext_vector_type(4)));
                             const h4g_t hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                             *reinterpret_cast<h4g_t*>(reinterpret_cast<_Float16*>(o_base) + (size_t)row * p.ldo + (wn0 >> 1) + c4) = hv;
@@ -125,10 +134,11 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = ds_silu(v[q]);
                 }
-                if (p.out_f16) {
+                if (H16 && p.out_f16) {
                     typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
                     const h4_t hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                     *reinterpret_cast<h4_t*>(reinterpret_cast<_Float16*>(o_base) + (size_t)row * p.ldo + col) = hv;
+                    v = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
                 } else if (NTS) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col));
                 else *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col) = v;
                 st_s += v; st_q += v * v;
@@ -202,7 +212,7 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
 // re-laid for 32 columns -- 8 lanes x float4 cover a row segment, lane >> 3 picks one of 8 rows per pass, 4 passes per 32-row group.
 // The launcher only takes this kernel where the vector path is legal (p.vec_ok, whole 32-column tiles) and there is no GEGLU gate.
 //   out = act((acc * acc_scale + colbias + cbias[img] + res) * scale), column sums / sums of squares of the wave's 64 rows to p.stats
-template <bool HALF>
+template <bool HALF, bool H16 = false>
 __device__ __forceinline__ void epilogue32(const KParams& p, const f32x16 (&acc)[2][2], float* stage, int lane, int wm0, int wn0, float* o_base) {
     static_assert(HALF, "8-wave tiles: 32 staging rows per wave, the two 32-row groups one after the other");
     const int c4 = (lane & 7) * 4;
@@ -220,6 +230,11 @@ __device__ __forceinline__ void epilogue32(const KParams& p, const f32x16 (&acc)
 #pragma unroll
             for (int pass = 0; pass < NP; ++pass) {
                 const int row = min(rbase + pass * 8 + (lane >> 3), p.M - 1);
+                if (H16 && p.res_f16) {
+                    typedef _Float16 h4r_t __attribute__((ext_vector_type(4)));
+                    const h4r_t hv = __builtin_nontemporal_load(reinterpret_cast<const h4r_t*>(reinterpret_cast<const _Float16*>(p.res) + (size_t)row * p.res_ld + col));
+                    rv[pass] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+                } else
                 rv[pass] = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.res_ld + col);
             }
         }
@@ -246,10 +261,11 @@ __device__ __forceinline__ void epilogue32(const KParams& p, const f32x16 (&acc)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = ds_silu(v[q]);
             }
-            if (p.out_f16) {
+            if (H16 && p.out_f16) {
                 typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
                 const h4_t hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                 *reinterpret_cast<h4_t*>(reinterpret_cast<_Float16*>(o_base) + (size_t)row * p.ldo + col) = hv;
+                v = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
             } else *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col) = v;
             st_s += v; st_q += v * v;
         }

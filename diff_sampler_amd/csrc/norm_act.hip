@@ -23,13 +23,18 @@ __global__ void __launch_bounds__(1024) gn_stats_kernel(const ds_norm_args a, in
     const int HW = a.h * a.w;
     const int cq = tid % CQ, pl = tid / CQ;
     if (pl < PL) {
-        const int c = cq * 4;
-        const float* src; int ld;
-        if (c < a.c0) { src = a.x0 + c; ld = a.ld0; } else { src = a.x1 + (c - a.c0); ld = a.ld1; }
-        src += (size_t)n * HW * ld;
+        int c = cq * 4;
+        const float* src; int ld; bool half;
+        if (c < a.c0) { src = a.x0; ld = a.ld0; half = a.in_f16 & 1; } else { src = a.x1; ld = a.ld1; half = a.in_f16 & 2; c -= a.c0; }
+        const _Float16* src16 = reinterpret_cast<const _Float16*>(src) + (size_t)n * HW * ld + c;       // fp16 source: ld in halfs
+        src += (size_t)n * HW * ld + c;
+        c = cq * 4;
+        typedef _Float16 h4s_t __attribute__((ext_vector_type(4)));
         double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
         for (int p = blockIdx.y * PL + pl; p < HW; p += PL * P) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)p * ld);
+            f32x4 v;
+            if (half) { const h4s_t hv = *reinterpret_cast<const h4s_t*>(src16 + (size_t)p * ld); v = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]}; }
+            else v = *reinterpret_cast<const f32x4*>(src + (size_t)p * ld);
 #pragma unroll
             for (int j = 0; j < 4; ++j) { s[j] += (double)v[j]; q[j] += (double)v[j] * (double)v[j]; }
         }
@@ -116,10 +121,12 @@ __global__ void __launch_bounds__(1024) norm_act_kernel(const ds_norm_args a, in
     if (pl >= PL) return;
     const int C = a.c0 + a.c1;
     const int c = cq * 4;
-    const float* src; int ld;
-    if (c < a.c0) { src = a.x0 + c; ld = a.ld0; } else { src = a.x1 + (c - a.c0); ld = a.ld1; }
+    const float* src; int ld; bool half;          // half: this thread's source is an fp16 tensor (in_f16 bit 0: x0, bit 1: x1), ld in halfs
+    int cs = c;                                   // channel inside its source
+    if (c < a.c0) { src = a.x0; ld = a.ld0; half = a.in_f16 & 1; } else { src = a.x1; ld = a.ld1; half = a.in_f16 & 2; cs = c - a.c0; }
     const int H = a.h, W = a.w;
-    src += (size_t)n * H * W * ld;
+    const _Float16* src16 = reinterpret_cast<const _Float16*>(src) + (size_t)n * H * W * ld + cs;
+    src += (size_t)n * H * W * ld + cs;
 
     float mu[4], A[4], Bc[4];
     const int cpg = a.mean ? C / a.groups : 1;
@@ -162,11 +169,9 @@ __global__ void __launch_bounds__(1024) norm_act_kernel(const ds_norm_args a, in
     float* dst = a.out + (size_t)n * OH * OW * a.out_ld + c;
     _Float16* dst16 = reinterpret_cast<_Float16*>(a.out) + (size_t)n * OH * OW * a.out_ld + c;
     _Float16* raw16 = a.raw_out ? reinterpret_cast<_Float16*>(a.raw_out) + (size_t)n * OH * OW * a.raw_ld + c : nullptr;
-    // in_f16: the (single) source is an fp16 tensor [rows][ld0 halfs] -- the conv0 output of a block in fp16 mode
-    const _Float16* src16 = reinterpret_cast<const _Float16*>(a.x0) + (size_t)n * H * W * a.ld0 + c;
     auto ld4 = [&](size_t pix) -> f32x4 {
-        if (a.in_f16) {
-            const h4 v = __builtin_nontemporal_load(reinterpret_cast<const h4*>(src16 + pix * a.ld0));
+        if (half) {
+            const h4 v = __builtin_nontemporal_load(reinterpret_cast<const h4*>(src16 + pix * ld));
             f32x4 o = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
             return o;
         }
@@ -290,55 +295,75 @@ __global__ void channel_mean_kernel(const float* __restrict__ x, int ld, int c, 
 // --------------------------------------------------------------------------------------------------------------
 // LayerNorm over the channel dimension of token rows: one wave per row, the row lives in registers (<= 8 float4 per
 // lane), two-pass mean / variance like ATen's row-wise moments.
-template <bool OUT16>
+template <bool OUT16, int LPR>
 __global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps, float* __restrict__ y, int ldy,
                                                              long long rows, int cols) {
-    const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    // LPR lanes share one row (16 for 320 columns: five 16-byte loads per lane, no idle lanes); a block holds 256 / LPR rows and
+    // walks the row set with a grid stride so that a wave lives for many rows.
+    constexpr int RPB = 256 / LPR;
+    const int lane = threadIdx.x & (LPR - 1);
     const int n4 = cols >> 2;
-    const float* xr = x + row * ldx;
-    f32x4 v[8];
-    float s = 0.f;
+    const float inv_n = 1.0f / (float)cols;
+    for (long long row = (long long)blockIdx.x * RPB + threadIdx.x / LPR; row < rows; row += (long long)gridDim.x * RPB) {
+        const float* xr = x + row * ldx;
+        f32x4 v[8];
+        float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int idx = lane + 64 * i;
-        if (idx < n4) { v[i] = *reinterpret_cast<const f32x4*>(xr + idx * 4); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
-    }
+        for (int i = 0; i < 8; ++i) {
+            const int idx = lane + LPR * i;
+            if (idx < n4) { v[i] = *reinterpret_cast<const f32x4*>(xr + idx * 4); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+        }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    const float mean = s / (float)cols;
-    float q = 0.f;
+        for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s * inv_n;
+        float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int idx = lane + 64 * i;
-        if (idx < n4) {
+        for (int i = 0; i < 8; ++i) {
+            const int idx = lane + LPR * i;
+            if (idx < n4) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+                for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+            }
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = 1.0f / sqrtf(q * inv_n + eps);
+        float* yr = y + row * ldy;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = lane + LPR * i;
+            if (idx < n4) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + idx * 4);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(beta + idx * 4);
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+                if (OUT16) {
+                    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+                    const h4_t hv = {(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+                    *reinterpret_cast<h4_t*>(reinterpret_cast<_Float16*>(y) + row * ldy + idx * 4) = hv;
+                } else
+                    *reinterpret_cast<f32x4*>(yr + idx * 4) = o;
+            }
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-    const float rstd = 1.0f / sqrtf(q / (float)cols + eps);
-    float* yr = y + row * ldy;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int idx = lane + 64 * i;
-        if (idx < n4) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + idx * 4);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + idx * 4);
-            f32x4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
-            if (OUT16) {
-                typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
-                const h4_t hv = {(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
-                *reinterpret_cast<h4_t*>(reinterpret_cast<_Float16*>(y) + row * ldy + idx * 4) = hv;
-            } else
-            *reinterpret_cast<f32x4*>(yr + idx * 4) = o;
-        }
-    }
+}
+
+template <bool OUT16>
+static void launch_layernorm_rows(const float* x, int ldx, const float* gamma, const float* beta, float eps, float* y, int ldy, long long rows,
+                                  int cols, hipStream_t stream) {
+    const int n4 = cols >> 2;
+    const int lpr = n4 <= 128 ? 16 : (n4 <= 256 ? 32 : 64);
+    const long long rpb = 256 / lpr;
+    long long blocks = (rows + rpb - 1) / rpb;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (lpr == 16)
+        hipLaunchKernelGGL((layernorm_rows_kernel<OUT16, 16>), dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, gamma, beta, eps, y, ldy, rows, cols);
+    else if (lpr == 32)
+        hipLaunchKernelGGL((layernorm_rows_kernel<OUT16, 32>), dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, gamma, beta, eps, y, ldy, rows, cols);
+    else
+        hipLaunchKernelGGL((layernorm_rows_kernel<OUT16, 64>), dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, gamma, beta, eps, y, ldy, rows, cols);
 }
 
 // y[r, c] = x[r, c] * gelu(x[r, inner + c]), exact GELU 0.5 g (1 + erf(g / sqrt 2)).
@@ -430,6 +455,7 @@ extern "C" int ds_gn_stats(const ds_norm_args* a, void* stream) {
     if (!a || !a->x0 || !a->mean || !a->rstd) return DS_E_ARG;
     if (a->groups <= 0 || a->groups > 64 || (a->c0 + a->c1) % a->groups) return DS_E_SHAPE;
     if ((a->ld0 & 3) || (a->c1 && (a->ld1 & 3))) return DS_E_ALIGN;
+    if ((a->in_f16 & ~3) || ((a->in_f16 & 2) && !a->c1)) return DS_E_ARG;
     int CQ, PL;
     int rc = norm_geometry(a, &CQ, &PL);
     if (rc) return rc;
@@ -457,7 +483,7 @@ extern "C" int ds_norm_act(const ds_norm_args* a, void* stream) {
     if ((a->mean == nullptr) != (a->rstd == nullptr)) return DS_E_ARG;
     if ((a->scale == nullptr) != (a->shift == nullptr)) return DS_E_ARG;
     if ((a->ld0 & 3) || (a->c1 && (a->ld1 & 3)) || (a->out_ld & 3)) return DS_E_ALIGN;
-    if (a->in_f16 && (a->c1 || (reinterpret_cast<uintptr_t>(a->x0) & 7u))) return DS_E_ARG;
+    if ((a->in_f16 & ~3) || ((a->in_f16 & 1) && (reinterpret_cast<uintptr_t>(a->x0) & 7u)) || ((a->in_f16 & 2) && (!a->c1 || (reinterpret_cast<uintptr_t>(a->x1) & 7u)))) return DS_E_ARG;
     if (a->raw_out && (!a->out_f16 || (a->raw_ld & 3) || (reinterpret_cast<uintptr_t>(a->raw_out) & 7u))) return DS_E_ARG;
     if (a->out_f16 && (reinterpret_cast<uintptr_t>(a->out) & 7u)) return DS_E_ALIGN;
     if (a->resample == DS_RESAMPLE_DOWN && ((a->h | a->w) & 1)) return DS_E_SHAPE;
@@ -541,10 +567,7 @@ extern "C" int ds_layernorm_rows(const float* x, int ldx, const float* gamma, co
     if (!x || !gamma || !beta || !y || rows <= 0 || cols <= 0) return DS_E_ARG;
     if ((cols & 3) || cols > 2048) return DS_E_SHAPE;
     if ((ldx & 3) || (ldy & 3) || !ds_aligned16(x) || !ds_aligned16(y) || !ds_aligned16(gamma) || !ds_aligned16(beta)) return DS_E_ALIGN;
-    const long long blocks = (rows + 3) / 4;
-    if (blocks > 0x7fffffffLL) return DS_E_SHAPE;
-    hipLaunchKernelGGL(layernorm_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, eps, y,
-                       ldy, rows, cols);
+    launch_layernorm_rows<false>(x, ldx, gamma, beta, eps, y, ldy, rows, cols, (hipStream_t)stream);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }
@@ -555,10 +578,7 @@ extern "C" int ds_layernorm_rows_f16(const float* x, int ldx, const float* gamma
     if (!x || !gamma || !beta || !y16 || rows <= 0 || cols <= 0) return DS_E_ARG;
     if ((cols & 3) || cols > 2048) return DS_E_SHAPE;
     if ((ldx & 3) || (ldy & 3) || !ds_aligned16(x) || (reinterpret_cast<uintptr_t>(y16) & 7u) || !ds_aligned16(gamma) || !ds_aligned16(beta)) return DS_E_ALIGN;
-    const long long blocks = (rows + 3) / 4;
-    if (blocks > 0x7fffffffLL) return DS_E_SHAPE;
-    hipLaunchKernelGGL(layernorm_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, eps,
-                       reinterpret_cast<float*>(y16), ldy, rows, cols);
+    launch_layernorm_rows<true>(x, ldx, gamma, beta, eps, reinterpret_cast<float*>(y16), ldy, rows, cols, (hipStream_t)stream);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }

@@ -211,6 +211,30 @@ class UNetEngine:
         conv(emb, E, E, Bs, 1, 1, w['aff.w'], self.aff_total, aff, self.aff_total, 1, 'affine_all', bias=w['aff.b'])
         bufs.update(emb=emb, aff=aff)
 
+        # ---- fp16 residual stream -------------------------------------------------------------------------------
+        # The reference's fp16 mode keeps EVERY activation of the U-Net body in fp16 (networks_edm.py:486 `x.to(dtype)`, :165-179 run in
+        # that dtype): when every block of this plan runs on the fp16-activation kernels, block outputs (the residual stream, the skip
+        # stack) are stored as fp16 rows too -- half the bytes of every epilogue and normalisation pass.  Arithmetic on them is fp32
+        # (values are widened when loaded).  Otherwise the stream stays fp32 (the mixed layout of smaller / unusual geometries).
+        def dma16_ok(b):
+            if self.conv_mode != 1 or w.get(f'{b.name}.conv0.w16') is None or w.get(f'{b.name}.conv1.w16') is None:
+                return False
+            Ho, M_ = b.res_out, B * b.res_out ** 2
+            if not (lib.ds_conv_f16dma_supported(B, Ho, Ho, b.cin, 0, b.cout)
+                    and lib.ds_conv_f16dma_supported(B, Ho, Ho, b.cout, b.cin if b.skip_conv else 0, b.cout)):
+                return False
+            return True
+
+        def attn16_ok(b):          # attention block on the fp16 kernels end to end (CIFAR-10's single 256-wide head is not: fp32 kernel)
+            M_ = B * b.res_out ** 2
+            return bool(self.conv_mode == 1 and lib.ds_attention_f16_supported(b.cout // b.heads)
+                        and lib.ds_gemm_f16dma_supported(M_, b.cout, 3 * b.cout) and lib.ds_gemm_f16dma_supported(M_, b.cout, b.cout))
+        stream16 = self.conv_mode == 1 and all(dma16_ok(b) for b in spec.blocks if b.kind == 'block')
+        P.stream16 = stream16
+        # a block whose attention runs on the fp32 kernels keeps fp32 outputs; every consumer reads a tensor in the dtype it has
+        blk16 = lambda b: stream16 and (not b.heads or attn16_ok(b))
+        as16 = lambda t: t.view(torch.float16)[:t.numel()]          # decoder ping-pong storage viewed as fp16 rows
+
         # ---- stem ---------------------------------------------------------------------------------------------
         x_cur = None          # (tensor, channels)
         skips: List[tuple] = []
@@ -253,7 +277,11 @@ class UNetEngine:
             if dma16:
                 a16, b16 = a16_buf[:M * cin].view(M, cin), b16_buf[:M * cout].view(M, cout)
                 h16 = h16_buf[:M * cout].view(M, cout)       # conv0 output: only read by norm1 -> stored in fp16 (networks_edm.py:486)
-                r16 = r16_buf[:M * cin].view(M, cin) if b.skip_conv else None
+                # raw (un-normalised) fp16 copy of the block input: operand of the fused 1x1 skip projection, and -- fp16 stream -- the
+                # resampled identity skip.  Not needed when the input already is one fp16 tensor of the right geometry.
+                direct = stream16 and x1 is None and rs == DS_RESAMPLE_NONE and x0.dtype == torch.float16
+                need_raw = (b.skip_conv and not direct) or (stream16 and not b.skip_conv and rs != DS_RESAMPLE_NONE)
+                r16 = r16_buf[:M * cin].view(M, cin) if need_raw else None
                 norm('stats', x0, c0, c0, n, Hin, Hin, nm + '.norm0.stats', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps,
                      gamma=w[f'{nm}.norm0.g'], beta=w[f'{nm}.norm0.b'], coefs=ncoef)
                 norm('apply', x0, c0, c0, n, Hin, Hin, nm + '.norm0', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps, use_stats=False,
@@ -267,7 +295,10 @@ class UNetEngine:
                      out=b16, out_ld=cout, out_f16=True, in_f16=True, coefs=ncoef)
                 if b.skip_conv:          # 1x1 skip projection fused into conv1 as extra K columns on the raw (resampled) fp16 input
                     c1_w, c1_b = w[f'{nm}.conv1s.w'], w[f'{nm}.conv1s.b']
-                    c1_skip = dict(e0=r16, ec0=cin)
+                    c1_skip = dict(e0=x0 if direct else r16, ec0=cin)
+                elif stream16 and rs != DS_RESAMPLE_NONE:
+                    c1_w, c1_b = w[f'{nm}.conv1.w'], w[f'{nm}.conv1.b']
+                    c1_skip = dict(res=r16, res_ld=cout)          # resampled raw input, already written by the norm0 pass
                 else:
                     s0 = x0
                     if rs != DS_RESAMPLE_NONE:
@@ -321,12 +352,13 @@ class UNetEngine:
                 c1_w, c1_b = w[f'{nm}.conv1.w'], w[f'{nm}.conv1.b']
                 c1_skip = dict(res=s0, res_ld=cout)
             # output buffer: encoder outputs are kept for the skip stack, decoder outputs ping-pong
+            f16_out = blk16(b)
             if b.pushes_skip:
-                out = new(M, cout)
+                out = bd.new16(M, cout) if f16_out else new(M, cout)
             else:
                 if dec_pp[dec_i] is None or dec_pp[dec_i].numel() < M * cout:
                     dec_pp[dec_i] = new(B * max_h)
-                out = dec_pp[dec_i]
+                out = as16(dec_pp[dec_i]) if f16_out else dec_pp[dec_i]
                 dec_i ^= 1
             if b.heads:
                 mid = out
@@ -352,11 +384,11 @@ class UNetEngine:
                 at.out_f16 = 1 if a16 else 0
                 add(lib.ds_attention_f16 if f16_attn else lib.ds_attention, (C.byref(at),), nm + '.attention', keep=(at,))
                 if b.pushes_skip:
-                    out2 = new(M, cout)
+                    out2 = bd.new16(M, cout) if f16_out else new(M, cout)
                 else:
                     if dec_pp[dec_i] is None:
                         dec_pp[dec_i] = new(B * max_h)
-                    out2 = dec_pp[dec_i]
+                    out2 = as16(dec_pp[dec_i]) if f16_out else dec_pp[dec_i]
                     dec_i ^= 1
                 conv(ao_, cout, cout, n, Ho, Ho, w[f'{nm}.proj.w'], cout, out2, cout, 1, nm + '.proj', bias=w[f'{nm}.proj.b'],
                      res=out, res_ld=cout, scale=b.skip_scale, stats=True)
@@ -368,7 +400,7 @@ class UNetEngine:
         assert not skips
         # ---- output head ------------------------------------------------------------------------------------------
         xo, co = x_cur
-        if lib.ds_conv3x3_halo_supported(R, R):
+        if lib.ds_conv3x3_halo_supported(R, R) and xo.dtype == torch.float32:
             norm('stats', xo, co, co, B, R, R, 'out.norm.stats', groups=arch.num_groups(co), eps=spec.out_eps, gamma=w['out.g'],
                  beta=w['out.b'], coefs=ncoef)
             conv(xo, co, co, B, R, R, w['outc.w'], spec.out_channels, bufs['out'], 4, 9, 'out.conv', bias=w['outc.b'],
@@ -503,7 +535,7 @@ class EDMDenoiser:
         NCHW tensor ``[B, C, h, w]`` a forward hook on that block of the reference module would see (solvers_amed.py:7-18 taps
         ``net.model.enc['8x8_block3']``).  A copy: the plan's own buffer is overwritten by the next evaluation."""
         plan, B = self._last
-        t = plan.bufs[name]
+        t = plan.bufs[name].float()          # fp16 residual stream (fp16 mode): widened for the caller
         hw = t.shape[0] // B
         h = int(round(hw ** 0.5))
         assert h * h == hw, (name, tuple(t.shape), B)
@@ -513,7 +545,7 @@ class EDMDenoiser:
         """Channel mean of the AMED bottleneck tap, [B, 8, 8] (solvers_amed.py:16-17, :24-28)."""
         from . import ops
         name = 'enc.8x8_block2' if class_cond else 'enc.8x8_block3'
-        t = plan.bufs[name]
+        t = plan.bufs[name].float()
         c = t.shape[1]
         out = torch.empty(B, 8, 8, dtype=torch.float32, device=self.device)
         ops.channel_mean(t, c, c, B * 64, out)

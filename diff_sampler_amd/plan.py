@@ -171,9 +171,12 @@ class Builder:
         a.out_nchw = out_nchw               # network output written channel-planar (NCHW) by the epilogue
         a.wgt_f16, a.wgt_shift = (self.conv_mode, shift) if f16 else (0, 0)
         a.in_f16 = 1 if in_f16 else 0
-        if out_f16 or out.dtype == torch.float16:          # fp16 output rows (a tensor that only feeds a normalisation pass or a projection)
-            assert in_f16 and out.dtype == torch.float16 and cout % 64 == 0
+        if out_f16 or out.dtype == torch.float16:          # fp16 output rows: conv0 outputs, projection operands, the fp16 residual stream
+            assert in_f16 and out.dtype == torch.float16 and cout % 64 == 0, name
             a.out_f16 = 1
+        if res is not None and res.dtype == torch.float16:  # the residual operand is a tensor of the fp16 stream
+            assert in_f16, name
+            a.res_f16 = 1
         self.stats_of.pop(out.data_ptr(), None)
         if stats and cout % 64 == 0 and out_ld == cout:
             sb = self.new(-(-(n * h * w) // 64) * 2 * cout)
@@ -218,13 +221,12 @@ class Builder:
                                    ptr(scale), ptr(shift), ss_ld, ss_rows, ptr(self.mean), ptr(self.rstd), ptr(coefs))
                 self.add(self.lib.ds_gn_finalize, (C.byref(f),), name + '.finalize', keep=(f,))
                 return
-        assert not (kind == 'stats' and x0.dtype == torch.float16), 'statistics of an fp16 tensor come from its producer (ds_gn_finalize)'
         a = NormArgs(ptr(x0), ptr(x1), c0, c1, ld0, ld1, n, h, w, groups, eps, ptr(self.mean) if use_stats else None,
                      ptr(self.rstd) if use_stats else None, ptr(gamma), ptr(beta), ptr(scale), ptr(shift), ss_ld, ss_rows, act,
                      resample, ptr(out), out_ld, ptr(coefs))
-        if in_f16:
-            assert kind == 'apply' and x0.dtype == torch.float16 and x1 is None
-            a.in_f16 = 1
+        # fp16 sources (conv0 outputs, tensors of the fp16 residual stream) are recognised by their dtype: bit 0 = x0, bit 1 = x1
+        a.in_f16 = (1 if x0.dtype == torch.float16 else 0) | (2 if x1 is not None and x1.dtype == torch.float16 else 0)
+        assert not in_f16 or (a.in_f16 & 1), name
         if out_f16:
             assert kind == 'apply' and out.dtype == torch.float16 and (raw_out is None or raw_out.dtype == torch.float16)
             a.out_f16, a.raw_out, a.raw_ld = 1, ptr(raw_out), raw_ld

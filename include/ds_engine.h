@@ -118,13 +118,15 @@ typedef struct ds_conv_args {
      * multiples of 8; c0 % 64 == 0, c1 == ec1 == 0), already normalised / activated by ds_norm_act(out_f16) -- the reference's storage
      * type in this mode (networks_edm.py:486 runs the U-Net body on x.to(float16)).  The convolution is then a pure matrix kernel
      * (csrc/conv3x3_f16dma.hip: both operands staged by LDS-DMA, 256-pixel x 64/128/192/256-channel tiles).  norm_coefs must be NULL.
-     * Bias / residual / output stay fp32.  Availability: ds_conv_f16dma_supported(); otherwise DS_E_SHAPE. */
+     * Bias is fp32; residual / output are fp32 unless res_f16 / out_f16.  Availability: ds_conv_f16dma_supported(); otherwise DS_E_SHAPE. */
     int in_f16;
     /* 1: the OUTPUT is written as fp16 NHWC rows [M][out_ld halfs] (rounded to nearest even from the fp32 epilogue value; the GroupNorm
-     * column sums of stats_out are taken before rounding).  For tensors that only feed a normalisation pass (the conv0 output of a
-     * block in fp16 mode: read back by ds_norm_act with in_f16).  Requires the aligned vector epilogue (cout % 64 == 0), no out_nchw,
-     * no GEGLU. */
+     * column sums of stats_out are those of the ROUNDED values, i.e. of the stored tensor).  The reference's fp16 mode keeps every
+     * activation of the U-Net body in fp16 (networks_edm.py:486, :165-179; torch.autocast in the latent-diffusion path, sample.py:296):
+     * conv0 outputs, block outputs (the residual stream) and projection outputs.  Requires in_f16, cout % 64 == 0, no out_nchw. */
     int out_f16;
+    /* 1 (with in_f16): `res` is an fp16 tensor [M][res_ld halfs] (res_ld % 4 == 0) -- the fp16 residual stream; added in fp32. */
+    int res_f16;
 } ds_conv_args;
 
 int ds_conv2d_nhwc(const ds_conv_args* a, void* stream);
@@ -249,8 +251,8 @@ typedef struct ds_norm_args {
      * With out_f16, a non-NULL `coefs` is an INPUT: the {mu, A, B} planes [n][3][c0+c1] a preceding ds_gn_finalize / ds_gn_stats wrote
      * (mean / rstd / gamma / beta / scale / shift are then ignored). */
     int out_f16; void* raw_out; int raw_ld;
-    /* ds_norm_act only.  in_f16 = 1: x0 is an fp16 tensor [rows][ld0 halfs] (c1 must be 0) -- a convolution output written with
-     * ds_conv_args.out_f16. */
+    /* ds_norm_act / ds_gn_stats.  in_f16 bit 0: x0 is an fp16 tensor [rows][ld0 halfs]; bit 1: x1 is (ld1 in halfs) -- tensors written
+     * with ds_conv_args.out_f16 (conv0 outputs, the fp16 residual stream).  Values are widened to fp32 before any arithmetic. */
     int in_f16;
 } ds_norm_args;
 

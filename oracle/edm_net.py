@@ -35,23 +35,33 @@ import torch.nn.functional as F
 # '...proj', '...attention') are rounded to fp16 (round to nearest even, like ``.to(torch.float16)``) and multiplied / accumulated in
 # fp32 -- the arithmetic of the product's fp16-operand kernels, on the CPU.  Everything else (norms, SiLU, softmax, residuals,
 # embedding path, storage) stays fp32.  Outside the context manager the oracle is the pinned fp32 restatement.
+# ``stored(prefix)`` (optional) names the layers whose OUTPUT the fp16 mode stores in fp16 -- '...conv0' (the tensor norm1 reads),
+# '...conv1' (the block output: the residual stream, networks_edm.py:165-179 run in x.dtype), '...proj' (the attention block's output):
+# that value is rounded to fp16 right where the reference holds an fp16 tensor; arithmetic on it stays fp32.
 _F16_PRED = None
+_F16_STORED = None
 
 
 @contextlib.contextmanager
-def operands_f16(pred):
-    global _F16_PRED
-    old, _F16_PRED = _F16_PRED, pred
+def operands_f16(pred, stored=None):
+    global _F16_PRED, _F16_STORED
+    old, _F16_PRED, _F16_STORED = (_F16_PRED, _F16_STORED), pred, stored
     try:
         yield
     finally:
-        _F16_PRED = old
+        _F16_PRED, _F16_STORED = old
 
 
 def _rnd(prefix, *ts):
     if _F16_PRED is not None and _F16_PRED(prefix):
         return tuple(t.to(torch.float16).to(torch.float32) for t in ts)
     return ts
+
+
+def _stored(prefix, t):
+    if _F16_STORED is not None and _F16_STORED(prefix):
+        return t.to(torch.float16).to(torch.float32)
+    return t
 
 
 def _silu(x):
@@ -110,16 +120,18 @@ def _block(p, prefix, x, emb, *, up, down, adaptive, skip_scale, eps, heads, tap
     params = _lin(p, prefix + '.affine', emb)[:, :, None, None]
     if adaptive:
         scale, shift = params.chunk(2, dim=1)
-        x = _silu(torch.addcmul(shift, _gn(p, prefix + '.norm1', x, eps), scale + 1))
+        x = _silu(torch.addcmul(shift, _gn(p, prefix + '.norm1', _stored(prefix + '.conv0', x), eps), scale + 1))
     else:
-        x = _silu(_gn(p, prefix + '.norm1', x + params, eps))
+        x = _silu(_gn(p, prefix + '.norm1', _stored(prefix + '.conv0', x + params), eps))
     x = _conv(p, prefix + '.conv1', x)
     has_skip_w = (prefix + '.skip.weight') in p
     if has_skip_w or up or down:
         s = _conv(p, prefix + '.skip', orig, up=up, down=down)
+        if not has_skip_w:
+            s = _stored(prefix + '.conv1', s)          # a resampled identity skip is itself an fp16 tensor in that mode
     else:
         s = orig
-    x = (x + s) * skip_scale
+    x = _stored(prefix + '.conv1', (x + s) * skip_scale)
     if heads:
         n, c = x.shape[0], x.shape[1]
         qkv = _conv(p, prefix + '.qkv', _gn(p, prefix + '.norm2', x, eps))
@@ -134,7 +146,7 @@ def _block(p, prefix, x, emb, *, up, down, adaptive, skip_scale, eps, heads, tap
         else:
             w = torch.einsum('ncq,nck->nqk', q, k / math.sqrt(k.shape[1])).softmax(dim=2)   # networks_edm.py:108
             a = torch.einsum('nqk,nck->ncq', w, v)
-        x = (_conv(p, prefix + '.proj', a.reshape(*x.shape)) + x) * skip_scale
+        x = _stored(prefix + '.proj', (_conv(p, prefix + '.proj', a.reshape(*x.shape)) + x) * skip_scale)
     return x
 
 

@@ -29,6 +29,13 @@ def edm_prefixes(plan):
     return out
 
 
+def edm_stored_prefixes(plan):
+    """Reference prefixes of the layers whose output the EDM engine stores in fp16 (ds_conv_args.out_f16 == 1): '...conv0', '...conv1'
+    (block outputs: the fp16 residual stream), '...proj' -- the `stored` predicate of oracle.edm_net.operands_f16."""
+    lib = _lib.load()
+    return {'model.' + op.name for op in plan.ops if op.fn is lib.ds_conv2d_nhwc and op.keep[0].out_f16 == 1}
+
+
 _LDM_MAP = {'.in_layers': ['.in_layers.2'], '.out_layers': ['.out_layers.3', '.skip_connection'], '.proj_in': ['.proj_in'],
             '.proj_out': ['.proj_out'], '.op': ['.op'], '.conv': ['.conv'],
             '.attn1.qkv': ['.transformer_blocks.0.attn1.to_q', '.transformer_blocks.0.attn1.to_k', '.transformer_blocks.0.attn1.to_v'],

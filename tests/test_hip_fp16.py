@@ -78,9 +78,11 @@ def test_edm_use_fp16_within_bound_of_fp32_oracle_and_of_torch_autocast(name, B)
     torch.cuda.synchronize()
     # the same arithmetic on the CPU: operands of exactly the layers this plan runs on the fp16-operand kernels rounded to fp16
     from oracle.edm_net import operands_f16
-    from _f16_names import edm_prefixes
-    f16_layers = edm_prefixes(net.engine.plan(B, B))
-    with torch.no_grad(), operands_f16(lambda prefix: prefix in f16_layers):
+    from _f16_names import edm_prefixes, edm_stored_prefixes
+    f16_layers, f16_stored = edm_prefixes(net.engine.plan(B, B)), edm_stored_prefixes(net.engine.plan(B, B))
+    # ... and the tensors it stores in fp16 (conv0 outputs, block outputs = the residual stream, attention-block outputs) rounded there
+    assert net.engine.plan(B, B).stream16 and sum(1 for n_ in f16_stored if n_.endswith('.conv1')) >= 20, sorted(f16_stored)[:8]
+    with torch.no_grad(), operands_f16(lambda prefix: prefix in f16_layers, stored=lambda prefix: prefix in f16_stored):
         ref16ops = edm_denoise(params, cfg, x, sig, lab)
     e16ops = _rel(out.cpu(), ref16ops)
     assert e16ops < 1.5e-3, e16ops

@@ -991,7 +991,8 @@ def test_conv_f16_output_rows_and_norm_pass_on_fp16_tensors():
     ref = ref.permute(0, 2, 3, 1).reshape(M, cout).float()
     assert _rel(h16.float().cpu(), ref.to(torch.float16).float()) < 1.5e-3          # one fp16 ulp where the fp32 sums straddle a rounding boundary
     st = stats.cpu().reshape(-1, 2, cout)
-    assert _rel(st[:, 0], ref.reshape(-1, 64, cout).sum(1)) < 1e-5                 # column sums are taken BEFORE rounding
+    stored = h16.float().cpu().reshape(-1, 64, cout)                               # column sums / sums of squares of the STORED (rounded) tensor
+    assert _rel(st[:, 0], stored.sum(1)) < 1e-5 and _rel(st[:, 1], (stored * stored).sum(1)) < 1e-5
     # second norm pass reads the fp16 tensor
     b16 = torch.zeros(M, cout, dtype=torch.float16, device=dev)
     nb = ops._norm_args(x, cout, cout, B, H, H, groups=32, eps=1e-5, mean=mean, rstd=rstd, act=1, out=b16, out_ld=cout)
