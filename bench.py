@@ -74,12 +74,12 @@ def parse(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--batch', type=int, default=256, help='images per GPU per sampler call')
+    ap.add_argument('--batch', type=int, default=None, help='images per GPU per sampler call (default: 256 cifar10, 128 ffhq, 64 imagenet64, 16 sd15 -- the batches the kept lines in profiles/ are quoted on)')
     ap.add_argument('--nfe', type=int, default=10)
     ap.add_argument('--solver', default='dpmpp', choices=['dpmpp', 'euler', 'ipndm', 'heun'])
     ap.add_argument('--config', default='cifar10')
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'fp16', 'fp16x3'],
-                    help="fp16 = the reference's use_fp16 / autocast mode (configs 3 and 5): fp16 operands in the 3x3 convolutions, 1x1 / Linear layers and attention, fp32 accumulation and storage; fp16x3 = fp32 EMULATED in the 3x3 convolutions by split fp16 hi/lo operands (3 MFMA products, fp32 tolerances)")
+                    help="fp16 = the reference's use_fp16 / autocast mode (configs 3 and 5): fp16 operands in the 3x3 convolutions, 1x1 / Linear layers and attention, fp16 activation storage, fp32 accumulation; fp16x3 = fp32 EMULATED in the 3x3 convolutions by split fp16 hi/lo operands (3 MFMA products, fp32 tolerances)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay the sampler call from a captured hipGraph')
     ap.add_argument('--cpu-batch', type=int, default=8)
@@ -88,7 +88,10 @@ def parse(argv=None):
     ap.add_argument('--no-launch-modes', action='store_true', help='skip the eager-vs-hipGraph comparison')
     ap.add_argument('--no-batch-sweep', action='store_true', help='skip the extra throughput measurement at 1024 images per call')
     ap.add_argument('--stub', action='store_true', help=argparse.SUPPRESS)   # launcher self-test: gloo ranks on CPU, no kernels
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.batch is None:
+        args.batch = {'ffhq': 128, 'imagenet64': 64, 'sd15': 16}.get(args.config, 256)
+    return args
 
 
 def sampler_call(solvers, solver, net, latents, nfe, ldm=None):
@@ -556,7 +559,7 @@ def main(argv=None):
             'metric': 'images/sec (whole node) at NFE=%d, %s' % (args.nfe, 'EDM CIFAR-10' if args.config == 'cifar10' else workload_name.split(' (')[0]),
             'value': round(total_images / dt, 2), 'unit': 'images/sec', 'n_gpus': n_comm, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'fp32': 'fp32', 'fp16': 'fp16 operands in the 3x3 convolutions (on fp16-stored activated tensors), 1x1 / Linear layers and attention; fp32 accumulate, fp32 softmax / norms / residual stream',
+            'dtype': {'fp32': 'fp32', 'fp16': 'fp16 operands in the 3x3 convolutions, 1x1 / Linear layers and attention, activations between layers stored in fp16 (residual stream included, as the reference does in this mode); fp32 accumulate, fp32 softmax / norm arithmetic',
                       'fp16x3': 'fp16x3 (fp32-emulated: split fp16 hi/lo operands, 3 MFMA products, fp32 accumulate) in the 3x3 convolutions, rest fp32'}[args.dtype],
             'data': 'synthetic N(0,1) latents, random-init (signal-carrying) weights',
             'config': {'workload': '%s, %s NFE=%d, batch %d/GPU' %

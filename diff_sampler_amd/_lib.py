@@ -98,7 +98,7 @@ class StemIm2colArgs(C.Structure):
 
 # ds_plan_add op codes (include/ds_engine.h)
 DS_OP_CONV2D, DS_OP_GEMM, DS_OP_GN_STATS, DS_OP_NORM_ACT, DS_OP_GN_FINALIZE, DS_OP_ATTENTION, DS_OP_ATTENTION_F16, DS_OP_LAYERNORM, \
-    DS_OP_GEGLU, DS_OP_NOISE_EMBED, DS_OP_STEM_IM2COL, DS_OP_LAYERNORM_F16 = range(1, 13)
+    DS_OP_GEGLU, DS_OP_NOISE_EMBED, DS_OP_STEM_IM2COL, DS_OP_LAYERNORM_F16, DS_OP_LAYERNORM_F16IO = range(1, 14)
 
 _SIGNATURES = {
     'ds_version': (C.c_int, []),
@@ -128,6 +128,7 @@ _SIGNATURES = {
     'ds_attention_f16_supported': (C.c_int, [C.c_int]),
     'ds_layernorm_rows': (C.c_int, [vp, C.c_int, vp, vp, C.c_float, vp, C.c_int, C.c_longlong, C.c_int, vp]),
     'ds_layernorm_rows_f16': (C.c_int, [vp, C.c_int, vp, vp, C.c_float, vp, C.c_int, C.c_longlong, C.c_int, vp]),
+    'ds_layernorm_rows_f16io': (C.c_int, [vp, C.c_int, vp, vp, C.c_float, vp, C.c_int, C.c_longlong, C.c_int, vp]),
     'ds_geglu': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_longlong, C.c_int, vp]),
     'ds_cfg_denoise': (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     'ds_noise_embed': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp]),

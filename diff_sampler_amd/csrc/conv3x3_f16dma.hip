@@ -249,13 +249,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
     }
     float* stage = smem + wave * 32 * EPI_LD;
     const int wn0 = n0 + wc * (NB * 32);
-    if constexpr (NB == 1) {
-        epilogue32<true, true>(p, accA, stage, lane, m0 + wr * 64, wn0, p.out);
-    } else {                                                   // non-temporal residual loads / output stores: +1 ... 2 % (A/B, profiles/r3_conv_f16dma_ablations.txt)
-        epilogue<0, true, true, true>(p, accA, stage, lane, m0 + wr * 64, wn0, p.out);
-        if constexpr (NB == 3) epilogue32<true, true>(p, accB, stage, lane, m0 + wr * 64, wn0 + 64, p.out);
-        if constexpr (NB == 4) epilogue<0, true, true, true>(p, accB, stage, lane, m0 + wr * 64, wn0 + 64, p.out);
-    }
+    // non-temporal residual loads / output stores: +1 ... 2 % (A/B, profiles/r3_conv_f16dma_ablations.txt); the launcher only takes this
+    // kernel on the vector path (vec_ok, cout a multiple of the tile width)
+    epilogue_pipe<0, true, true, (NB == 1 ? 32 : 64), (NB == 3 ? 32 : (NB == 4 ? 64 : 0))>(p, accA, accB, stage, lane, m0 + wr * 64, wn0, p.out);
 }
 
 }  // namespace

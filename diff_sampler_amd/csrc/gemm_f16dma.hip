@@ -137,13 +137,7 @@ __global__ void __launch_bounds__(512, 2) gemm_f16dma_kernel(const KParams p) {
 
     float* stage = smem + wave * 32 * EPI_LD;
     const int wn0 = n0 + wc * (NB * 32);
-    if constexpr (NB == 1) {
-        epilogue32<true, true>(p, accA, stage, lane, m0 + wr * 64, wn0, p.out);
-    } else {
-        epilogue<0, true, false, true>(p, accA, stage, lane, m0 + wr * 64, wn0, p.out);
-        if constexpr (NB == 3) epilogue32<true, true>(p, accB, stage, lane, m0 + wr * 64, wn0 + 64, p.out);
-        if constexpr (NB == 4) epilogue<0, true, false, true>(p, accB, stage, lane, m0 + wr * 64, wn0 + 64, p.out);
-    }
+    epilogue_pipe<0, false, true, (NB == 1 ? 32 : 64), (NB == 3 ? 32 : (NB == 4 ? 64 : 0))>(p, accA, accB, stage, lane, m0 + wr * 64, wn0, p.out);
 }
 
 template <int NB>

@@ -58,9 +58,7 @@ struct KParams {
 // 256 x 256 conv tile; as a run-time option for every other kernel of the family (fp32 / fp16 GEMMs, fp16 convolutions; outputs of at
 // least 32 MiB) it changed nothing on the CIFAR-10, ImageNet-64 fp16 and SD-1.5 fp16 benches (profiles/r2_conv_tile_options.txt), so
 // only that kernel instantiates it.
-// H16: fp16 output rows / fp16 residual rows (p.out_f16, p.res_f16) -- compiled into the fp16-activation kernels only; the column sums
-// left for the consumer's GroupNorm are then those of the ROUNDED values, i.e. of the tensor that is actually stored.
-template <int MODE, bool HALF = false, bool NTS = false, bool H16 = false>
+template <int MODE, bool HALF = false, bool NTS = false>
 __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2][2], float* stage, int lane, int wm0, int wn0,
                                          float* o_base) {
     // HALF: the staging area holds 32 x EPI_LD floats per wave (8-wave blocks) and the two 32-row halves go one after
@@ -86,12 +84,6 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
 #pragma unroll
                 for (int pass = 0; pass < NP; ++pass) {
                     const int row = min(rbase + pass * 4 + (lane >> 4), p.M - 1);
-                    if (H16 && p.res_f16) {
-                        typedef _Float16 h4r_t __attribute__((ext_vector_type(4)));
-                        const h4r_t hv = __builtin_nontemporal_load(reinterpret_cast<const h4r_t*>(reinterpret_cast<const _Float16*>(p.res) + (size_t)row * p.res_ld + col));
-                        rv[pass] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
-                        continue;
-                    }
                     const f32x4* rp = reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.res_ld + col);
                     rv[pass] = NTS ? __builtin_nontemporal_load(rp) : *rp;
                 }
@@ -121,11 +113,6 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
                         const f32x4 gt = *reinterpret_cast<const f32x4*>(stage + rr * EPI_LD + c4 + 32) + cbg;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[q] *= 0.5f * gt[q] * (1.0f + erff(gt[q] * 0.70710678118654752440f));
-                        if (H16 && p.out_f16) {
-                            typedef _Float16 h4g_t __attribute__((ext_vector_type(4)));
-                            const h4g_t hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                            *reinterpret_cast<h4g_t*>(reinterpret_cast<_Float16*>(o_base) + (size_t)row * p.ldo + (wn0 >> 1) + c4) = hv;
-                        } else
                         *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + (wn0 >> 1) + c4) = v;
                     }
                     continue;
@@ -134,12 +121,7 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = ds_silu(v[q]);
                 }
-                if (H16 && p.out_f16) {
-                    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
-                    const h4_t hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                    *reinterpret_cast<h4_t*>(reinterpret_cast<_Float16*>(o_base) + (size_t)row * p.ldo + col) = hv;
-                    v = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
-                } else if (NTS) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col));
+                if (NTS) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col));
                 else *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col) = v;
                 st_s += v; st_q += v * v;
             }
@@ -212,7 +194,7 @@ __device__ __forceinline__ void epilogue(const KParams& p, const f32x16 (&acc)[2
 // re-laid for 32 columns -- 8 lanes x float4 cover a row segment, lane >> 3 picks one of 8 rows per pass, 4 passes per 32-row group.
 // The launcher only takes this kernel where the vector path is legal (p.vec_ok, whole 32-column tiles) and there is no GEGLU gate.
 //   out = act((acc * acc_scale + colbias + cbias[img] + res) * scale), column sums / sums of squares of the wave's 64 rows to p.stats
-template <bool HALF, bool H16 = false>
+template <bool HALF>
 __device__ __forceinline__ void epilogue32(const KParams& p, const f32x16 (&acc)[2][2], float* stage, int lane, int wm0, int wn0, float* o_base) {
     static_assert(HALF, "8-wave tiles: 32 staging rows per wave, the two 32-row groups one after the other");
     const int c4 = (lane & 7) * 4;
@@ -230,11 +212,6 @@ __device__ __forceinline__ void epilogue32(const KParams& p, const f32x16 (&acc)
 #pragma unroll
             for (int pass = 0; pass < NP; ++pass) {
                 const int row = min(rbase + pass * 8 + (lane >> 3), p.M - 1);
-                if (H16 && p.res_f16) {
-                    typedef _Float16 h4r_t __attribute__((ext_vector_type(4)));
-                    const h4r_t hv = __builtin_nontemporal_load(reinterpret_cast<const h4r_t*>(reinterpret_cast<const _Float16*>(p.res) + (size_t)row * p.res_ld + col));
-                    rv[pass] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
-                } else
                 rv[pass] = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.res_ld + col);
             }
         }
@@ -261,12 +238,7 @@ __device__ __forceinline__ void epilogue32(const KParams& p, const f32x16 (&acc)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = ds_silu(v[q]);
             }
-            if (H16 && p.out_f16) {
-                typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
-                const h4_t hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                *reinterpret_cast<h4_t*>(reinterpret_cast<_Float16*>(o_base) + (size_t)row * p.ldo + col) = hv;
-                v = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
-            } else *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col) = v;
+            *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col) = v;
             st_s += v; st_q += v * v;
         }
     }
@@ -282,6 +254,154 @@ __device__ __forceinline__ void epilogue32(const KParams& p, const f32x16 (&acc)
             *reinterpret_cast<f32x4*>(sp) = st_s;
             *reinterpret_cast<f32x4*>(sp + p.N) = st_q;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Pipelined vector epilogue of a 64-row wave tile made of one or two column blocks (WA = 32 / 64 columns at wn0, WB = 0 / 32 / 64 more
+// at wn0 + WA): the same arithmetic as epilogue / epilogue32 above, group by group (a group = 32 rows of one block), but the residual
+// rows and per-image bias of group g + 1 are REQUESTED BEFORE the stores of group g are issued.  On this ISA loads and stores retire
+// through one in-order counter (vmcnt): a load issued after a burst of stores cannot be waited for without waiting for those stores
+// to be acknowledged by memory, so with the request placed after the previous group's stores every group paid a full store round
+// trip (measured: the residual operand cost 25 % of a K = 1 728 convolution).  Two register sets of 8 rows alternate.
+template <int W> struct EpiGeo { static constexpr int LPR = W / 4, RPP = 64 / LPR, NP = 32 / RPP; };
+
+typedef _Float16 epi_h4 __attribute__((ext_vector_type(4)));
+// The requested rows of one group: fp32 rows in rv, fp16 rows RAW in rh -- they are widened where they are used (a conversion here would
+// wait for the data before the tile is staged, exposing the whole memory latency: measured +0.05 ms on a 0.25 ms convolution).
+struct EpiRows { f32x4 rv[8]; epi_h4 rh[8]; f32x4 cvu; };
+
+template <int W, bool NTS, bool H16>
+__device__ __forceinline__ void epi_request(const KParams& p, int rbase, int col, int lane, EpiRows& e) {
+    using G = EpiGeo<W>;
+    f32x4 (&rv)[8] = e.rv;
+    f32x4& cvu = e.cvu;
+    if (p.res) {
+#pragma unroll
+        for (int pass = 0; pass < G::NP; ++pass) {
+            const int row = min(rbase + pass * G::RPP + lane / G::LPR, p.M - 1);
+            if (H16 && p.res_f16) {
+                e.rh[pass] = __builtin_nontemporal_load(reinterpret_cast<const epi_h4*>(reinterpret_cast<const _Float16*>(p.res) + (size_t)row * p.res_ld + col));
+            } else {
+                const f32x4* rp = reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.res_ld + col);
+                rv[pass] = NTS ? __builtin_nontemporal_load(rp) : *rp;
+            }
+        }
+    }
+    cvu = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.cbias && (p.cbias_bcast || p.HW % 32 == 0)) {
+        const int img = p.cbias_bcast ? 0 : __builtin_amdgcn_readfirstlane(min(rbase, p.M - 1)) / p.HW;
+        cvu = *reinterpret_cast<const f32x4*>(p.cbias + (size_t)img * p.cbias_ld + col);
+    }
+}
+
+// a0 / a1: the group's accumulators of columns [0, 32) / [32, 64) of the block (a1 unused for W = 32); bn0 = first column of the block
+template <int MODE, int W, bool NTS, bool H16>
+__device__ __forceinline__ void epi_group(const KParams& p, const f32x16& a0, const f32x16& a1, float* stage, int rbase, const EpiRows& e,
+                                          int lane, int bn0, float* o_base, const f32x4& cb, const f32x4& cbg, f32x4& st_s, f32x4& st_q) {
+    using G = EpiGeo<W>;
+    const f32x4& cvu = e.cvu;
+    const int c4 = (lane & (G::LPR - 1)) * 4, col = bn0 + c4;
+    const bool cb_uniform = p.cbias && (p.cbias_bcast || p.HW % 32 == 0);
+    const bool geglu = (MODE == 0) && W == 64 && p.act == DS_ACT_GEGLU;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int sr = ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_LD + (lane & 31);
+        stage[sr] = a0[r];
+        if (W == 64) stage[sr + 32] = a1[r];
+    }
+#pragma unroll
+    for (int pass = 0; pass < G::NP; ++pass) {
+        const int rr = pass * G::RPP + lane / G::LPR;
+        const int row = rbase + rr;
+        if (row >= p.M) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * EPI_LD + c4);
+        if (MODE == 0) v *= p.acc_scale;
+        if (MODE == 1) v *= p.scale;
+        v += cb;
+        if (p.rowbias) v += p.rowbias[row];
+        if (cb_uniform) v += cvu;
+        else if (p.cbias) v += *reinterpret_cast<const f32x4*>(p.cbias + (size_t)(row / p.HW) * p.cbias_ld + col);
+        if (p.res) {
+            if (H16 && p.res_f16) { const epi_h4 hr = e.rh[pass]; v += f32x4{(float)hr[0], (float)hr[1], (float)hr[2], (float)hr[3]}; }
+            else v += e.rv[pass];
+        }
+        if (MODE == 0) v *= p.scale;
+        if (geglu) {
+            if (c4 < 32) {
+                const f32x4 gt = *reinterpret_cast<const f32x4*>(stage + rr * EPI_LD + c4 + 32) + cbg;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] *= 0.5f * gt[q] * (1.0f + erff(gt[q] * 0.70710678118654752440f));
+                if (H16 && p.out_f16) {
+                    typedef _Float16 h4g_t __attribute__((ext_vector_type(4)));
+                    const h4g_t hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                    *reinterpret_cast<h4g_t*>(reinterpret_cast<_Float16*>(o_base) + (size_t)row * p.ldo + (bn0 >> 1) + c4) = hv;
+                } else
+                    *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + (bn0 >> 1) + c4) = v;
+            }
+            continue;
+        }
+        if (p.act == DS_ACT_SILU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = ds_silu(v[q]);
+        }
+        if (H16 && p.out_f16) {
+            typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+            const h4_t hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            *reinterpret_cast<h4_t*>(reinterpret_cast<_Float16*>(o_base) + (size_t)row * p.ldo + col) = hv;
+            v = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+        } else if (NTS) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col));
+        else *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col) = v;
+        st_s += v; st_q += v * v;
+    }
+}
+
+template <int W>
+__device__ __forceinline__ void epi_stats(const KParams& p, int lane, int wm0, int col, f32x4 st_s, f32x4 st_q) {
+    if (!p.stats || wm0 >= p.M) return;
+    using G = EpiGeo<W>;
+    // column sums of this wave's 64 rows: the lane groups (lane / LPR) hold disjoint rows of the same 4 columns
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int o = G::LPR; o < 64; o <<= 1) { st_s[q] += __shfl_xor(st_s[q], o); st_q[q] += __shfl_xor(st_q[q], o); }
+    }
+    if (lane < G::LPR) {
+        float* sp = p.stats + (size_t)(wm0 >> 6) * 2 * p.N + col;
+        *reinterpret_cast<f32x4*>(sp) = st_s;
+        *reinterpret_cast<f32x4*>(sp + p.N) = st_q;
+    }
+}
+
+// stage: 32 x EPI_LD floats owned by the wave.  The caller guarantees the vector path (p.vec_ok, whole blocks inside N, no split).
+template <int MODE, bool NTS, bool H16, int WA, int WB>
+__device__ __forceinline__ void epilogue_pipe(const KParams& p, const f32x16 (&accA)[2][2], const f32x16 (&accB)[2][2], float* stage, int lane,
+                                              int wm0, int wn0, float* o_base) {
+    const int colA = wn0 + (lane & (WA / 4 - 1)) * 4;
+    const int colB = wn0 + WA + (lane & ((WB ? WB : 32) / 4 - 1)) * 4;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 cbA = zero, cbB = zero, cbgA = zero, cbgB = zero;
+    const bool geglu = (MODE == 0) && p.act == DS_ACT_GEGLU;
+    if (p.colbias) {
+        cbA = *reinterpret_cast<const f32x4*>(p.colbias + colA);
+        if (WB) cbB = *reinterpret_cast<const f32x4*>(p.colbias + colB);
+        if (geglu && WA == 64 && (lane & 15) < 8) cbgA = *reinterpret_cast<const f32x4*>(p.colbias + colA + 32);
+        if (geglu && WB == 64 && (lane & 15) < 8) cbgB = *reinterpret_cast<const f32x4*>(p.colbias + colB + 32);
+    }
+    EpiRows e0, e1;
+    f32x4 sA = zero, qA = zero, sB = zero, qB = zero;
+    epi_request<WA, NTS, H16>(p, wm0, colA, lane, e0);
+    epi_request<WA, NTS, H16>(p, wm0 + 32, colA, lane, e1);
+    epi_group<MODE, WA, NTS, H16>(p, accA[0][0], accA[0][1], stage, wm0, e0, lane, wn0, o_base, cbA, cbgA, sA, qA);
+    if constexpr (WB != 0) epi_request<(WB ? WB : 32), NTS, H16>(p, wm0, colB, lane, e0);
+    epi_group<MODE, WA, NTS, H16>(p, accA[1][0], accA[1][1], stage, wm0 + 32, e1, lane, wn0, o_base, cbA, cbgA, sA, qA);
+    epi_stats<WA>(p, lane, wm0, colA, sA, qA);
+    if constexpr (WB != 0) {
+        constexpr int WBB = WB ? WB : 32;
+        epi_request<WBB, NTS, H16>(p, wm0 + 32, colB, lane, e1);
+        epi_group<MODE, WBB, NTS, H16>(p, accB[0][0], accB[0][1], stage, wm0, e0, lane, wn0 + WA, o_base, cbB, cbgB, sB, qB);
+        epi_group<MODE, WBB, NTS, H16>(p, accB[1][0], accB[1][1], stage, wm0 + 32, e1, lane, wn0 + WA, o_base, cbB, cbgB, sB, qB);
+        epi_stats<WBB>(p, lane, wm0, colB, sB, qB);
     }
 }
 

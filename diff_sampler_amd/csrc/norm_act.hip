@@ -295,7 +295,7 @@ __global__ void channel_mean_kernel(const float* __restrict__ x, int ld, int c, 
 // --------------------------------------------------------------------------------------------------------------
 // LayerNorm over the channel dimension of token rows: one wave per row, the row lives in registers (<= 8 float4 per
 // lane), two-pass mean / variance like ATen's row-wise moments.
-template <bool OUT16, int LPR>
+template <bool OUT16, int LPR, bool IN16 = false>
 __global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps, float* __restrict__ y, int ldy,
                                                              long long rows, int cols) {
@@ -312,7 +312,14 @@ __global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __rest
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int idx = lane + LPR * i;
-            if (idx < n4) { v[i] = *reinterpret_cast<const f32x4*>(xr + idx * 4); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+            if (idx < n4) {
+                if (IN16) {          // x is an fp16 tensor (ldx in halfs): the fp16 residual stream, widened before any arithmetic
+                    typedef _Float16 h4i_t __attribute__((ext_vector_type(4)));
+                    const h4i_t hv = *reinterpret_cast<const h4i_t*>(reinterpret_cast<const _Float16*>(x) + row * ldx + idx * 4);
+                    v[i] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+                } else v[i] = *reinterpret_cast<const f32x4*>(xr + idx * 4);
+                s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            }
         }
 #pragma unroll
         for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -350,7 +357,7 @@ __global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __rest
     }
 }
 
-template <bool OUT16>
+template <bool OUT16, bool IN16 = false>
 static void launch_layernorm_rows(const float* x, int ldx, const float* gamma, const float* beta, float eps, float* y, int ldy, long long rows,
                                   int cols, hipStream_t stream) {
     const int n4 = cols >> 2;
@@ -359,11 +366,11 @@ static void launch_layernorm_rows(const float* x, int ldx, const float* gamma, c
     long long blocks = (rows + rpb - 1) / rpb;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (lpr == 16)
-        hipLaunchKernelGGL((layernorm_rows_kernel<OUT16, 16>), dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, gamma, beta, eps, y, ldy, rows, cols);
+        hipLaunchKernelGGL((layernorm_rows_kernel<OUT16, 16, IN16>), dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, gamma, beta, eps, y, ldy, rows, cols);
     else if (lpr == 32)
-        hipLaunchKernelGGL((layernorm_rows_kernel<OUT16, 32>), dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, gamma, beta, eps, y, ldy, rows, cols);
+        hipLaunchKernelGGL((layernorm_rows_kernel<OUT16, 32, IN16>), dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, gamma, beta, eps, y, ldy, rows, cols);
     else
-        hipLaunchKernelGGL((layernorm_rows_kernel<OUT16, 64>), dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, gamma, beta, eps, y, ldy, rows, cols);
+        hipLaunchKernelGGL((layernorm_rows_kernel<OUT16, 64, IN16>), dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, gamma, beta, eps, y, ldy, rows, cols);
 }
 
 // y[r, c] = x[r, c] * gelu(x[r, inner + c]), exact GELU 0.5 g (1 + erf(g / sqrt 2)).
@@ -579,6 +586,18 @@ extern "C" int ds_layernorm_rows_f16(const float* x, int ldx, const float* gamma
     if ((cols & 3) || cols > 2048) return DS_E_SHAPE;
     if ((ldx & 3) || (ldy & 3) || !ds_aligned16(x) || (reinterpret_cast<uintptr_t>(y16) & 7u) || !ds_aligned16(gamma) || !ds_aligned16(beta)) return DS_E_ALIGN;
     launch_layernorm_rows<true>(x, ldx, gamma, beta, eps, reinterpret_cast<float*>(y16), ldy, rows, cols, (hipStream_t)stream);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
+extern "C" int ds_layernorm_rows_f16io(const void* x16, int ldx, const float* gamma, const float* beta, float eps, void* y16, int ldy,
+                                       long long rows, int cols, void* stream) {
+    (void)hipGetLastError();
+    if (!x16 || !gamma || !beta || !y16 || rows <= 0 || cols <= 0) return DS_E_ARG;
+    if ((cols & 3) || cols > 2048) return DS_E_SHAPE;
+    if ((ldx & 3) || (ldy & 3) || (reinterpret_cast<uintptr_t>(x16) & 7u) || (reinterpret_cast<uintptr_t>(y16) & 7u) || !ds_aligned16(gamma) || !ds_aligned16(beta))
+        return DS_E_ALIGN;
+    launch_layernorm_rows<true, true>(reinterpret_cast<const float*>(x16), ldx, gamma, beta, eps, reinterpret_cast<float*>(y16), ldy, rows, cols, (hipStream_t)stream);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }

@@ -22,7 +22,7 @@ size_t arg_size(int op) {
         case DS_OP_GN_STATS: case DS_OP_NORM_ACT: return sizeof(ds_norm_args);
         case DS_OP_GN_FINALIZE: return sizeof(ds_gn_finalize_args);
         case DS_OP_ATTENTION: case DS_OP_ATTENTION_F16: return sizeof(ds_attn_args);
-        case DS_OP_LAYERNORM: case DS_OP_LAYERNORM_F16: return sizeof(ds_layernorm_args);
+        case DS_OP_LAYERNORM: case DS_OP_LAYERNORM_F16: case DS_OP_LAYERNORM_F16IO: return sizeof(ds_layernorm_args);
         case DS_OP_GEGLU: return sizeof(ds_geglu_args);
         case DS_OP_NOISE_EMBED: return sizeof(ds_noise_embed_args);
         case DS_OP_STEM_IM2COL: return sizeof(ds_stem_im2col_args);
@@ -43,6 +43,8 @@ int issue(const Node& n, void* stream) {
             return ds_layernorm_rows(l.x, l.ldx, l.gamma, l.beta, l.eps, l.y, l.ldy, l.rows, l.cols, stream); }
         case DS_OP_LAYERNORM_F16: { const ds_layernorm_args& l = n.a.ln;
             return ds_layernorm_rows_f16(l.x, l.ldx, l.gamma, l.beta, l.eps, l.y, l.ldy, l.rows, l.cols, stream); }
+        case DS_OP_LAYERNORM_F16IO: { const ds_layernorm_args& l = n.a.ln;
+            return ds_layernorm_rows_f16io(l.x, l.ldx, l.gamma, l.beta, l.eps, l.y, l.ldy, l.rows, l.cols, stream); }
         case DS_OP_GEGLU: { const ds_geglu_args& g = n.a.geglu; return ds_geglu(g.x, g.ldx, g.y, g.ldy, g.rows, g.inner, stream); }
         case DS_OP_NOISE_EMBED: { const ds_noise_embed_args& e = n.a.ne;
             return ds_noise_embed(e.sigma, e.bs, e.freqs, e.nch, e.swap, e.out, e.out_ld, stream); }

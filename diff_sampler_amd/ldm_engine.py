@@ -142,6 +142,24 @@ class LDMUNetEngine:
         bd.linear(e0, E, emb_rows, w['te2.w'], E, emb, 'time_embed.2', bias=w['te2.b'], act=DS_ACT_SILU)   # SiLU of emb_layers[0]
         bd.linear(emb, E, emb_rows, w['aff.w'], self.aff_total, aff, 'emb_layers_all', bias=w['aff.b'])
 
+        # ---- fp16 residual stream: under torch.autocast (sample.py:293-297) the reference's convolutions and Linear layers emit fp16
+        # tensors, so every activation between layers is fp16.  Every ResBlock / SpatialTransformer / upsampling convolution that runs on
+        # the fp16-activation kernels stores its output (the residual stream h, the skip stack hs, the transformer's x) as fp16 rows
+        # too; arithmetic on them is fp32 (widened on load).  A layer without such a kernel at its geometry reads an fp32 copy
+        # (widen) and writes fp32; every consumer takes a tensor in the dtype it has.
+        stream16 = bd.conv_mode == 1
+        P.stream16 = stream16
+        new_act = (lambda *shape: bd.new16(*shape)) if stream16 else new
+
+        def widen(t, c, side, name):
+            """fp32 copy of an fp16 stream tensor, for a layer that has no fp16-activation kernel at this geometry (8x8 images of a
+            batch that is not a multiple of four; the strided convolutions)."""
+            if t is None or t.dtype != torch.float16:
+                return t
+            wide = new(N * side * side, c)
+            bd.norm('apply', t, c, c, N, side, side, name + '.widen', use_stats=False, out=wide, out_ld=c)
+            return wide
+
         def gn_conv(x0, c0, x1, c1, side, gk, bk, eps, wgt, bias, cout, out, out_ld, name, w16=None, dma16=False, raw16=None, e16=None, **kw):
             """GroupNorm(32) + SiLU + 3x3 conv over the concatenation [x0 | x1]; the normalisation rides in the conv's loader
             when the LDS-halo kernel takes the shape, otherwise it is a separate pass (also when the fp16-operand kernel is
@@ -163,7 +181,7 @@ class LDMUNetEngine:
                         out_f16=(out.dtype == torch.float16), **ex, **kw)
                 return
             unfused_f16 = w16 is not None and bd.f16_level(N, side, side, cin, 0, kw.get('ec0', 0), kw.get('ec1', 0)) == 1
-            if lib.ds_conv3x3_halo_supported(side, side) and not unfused_f16:
+            if lib.ds_conv3x3_halo_supported(side, side) and not unfused_f16 and x0.dtype == torch.float32 and (x1 is None or x1.dtype == torch.float32):
                 bd.norm('stats', x0, c0, c0, N, side, side, name + '.gn.stats', x1=x1, c1=c1, ld1=c1, groups=32, eps=eps, gamma=gk,
                         beta=bk, coefs=ncoef)
                 bd.conv(x0, c0, c0, N, side, side, wgt, cout, out, out_ld, 9, name, x1=x1, c1=c1, ld1=c1, bias=bias, norm_coefs=ncoef,
@@ -184,18 +202,20 @@ class LDMUNetEngine:
             dma16 = bool(w16_0 is not None and w16_1 is not None and bd.conv_mode == 1
                          and lib.ds_conv_f16dma_supported(N, res, res, cin, 0, cout)
                          and lib.ds_conv_f16dma_supported(N, res, res, cout, cin if l.skip_conv else 0, cout))
-            out = new(M, cout)
+            out = new_act(M, cout) if dma16 else new(M, cout)
             if dma16:
                 h1 = bd.new16(M, cout)                       # in_layers output: only read by the out_layers normalisation
-                r16 = bd.new16(M, cin) if l.skip_conv else None
+                direct = x1 is None and x0.dtype == torch.float16          # the input already is one fp16 tensor: no raw copy for the skip_connection
+                r16 = bd.new16(M, cin) if l.skip_conv and not direct else None
                 gn_conv(x0, c0, x1, c1, res, w[f'{p}.n0.g'], w[f'{p}.n0.b'], 1e-5, w[f'{p}.c0.w'], w[f'{p}.c0.b'], cout, h1, cout,
                         p + '.in_layers', w16=w16_0, dma16=True, raw16=r16, cbias=aff[:, ao:], cbias_ld=self.aff_total, cbias_rows=emb_rows)
-                skip = dict(e16=(r16, cin)) if l.skip_conv else dict(res=x0, res_ld=cout)
+                skip = dict(e16=(x0 if direct else r16, cin)) if l.skip_conv else dict(res=x0, res_ld=cout)
                 if not l.skip_conv:
                     assert x1 is None and c0 == cout
                 gn_conv(h1, cout, None, 0, res, w[f'{p}.n1.g'], w[f'{p}.n1.b'], 1e-5, w[f'{p}.c1.w'], w[f'{p}.c1.b'], cout, out, cout,
                         p + '.out_layers', w16=w16_1, dma16=True, **skip)
                 return out, cout
+            x0, x1 = widen(x0, c0, res, p + '.x0'), widen(x1, c1, res, p + '.x1')
             h1 = new(M, cout)
             gn_conv(x0, c0, x1, c1, res, w[f'{p}.n0.g'], w[f'{p}.n0.b'], 1e-5, w[f'{p}.c0.w'], w[f'{p}.c0.b'], cout, h1, cout,
                     p + '.in_layers', w16=w.get(f'{p}.c0.w16'), cbias=aff[:, ao:], cbias_ld=self.aff_total, cbias_rows=emb_rows)
@@ -221,20 +241,23 @@ class LDMUNetEngine:
                        and lib.ds_gemm_f16dma_supported(M, c, 3 * c) and lib.ds_gemm_f16dma_supported(M, c, 8 * c)
                        and lib.ds_gemm_f16dma_supported(M, 4 * c, c))
             mk = bd.new16 if h16 else new
-            n2, t0, ln, ao = mk(M, c), new(M, c), mk(M, c), mk(M, c)
+            ts = new_act if h16 else new                     # the transformer's residual stream t0 .. t3 and its output
+            if not h16:
+                x_in = widen(x_in, c, res, p + '.x')
+            n2, t0, ln, ao = mk(M, c), ts(M, c), mk(M, c), mk(M, c)
             bd.norm('stats', x_in, c, c, N, res, res, p + '.norm.stats', groups=32, eps=1e-6)
             bd.norm('apply', x_in, c, c, N, res, res, p + '.norm', groups=32, eps=1e-6, gamma=w[f'{p}.n.g'], beta=w[f'{p}.n.b'],
                     out=n2, out_ld=c, out_f16=h16)
             bd.conv(n2, c, c, N, res, res, w[f'{p}.pi.w'], c, t0, c, 1, p + '.proj_in', bias=w[f'{p}.pi.b'])
             # self-attention
-            qkv, t1 = new(M, 3 * c), new(M, c)
+            qkv, t1 = new(M, 3 * c), ts(M, c)
             bd.layernorm(t0, c, w[f'{p}.norm1.g'], w[f'{p}.norm1.b'], 1e-5, ln, c, M, c, p + '.norm1')
             bd.linear(ln, c, M, w[f'{p}.qkv1.w'], 3 * c, qkv, p + '.attn1.qkv')
             bd.attention(qkv, qkv[:, c:], qkv[:, 2 * c:], ao, p + '.attn1', batch=N, heads=hd, sq=S, skv=S, d=d, ldq=3 * c, ldk=3 * c,
                          ldv=3 * c, ldo=c, q_bs=S * 3 * c, k_bs=S * 3 * c, v_bs=S * 3 * c, o_bs=S * c, scale=d ** -0.5)
             bd.linear(ao, c, M, w[f'{p}.attn1.o.w'], c, t1, p + '.attn1.to_out', bias=w[f'{p}.attn1.o.b'], res=t0, res_ld=c)
             # cross-attention over the context tokens
-            q2, kv2, t2 = new(M, c), new(N * L, 2 * c), new(M, c)
+            q2, kv2, t2 = new(M, c), new(N * L, 2 * c), ts(M, c)
             bd.layernorm(t1, c, w[f'{p}.norm2.g'], w[f'{p}.norm2.b'], 1e-5, ln, c, M, c, p + '.norm2')
             bd.linear(ln, c, M, w[f'{p}.q2.w'], c, q2, p + '.attn2.q')
             bd.linear(bufs['context'], spec.context_dim, N * L, w[f'{p}.kv2.w'], 2 * c, kv2, p + '.attn2.kv')
@@ -242,11 +265,11 @@ class LDMUNetEngine:
                          q_bs=S * c, k_bs=L * 2 * c, v_bs=L * 2 * c, o_bs=S * c, scale=d ** -0.5)
             bd.linear(ao, c, M, w[f'{p}.attn2.o.w'], c, t2, p + '.attn2.to_out', bias=w[f'{p}.attn2.o.b'], res=t1, res_ld=c)
             # GEGLU feed-forward
-            gg, t3 = mk(M, 4 * c), new(M, c)
+            gg, t3 = mk(M, 4 * c), ts(M, c)
             bd.layernorm(t2, c, w[f'{p}.norm3.g'], w[f'{p}.norm3.b'], 1e-5, ln, c, M, c, p + '.norm3')
             bd.linear(ln, c, M, w[f'{p}.ff0.w'], 8 * c, gg, p + '.ff.proj_geglu', out_ld=4 * c, bias=w[f'{p}.ff0.b'], act=DS_ACT_GEGLU)
             bd.linear(gg, 4 * c, M, w[f'{p}.ff2.w'], c, t3, p + '.ff.out', bias=w[f'{p}.ff2.b'], res=t2, res_ld=c)
-            out = new(M, c)
+            out = ts(M, c)
             bd.conv(t3, c, c, N, res, res, w[f'{p}.po.w'], c, out, c, 1, p + '.proj_out', bias=w[f'{p}.po.b'], res=x_in, res_ld=c,
                     stats=True)
             return out, c
@@ -274,11 +297,13 @@ class LDMUNetEngine:
                     cur = st_layer(l, cur[0], cur[1])
                 elif l.kind == 'down':
                     out = new(N * l.res_out ** 2, l.cout)
+                    cur = (widen(cur[0], l.cin, l.res_in, p), l.cin)      # the strided convolution reads fp32 rows
                     bd.conv(cur[0], l.cin, l.cin, N, l.res_out, l.res_out, w[f'{p}.w'], l.cout, out, l.cout, 9, p + '.op',
                             bias=w[f'{p}.b'], stride=2, stats=True)
                     cur = (out, l.cout)
                 elif l.kind == 'up':
-                    out = new(N * l.res_out ** 2, l.cout)
+                    f16up = bool(w.get(f'{p}.w16') is not None and bd.conv_mode == 1 and lib.ds_conv_f16dma_supported(N, l.res_out, l.res_out, l.cin, 0, l.cout))
+                    out = new_act(N * l.res_out ** 2, l.cout) if f16up else new(N * l.res_out ** 2, l.cout)
                     if w.get(f'{p}.w16') is not None and bd.conv_mode == 1 and lib.ds_conv_f16dma_supported(N, l.res_out, l.res_out, l.cin, 0, l.cout):
                         up = bd.new16(N * l.res_out ** 2, l.cin)     # nearest x2 of the raw tensor, stored in fp16 for the matrix kernel
                         bd.norm('apply', cur[0], l.cin, l.cin, N, l.res_in, l.res_in, p + '.nearest', use_stats=False,

@@ -89,7 +89,8 @@ def _native_plan(ops):
               id(lib.ds_attention): _lib.DS_OP_ATTENTION, id(lib.ds_attention_f16): _lib.DS_OP_ATTENTION_F16}
     by_val = {id(lib.ds_layernorm_rows): (_lib.DS_OP_LAYERNORM, _lib.LayerNormArgs), id(lib.ds_geglu): (_lib.DS_OP_GEGLU, _lib.GegluArgs),
               id(lib.ds_noise_embed): (_lib.DS_OP_NOISE_EMBED, _lib.NoiseEmbedArgs), id(lib.ds_stem_im2col): (_lib.DS_OP_STEM_IM2COL, _lib.StemIm2colArgs),
-              id(lib.ds_layernorm_rows_f16): (_lib.DS_OP_LAYERNORM_F16, _lib.LayerNormArgs)}
+              id(lib.ds_layernorm_rows_f16): (_lib.DS_OP_LAYERNORM_F16, _lib.LayerNormArgs),
+              id(lib.ds_layernorm_rows_f16io): (_lib.DS_OP_LAYERNORM_F16IO, _lib.LayerNormArgs)}
     h = C.c_void_p()
     _lib.check(lib.ds_plan_create(C.byref(h)), 'ds_plan_create')
     try:
@@ -253,7 +254,11 @@ class Builder:
         self.add(self.lib.ds_attention_f16 if f16 else self.lib.ds_attention, (C.byref(a),), name, keep=(a,))
 
     def layernorm(self, x, ldx, gamma, beta, eps, y, ldy, rows, cols, name):
-        fn = self.lib.ds_layernorm_rows_f16 if y.dtype == torch.float16 else self.lib.ds_layernorm_rows
+        if x.dtype == torch.float16:          # a tensor of the fp16 residual stream
+            assert y.dtype == torch.float16, name
+            fn = self.lib.ds_layernorm_rows_f16io
+        else:
+            fn = self.lib.ds_layernorm_rows_f16 if y.dtype == torch.float16 else self.lib.ds_layernorm_rows
         self.add(fn, (ptr(x), ldx, ptr(gamma), ptr(beta), eps, ptr(y), ldy, rows, cols), name)
 
     def geglu(self, x, ldx, y, ldy, rows, inner, name):

@@ -311,6 +311,10 @@ int ds_layernorm_rows(const float* x, int ldx, const float* gamma, const float* 
  * the operand of the following projection (torch.autocast casts nn.Linear inputs to fp16). */
 int ds_layernorm_rows_f16(const float* x, int ldx, const float* gamma, const float* beta, float eps, void* y16, int ldy,
                           long long rows, int cols, void* stream);
+/* ... and with an fp16 input tensor x16[rows][ldx halfs] as well (a tensor of the fp16 residual stream; statistics and the affine map
+ * in fp32 on the widened values). */
+int ds_layernorm_rows_f16io(const void* x16, int ldx, const float* gamma, const float* beta, float eps, void* y16, int ldy,
+                            long long rows, int cols, void* stream);
 
 /* GEGLU gate (ldm/modules/attention.py:45-52): y[r, c] = x[r, c] * gelu(x[r, inner + c]) with the exact (erf) GELU. */
 int ds_geglu(const float* x, int ldx, float* y, int ldy, long long rows, int inner, void* stream);
@@ -500,7 +504,8 @@ enum { DS_OP_CONV2D = 1,        /* ds_conv_args        -> ds_conv2d_nhwc      */
        DS_OP_GEGLU = 9,         /* ds_geglu_args       -> ds_geglu            */
        DS_OP_NOISE_EMBED = 10,  /* ds_noise_embed_args -> ds_noise_embed      */
        DS_OP_STEM_IM2COL = 11,  /* ds_stem_im2col_args -> ds_stem_im2col      */
-       DS_OP_LAYERNORM_F16 = 12 /* ds_layernorm_args   -> ds_layernorm_rows_f16 (y = fp16 rows) */ };
+       DS_OP_LAYERNORM_F16 = 12, /* ds_layernorm_args  -> ds_layernorm_rows_f16 (y = fp16 rows) */
+       DS_OP_LAYERNORM_F16IO = 13 /* ds_layernorm_args -> ds_layernorm_rows_f16io (x and y = fp16 rows) */ };
 
 typedef struct ds_plan ds_plan;
 int ds_plan_create(ds_plan** out);

@@ -3,8 +3,8 @@
     python oracle/gen_f16_golden.py        # writes tests/golden/ldm_sd15_f16ops.npz  (about 3 minutes of CPU)
 
 Inputs = those of tests/golden/ldm_sd15.npz (which the REAL reference produced, oracle/gen_golden.py --part ldm); the set of layers
-whose multiplicands are rounded to fp16 is read off the product's own launch plan (built on the CPU: no kernel runs) through
-tests/_f16_names.ldm_prefixes and stored in the file, so that the GPU test can assert the engine still routes exactly those layers to
+whose multiplicands are rounded to fp16 (and of layers whose output is stored in fp16) is read off the product's own launch plan (built on the CPU: no kernel runs) through
+tests/_f16_names.ldm_prefixes / ldm_stored_prefixes and stored in the file, so that the GPU test can assert the engine still routes exactly those layers to
 the fp16-operand kernels before it compares numbers.  The fp32 mode of the same oracle is pinned to the real reference by
 tests/test_oracle_golden.py; this variant differs from it only by the rounding hook."""
 import os
@@ -30,17 +30,19 @@ def main():
     eng = LDMUNetEngine(spec, params, device='cpu', use_fp16=True)
     plan = eng.plan(2, 2, 77)                       # one latent, CFG-doubled, per-sample sigma rows (the golden passes sigma as a vector)
     pre = sorted(_f16_names.ldm_prefixes(plan))
+    sto = sorted(_f16_names.ldm_stored_prefixes(plan))       # ... and the layers whose output is stored as an fp16 tensor (rounded there)
     net = ldm_net.OracleCFG(params, kw, la.alphas_cumprod(spec), guidance_rate=7.5)
     x, cond, uncond, sigma = (torch.from_numpy(z[k]) for k in ('x', 'cond', 'uncond', 'sigma'))
-    s = set(pre)
-    with torch.no_grad(), ldm_net.operands_f16(lambda name: name in s):
+    s, st = set(pre), set(sto)
+    with torch.no_grad(), ldm_net.operands_f16(lambda name: name in s, stored=lambda name: name in st):
         out = net(x, sigma, condition=cond, unconditional_condition=uncond)
+        eps = torch.cat(net.last_eps)                # [2, 4, 64, 64]: unconditional, conditional noise predictions of that evaluation
     with torch.no_grad():
         out32 = net(x, sigma, condition=cond, unconditional_condition=uncond)
     ref = torch.from_numpy(z['out_vec'])
     rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
     print('f16-operand oracle vs real-reference fp32 golden:', rel(out, ref), ' fp32 oracle vs golden:', rel(out32, ref))
-    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'ldm_sd15_f16ops.npz'), out_f16ops=out.numpy(), f16_layers=np.array(pre),
+    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'ldm_sd15_f16ops.npz'), out_f16ops=out.numpy(), eps_f16ops=eps.numpy(), f16_layers=np.array(pre), f16_stored=np.array(sto),
                         rel_vs_fp32_golden=rel(out, ref))
 
 

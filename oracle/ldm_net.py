@@ -21,23 +21,33 @@ import torch.nn.functional as F
 # Reduced-precision variant (the reference runs this U-Net under torch.autocast, sample.py:293-297): inside ``operands_f16(pred)`` the
 # multiplicands of every layer whose state_dict prefix satisfies ``pred`` are rounded to fp16 and multiplied / accumulated in fp32
 # (attention layers are named '<transformer block>.attn1' / '.attn2': q, k, v and the softmax weights are rounded).  See oracle/edm_net.py.
+# ``stored(prefix)`` (optional) names the layers whose OUTPUT that mode holds as an fp16 tensor -- under autocast every convolution /
+# Linear emits fp16, so the residual stream h, the skip stack and the transformer's x are fp16: the value is rounded right after the
+# layer's bias / embedding / residual additions (where the product's epilogue stores it); arithmetic on it stays fp32.
 _F16_PRED = None
+_F16_STORED = None
 
 
 @contextlib.contextmanager
-def operands_f16(pred):
-    global _F16_PRED
-    old, _F16_PRED = _F16_PRED, pred
+def operands_f16(pred, stored=None):
+    global _F16_PRED, _F16_STORED
+    old, _F16_PRED, _F16_STORED = (_F16_PRED, _F16_STORED), pred, stored
     try:
         yield
     finally:
-        _F16_PRED = old
+        _F16_PRED, _F16_STORED = old
 
 
 def _rnd(prefix, *ts):
     if _F16_PRED is not None and _F16_PRED(prefix):
         return tuple(t.to(torch.float16).to(torch.float32) for t in ts)
     return ts
+
+
+def _stored(prefix, t):
+    if _F16_STORED is not None and _F16_STORED(prefix):
+        return t.to(torch.float16).to(torch.float32)
+    return t
 
 
 def _gn32(p, prefix, x, eps):
@@ -63,10 +73,10 @@ def timestep_embedding(t, dim, max_period=10000):
 
 def _res(p, prefix, x, emb):
     h = _conv(p, prefix + '.in_layers.2', F.silu(_gn32(p, prefix + '.in_layers.0', x, 1e-5)))
-    h = h + _lin(p, prefix + '.emb_layers.1', F.silu(emb))[:, :, None, None]
+    h = _stored(prefix + '.in_layers.2', h + _lin(p, prefix + '.emb_layers.1', F.silu(emb))[:, :, None, None])
     h = _conv(p, prefix + '.out_layers.3', F.silu(_gn32(p, prefix + '.out_layers.0', h, 1e-5)))
     skip = _conv(p, prefix + '.skip_connection', x) if (prefix + '.skip_connection.weight') in p else x
-    return skip + h
+    return _stored(prefix + '.out_layers.3', skip + h)
 
 
 def _attn(p, prefix, x, context, heads):
@@ -95,16 +105,16 @@ def _attn(p, prefix, x, context, heads):
 def _st(p, prefix, x, context, heads):
     b, c, h, w = x.shape
     x_in = x
-    x = _conv(p, prefix + '.proj_in', F.group_norm(x, 32, p[prefix + '.norm.weight'], p[prefix + '.norm.bias'], 1e-6))
+    x = _stored(prefix + '.proj_in', _conv(p, prefix + '.proj_in', F.group_norm(x, 32, p[prefix + '.norm.weight'], p[prefix + '.norm.bias'], 1e-6)))
     x = x.permute(0, 2, 3, 1).reshape(b, h * w, c)
     t = prefix + '.transformer_blocks.0'
     ln = lambda name, v: F.layer_norm(v, (c,), p[f'{t}.{name}.weight'], p[f'{t}.{name}.bias'], 1e-5)
-    x = _attn(p, t + '.attn1', ln('norm1', x), None, heads) + x
-    x = _attn(p, t + '.attn2', ln('norm2', x), context, heads) + x
+    x = _stored(t + '.attn1.to_out.0', _attn(p, t + '.attn1', ln('norm1', x), None, heads) + x)
+    x = _stored(t + '.attn2.to_out.0', _attn(p, t + '.attn2', ln('norm2', x), context, heads) + x)
     y, gate = _lin(p, t + '.ff.net.0.proj', ln('norm3', x)).chunk(2, dim=-1)
-    x = _lin(p, t + '.ff.net.2', y * F.gelu(gate)) + x
+    x = _stored(t + '.ff.net.2', _lin(p, t + '.ff.net.2', y * F.gelu(gate)) + x)
     x = x.reshape(b, h, w, c).permute(0, 3, 1, 2)
-    return _conv(p, prefix + '.proj_out', x) + x_in
+    return _stored(prefix + '.proj_out', _conv(p, prefix + '.proj_out', x) + x_in)
 
 
 def _block(p, name, h, emb, context, heads, taps):
@@ -118,7 +128,7 @@ def _block(p, name, h, emb, context, heads, taps):
         elif (q + '.op.weight') in p:
             h = _conv(p, q + '.op', h, stride=2)
         elif (q + '.conv.weight') in p:
-            h = _conv(p, q + '.conv', F.interpolate(h, scale_factor=2, mode='nearest'))
+            h = _stored(q + '.conv', _conv(p, q + '.conv', F.interpolate(h, scale_factor=2, mode='nearest')))
         elif (q + '.weight') in p and p[q + '.weight'].dim() == 4:
             h = _conv(p, q, h)
         else:
@@ -205,5 +215,6 @@ class OracleCFG:
         else:
             nu, nc = self.eps(torch.cat([xin] * 2), torch.cat([c_noise] * 2),
                               torch.cat([unconditional_condition, condition])).chunk(2)
+            self.last_eps = (nu, nc)          # the two raw U-Net outputs of this call (tests pin them separately from the guided combination)
             f = nu + self.guidance_rate * (nc - nu)
         return x + (-sigma).reshape(-1, 1, 1, 1) * f

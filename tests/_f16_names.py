@@ -60,3 +60,25 @@ def ldm_prefixes(plan):
         assert n.endswith('.attn1') or n.endswith('.attn2'), n
         out.add(n[:-len('.attn1')] + '.transformer_blocks.0' + n[-len('.attn1'):])
     return out
+
+
+_LDM_STORED = {'.in_layers': '.in_layers.2', '.out_layers': '.out_layers.3', '.proj_in': '.proj_in', '.proj_out': '.proj_out', '.conv': '.conv',
+               '.attn1.to_out': '.transformer_blocks.0.attn1.to_out.0', '.attn2.to_out': '.transformer_blocks.0.attn2.to_out.0',
+               '.ff.out': '.transformer_blocks.0.ff.net.2'}
+
+
+def ldm_stored_prefixes(plan):
+    """State_dict prefixes of the layers whose output the latent-diffusion engine stores in fp16 (ds_conv_args.out_f16 == 1 on the launch):
+    the `stored` predicate of oracle.ldm_net.operands_f16.  (The GEGLU product is an fp16 tensor too, but it is only the operand of
+    ff.net.2, whose operand rounding already covers it.)"""
+    lib = _lib.load()
+    out = set()
+    for op in plan.ops:
+        if op.fn is lib.ds_conv2d_nhwc and op.keep[0].out_f16 == 1 and not op.name.endswith('.ff.proj_geglu'):
+            for suf in sorted(_LDM_STORED, key=len, reverse=True):
+                if op.name.endswith(suf):
+                    out.add(op.name[:-len(suf)] + _LDM_STORED[suf])
+                    break
+            else:
+                raise KeyError(op.name)
+    return out

@@ -11,7 +11,8 @@ Three comparisons per network evaluation, all stated and e
   * against the oracle's restatement executed by PyTorch-ROCm under torch.autocast(float16) on the same GPU -- what the reference's
     own reduced-precision arithmetic gives here -- 5e-3 (both sides carry an fp16 rounding error of the same size).
 SD-1.5 (config 5) is pinned at full size against the REAL reference's fp32 output (tests/golden/ldm_sd15.npz, 5e-3) and against the
-fp16-operand oracle's golden (tests/golden/ldm_sd15_f16ops.npz, made by oracle/gen_f16_golden.py; 5e-3: under 7.5x guidance the
+fp16-operand oracle's golden (tests/golden/ldm_sd15_f16ops.npz, made by oracle/gen_f16_golden.py; the two raw U-Net outputs of the
+evaluation within 2.5e-3, their guided combination within 5e-3: under 7.5x guidance the
 placement of the attention roundings alone moves the ORACLE's own output by 3.5e-3 -- two legitimate placements, measured -- so on this net
 the fp16-operand comparison cannot be tighter than the fp32 one; the oracle mirrors the kernel's placement, oracle/ldm_net.py:_attn)."""
 import json
@@ -128,7 +129,7 @@ def test_sd15_autocast_mode_pinned_to_reference_golden_and_f16_operand_oracle():
     import numpy as np
     from diff_sampler_amd import _lib
     from diff_sampler_amd.ldm_engine import CFGDenoiser
-    from _f16_names import ldm_prefixes
+    from _f16_names import ldm_prefixes, ldm_stored_prefixes
     dev = torch.device('cuda')
     G = os.path.join(ROOT, 'tests', 'golden')
     z, z16 = np.load(os.path.join(G, 'ldm_sd15.npz')), np.load(os.path.join(G, 'ldm_sd15_f16ops.npz'))
@@ -139,6 +140,7 @@ def test_sd15_autocast_mode_pinned_to_reference_golden_and_f16_operand_oracle():
     lib = _lib.load()
     plan = next(iter(n16.engine._plans.values()))
     assert sorted(ldm_prefixes(plan)) == [str(v) for v in z16['f16_layers']]
+    assert plan.stream16 and sorted(ldm_stored_prefixes(plan)) == [str(v) for v in z16['f16_stored']]      # the fp16 residual stream
     k16, k32 = _count_f16(plan, lib)
     assert k16 >= 30, (k16, k32)
     g16, g32, a16, a32 = _count_f16_other(plan, lib)
@@ -146,10 +148,21 @@ def test_sd15_autocast_mode_pinned_to_reference_golden_and_f16_operand_oracle():
     assert g16 > 100, (g16, g32)                      # every Linear / 1x1 over the image rows; context and time projections stay fp32
     e32 = _rel(out, torch.from_numpy(z['out_vec']))
     e16 = _rel(out, torch.from_numpy(z16['out_f16ops']))
+    # the two raw U-Net outputs (unconditional, conditional) of the same evaluation, before the guidance combination
+    # nu + 7.5 (nc - nu) amplifies their differences up to 14x
+    f_rows = n16.raw(x, torch.from_numpy(z['sigma']).to(dev), cond, uncond)[0]
+    torch.cuda.synchronize()
+    eps = f_rows.reshape(2, 64, 64, 4).permute(0, 3, 1, 2).cpu()
+    e16_eps = _rel(eps, torch.from_numpy(z16['eps_f16ops']))
     REPORT['sd15'] = dict(batch=1, f16_convs=k16, fp32_convs=k32, f16_linears=g16, fp32_linears=g32, f16_attention=a16, fp32_attention=a32,
-                         hip_fp16_vs_reference_fp32_golden=e32, hip_fp16_vs_fp16_operand_oracle=e16,
+                         hip_fp16_vs_reference_fp32_golden=e32, hip_fp16_vs_fp16_operand_oracle=e16, hip_fp16_unet_outputs_vs_fp16_operand_oracle=e16_eps,
                          fp16_operand_oracle_vs_reference_fp32_golden=float(z16['rel_vs_fp32_golden']))
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     json.dump(REPORT, open(os.path.join(ROOT, 'gpurun_out', 'fp16_parity.json'), 'w'), indent=1)
     assert e32 < 5e-3, e32
     assert e16 < 5e-3, e16
+    # per U-Net evaluation: 2.5e-3 (measured 1.7e-3; the EDM nets: 1.2e-3 against a 1.5e-3 bound).  Kernel and oracle round the same tensors,
+    # but their fp32 sums differ in the last bits, so ~0.2 % of the fp16 roundings fall on the other side of a boundary; this net (16
+    # transformer blocks, random weights) amplifies such perturbations ~100x -- the same factor that turns fp32 rounding (1e-7) into the
+    # 1e-5 agreement of the fp32 mode
+    assert e16_eps < 2.5e-3, e16_eps

@@ -49,6 +49,9 @@ ap.add_argument('--dma16', action='store_true', help='with --f16: fp16 ACTIVATIO
 ap.add_argument('--nb', type=int, default=0, help='with --dma16: force the column-tile width (64 * nb)')
 ap.add_argument('--ablate', type=int, default=0, help='with --dma16: ds_debug_f16dma_ablate mask (timing only)')
 ap.add_argument('--no-res', action='store_true', help='no residual operand in the epilogue')
+ap.add_argument('--f16out', action='store_true', help='with --dma16: fp16 output rows only')
+ap.add_argument('--f16res', action='store_true', help='with --dma16: fp16 residual rows only')
+ap.add_argument('--f16io', action='store_true', help='with --dma16: fp16 output rows and fp16 residual rows (ds_conv_args.out_f16 / res_f16: the fp16 residual stream)')
 ap.add_argument('--extra', action='store_true', help='append the fused 1x1 skip projection (ec0 = c0 + c1 raw columns) as conv1 of a block with a skip conv has it')
 ap.add_argument('--ws', action='store_true', help='give the launcher a split-K workspace (256 MiB), as the engine plans do (the persistent schedule needs it)')
 ap.add_argument('--norm', action='store_true', help='fused GroupNorm affine + SiLU in the halo loader, as the network uses it')
@@ -104,6 +107,12 @@ for si, (res, c0, c1, cout, taps) in enumerate(SHAPES):
         if args.extra and taps == 9:
             e16 = torch.randn(M, c0 + c1, device=dev).to(torch.float16)
             a.e0, a.ec0, a.eld0 = e16.data_ptr(), c0 + c1, c0 + c1
+        if args.f16io or args.f16out:
+            out16 = torch.zeros(M, cout, device=dev, dtype=torch.float16)
+            a.out, a.out_f16 = out16.data_ptr(), 1
+        if (args.f16io or args.f16res) and not args.no_res:
+            res16 = res_t.to(torch.float16)
+            a.res, a.res_f16 = res16.data_ptr(), 1
         lib.ds_debug_f16dma_nb(args.nb)
         lib.ds_debug_f16dma_ablate(args.ablate)
     if args.norm and taps == 9:
