@@ -114,6 +114,7 @@ _SIGNATURES = {
     'ds_conv_f16dma_supported': (C.c_int, [C.c_int] * 6),
     'ds_gemm_f16dma_supported': (C.c_int, [C.c_longlong, C.c_int, C.c_int]),
     'ds_debug_f16dma_nb': (C.c_int, [C.c_int]),
+    'ds_debug_f16dma_nw': (C.c_int, [C.c_int]),
     'ds_debug_f16dma_ablate': (C.c_int, [C.c_int]),
     'ds_conv_split_supported': (C.c_int, [C.c_int] * 7),
     'ds_gemm_f16_supported': (C.c_int, [C.c_longlong, C.c_int, C.c_int]),

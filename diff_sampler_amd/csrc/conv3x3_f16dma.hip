@@ -243,15 +243,18 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
 #undef DSD_MM
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (no fragment read is pending after the last tap; cheap insurance)
 
-    if (abl & 4) {                                             // no epilogue: keep the accumulators alive with one store
-        if (accA[0][0][0] + accA[1][1][5] + accB[0][0][3] + accB[1][1][7] == 123.456f) p.out[0] = 1.f;
+    if (abl & 4) {                                             // no epilogue: every accumulator block (and so every MFMA) is kept alive
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { asm volatile("" :: "v"(accA[i][j])); asm volatile("" :: "v"(accB[i][j])); }
         return;
     }
     float* stage = smem + wave * 32 * EPI_LD;
     const int wn0 = n0 + wc * (NB * 32);
     // non-temporal residual loads / output stores: +1 ... 2 % (A/B, profiles/r3_conv_f16dma_ablations.txt); the launcher only takes this
     // kernel on the vector path (vec_ok, cout a multiple of the tile width)
-    epilogue_pipe<0, true, true, (NB == 1 ? 32 : 64), (NB == 3 ? 32 : (NB == 4 ? 64 : 0))>(p, accA, accB, stage, lane, m0 + wr * 64, wn0, p.out);
+    epilogue_pipe<0, true, (NB == 1 ? 32 : 64), (NB == 3 ? 32 : (NB == 4 ? 64 : 0))>(p, accA, accB, stage, lane, m0 + wr * 64, wn0, p.out);
 }
 
 }  // namespace
@@ -290,6 +293,7 @@ int launch_w(const KParams& p, int nb, int n_begin, int ntiles, hipStream_t stre
 }  // namespace
 
 int g_f16dma_nb = 0;            // benchmarks / tests: > 0 forces the column-tile width of the main launch (64 * nb columns)
+int g_f16dma_nw = 0;            // benchmarks / tests: 4 / 8 forces the wave count of gemm_f16dma_kernel (128- / 256-row tiles); 0 = by K
 
 // widest column tile the LDS holds next to two halo buffers
 static int max_nb(int W) { return (W == 16 || W == 32) ? 4 : 3; }

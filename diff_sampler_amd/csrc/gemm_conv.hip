@@ -301,8 +301,8 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     if (a->taps != 1 && a->taps != 9) return DS_E_ARG;
     if (a->c0 <= 0 || a->c0 % 32 || a->c1 < 0 || a->c1 % 32) return DS_E_SHAPE;
     if (a->c1 && !a->x1) return DS_E_ARG;
-    if (a->out_f16 && (!a->in_f16 || (a->cout & 63) || (a->out_ld & 3))) return DS_E_ARG;   // fp16 output rows: the fp16-activation kernels only
-    if (a->res_f16 && (!a->in_f16 || !a->res || (a->res_ld & 3))) return DS_E_ARG;          // fp16 residual rows: the same kernels
+    if (a->out_f16 && (!a->in_f16 || (a->cout & 63) || (a->out_ld & 7) || !ds_aligned16(a->out))) return DS_E_ARG;   // fp16 output rows: the fp16-activation kernels only
+    if (a->res_f16 && (!a->in_f16 || !a->res || (a->res_ld & 7) || !ds_aligned16(a->res))) return DS_E_ARG;          // fp16 residual rows: the same kernels
     if (a->in_f16) {          // fp16 activations: pure matrix kernels (conv3x3_f16dma.hip / gemm_f16dma.hip); ld in halfs, 16-byte chunks
         if (a->wgt_f16 != 1 || a->c1 || a->ec1 || a->norm_coefs || a->out_nchw || (a->stride && a->stride != 1)) return DS_E_ARG;
         if (a->taps == 1 && a->ec0) return DS_E_ARG;
@@ -434,6 +434,7 @@ extern "C" int ds_gemm_f16dma_supported(long long rows, int k, int cout) {
     return gemm_f16dma_applicable(p) ? 1 : 0;
 }
 extern "C" int ds_debug_f16dma_nb(int nb) { const int o = g_f16dma_nb; g_f16dma_nb = nb; return o; }
+extern "C" int ds_debug_f16dma_nw(int nw) { const int o = g_f16dma_nw; g_f16dma_nw = nw; return o; }
 extern "C" int ds_debug_f16dma_ablate(int mask) { const int o = g_f16dma_ablate; g_f16dma_ablate = mask; return o; }
 extern "C" int ds_gemm_f16_supported(long long rows, int c0, int c1) {
     KParams p{};

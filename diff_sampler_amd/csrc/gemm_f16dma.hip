@@ -16,12 +16,16 @@ namespace {
 
 __device__ __attribute__((aligned(128))) _Float16 g_zero_halfs_g[64];
 
-template <int NB>
-constexpr unsigned gemm16_smem() { return 2u * (32768u + NB * 8192u); }
+// NW = 8 waves: 256-row tiles, one workgroup per CU.  NW = 4 waves (2 x 2): 128-row tiles whose LDS footprint (NB <= 3) lets TWO workgroups
+// share a CU -- for the short-K, output-heavy projections of the transformer blocks (K = 320 ... 1 280: five to twenty K tiles, then an
+// epilogue that moves as many bytes as the whole main loop) the epilogue of one workgroup then runs under the loads and MFMAs of the other.
+template <int NB, int NW>
+constexpr unsigned gemm16_smem() { return 2u * (NW * 4096u + NB * 8192u); }
 
-template <int NB>
-__global__ void __launch_bounds__(512, 2) gemm_f16dma_kernel(const KParams p) {
-    constexpr unsigned AB = 32768u, WB = NB * 8192u;           // bytes of one A / W stage
+template <int NB, int NW>
+__global__ void __launch_bounds__(NW * 64, 2) gemm_f16dma_kernel(const KParams p) {
+    constexpr unsigned AB = NW * 4096u, WB = NB * 8192u;       // bytes of one A / W stage
+    constexpr int BM = NW * 32, NT = NW * 64;                  // rows per tile, threads
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* lds = reinterpret_cast<char*>(smem);                 // [A 0 | A 1 | W 0 | W 1]
     typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -30,18 +34,18 @@ __global__ void __launch_bounds__(512, 2) gemm_f16dma_kernel(const KParams p) {
     const int wr = wave >> 1, wc = wave & 1;
     int mt, nt;
     if (!decode_tile(blockIdx.x, p.mtiles, p.ntiles, mt, nt, 0)) return;
-    const int m0 = mt * 256, n0 = p.n_begin + nt * (NB * 64);
+    const int m0 = mt * BM, n0 = p.n_begin + nt * (NB * 64);
     const _Float16* a0 = reinterpret_cast<const _Float16*>(p.a0);
     const _Float16* wgt = reinterpret_cast<const _Float16*>(p.b);
     const size_t ldbh = (size_t)p.ldb * 2;
     const int KT = p.K / 64;
 
-    // DMA: thread tid owns 16-B unit j * 512 + tid of round j: row j * 64 + (tid >> 3), LDS chunk slot tid & 7 = source chunk ^ ((row >> 1) & 7)
+    // DMA: thread tid owns 16-B unit j * NT + tid of round j: row j * (NT / 8) + (tid >> 3), LDS chunk slot tid & 7 = source chunk ^ ((row >> 1) & 7)
     const int sw = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;
     const _Float16* asrc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int row = m0 + j * 64 + (tid >> 3);
+        const int row = m0 + j * (NT / 8) + (tid >> 3);
         asrc[j] = row < p.M ? a0 + (size_t)row * p.lda0 + sw : nullptr;
     }
     const _Float16* wsrc = wgt + (size_t)(n0 + (tid >> 3)) * ldbh + sw;
@@ -49,12 +53,12 @@ __global__ void __launch_bounds__(512, 2) gemm_f16dma_kernel(const KParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const _Float16* g = asrc[j] ? asrc[j] + (size_t)kt * 64 : g_zero_halfs_g;
-            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + buf * AB + (j * 512 + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + buf * AB + (j * NT + wave * 64) * 16), 16, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (size_t)i * 64 * ldbh + (size_t)kt * 64),
-                                             (lptr_t)(lds + 2 * AB + buf * WB + (i * 64 + wave * 8) * 128), 16, 0, 0);
+        for (int i = 0; i < NB * 512 / NT; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (size_t)i * (NT / 8) * ldbh + (size_t)kt * 64),
+                                             (lptr_t)(lds + 2 * AB + buf * WB + (i * (NT / 8) + wave * 8) * 128), 16, 0, 0);
     };
 
     const unsigned lds0 = lds_addr2(smem);
@@ -137,20 +141,20 @@ __global__ void __launch_bounds__(512, 2) gemm_f16dma_kernel(const KParams p) {
 
     float* stage = smem + wave * 32 * EPI_LD;
     const int wn0 = n0 + wc * (NB * 32);
-    epilogue_pipe<0, false, true, (NB == 1 ? 32 : 64), (NB == 3 ? 32 : (NB == 4 ? 64 : 0))>(p, accA, accB, stage, lane, m0 + wr * 64, wn0, p.out);
+    epilogue_pipe<0, false, (NB == 1 ? 32 : 64), (NB == 3 ? 32 : (NB == 4 ? 64 : 0))>(p, accA, accB, stage, lane, m0 + wr * 64, wn0, p.out);
 }
 
-template <int NB>
+template <int NB, int NW>
 int launch_nb(KParams p, int n_begin, int ntiles, hipStream_t stream) {
-    p.mtiles = (p.M + 255) / 256;
+    p.mtiles = (p.M + NW * 32 - 1) / (NW * 32);
     p.ntiles = ntiles;
     p.n_begin = n_begin;
     p.splits = 1;
-    int smem = (int)gemm16_smem<NB>();
-    const int epi = 8 * 32 * EPI_LD * (int)sizeof(float);
+    int smem = (int)gemm16_smem<NB, NW>();
+    const int epi = NW * 32 * EPI_LD * (int)sizeof(float);
     if (smem < epi) smem = epi;
-    DS_ENSURE_DYN_LDS((&gemm_f16dma_kernel<NB>), 160 * 1024);
-    hipLaunchKernelGGL((gemm_f16dma_kernel<NB>), dim3(grid_1d(p.mtiles, p.ntiles), 1), dim3(512), smem, stream, p);
+    DS_ENSURE_DYN_LDS((&gemm_f16dma_kernel<NB, NW>), 160 * 1024);
+    hipLaunchKernelGGL((gemm_f16dma_kernel<NB, NW>), dim3(grid_1d(p.mtiles, p.ntiles), 1), dim3(NW * 64), smem, stream, p);
     DS_CHECK_LAUNCH();
     return DS_OK;
 }
@@ -163,38 +167,45 @@ bool gemm_f16dma_applicable(const KParams& p) {
     return true;
 }
 
-// Column tiling as in conv3x3_f16dma.hip (cost 1 + nb per round of 256 workgroups); the GEGLU epilogue pairs 32 value columns with their
-// 32 gate columns inside a 64-column half of a wave tile, so it takes even widths only.
+// Column tiling as in conv3x3_f16dma.hip (cost 1 + nb per round of resident workgroups); the GEGLU epilogue pairs 32 value columns with
+// their 32 gate columns inside a 64-column half of a wave tile, so it takes even widths only.  Projections with K <= 2 560 and N <= 1 280
+// take the four-wave, 128-row variant (two workgroups per CU, NB <= 3): 5 - 10 % faster there, slower on wide outputs (A/B per shape in
+// profiles/r3_gemm_f16dma_epilogue.txt); g_f16dma_nw (benchmarks) forces 4 or 8.
 int launch_gemm_f16dma(KParams& p, hipStream_t stream) {
-    const int mtiles = (p.M + 255) / 256;
     const bool geglu = p.act == DS_ACT_GEGLU;
     if (geglu && (p.N % 128)) return DS_E_SHAPE;
+    int nw = (p.K <= 2560 && p.N <= 1280) ? 4 : 8;
+    if (g_f16dma_nw == 4 || g_f16dma_nw == 8) nw = g_f16dma_nw;
+    const int mtiles = (p.M + nw * 32 - 1) / (nw * 32), slots = nw == 4 ? 512 : 256, max_nb = nw == 4 ? 3 : 4;
     auto tiling = [&](int nb0, int (*out)[3], int* cost) {
         int n = 0, col = 0, c = 0;
         for (int w = nb0; w >= 1 && col < p.N; --w) {
             if (geglu && (w & 1)) continue;
             const int t = (p.N - col) / (64 * w);
-            if (t > 0) { out[n][0] = col; out[n][1] = t; out[n][2] = w; ++n; col += t * 64 * w; c += (int)(((long long)mtiles * t + 255) / 256) * (1 + w); }
+            if (t > 0) { out[n][0] = col; out[n][1] = t; out[n][2] = w; ++n; col += t * 64 * w; c += (int)(((long long)mtiles * t + slots - 1) / slots) * (1 + w); }
         }
         *cost = c;
         return n;
     };
-    int best_nb = 4, best_cost = 0x7fffffff, best_n = 99, cost, tmp[4][3];
-    for (int nb = 4; nb >= 1; --nb) {
+    int best_nb = max_nb, best_cost = 0x7fffffff, best_n = 99, cost, tmp[4][3];
+    for (int nb = max_nb; nb >= 1; --nb) {
         if (geglu && (nb & 1)) continue;
         const int n = tiling(nb, tmp, &cost);
         if (cost < best_cost || (cost == best_cost && n < best_n)) { best_cost = cost; best_n = n; best_nb = nb; }
     }
-    if (g_f16dma_nb > 0 && !(geglu && (g_f16dma_nb & 1))) best_nb = g_f16dma_nb < 4 ? g_f16dma_nb : 4;
+    if (g_f16dma_nb > 0 && !(geglu && (g_f16dma_nb & 1))) best_nb = g_f16dma_nb < max_nb ? g_f16dma_nb : max_nb;
     int plan[4][3];
     const int n = tiling(best_nb, plan, &cost);
     for (int i = 0; i < n; ++i) {
         int rc;
-        switch (plan[i][2]) {
-            case 1: rc = launch_nb<1>(p, plan[i][0], plan[i][1], stream); break;
-            case 2: rc = launch_nb<2>(p, plan[i][0], plan[i][1], stream); break;
-            case 3: rc = launch_nb<3>(p, plan[i][0], plan[i][1], stream); break;
-            default: rc = launch_nb<4>(p, plan[i][0], plan[i][1], stream); break;
+        switch (plan[i][2] + (nw == 4 ? 10 : 0)) {
+            case 1: rc = launch_nb<1, 8>(p, plan[i][0], plan[i][1], stream); break;
+            case 2: rc = launch_nb<2, 8>(p, plan[i][0], plan[i][1], stream); break;
+            case 3: rc = launch_nb<3, 8>(p, plan[i][0], plan[i][1], stream); break;
+            case 4: rc = launch_nb<4, 8>(p, plan[i][0], plan[i][1], stream); break;
+            case 11: rc = launch_nb<1, 4>(p, plan[i][0], plan[i][1], stream); break;
+            case 12: rc = launch_nb<2, 4>(p, plan[i][0], plan[i][1], stream); break;
+            default: rc = launch_nb<3, 4>(p, plan[i][0], plan[i][1], stream); break;
         }
         if (rc) return rc;
     }

@@ -258,50 +258,53 @@ __device__ __forceinline__ void epilogue32(const KParams& p, const f32x16 (&acc)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// Pipelined vector epilogue of a 64-row wave tile made of one or two column blocks (WA = 32 / 64 columns at wn0, WB = 0 / 32 / 64 more
-// at wn0 + WA): the same arithmetic as epilogue / epilogue32 above, group by group (a group = 32 rows of one block), but the residual
-// rows and per-image bias of group g + 1 are REQUESTED BEFORE the stores of group g are issued.  On this ISA loads and stores retire
-// through one in-order counter (vmcnt): a load issued after a burst of stores cannot be waited for without waiting for those stores
-// to be acknowledged by memory, so with the request placed after the previous group's stores every group paid a full store round
-// trip (measured: the residual operand cost 25 % of a K = 1 728 convolution).  Two register sets of 8 rows alternate.
-template <int W> struct EpiGeo { static constexpr int LPR = W / 4, RPP = 64 / LPR, NP = 32 / RPP; };
+// Epilogue of the fp16-activation kernels (conv3x3_f16dma.hip, gemm_f16dma.hip): a 64-row wave tile made of one or two column blocks
+// (WA = 32 / 64 columns at wn0, WB = 0 / 32 / 64 more at wn0 + WA), the same arithmetic as epilogue / epilogue32 above, with
+//   * fp16 or fp32 residual rows and output rows (p.res_f16 / p.out_f16: the fp16 residual stream of the reference's fp16 mode);
+//   * EIGHT columns per lane: a lane's residual / output access is one 16-byte vector of fp16 (two of fp32), a wave instruction covers
+//     eight (W = 64) or sixteen (W = 32) whole row segments.  These layers are output-heavy (a K = 320 projection moves as many bytes
+//     in its epilogue as in its main loop) and the epilogue is bound by the bytes a wave keeps in flight: with four columns per lane
+//     (512 B per instruction) it was 5 - 10 % slower on the fp16 tensors (profiles/r3_gemm_f16dma_epilogue.txt);
+//   * group by group (a group = 32 rows of one block) with the residual rows and per-image bias of the NEXT group requested before the
+//     current group is staged, widened only where they are used (a conversion at the request would wait for the data: measured
+//     +0.05 ms on a 0.25 ms convolution);
+//   * the column sums left for the consumer's GroupNorm are those of the values as STORED (rounded when the output is fp16).
+template <int W> struct EpiGeo { static constexpr int LPR = W / 8, RPP = 64 / LPR, NP = 32 / RPP; };
+typedef _Float16 epi_h8 __attribute__((ext_vector_type(8)));
+struct EpiRows { f32x4 rv[4][2]; epi_h8 rh[4]; f32x4 cvu[2]; };
 
-typedef _Float16 epi_h4 __attribute__((ext_vector_type(4)));
-// The requested rows of one group: fp32 rows in rv, fp16 rows RAW in rh -- they are widened where they are used (a conversion here would
-// wait for the data before the tile is staged, exposing the whole memory latency: measured +0.05 ms on a 0.25 ms convolution).
-struct EpiRows { f32x4 rv[8]; epi_h4 rh[8]; f32x4 cvu; };
-
-template <int W, bool NTS, bool H16>
+template <int W, bool NTS>
 __device__ __forceinline__ void epi_request(const KParams& p, int rbase, int col, int lane, EpiRows& e) {
     using G = EpiGeo<W>;
-    f32x4 (&rv)[8] = e.rv;
-    f32x4& cvu = e.cvu;
     if (p.res) {
 #pragma unroll
         for (int pass = 0; pass < G::NP; ++pass) {
             const int row = min(rbase + pass * G::RPP + lane / G::LPR, p.M - 1);
-            if (H16 && p.res_f16) {
-                e.rh[pass] = __builtin_nontemporal_load(reinterpret_cast<const epi_h4*>(reinterpret_cast<const _Float16*>(p.res) + (size_t)row * p.res_ld + col));
+            if (p.res_f16) {
+                e.rh[pass] = __builtin_nontemporal_load(reinterpret_cast<const epi_h8*>(reinterpret_cast<const _Float16*>(p.res) + (size_t)row * p.res_ld + col));
             } else {
                 const f32x4* rp = reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.res_ld + col);
-                rv[pass] = NTS ? __builtin_nontemporal_load(rp) : *rp;
+                e.rv[pass][0] = NTS ? __builtin_nontemporal_load(rp) : rp[0];
+                e.rv[pass][1] = NTS ? __builtin_nontemporal_load(rp + 1) : rp[1];
             }
         }
     }
-    cvu = f32x4{0.f, 0.f, 0.f, 0.f};
+    e.cvu[0] = e.cvu[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (p.cbias && (p.cbias_bcast || p.HW % 32 == 0)) {
         const int img = p.cbias_bcast ? 0 : __builtin_amdgcn_readfirstlane(min(rbase, p.M - 1)) / p.HW;
-        cvu = *reinterpret_cast<const f32x4*>(p.cbias + (size_t)img * p.cbias_ld + col);
+        const f32x4* cp = reinterpret_cast<const f32x4*>(p.cbias + (size_t)img * p.cbias_ld + col);
+        e.cvu[0] = cp[0]; e.cvu[1] = cp[1];
     }
 }
 
-// a0 / a1: the group's accumulators of columns [0, 32) / [32, 64) of the block (a1 unused for W = 32); bn0 = first column of the block
-template <int MODE, int W, bool NTS, bool H16>
+// a0 / a1: the group's accumulators of columns [0, 32) / [32, 64) of the block (a1 unused for W = 32); bn0 = first column of the block;
+// cb / cbg: the lane's eight column biases (and, GEGLU, the biases of its eight gate columns); st: column sums, sums of squares
+template <int MODE, int W, bool NTS>
 __device__ __forceinline__ void epi_group(const KParams& p, const f32x16& a0, const f32x16& a1, float* stage, int rbase, const EpiRows& e,
-                                          int lane, int bn0, float* o_base, const f32x4& cb, const f32x4& cbg, f32x4& st_s, f32x4& st_q) {
+                                          int lane, int bn0, float* o_base, const f32x4 (&cb)[2], const f32x4 (&cbg)[2], f32x4 (&st_s)[2],
+                                          f32x4 (&st_q)[2]) {
     using G = EpiGeo<W>;
-    const f32x4& cvu = e.cvu;
-    const int c4 = (lane & (G::LPR - 1)) * 4, col = bn0 + c4;
+    const int c8 = (lane & (G::LPR - 1)) * 8, col = bn0 + c8;
     const bool cb_uniform = p.cbias && (p.cbias_bcast || p.HW % 32 == 0);
     const bool geglu = (MODE == 0) && W == 64 && p.act == DS_ACT_GEGLU;
 #pragma unroll
@@ -315,92 +318,108 @@ __device__ __forceinline__ void epi_group(const KParams& p, const f32x16& a0, co
         const int rr = pass * G::RPP + lane / G::LPR;
         const int row = rbase + rr;
         if (row >= p.M) continue;
-        f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * EPI_LD + c4);
-        if (MODE == 0) v *= p.acc_scale;
-        if (MODE == 1) v *= p.scale;
-        v += cb;
-        if (p.rowbias) v += p.rowbias[row];
-        if (cb_uniform) v += cvu;
-        else if (p.cbias) v += *reinterpret_cast<const f32x4*>(p.cbias + (size_t)(row / p.HW) * p.cbias_ld + col);
-        if (p.res) {
-            if (H16 && p.res_f16) { const epi_h4 hr = e.rh[pass]; v += f32x4{(float)hr[0], (float)hr[1], (float)hr[2], (float)hr[3]}; }
-            else v += e.rv[pass];
-        }
-        if (MODE == 0) v *= p.scale;
-        if (geglu) {
-            if (c4 < 32) {
-                const f32x4 gt = *reinterpret_cast<const f32x4*>(stage + rr * EPI_LD + c4 + 32) + cbg;
+        f32x4 v[2];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] *= 0.5f * gt[q] * (1.0f + erff(gt[q] * 0.70710678118654752440f));
-                if (H16 && p.out_f16) {
-                    typedef _Float16 h4g_t __attribute__((ext_vector_type(4)));
-                    const h4g_t hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                    *reinterpret_cast<h4g_t*>(reinterpret_cast<_Float16*>(o_base) + (size_t)row * p.ldo + (bn0 >> 1) + c4) = hv;
-                } else
-                    *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + (bn0 >> 1) + c4) = v;
+        for (int h = 0; h < 2; ++h) {
+            v[h] = *reinterpret_cast<const f32x4*>(stage + rr * EPI_LD + c8 + 4 * h);
+            if (MODE == 0) v[h] *= p.acc_scale;
+            if (MODE == 1) v[h] *= p.scale;
+            v[h] += cb[h];
+            if (p.rowbias) v[h] += p.rowbias[row];
+            if (cb_uniform) v[h] += e.cvu[h];
+            else if (p.cbias) v[h] += *reinterpret_cast<const f32x4*>(p.cbias + (size_t)(row / p.HW) * p.cbias_ld + col + 4 * h);
+            if (p.res) {
+                if (p.res_f16) { const epi_h8 hr = e.rh[pass]; v[h] += f32x4{(float)hr[4 * h], (float)hr[4 * h + 1], (float)hr[4 * h + 2], (float)hr[4 * h + 3]}; }
+                else v[h] += e.rv[pass][h];
             }
-            continue;
+            if (MODE == 0) v[h] *= p.scale;
         }
-        if (p.act == DS_ACT_SILU) {
+        size_t ocol = (size_t)row * p.ldo + col;
+        if (geglu) {
+            if (c8 >= 32) continue;                                 // gate columns: consumed by the value lanes
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = ds_silu(v[q]);
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 gt = *reinterpret_cast<const f32x4*>(stage + rr * EPI_LD + c8 + 32 + 4 * h) + cbg[h];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[h][q] *= 0.5f * gt[q] * (1.0f + erff(gt[q] * 0.70710678118654752440f));
+            }
+            ocol = (size_t)row * p.ldo + (bn0 >> 1) + c8;
+        } else if (p.act == DS_ACT_SILU) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[h][q] = ds_silu(v[h][q]);
         }
-        if (H16 && p.out_f16) {
-            typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
-            const h4_t hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-            *reinterpret_cast<h4_t*>(reinterpret_cast<_Float16*>(o_base) + (size_t)row * p.ldo + col) = hv;
-            v = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
-        } else if (NTS) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col));
-        else *reinterpret_cast<f32x4*>(o_base + (size_t)row * p.ldo + col) = v;
-        st_s += v; st_q += v * v;
+        if (p.out_f16) {
+            const epi_h8 hv = {(_Float16)v[0][0], (_Float16)v[0][1], (_Float16)v[0][2], (_Float16)v[0][3],
+                               (_Float16)v[1][0], (_Float16)v[1][1], (_Float16)v[1][2], (_Float16)v[1][3]};
+            epi_h8* op = reinterpret_cast<epi_h8*>(reinterpret_cast<_Float16*>(o_base) + ocol);
+            if (NTS) __builtin_nontemporal_store(hv, op); else *op = hv;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) v[h] = f32x4{(float)hv[4 * h], (float)hv[4 * h + 1], (float)hv[4 * h + 2], (float)hv[4 * h + 3]};
+        } else {
+            f32x4* op = reinterpret_cast<f32x4*>(o_base + ocol);
+            if (NTS) { __builtin_nontemporal_store(v[0], op); __builtin_nontemporal_store(v[1], op + 1); }
+            else { op[0] = v[0]; op[1] = v[1]; }
+        }
+        if (!geglu) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { st_s[h] += v[h]; st_q[h] += v[h] * v[h]; }
+        }
     }
 }
 
 template <int W>
-__device__ __forceinline__ void epi_stats(const KParams& p, int lane, int wm0, int col, f32x4 st_s, f32x4 st_q) {
+__device__ __forceinline__ void epi_stats(const KParams& p, int lane, int wm0, int col, f32x4 (&st_s)[2], f32x4 (&st_q)[2]) {
     if (!p.stats || wm0 >= p.M) return;
     using G = EpiGeo<W>;
-    // column sums of this wave's 64 rows: the lane groups (lane / LPR) hold disjoint rows of the same 4 columns
+    // column sums of this wave's 64 rows: the lane groups (lane / LPR) hold disjoint rows of the same 8 columns
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int o = G::LPR; o < 64; o <<= 1) { st_s[q] += __shfl_xor(st_s[q], o); st_q[q] += __shfl_xor(st_q[q], o); }
-    }
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int o = G::LPR; o < 64; o <<= 1) { st_s[h][q] += __shfl_xor(st_s[h][q], o); st_q[h][q] += __shfl_xor(st_q[h][q], o); }
+        }
     if (lane < G::LPR) {
         float* sp = p.stats + (size_t)(wm0 >> 6) * 2 * p.N + col;
-        *reinterpret_cast<f32x4*>(sp) = st_s;
-        *reinterpret_cast<f32x4*>(sp + p.N) = st_q;
+        reinterpret_cast<f32x4*>(sp)[0] = st_s[0]; reinterpret_cast<f32x4*>(sp)[1] = st_s[1];
+        reinterpret_cast<f32x4*>(sp + p.N)[0] = st_q[0]; reinterpret_cast<f32x4*>(sp + p.N)[1] = st_q[1];
     }
 }
 
 // stage: 32 x EPI_LD floats owned by the wave.  The caller guarantees the vector path (p.vec_ok, whole blocks inside N, no split).
-template <int MODE, bool NTS, bool H16, int WA, int WB>
+template <int MODE, bool NTS, int WA, int WB>
 __device__ __forceinline__ void epilogue_pipe(const KParams& p, const f32x16 (&accA)[2][2], const f32x16 (&accB)[2][2], float* stage, int lane,
                                               int wm0, int wn0, float* o_base) {
-    const int colA = wn0 + (lane & (WA / 4 - 1)) * 4;
-    const int colB = wn0 + WA + (lane & ((WB ? WB : 32) / 4 - 1)) * 4;
+    constexpr int WBB = WB ? WB : 32;
+    const int colA = wn0 + (lane & (WA / 8 - 1)) * 8;
+    const int colB = wn0 + WA + (lane & (WBB / 8 - 1)) * 8;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 cbA = zero, cbB = zero, cbgA = zero, cbgB = zero;
+    f32x4 cbA[2] = {zero, zero}, cbB[2] = {zero, zero}, cbgA[2] = {zero, zero}, cbgB[2] = {zero, zero};
     const bool geglu = (MODE == 0) && p.act == DS_ACT_GEGLU;
     if (p.colbias) {
-        cbA = *reinterpret_cast<const f32x4*>(p.colbias + colA);
-        if (WB) cbB = *reinterpret_cast<const f32x4*>(p.colbias + colB);
-        if (geglu && WA == 64 && (lane & 15) < 8) cbgA = *reinterpret_cast<const f32x4*>(p.colbias + colA + 32);
-        if (geglu && WB == 64 && (lane & 15) < 8) cbgB = *reinterpret_cast<const f32x4*>(p.colbias + colB + 32);
+        const f32x4* ca = reinterpret_cast<const f32x4*>(p.colbias + colA);
+        cbA[0] = ca[0]; cbA[1] = ca[1];
+        if (geglu && WA == 64 && (lane & 7) < 4) { cbgA[0] = ca[8]; cbgA[1] = ca[9]; }
+        if (WB) {
+            const f32x4* cbp = reinterpret_cast<const f32x4*>(p.colbias + colB);
+            cbB[0] = cbp[0]; cbB[1] = cbp[1];
+            if (geglu && WB == 64 && (lane & 7) < 4) { cbgB[0] = cbp[8]; cbgB[1] = cbp[9]; }
+        }
     }
     EpiRows e0, e1;
-    f32x4 sA = zero, qA = zero, sB = zero, qB = zero;
-    epi_request<WA, NTS, H16>(p, wm0, colA, lane, e0);
-    epi_request<WA, NTS, H16>(p, wm0 + 32, colA, lane, e1);
-    epi_group<MODE, WA, NTS, H16>(p, accA[0][0], accA[0][1], stage, wm0, e0, lane, wn0, o_base, cbA, cbgA, sA, qA);
-    if constexpr (WB != 0) epi_request<(WB ? WB : 32), NTS, H16>(p, wm0, colB, lane, e0);
-    epi_group<MODE, WA, NTS, H16>(p, accA[1][0], accA[1][1], stage, wm0 + 32, e1, lane, wn0, o_base, cbA, cbgA, sA, qA);
+    f32x4 sA[2] = {zero, zero}, qA[2] = {zero, zero}, sB[2] = {zero, zero}, qB[2] = {zero, zero};
+    epi_request<WA, NTS>(p, wm0, colA, lane, e0);
+    epi_request<WA, NTS>(p, wm0 + 32, colA, lane, e1);
+    epi_group<MODE, WA, NTS>(p, accA[0][0], accA[0][1], stage, wm0, e0, lane, wn0, o_base, cbA, cbgA, sA, qA);
+    if constexpr (WB != 0) epi_request<WBB, NTS>(p, wm0, colB, lane, e0);
+    epi_group<MODE, WA, NTS>(p, accA[1][0], accA[1][1], stage, wm0 + 32, e1, lane, wn0, o_base, cbA, cbgA, sA, qA);
     epi_stats<WA>(p, lane, wm0, colA, sA, qA);
     if constexpr (WB != 0) {
-        constexpr int WBB = WB ? WB : 32;
-        epi_request<WBB, NTS, H16>(p, wm0 + 32, colB, lane, e1);
-        epi_group<MODE, WBB, NTS, H16>(p, accB[0][0], accB[0][1], stage, wm0, e0, lane, wn0 + WA, o_base, cbB, cbgB, sB, qB);
-        epi_group<MODE, WBB, NTS, H16>(p, accB[1][0], accB[1][1], stage, wm0 + 32, e1, lane, wn0 + WA, o_base, cbB, cbgB, sB, qB);
+        epi_request<WBB, NTS>(p, wm0 + 32, colB, lane, e1);
+        epi_group<MODE, WBB, NTS>(p, accB[0][0], accB[0][1], stage, wm0, e0, lane, wn0 + WA, o_base, cbB, cbgB, sB, qB);
+        epi_group<MODE, WBB, NTS>(p, accB[1][0], accB[1][1], stage, wm0 + 32, e1, lane, wn0 + WA, o_base, cbB, cbgB, sB, qB);
         epi_stats<WBB>(p, lane, wm0, colB, sB, qB);
     }
 }
@@ -507,7 +526,7 @@ extern long long g_halo2_launches;
 // conv3x3_f16dma.hip: 3x3 on fp16 activations, both operands by LDS-DMA, 256-pixel x 64/128/192/256-channel tiles
 bool conv3x3_f16dma_applicable(const KParams& p);
 int launch_conv3x3_f16dma(KParams& p, hipStream_t stream);
-extern int g_f16dma_nb, g_f16dma_ablate;
+extern int g_f16dma_nb, g_f16dma_nw, g_f16dma_ablate;
 
 // gemm_f16dma.hip: 1x1 / Linear on fp16 activations (both operands by LDS-DMA)
 bool gemm_f16dma_applicable(const KParams& p);

@@ -123,9 +123,9 @@ typedef struct ds_conv_args {
     /* 1: the OUTPUT is written as fp16 NHWC rows [M][out_ld halfs] (rounded to nearest even from the fp32 epilogue value; the GroupNorm
      * column sums of stats_out are those of the ROUNDED values, i.e. of the stored tensor).  The reference's fp16 mode keeps every
      * activation of the U-Net body in fp16 (networks_edm.py:486, :165-179; torch.autocast in the latent-diffusion path, sample.py:296):
-     * conv0 outputs, block outputs (the residual stream) and projection outputs.  Requires in_f16, cout % 64 == 0, no out_nchw. */
+     * conv0 outputs, block outputs (the residual stream) and projection outputs.  Requires in_f16, cout % 64 == 0, out_ld % 8 == 0, no out_nchw. */
     int out_f16;
-    /* 1 (with in_f16): `res` is an fp16 tensor [M][res_ld halfs] (res_ld % 4 == 0) -- the fp16 residual stream; added in fp32. */
+    /* 1 (with in_f16): `res` is an fp16 tensor [M][res_ld halfs] (res_ld % 8 == 0, 16-byte aligned) -- the fp16 residual stream; added in fp32. */
     int res_f16;
 } ds_conv_args;
 
@@ -153,6 +153,7 @@ int ds_conv_f16dma_supported(int n, int h, int w, int c0, int ec0, int cout);
 int ds_gemm_f16dma_supported(long long rows, int k, int cout);
 /* benchmarks / tests: force the column-tile width (64 * nb columns, nb = 1..4; 0 = cost model) of the fp16-activation kernel; returns the previous value */
 int ds_debug_f16dma_nb(int nb);
+int ds_debug_f16dma_nw(int nw);   /* benchmarks / tests: 4 / 8 forces the 128- / 256-row variant of the fp16-activation GEMM, 0 = by K (returns the old value) */
 /* benchmarks only (results are WRONG when set): timing ablations of the fp16-activation kernel -- bit 0: no weight DMA after the
  * prologue, bit 1: no halo DMA after the first slab, bit 2: no epilogue, bit 4: no per-tap barrier, bit 5: no LDS fragment reads;
  * returns the previous mask */

@@ -34,8 +34,14 @@ SHAPES_SD15 = [  # SD-1.5 latent U-Net 3x3 convs (320 / 640 / 1280 channels at 6
     (64, 320, 0, 320, 9), (64, 320, 320, 320, 9), (32, 640, 0, 640, 9), (32, 640, 640, 640, 9), (16, 1280, 0, 1280, 9), (16, 1280, 1280, 1280, 9),
 ]
 
+SHAPES_SD15_GEMM = [  # SD-1.5 transformer projections / 1x1s on the image rows (taps = 1): bench with --batch 32 --f16 --dma16 [--f16io]
+    (64, 320, 0, 320, 1), (64, 320, 0, 960, 1), (64, 1280, 0, 320, 1), (32, 640, 0, 640, 1), (32, 640, 0, 1920, 1), (32, 2560, 0, 640, 1),
+    (16, 1280, 0, 1280, 1), (16, 1280, 0, 3840, 1), (16, 5120, 0, 1280, 1),
+    (64, 320, 0, 256, 1), (64, 320, 0, 64, 1), (64, 320, 0, 128, 1), (64, 320, 0, 192, 1),   # [9..12] locality experiments: N = one tile
+]
+
 ap = argparse.ArgumentParser()
-ap.add_argument('--shapes', default='cifar10', choices=['cifar10', 'imagenet64', 'sd15', 'ffhq'])
+ap.add_argument('--shapes', default='cifar10', choices=['cifar10', 'imagenet64', 'sd15', 'ffhq', 'sd15gemm'])
 ap.add_argument('--batch', type=int, default=256)
 ap.add_argument('--entry', default='ds_conv2d_nhwc')
 ap.add_argument('--iters', type=int, default=10)
@@ -47,6 +53,8 @@ ap.add_argument('--split', action='store_true', help='split-fp16 fp32-emulated k
 ap.add_argument('--f16', action='store_true', help='fp16-operand kernel (ds_conv_args.wgt_f16), 3x3 shapes only')
 ap.add_argument('--dma16', action='store_true', help='with --f16: fp16 ACTIVATIONS (ds_conv_args.in_f16, csrc/conv3x3_f16dma.hip); single source (c0 + c1 channels), no --norm')
 ap.add_argument('--nb', type=int, default=0, help='with --dma16: force the column-tile width (64 * nb)')
+ap.add_argument('--lda', type=int, default=0, help='with --dma16: override the leading dimension of the fp16 input (timing experiments on access locality; results are then meaningless)')
+ap.add_argument('--nw', type=int, default=0, help='with --dma16, taps = 1 shapes: force the 4- / 8-wave GEMM variant')
 ap.add_argument('--ablate', type=int, default=0, help='with --dma16: ds_debug_f16dma_ablate mask (timing only)')
 ap.add_argument('--no-res', action='store_true', help='no residual operand in the epilogue')
 ap.add_argument('--f16out', action='store_true', help='with --dma16: fp16 output rows only')
@@ -56,7 +64,7 @@ ap.add_argument('--extra', action='store_true', help='append the fused 1x1 skip 
 ap.add_argument('--ws', action='store_true', help='give the launcher a split-K workspace (256 MiB), as the engine plans do (the persistent schedule needs it)')
 ap.add_argument('--norm', action='store_true', help='fused GroupNorm affine + SiLU in the halo loader, as the network uses it')
 args = ap.parse_args()
-SHAPES = {'cifar10': SHAPES, 'imagenet64': SHAPES_IMAGENET64, 'sd15': SHAPES_SD15, 'ffhq': SHAPES_FFHQ}[args.shapes]
+SHAPES = {'cifar10': SHAPES, 'imagenet64': SHAPES_IMAGENET64, 'sd15': SHAPES_SD15, 'ffhq': SHAPES_FFHQ, 'sd15gemm': SHAPES_SD15_GEMM}[args.shapes]
 
 lib = _lib.load()
 lib.ds_debug_force_generic_conv(int(os.environ.get("DS_CONV", "0")))
@@ -81,7 +89,7 @@ for si, (res, c0, c1, cout, taps) in enumerate(SHAPES):
                  None, 0, 1, res_t.data_ptr() if cout >= 4 else None, cout, 0.70710678, 0, out.data_ptr(), old)
     if args.no_res:
         a.res = None
-    if (args.f16 or args.split) and (taps != 9 or cout < 64 or (args.norm and res < 16)):
+    if (args.f16 or args.split) and ((taps != 9 and not args.dma16) or cout < 64 or (args.norm and res < 16)):
         continue
     if args.extra and taps == 9:
         ec = c0 + c1
@@ -96,7 +104,7 @@ for si, (res, c0, c1, cout, taps) in enumerate(SHAPES):
         wp, a.wgt_shift = ops.pack_conv_weight_split(w)
         a.wgt = wp.data_ptr()
     elif args.f16:
-        wp = ops.pack_conv_weight_f16(w)
+        wp = ops.pack_conv_weight_f16(w) if taps == 9 else ops.pack_linear_weight_f16(wp)
         a.wgt = wp.data_ptr()
     if args.f16 or args.split:
         a.wgt_f16 = 2 if args.split else 1
@@ -113,7 +121,10 @@ for si, (res, c0, c1, cout, taps) in enumerate(SHAPES):
         if (args.f16io or args.f16res) and not args.no_res:
             res16 = res_t.to(torch.float16)
             a.res, a.res_f16 = res16.data_ptr(), 1
+        if args.lda:
+            a.ld0 = args.lda
         lib.ds_debug_f16dma_nb(args.nb)
+        lib.ds_debug_f16dma_nw(args.nw)
         lib.ds_debug_f16dma_ablate(args.ablate)
     if args.norm and taps == 9:
         coefs = torch.randn(B, 3, c0 + c1, device=dev) * 0.1 + torch.tensor([0., 1., 0.], device=dev).reshape(1, 3, 1)
@@ -152,6 +163,9 @@ for si, (res, c0, c1, cout, taps) in enumerate(SHAPES):
     fl = 2.0 * M * taps * (c0 + c1) * cout
     tot_fl += fl; tot_t += ms
     msg = f'[{si}] {res}x{res} {c0}+{c1}->{cout} taps={taps} M={M}: {ms:8.3f} ms  {fl/ms/1e9:7.1f} TFLOP/s'
+    if args.dma16:        # the launch's algorithmic HBM bytes: fp16 activations in, output and residual rows out / in
+        byt = M * (c0 + c1) * 2 + M * cout * (2 if a.out_f16 else 4) + (M * cout * (2 if a.res_f16 else 4) if a.res else 0)
+        msg += f'  {byt / ms / 1e6:6.0f} GB/s'
     if args.check:
         xin = torch.cat([x0, x1], 1) if c1 else x0
         xin = xin.reshape(B, res, res, c0 + c1).permute(0, 3, 1, 2)
