@@ -269,6 +269,19 @@ __device__ __forceinline__ void epilogue32(const KParams& p, const f32x16 (&acc)
 //     current group is staged, widened only where they are used (a conversion at the request would wait for the data: measured
 //     +0.05 ms on a 0.25 ms convolution);
 //   * the column sums left for the consumer's GroupNorm are those of the values as STORED (rounded when the output is fp16).
+// GELU gate of the fp16-mode GEGLU epilogue: 0.5 g (1 + erf(g / sqrt 2)) with erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute,
+// evaluated as erfc on the negative side so the tail does not cancel) on the hardware reciprocal and exp2 -- about a third of erff's
+// instructions.  The product is rounded to fp16 (2**-11 relative) right after, and the fp32 mode keeps erff (igemm_common.h:epilogue,
+// norm_act.hip:geglu_kernel).  On SD-1.5 the 320 -> 2 560 GEGLU projection evaluates 168 M gates per call: with erff the epilogue's
+// VALU work was as long as the whole main loop.
+__device__ __forceinline__ float ds_gelu_gate_fast(float g) {
+    const float x = g * 0.70710678118654752440f, ax = __builtin_fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
+    const float poly = t * __builtin_fmaf(t, __builtin_fmaf(t, __builtin_fmaf(t, __builtin_fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float pe = poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);          // erfc(|x|)
+    return 0.5f * g * (x < 0.f ? pe : 2.0f - pe);
+}
+
 template <int W> struct EpiGeo { static constexpr int LPR = W / 8, RPP = 64 / LPR, NP = 32 / RPP; };
 typedef _Float16 epi_h8 __attribute__((ext_vector_type(8)));
 struct EpiRows { f32x4 rv[4][2]; epi_h8 rh[4]; f32x4 cvu[2]; };
@@ -341,7 +354,7 @@ __device__ __forceinline__ void epi_group(const KParams& p, const f32x16& a0, co
             for (int h = 0; h < 2; ++h) {
                 const f32x4 gt = *reinterpret_cast<const f32x4*>(stage + rr * EPI_LD + c8 + 32 + 4 * h) + cbg[h];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[h][q] *= 0.5f * gt[q] * (1.0f + erff(gt[q] * 0.70710678118654752440f));
+                for (int q = 0; q < 4; ++q) v[h][q] *= ds_gelu_gate_fast(gt[q]);
             }
             ocol = (size_t)row * p.ldo + (bn0 >> 1) + c8;
         } else if (p.act == DS_ACT_SILU) {
