@@ -284,7 +284,9 @@ __device__ __forceinline__ float ds_gelu_gate_fast(float g) {
 
 template <int W> struct EpiGeo { static constexpr int LPR = W / 8, RPP = 64 / LPR, NP = 32 / RPP; };
 typedef _Float16 epi_h8 __attribute__((ext_vector_type(8)));
-struct EpiRows { f32x4 rv[4][2]; epi_h8 rh[4]; f32x4 cvu[2]; };
+typedef unsigned epi_u4 __attribute__((ext_vector_type(4)));
+// The requested rows of one group, RAW: an fp16 row segment (8 halfs) in raw[pass][0], an fp32 one (8 floats) in raw[pass][0 .. 1].
+struct EpiRows { epi_u4 raw[4][2]; f32x4 cvu[2]; };
 
 template <int W, bool NTS>
 __device__ __forceinline__ void epi_request(const KParams& p, int rbase, int col, int lane, EpiRows& e) {
@@ -294,11 +296,11 @@ __device__ __forceinline__ void epi_request(const KParams& p, int rbase, int col
         for (int pass = 0; pass < G::NP; ++pass) {
             const int row = min(rbase + pass * G::RPP + lane / G::LPR, p.M - 1);
             if (p.res_f16) {
-                e.rh[pass] = __builtin_nontemporal_load(reinterpret_cast<const epi_h8*>(reinterpret_cast<const _Float16*>(p.res) + (size_t)row * p.res_ld + col));
+                e.raw[pass][0] = __builtin_nontemporal_load(reinterpret_cast<const epi_u4*>(reinterpret_cast<const _Float16*>(p.res) + (size_t)row * p.res_ld + col));
             } else {
-                const f32x4* rp = reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.res_ld + col);
-                e.rv[pass][0] = NTS ? __builtin_nontemporal_load(rp) : rp[0];
-                e.rv[pass][1] = NTS ? __builtin_nontemporal_load(rp + 1) : rp[1];
+                const epi_u4* rp = reinterpret_cast<const epi_u4*>(p.res + (size_t)row * p.res_ld + col);
+                e.raw[pass][0] = NTS ? __builtin_nontemporal_load(rp) : rp[0];
+                e.raw[pass][1] = NTS ? __builtin_nontemporal_load(rp + 1) : rp[1];
             }
         }
     }
@@ -310,22 +312,25 @@ __device__ __forceinline__ void epi_request(const KParams& p, int rbase, int col
     }
 }
 
-// a0 / a1: the group's accumulators of columns [0, 32) / [32, 64) of the block (a1 unused for W = 32); bn0 = first column of the block;
-// cb / cbg: the lane's eight column biases (and, GEGLU, the biases of its eight gate columns); st: column sums, sums of squares
-template <int MODE, int W, bool NTS>
-__device__ __forceinline__ void epi_group(const KParams& p, const f32x16& a0, const f32x16& a1, float* stage, int rbase, const EpiRows& e,
-                                          int lane, int bn0, float* o_base, const f32x4 (&cb)[2], const f32x4 (&cbg)[2], f32x4 (&st_s)[2],
-                                          f32x4 (&st_q)[2]) {
-    using G = EpiGeo<W>;
-    const int c8 = (lane & (G::LPR - 1)) * 8, col = bn0 + c8;
-    const bool cb_uniform = p.cbias && (p.cbias_bcast || p.HW % 32 == 0);
-    const bool geglu = (MODE == 0) && W == 64 && p.act == DS_ACT_GEGLU;
+// a0 / a1: the group's accumulators of columns [0, 32) / [32, 64) of the block (a1 unused for W = 32) -> the wave's 32 staging rows
+template <int W>
+__device__ __forceinline__ void epi_stage(const f32x16& a0, const f32x16& a1, float* stage, int lane) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int sr = ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_LD + (lane & 31);
         stage[sr] = a0[r];
         if (W == 64) stage[sr + 32] = a1[r];
     }
+}
+
+// bn0 = first column of the block; cb: the lane's eight column biases; st: column sums, sums of squares
+template <int MODE, int W, bool NTS>
+__device__ __forceinline__ void epi_process(const KParams& p, const float* stage, int rbase, const EpiRows& e, int lane, int bn0, float* o_base,
+                                            const f32x4 (&cb)[2], f32x4 (&st_s)[2], f32x4 (&st_q)[2]) {
+    using G = EpiGeo<W>;
+    const int c8 = (lane & (G::LPR - 1)) * 8, col = bn0 + c8;
+    const bool cb_uniform = p.cbias && (p.cbias_bcast || p.HW % 32 == 0);
+    const bool geglu = (MODE == 0) && W == 64 && p.act == DS_ACT_GEGLU;
 #pragma unroll
     for (int pass = 0; pass < G::NP; ++pass) {
         const int rr = pass * G::RPP + lane / G::LPR;
@@ -342,8 +347,10 @@ __device__ __forceinline__ void epi_group(const KParams& p, const f32x16& a0, co
             if (cb_uniform) v[h] += e.cvu[h];
             else if (p.cbias) v[h] += *reinterpret_cast<const f32x4*>(p.cbias + (size_t)(row / p.HW) * p.cbias_ld + col + 4 * h);
             if (p.res) {
-                if (p.res_f16) { const epi_h8 hr = e.rh[pass]; v[h] += f32x4{(float)hr[4 * h], (float)hr[4 * h + 1], (float)hr[4 * h + 2], (float)hr[4 * h + 3]}; }
-                else v[h] += e.rv[pass][h];
+                if (p.res_f16) {
+                    const epi_h8 hr = __builtin_bit_cast(epi_h8, e.raw[pass][0]);
+                    v[h] += f32x4{(float)hr[4 * h], (float)hr[4 * h + 1], (float)hr[4 * h + 2], (float)hr[4 * h + 3]};
+                } else v[h] += __builtin_bit_cast(f32x4, e.raw[pass][h]);
             }
             if (MODE == 0) v[h] *= p.scale;
         }
@@ -352,7 +359,8 @@ __device__ __forceinline__ void epi_group(const KParams& p, const f32x16& a0, co
             if (c8 >= 32) continue;                                 // gate columns: consumed by the value lanes
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const f32x4 gt = *reinterpret_cast<const f32x4*>(stage + rr * EPI_LD + c8 + 32 + 4 * h) + cbg[h];
+                f32x4 gt = *reinterpret_cast<const f32x4*>(stage + rr * EPI_LD + c8 + 32 + 4 * h);
+                if (p.colbias) gt += *reinterpret_cast<const f32x4*>(p.colbias + col + 32 + 4 * h);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[h][q] *= ds_gelu_gate_fast(gt[q]);
             }
@@ -368,14 +376,16 @@ __device__ __forceinline__ void epi_group(const KParams& p, const f32x16& a0, co
                                (_Float16)v[1][0], (_Float16)v[1][1], (_Float16)v[1][2], (_Float16)v[1][3]};
             epi_h8* op = reinterpret_cast<epi_h8*>(reinterpret_cast<_Float16*>(o_base) + ocol);
             if (NTS) __builtin_nontemporal_store(hv, op); else *op = hv;
+            if (p.stats) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) v[h] = f32x4{(float)hv[4 * h], (float)hv[4 * h + 1], (float)hv[4 * h + 2], (float)hv[4 * h + 3]};
+                for (int h = 0; h < 2; ++h) v[h] = f32x4{(float)hv[4 * h], (float)hv[4 * h + 1], (float)hv[4 * h + 2], (float)hv[4 * h + 3]};
+            }
         } else {
             f32x4* op = reinterpret_cast<f32x4*>(o_base + ocol);
             if (NTS) { __builtin_nontemporal_store(v[0], op); __builtin_nontemporal_store(v[1], op + 1); }
             else { op[0] = v[0]; op[1] = v[1]; }
         }
-        if (!geglu) {
+        if (p.stats) {                                              // (never with GEGLU: the launcher rejects that combination)
 #pragma unroll
             for (int h = 0; h < 2; ++h) { st_s[h] += v[h]; st_q[h] += v[h] * v[h]; }
         }
@@ -401,40 +411,36 @@ __device__ __forceinline__ void epi_stats(const KParams& p, int lane, int wm0, i
     }
 }
 
+// One column block (W columns at bn0) of the wave tile: its two 32-row groups.  `cur` holds the requested rows of the first group on
+// entry; the rows of the second group are requested once the first is staged (its accumulators are dead by then: the two row sets
+// never coexist with the whole accumulator tile), and -- if NEXT_W != 0 -- those of the next block's first group once the second is,
+// so every request is issued BEFORE the stores of the group in front of it.  On return `cur` holds the next block's first group.
+template <int MODE, bool NTS, int W, int NEXT_W>
+__device__ __forceinline__ void epi_block(const KParams& p, const f32x16 (&acc)[2][2], float* stage, int lane, int wm0, int bn0, int next_col,
+                                          float* o_base, EpiRows& cur, EpiRows& oth) {
+    const int col = bn0 + (lane & (W / 8 - 1)) * 8;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 cb[2] = {zero, zero}, st_s[2] = {zero, zero}, st_q[2] = {zero, zero};
+    if (p.colbias) { const f32x4* c = reinterpret_cast<const f32x4*>(p.colbias + col); cb[0] = c[0]; cb[1] = c[1]; }
+    epi_stage<W>(acc[0][0], acc[0][1], stage, lane);
+    epi_request<W, NTS>(p, wm0 + 32, col, lane, oth);
+    epi_process<MODE, W, NTS>(p, stage, wm0, cur, lane, bn0, o_base, cb, st_s, st_q);
+    epi_stage<W>(acc[1][0], acc[1][1], stage, lane);
+    if constexpr (NEXT_W != 0) epi_request<(NEXT_W ? NEXT_W : 32), NTS>(p, wm0, next_col, lane, cur);
+    epi_process<MODE, W, NTS>(p, stage, wm0 + 32, oth, lane, bn0, o_base, cb, st_s, st_q);
+    epi_stats<W>(p, lane, wm0, col, st_s, st_q);
+}
+
 // stage: 32 x EPI_LD floats owned by the wave.  The caller guarantees the vector path (p.vec_ok, whole blocks inside N, no split).
 template <int MODE, bool NTS, int WA, int WB>
 __device__ __forceinline__ void epilogue_pipe(const KParams& p, const f32x16 (&accA)[2][2], const f32x16 (&accB)[2][2], float* stage, int lane,
                                               int wm0, int wn0, float* o_base) {
     constexpr int WBB = WB ? WB : 32;
-    const int colA = wn0 + (lane & (WA / 8 - 1)) * 8;
     const int colB = wn0 + WA + (lane & (WBB / 8 - 1)) * 8;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 cbA[2] = {zero, zero}, cbB[2] = {zero, zero}, cbgA[2] = {zero, zero}, cbgB[2] = {zero, zero};
-    const bool geglu = (MODE == 0) && p.act == DS_ACT_GEGLU;
-    if (p.colbias) {
-        const f32x4* ca = reinterpret_cast<const f32x4*>(p.colbias + colA);
-        cbA[0] = ca[0]; cbA[1] = ca[1];
-        if (geglu && WA == 64 && (lane & 7) < 4) { cbgA[0] = ca[8]; cbgA[1] = ca[9]; }
-        if (WB) {
-            const f32x4* cbp = reinterpret_cast<const f32x4*>(p.colbias + colB);
-            cbB[0] = cbp[0]; cbB[1] = cbp[1];
-            if (geglu && WB == 64 && (lane & 7) < 4) { cbgB[0] = cbp[8]; cbgB[1] = cbp[9]; }
-        }
-    }
     EpiRows e0, e1;
-    f32x4 sA[2] = {zero, zero}, qA[2] = {zero, zero}, sB[2] = {zero, zero}, qB[2] = {zero, zero};
-    epi_request<WA, NTS>(p, wm0, colA, lane, e0);
-    epi_request<WA, NTS>(p, wm0 + 32, colA, lane, e1);
-    epi_group<MODE, WA, NTS>(p, accA[0][0], accA[0][1], stage, wm0, e0, lane, wn0, o_base, cbA, cbgA, sA, qA);
-    if constexpr (WB != 0) epi_request<WBB, NTS>(p, wm0, colB, lane, e0);
-    epi_group<MODE, WA, NTS>(p, accA[1][0], accA[1][1], stage, wm0 + 32, e1, lane, wn0, o_base, cbA, cbgA, sA, qA);
-    epi_stats<WA>(p, lane, wm0, colA, sA, qA);
-    if constexpr (WB != 0) {
-        epi_request<WBB, NTS>(p, wm0 + 32, colB, lane, e1);
-        epi_group<MODE, WBB, NTS>(p, accB[0][0], accB[0][1], stage, wm0, e0, lane, wn0 + WA, o_base, cbB, cbgB, sB, qB);
-        epi_group<MODE, WBB, NTS>(p, accB[1][0], accB[1][1], stage, wm0 + 32, e1, lane, wn0 + WA, o_base, cbB, cbgB, sB, qB);
-        epi_stats<WBB>(p, lane, wm0, colB, sB, qB);
-    }
+    epi_request<WA, NTS>(p, wm0, wn0 + (lane & (WA / 8 - 1)) * 8, lane, e0);
+    epi_block<MODE, NTS, WA, WB>(p, accA, stage, lane, wm0, wn0, colB, o_base, e0, e1);
+    if constexpr (WB != 0) epi_block<MODE, NTS, WBB, 0>(p, accB, stage, lane, wm0, wn0 + WA, 0, o_base, e0, e1);
 }
 
 // XCD-aware decode of a 1-D workgroup id into (m tile, n tile): the dispatcher places workgroup b on XCD b % 8, so
