@@ -1104,3 +1104,121 @@ def test_layernorm_and_attention_fp16_outputs():
     assert lib.ds_attention_f16(C.byref(a), _lib.stream_ptr()) == 0
     torch.cuda.synchronize()
     assert torch.equal(o16, o32.to(torch.float16))
+
+
+@pytest.mark.parametrize('resample', [0, 1, 2])
+def test_norm_passes_read_fp16_sources_like_their_fp32_copies(resample):
+    """ds_gn_stats / ds_norm_act with in_f16 (bit 0: x0, bit 1: x1 -- tensors of the fp16 residual stream, ds_engine.h): values are widened
+    before any arithmetic, so the results equal those of the same call on fp32 copies of the tensors, bit for bit; the decoder's mixed
+    concatenation [fp16 stream | fp32 stem output] included."""
+    import ctypes as C
+    from diff_sampler_amd import _lib, ops
+    lib = _lib.load()
+    dev = 'cuda'
+    B, H, c0, c1 = 4, 16, 128, 64
+    g = torch.Generator().manual_seed(20 + resample)
+    x0 = torch.randn(B * H * H, c0, generator=g).to(dev).to(torch.float16)
+    x1h = torch.randn(B * H * H, c1, generator=g).to(dev).to(torch.float16)
+    gm, bt = (1 + 0.1 * torch.randn(c0 + c1, generator=g)).to(dev), (0.1 * torch.randn(c0 + c1, generator=g)).to(dev)
+    OH = {0: H, 1: H // 2, 2: H * 2}[resample]             # DS_RESAMPLE_NONE / DOWN / UP
+    for mask, x1 in ((3, x1h), (1, x1h.float())):          # both fp16; fp16 stream + fp32 second source
+        res = []
+        for use16 in (True, False):
+            a0 = x0 if use16 else x0.float()
+            a1 = x1 if use16 else x1.float()
+            mean, rstd = torch.empty(B * 32, device=dev), torch.empty(B * 32, device=dev)
+            st = ops._norm_args(a0, c0, c0, B, H, H, x1=a1, c1=c1, ld1=c1, groups=32, eps=1e-5, mean=mean, rstd=rstd)
+            st.in_f16 = mask if use16 else 0
+            assert lib.ds_gn_stats(C.byref(st), _lib.stream_ptr()) == 0
+            out = torch.empty(B * OH * OH, c0 + c1, device=dev)
+            ap = ops._norm_args(a0, c0, c0, B, H, H, x1=a1, c1=c1, ld1=c1, groups=32, eps=1e-5, mean=mean, rstd=rstd, gamma=gm, beta=bt, act=1,
+                                resample=resample, out=out, out_ld=c0 + c1)
+            ap.in_f16 = mask if use16 else 0
+            assert lib.ds_norm_act(C.byref(ap), _lib.stream_ptr()) == 0
+            torch.cuda.synchronize()
+            res.append((mean.clone(), rstd.clone(), out))
+        for t16, t32 in zip(*res):
+            assert torch.equal(t16, t32)
+    bad = ops._norm_args(x0, c0, c0, B, H, H, groups=32, mean=mean, rstd=rstd)
+    bad.in_f16 = 2                                          # bit 1 without a second source
+    assert lib.ds_gn_stats(C.byref(bad), _lib.stream_ptr()) != 0
+
+
+def test_layernorm_rows_on_fp16_rows():
+    """ds_layernorm_rows_f16io (fp16 in, fp16 out: LayerNorm of a tensor of the fp16 residual stream) == ds_layernorm_rows_f16 on the widened
+    rows, for every lanes-per-row variant of the kernel (320 / 640 / 1280 columns) and a ragged row count."""
+    from diff_sampler_amd import _lib
+    lib = _lib.load()
+    dev = 'cuda'
+    for rows, cols in ((1001, 320), (515, 640), (130, 1280), (7, 2048)):
+        g = torch.Generator().manual_seed(cols)
+        x16 = (3 * torch.randn(rows, cols, generator=g)).to(dev).to(torch.float16)
+        gm, bt = (1 + 0.1 * torch.randn(cols, generator=g)).to(dev), (0.1 * torch.randn(cols, generator=g)).to(dev)
+        ya, yb = torch.empty(rows, cols, dtype=torch.float16, device=dev), torch.empty(rows, cols, dtype=torch.float16, device=dev)
+        x32 = x16.float()
+        assert lib.ds_layernorm_rows_f16io(x16.data_ptr(), cols, gm.data_ptr(), bt.data_ptr(), 1e-5, ya.data_ptr(), cols, rows, cols, _lib.stream_ptr()) == 0
+        assert lib.ds_layernorm_rows_f16(x32.data_ptr(), cols, gm.data_ptr(), bt.data_ptr(), 1e-5, yb.data_ptr(), cols, rows, cols, _lib.stream_ptr()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(ya, yb)
+        ref = F.layer_norm(x32.double(), (cols,), gm.double(), bt.double(), 1e-5).float()
+        assert _rel(ya.float(), ref.to(torch.float16).float()) < 1.5e-3
+    assert lib.ds_layernorm_rows_f16io(x16.data_ptr(), 2046, gm.data_ptr(), bt.data_ptr(), 1e-5, ya.data_ptr(), 2046, 7, 2046, _lib.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize('kind,nw', [('gemm', 4), ('gemm', 8), ('conv', 0)])
+def test_f16_activation_kernels_with_fp16_residual_and_output_rows(kind, nw):
+    """The epilogue of the fp16 residual stream (ds_conv_args.res_f16 + out_f16, csrc/igemm_common.h:epilogue_pipe): the residual operand
+    is an fp16 tensor, the sum is formed in fp32 and stored as fp16 rows; every column-tile width, both wave counts of the GEMM, ragged
+    rows; the GroupNorm column sums are those of the stored (rounded) tensor.  Reference: fp16 operands, fp64 sums, on the CPU."""
+    import ctypes as C
+    from diff_sampler_amd import _lib, ops
+    lib = _lib.load()
+    dev = 'cuda'
+    shapes = [(1000, 320, 320), (640, 640, 192), (256, 64, 448)] if kind == 'gemm' else [(4, 16, 192, 192), (2, 32, 128, 320), (8, 8, 256, 64)]
+    for shp in shapes:
+        for nb in (0, 1, 2, 3, 4):
+            g = torch.Generator().manual_seed(sum(shp) + nb)
+            if kind == 'gemm':
+                rows, k, cout = shp
+                n, h, taps, cin = rows, 1, 1, k
+                x = torch.randn(rows, k, generator=g).to(torch.float16)
+                wt = torch.randn(cout, k, generator=g) / k ** 0.5
+                wp = ops.pack_linear_weight_f16(ops.pack_linear_weight(wt.to(dev)))
+                y = x.double() @ wt.to(torch.float16).double().t()
+            else:
+                n, h, cin, cout = shp
+                rows, taps = n * h * h, 9
+                if not lib.ds_conv_f16dma_supported(n, h, h, cin, 0, cout):
+                    continue
+                x = torch.randn(rows, cin, generator=g).to(torch.float16)
+                wt = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+                wp = ops.pack_conv_weight_f16(wt.to(dev))
+                y = F.conv2d(x.double().reshape(n, h, h, cin).permute(0, 3, 1, 2), wt.to(torch.float16).double(), padding=1)
+                y = y.permute(0, 2, 3, 1).reshape(rows, cout)
+            bias = torch.randn(cout, generator=g)
+            res16 = torch.randn(rows, cout, generator=g).to(torch.float16)
+            ref = ((y + bias.double() + res16.double()) * 0.7071).float().to(torch.float16)
+            out = torch.full((rows, cout), float('nan'), dtype=torch.float16, device=dev)
+            stats = torch.full((-(-rows // 64) * 2 * cout,), float('nan'), device=dev)
+            xd, bd_, rd = x.to(dev), bias.to(dev), res16.to(dev)
+            a = _lib.ConvArgs(xd.data_ptr(), None, cin, 0, cin, 0, n, h, h, taps, wp.data_ptr(), cout, bd_.data_ptr(), None, 0, 1, rd.data_ptr(), cout,
+                              0.7071, 0, out.data_ptr(), cout)
+            a.wgt_f16, a.in_f16, a.out_f16, a.res_f16, a.stats_out = 1, 1, 1, 1, stats.data_ptr()
+            p_nb, p_nw = lib.ds_debug_f16dma_nb(nb), lib.ds_debug_f16dma_nw(nw)
+            try:
+                rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
+                torch.cuda.synchronize()
+            finally:
+                lib.ds_debug_f16dma_nb(p_nb); lib.ds_debug_f16dma_nw(p_nw)
+            assert rc == 0, (shp, nb, lib.ds_error_string(rc))
+            got = out.float().cpu()
+            assert torch.isfinite(got).all(), (shp, nb)
+            assert _rel(got, ref.float()) < 1.5e-3, (shp, nb)                    # one fp16 ulp where the fp32 sum straddles a rounding boundary
+            if rows % 64 == 0:
+                st = stats.cpu().reshape(-1, 2, cout)
+                assert _rel(st[:, 0], got.reshape(-1, 64, cout).sum(1)) < 1e-5 and _rel(st[:, 1], (got * got).reshape(-1, 64, cout).sum(1)) < 1e-5
+    # misuse fails loudly: fp16 residual rows need the fp16-activation kernels and 16-byte rows
+    a.in_f16 = 0
+    assert lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr()) != 0
+    a.in_f16, a.res_ld = 1, cout + 4
+    assert lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr()) != 0
