@@ -76,7 +76,8 @@ def parse(argv=None):
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=None, help='images per GPU per sampler call (default: 256 cifar10, 128 ffhq, 64 imagenet64, 16 sd15 -- the batches the kept lines in profiles/ are quoted on)')
     ap.add_argument('--nfe', type=int, default=10)
-    ap.add_argument('--solver', default='dpmpp', choices=['dpmpp', 'euler', 'ipndm', 'heun'])
+    ap.add_argument('--solver', default=None, choices=['dpmpp', 'euler', 'ipndm', 'heun'],
+                    help='default: dpmpp (the headline, BASELINE config 2; also ffhq, sd15); ipndm for imagenet64 (BASELINE config 3: iPNDM order 4)')
     ap.add_argument('--config', default='cifar10')
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'fp16', 'fp16x3'],
                     help="fp16 = the reference's use_fp16 / autocast mode (configs 3 and 5): fp16 operands in the 3x3 convolutions, 1x1 / Linear layers and attention, fp16 activation storage, fp32 accumulation; fp16x3 = fp32 EMULATED in the 3x3 convolutions by split fp16 hi/lo operands (3 MFMA products, fp32 tolerances)")
@@ -89,6 +90,8 @@ def parse(argv=None):
     ap.add_argument('--no-batch-sweep', action='store_true', help='skip the extra throughput measurement at 1024 images per call')
     ap.add_argument('--stub', action='store_true', help=argparse.SUPPRESS)   # launcher self-test: gloo ranks on CPU, no kernels
     args = ap.parse_args(argv)
+    if args.solver is None:
+        args.solver = 'ipndm' if args.config == 'imagenet64' else 'dpmpp'
     if args.batch is None:
         args.batch = {'ffhq': 128, 'imagenet64': 64, 'sd15': 16}.get(args.config, 256)
     return args
