@@ -233,7 +233,11 @@ class UNetEngine:
         P.stream16 = stream16
         # a block whose attention runs on the fp32 kernels keeps fp32 outputs; every consumer reads a tensor in the dtype it has
         blk16 = lambda b: stream16 and (not b.heads or attn16_ok(b))
-        as16 = lambda t: t.view(torch.float16)[:t.numel()]          # decoder ping-pong storage viewed as fp16 rows
+        P.f16_views = []          # (address, bytes) of fp32-typed storage that some launches use as fp16 rows (tests/test_plan_cpu.py's dtype lint)
+
+        def as16(t):              # decoder ping-pong storage viewed as fp16 rows
+            P.f16_views.append((t.data_ptr(), t.numel() * 2))
+            return t.view(torch.float16)[:t.numel()]
 
         # ---- stem ---------------------------------------------------------------------------------------------
         x_cur = None          # (tensor, channels)

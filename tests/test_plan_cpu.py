@@ -93,3 +93,90 @@ def test_headline_plan_kernel_routing_at_the_benchmark_batch():
             if a.taps == 9 and (a.stride or 1) == 1 and a.cout >= 128:
                 ids[lib.ds_conv_kernel_id(C.byref(a))] += 1
     assert ids[1284] >= 30 and ids[0] == 0 and ids[2565] == 0, ids
+
+
+def _dtype_lint(P, lib):
+    """Every pointer a launch reads or writes as activation rows must point into a plan-owned tensor of the dtype the launch's flags
+    claim (ds_conv_args.in_f16 / out_f16 / res_f16, ds_norm_args.in_f16 bits / out_f16, the LayerNorm entry point, ds_attn_args.out_f16):
+    a mismatch would not crash, it would silently reinterpret fp16 bytes as fp32.  Returns the number of (pointer, flag) pairs checked."""
+    import torch
+    spans = []
+    for t in list(P.keep) + [v for v in P.bufs.values() if isinstance(v, torch.Tensor)]:
+        spans.append((t.data_ptr(), t.data_ptr() + t.numel() * t.element_size(), t.dtype))
+    wild = [(a, a + n) for a, n in getattr(P, 'f16_views', [])]
+
+    def dtype_at(ptr):
+        if any(a <= ptr < b for a, b in wild):
+            return None                                   # fp32-sized ping-pong storage that blocks use in either dtype
+        hits = {d for a, b, d in spans if a <= ptr < b}
+        assert len(hits) == 1, (hex(ptr), hits)
+        return hits.pop()
+
+    n = 0
+
+    def check(ptr, is16, what):
+        nonlocal n
+        if not ptr:
+            return
+        d = dtype_at(int(ptr))
+        if d is not None:
+            assert d == (torch.float16 if is16 else torch.float32), what
+            n += 1
+
+    for op in P.ops:
+        if op.fn is lib.ds_conv2d_nhwc:
+            a = op.keep[0]
+            check(a.x0, a.in_f16, op.name + '.x0'); check(a.x1, False, op.name + '.x1'); check(a.e0, a.in_f16 and a.ec0, op.name + '.e0')
+            check(a.res, a.res_f16, op.name + '.res'); check(a.out, a.out_f16, op.name + '.out')
+            assert not (a.res_f16 or a.out_f16) or a.in_f16, op.name
+        elif op.fn in (lib.ds_norm_act, lib.ds_gn_stats):
+            a = op.keep[0]
+            check(a.x0, a.in_f16 & 1, op.name + '.x0'); check(a.x1, a.in_f16 & 2, op.name + '.x1')
+            if op.fn is lib.ds_norm_act:
+                check(a.out, a.out_f16, op.name + '.out'); check(a.raw_out, True, op.name + '.raw_out')
+        elif op.fn in (lib.ds_layernorm_rows, lib.ds_layernorm_rows_f16, lib.ds_layernorm_rows_f16io):
+            check(op.args[0].value, op.fn is lib.ds_layernorm_rows_f16io, op.name + '.x')
+            check(op.args[5].value, op.fn is not lib.ds_layernorm_rows, op.name + '.y')
+        elif op.fn in (lib.ds_attention, lib.ds_attention_f16):
+            a = op.keep[0]
+            check(a.q, False, op.name + '.q'); check(a.out, a.out_f16, op.name + '.out')
+    return n
+
+
+@pytest.mark.parametrize('name,B,kw', [('cifar10', 4, dict(use_fp16=True)), ('imagenet64', 4, dict(use_fp16=True)), ('imagenet64', 2, dict(use_fp16=True)),
+                                       ('ffhq', 8, dict(use_fp16=True)), ('cifar10', 8, dict()), ('cifar10', 8, dict(split_fp16=True))])
+def test_plan_flags_match_the_dtypes_of_the_tensors_they_point_to(name, B, kw):
+    """The fp16 residual stream is dtype-driven (plan.Builder sets in_f16 / res_f16 / out_f16 from the tensors it is handed): lint the
+    whole plan, including the mixed cases -- the fp32 stem output concatenated with an fp16 stream tensor, CIFAR-10's fp32 attention
+    blocks inside an fp16 stream, batches whose 8x8 layers have no fp16-activation kernel (no fp16 stream then)."""
+    lib = _lib.load()
+    spec, eng = _engine(name, **kw)
+    P = eng.plan(B, B)
+    n = _dtype_lint(P, lib)
+    assert n > 100
+    n16 = sum(1 for op in P.ops if op.fn is lib.ds_conv2d_nhwc and op.keep[0].res_f16)
+    if kw.get('use_fp16') and P.stream16:
+        assert n16 >= 5, n16
+    else:
+        assert n16 == 0
+
+
+@pytest.mark.parametrize('N', [2, 4])
+def test_ldm_plan_flags_match_the_dtypes_of_the_tensors_they_point_to(N):
+    """The same lint on the latent-diffusion plan (SD-1.5 layer structure at reduced width): the fp16 stream through ResBlocks,
+    transformer blocks and upsampling, widened copies in front of the strided convolutions (and, at N = 2, in front of the 8x8 layers)."""
+    import diff_sampler_amd.ldm_arch as la
+    from diff_sampler_amd.ldm_engine import LDMUNetEngine
+    lib = _lib.load()
+    kw = dict(la.NAMED_LDM_CONFIGS['sd15'])
+    spec = la.ldm_unet_spec(**kw)
+    eng = LDMUNetEngine(spec, la.init_ldm_params(spec, seed=0), device='cpu', use_fp16=True)
+    P = eng.plan(N, 1, 77)
+    assert P.stream16
+    n = _dtype_lint(P, lib)
+    assert n > 300
+    widen = [op.name for op in P.ops if op.name.endswith('.widen')]
+    assert len(widen) >= 3                                       # the three Downsample convolutions
+    assert (len(widen) > 3) == (N % 4 != 0)                      # 8x8 layers of a batch that is not a multiple of four
+    for part in (P.ctx,):
+        assert all(op.name.endswith('.attn2.kv') for op in part.ops)
