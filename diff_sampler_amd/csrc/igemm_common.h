@@ -287,11 +287,25 @@ typedef _Float16 epi_h8 __attribute__((ext_vector_type(8)));
 typedef unsigned epi_u4 __attribute__((ext_vector_type(4)));
 // The requested rows of one group, RAW: an fp16 row segment (8 halfs) in raw[pass][0], an fp32 one (8 floats) in raw[pass][0 .. 1].
 struct EpiRows { epi_u4 raw[4][2]; f32x4 cvu[2]; };
+// fp16 residual rows of one group (16 VGPRs): small enough to request the rows of ALL groups of the wave tile when the epilogue starts --
+// one memory latency for the tile instead of one per group (the request one group ahead is ~1 us ahead; HBM under load answers in 2 - 4).
+struct EpiRes16 { epi_u4 r[4]; };
 
-template <int W, bool NTS>
+template <int W>
+__device__ __forceinline__ void epi_request_res16(const KParams& p, int rbase, int col, int lane, EpiRes16& e) {
+    using G = EpiGeo<W>;
+#pragma unroll
+    for (int pass = 0; pass < G::NP; ++pass) {
+        const int row = min(rbase + pass * G::RPP + lane / G::LPR, p.M - 1);
+        e.r[pass] = __builtin_nontemporal_load(reinterpret_cast<const epi_u4*>(reinterpret_cast<const _Float16*>(p.res) + (size_t)row * p.res_ld + col));
+    }
+}
+
+// R16: the residual rows are fp16 and were requested up front (EpiRes16): only the per-image bias row is fetched here
+template <int W, bool NTS, bool R16 = false>
 __device__ __forceinline__ void epi_request(const KParams& p, int rbase, int col, int lane, EpiRows& e) {
     using G = EpiGeo<W>;
-    if (p.res) {
+    if (!R16 && p.res) {
 #pragma unroll
         for (int pass = 0; pass < G::NP; ++pass) {
             const int row = min(rbase + pass * G::RPP + lane / G::LPR, p.M - 1);
@@ -324,9 +338,9 @@ __device__ __forceinline__ void epi_stage(const f32x16& a0, const f32x16& a1, fl
 }
 
 // bn0 = first column of the block; cb: the lane's eight column biases; st: column sums, sums of squares
-template <int MODE, int W, bool NTS>
-__device__ __forceinline__ void epi_process(const KParams& p, const float* stage, int rbase, const EpiRows& e, int lane, int bn0, float* o_base,
-                                            const f32x4 (&cb)[2], f32x4 (&st_s)[2], f32x4 (&st_q)[2]) {
+template <int MODE, int W, bool NTS, bool R16 = false>
+__device__ __forceinline__ void epi_process(const KParams& p, const float* stage, int rbase, const EpiRows& e, const EpiRes16& r16, int lane, int bn0,
+                                            float* o_base, const f32x4 (&cb)[2], f32x4 (&st_s)[2], f32x4 (&st_q)[2]) {
     using G = EpiGeo<W>;
     const int c8 = (lane & (G::LPR - 1)) * 8, col = bn0 + c8;
     const bool cb_uniform = p.cbias && (p.cbias_bcast || p.HW % 32 == 0);
@@ -346,9 +360,9 @@ __device__ __forceinline__ void epi_process(const KParams& p, const float* stage
             if (p.rowbias) v[h] += p.rowbias[row];
             if (cb_uniform) v[h] += e.cvu[h];
             else if (p.cbias) v[h] += *reinterpret_cast<const f32x4*>(p.cbias + (size_t)(row / p.HW) * p.cbias_ld + col + 4 * h);
-            if (p.res) {
-                if (p.res_f16) {
-                    const epi_h8 hr = __builtin_bit_cast(epi_h8, e.raw[pass][0]);
+            if (R16 || p.res) {
+                if (R16 || p.res_f16) {
+                    const epi_h8 hr = __builtin_bit_cast(epi_h8, R16 ? r16.r[pass] : e.raw[pass][0]);
                     v[h] += f32x4{(float)hr[4 * h], (float)hr[4 * h + 1], (float)hr[4 * h + 2], (float)hr[4 * h + 3]};
                 } else v[h] += __builtin_bit_cast(f32x4, e.raw[pass][h]);
             }
@@ -415,19 +429,28 @@ __device__ __forceinline__ void epi_stats(const KParams& p, int lane, int wm0, i
 // entry; the rows of the second group are requested once the first is staged (its accumulators are dead by then: the two row sets
 // never coexist with the whole accumulator tile), and -- if NEXT_W != 0 -- those of the next block's first group once the second is,
 // so every request is issued BEFORE the stores of the group in front of it.  On return `cur` holds the next block's first group.
-template <int MODE, bool NTS, int W, int NEXT_W>
+// R16: fp16 residual rows requested up front (r0 / r1 = the block's two groups); the requests here then fetch the bias rows only.
+// R16: fp16 residual rows held raw in EpiRes16 (r0 / r1 = this block's two groups, requested by the caller); the rows of the NEXT block's
+// groups (n0 / n1) are requested here as soon as a group's accumulators are staged and dead -- two groups ahead of their use, and with
+// the first block's rows requested before anything else every residual row of the tile is in flight early, without ever holding more
+// than three groups' rows next to the live accumulators.  The EpiRows requests then fetch the per-image bias rows only.
+template <int MODE, bool NTS, int W, int NEXT_W, bool R16>
 __device__ __forceinline__ void epi_block(const KParams& p, const f32x16 (&acc)[2][2], float* stage, int lane, int wm0, int bn0, int next_col,
-                                          float* o_base, EpiRows& cur, EpiRows& oth) {
+                                          float* o_base, EpiRows& cur, EpiRows& oth, const EpiRes16& r0, const EpiRes16& r1, EpiRes16& n0,
+                                          EpiRes16& n1) {
+    constexpr int NW_ = NEXT_W ? NEXT_W : 32;
     const int col = bn0 + (lane & (W / 8 - 1)) * 8;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 cb[2] = {zero, zero}, st_s[2] = {zero, zero}, st_q[2] = {zero, zero};
     if (p.colbias) { const f32x4* c = reinterpret_cast<const f32x4*>(p.colbias + col); cb[0] = c[0]; cb[1] = c[1]; }
     epi_stage<W>(acc[0][0], acc[0][1], stage, lane);
-    epi_request<W, NTS>(p, wm0 + 32, col, lane, oth);
-    epi_process<MODE, W, NTS>(p, stage, wm0, cur, lane, bn0, o_base, cb, st_s, st_q);
+    if constexpr (R16 && NEXT_W != 0) epi_request_res16<NW_>(p, wm0, next_col, lane, n0);
+    epi_request<W, NTS, R16>(p, wm0 + 32, col, lane, oth);
+    epi_process<MODE, W, NTS, R16>(p, stage, wm0, cur, r0, lane, bn0, o_base, cb, st_s, st_q);
     epi_stage<W>(acc[1][0], acc[1][1], stage, lane);
-    if constexpr (NEXT_W != 0) epi_request<(NEXT_W ? NEXT_W : 32), NTS>(p, wm0, next_col, lane, cur);
-    epi_process<MODE, W, NTS>(p, stage, wm0 + 32, oth, lane, bn0, o_base, cb, st_s, st_q);
+    if constexpr (R16 && NEXT_W != 0) epi_request_res16<NW_>(p, wm0 + 32, next_col, lane, n1);
+    if constexpr (NEXT_W != 0) epi_request<NW_, NTS, R16>(p, wm0, next_col, lane, cur);
+    epi_process<MODE, W, NTS, R16>(p, stage, wm0 + 32, oth, r1, lane, bn0, o_base, cb, st_s, st_q);
     epi_stats<W>(p, lane, wm0, col, st_s, st_q);
 }
 
@@ -436,11 +459,22 @@ template <int MODE, bool NTS, int WA, int WB>
 __device__ __forceinline__ void epilogue_pipe(const KParams& p, const f32x16 (&accA)[2][2], const f32x16 (&accB)[2][2], float* stage, int lane,
                                               int wm0, int wn0, float* o_base) {
     constexpr int WBB = WB ? WB : 32;
+    const int colA = wn0 + (lane & (WA / 8 - 1)) * 8;
     const int colB = wn0 + WA + (lane & (WBB / 8 - 1)) * 8;
     EpiRows e0, e1;
-    epi_request<WA, NTS>(p, wm0, wn0 + (lane & (WA / 8 - 1)) * 8, lane, e0);
-    epi_block<MODE, NTS, WA, WB>(p, accA, stage, lane, wm0, wn0, colB, o_base, e0, e1);
-    if constexpr (WB != 0) epi_block<MODE, NTS, WBB, 0>(p, accB, stage, lane, wm0, wn0 + WA, 0, o_base, e0, e1);
+    if (p.res && p.res_f16) {                                     // the fp16 residual stream: raw rows, requested early (see epi_block)
+        EpiRes16 a0, a1, b0, b1;
+        epi_request_res16<WA>(p, wm0, colA, lane, a0);
+        epi_request_res16<WA>(p, wm0 + 32, colA, lane, a1);
+        epi_request<WA, NTS, true>(p, wm0, colA, lane, e0);
+        epi_block<MODE, NTS, WA, WB, true>(p, accA, stage, lane, wm0, wn0, colB, o_base, e0, e1, a0, a1, b0, b1);
+        if constexpr (WB != 0) epi_block<MODE, NTS, WBB, 0, true>(p, accB, stage, lane, wm0, wn0 + WA, 0, o_base, e0, e1, b0, b1, a0, a1);
+        return;
+    }
+    EpiRes16 none;
+    epi_request<WA, NTS>(p, wm0, colA, lane, e0);
+    epi_block<MODE, NTS, WA, WB, false>(p, accA, stage, lane, wm0, wn0, colB, o_base, e0, e1, none, none, none, none);
+    if constexpr (WB != 0) epi_block<MODE, NTS, WBB, 0, false>(p, accB, stage, lane, wm0, wn0 + WA, 0, o_base, e0, e1, none, none, none, none);
 }
 
 // XCD-aware decode of a 1-D workgroup id into (m tile, n tile): the dispatcher places workgroup b on XCD b % 8, so
