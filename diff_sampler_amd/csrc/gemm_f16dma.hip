@@ -150,6 +150,7 @@ int launch_nb(KParams p, int n_begin, int ntiles, hipStream_t stream) {
     p.ntiles = ntiles;
     p.n_begin = n_begin;
     p.splits = 1;
+    p.coef_lds = g_f16dma_ablate;
     int smem = (int)gemm16_smem<NB, NW>();
     const int epi = NW * 32 * EPI_LD * (int)sizeof(float);
     if (smem < epi) smem = epi;

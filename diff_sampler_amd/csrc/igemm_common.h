@@ -462,7 +462,7 @@ __device__ __forceinline__ void epilogue_pipe(const KParams& p, const f32x16 (&a
     const int colA = wn0 + (lane & (WA / 8 - 1)) * 8;
     const int colB = wn0 + WA + (lane & (WBB / 8 - 1)) * 8;
     EpiRows e0, e1;
-    if (p.res && p.res_f16) {                                     // the fp16 residual stream: raw rows, requested early (see epi_block)
+    if (p.res && p.res_f16 && !(p.coef_lds & 1024)) {             // the fp16 residual stream: raw rows, requested early (see epi_block); bit 10 of ds_debug_f16dma_ablate = A/B switch
         EpiRes16 a0, a1, b0, b1;
         epi_request_res16<WA>(p, wm0, colA, lane, a0);
         epi_request_res16<WA>(p, wm0 + 32, colA, lane, a1);
