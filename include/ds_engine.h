@@ -154,9 +154,10 @@ int ds_gemm_f16dma_supported(long long rows, int k, int cout);
 /* benchmarks / tests: force the column-tile width (64 * nb columns, nb = 1..4; 0 = cost model) of the fp16-activation kernel; returns the previous value */
 int ds_debug_f16dma_nb(int nb);
 int ds_debug_f16dma_nw(int nw);   /* benchmarks / tests: 4 / 8 forces the 128- / 256-row variant of the fp16-activation GEMM, 0 = by K (returns the old value) */
-/* benchmarks only (results are WRONG when set): timing ablations of the fp16-activation kernel -- bit 0: no weight DMA after the
- * prologue, bit 1: no halo DMA after the first slab, bit 2: no epilogue, bit 4: no per-tap barrier, bit 5: no LDS fragment reads;
- * returns the previous mask */
+/* benchmarks only (results are WRONG when bits 0 - 5 are set): timing ablations of the fp16-activation convolution -- bit 0: no weight
+ * DMA after the prologue, bit 1: no halo DMA after the first slab, bit 2: no epilogue, bit 4: no per-tap barrier, bit 5: no LDS fragment
+ * reads; bit 10 (convolution and GEMM; results stay correct): fp16 residual rows requested one group ahead instead of early -- the A/B
+ * switch of profiles/r3_gemm_f16dma_epilogue.txt; returns the previous mask */
 int ds_debug_f16dma_ablate(int mask);
 
 /* 1x1 convolution / Linear with fp16 operands (wgt_f16 == 1 and taps == 1: `wgt` = [cout_pad][K] halfs in plain K order; the fp32
