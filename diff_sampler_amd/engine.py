@@ -37,10 +37,11 @@ class UNetEngine:
         products per multiplication, fp32 accumulation (ds_conv_args.wgt_f16 == 2); 2**-22 relative per product, i.e. inside every
         fp32 tolerance of this engine, at 16/3 of the fp32 matrix rate.  Not a reduced-precision mode: it is tested against the same
         fp32 goldens and tolerances as the exact fp32 path.
-        use_fp16: the reference's reduced-precision mode (networks_edm.py:486).  Stage 1 of it here: every 3x3 convolution the
-        fp16-operand kernel supports (ds_conv_f16_supported: 8x8 ... 64x64 images, 64-channel multiples) multiplies fp16-rounded
-        activations and weights on the fp16 matrix pipe with fp32 accumulation; activations in HBM, GroupNorm, SiLU, softmax, the
-        1x1 / Linear layers and the embedding path stay fp32 (the reference additionally rounds every activation tensor to fp16)."""
+        use_fp16: the reference's reduced-precision mode (networks_edm.py:486: the U-Net body on x.to(float16)).  3x3 convolutions,
+        1x1 / Linear layers over image rows and attention multiply fp16 operands on the fp16 matrix pipe with fp32 accumulation, and the
+        activations between layers -- the activated GroupNorm outputs, conv0 outputs, the residual stream and the skip stack -- are
+        stored in fp16 where the fp16-activation kernels take the geometry (plan(): `stream16`); GroupNorm / SiLU / softmax arithmetic,
+        q / k / v and the embedding path are fp32.  DESIGN.md section 2 states the bounds, tests/test_hip_fp16.py enforces them."""
         self.spec = spec
         self.device = torch.device(device)
         self.use_fp16 = bool(use_fp16)
@@ -274,7 +275,7 @@ class UNetEngine:
             cb = dict(cbias=aff[:, aoff:], cbias_ld=self.aff_total, cbias_rows=Bs) if not b.adaptive_scale else {}
             # fp16 mode, the reference's storage (networks_edm.py:486 runs the body on x.to(float16)): norm + SiLU (+ resample, + the
             # decoder's concatenation) are ONE pass that writes the activated tensor in fp16, and the convolution is a pure matrix
-            # kernel on fp16 activations (csrc/conv3x3_f16dma.hip).  Outputs, norms and the residual stream stay fp32.
+            # kernel on fp16 activations (csrc/conv3x3_f16dma.hip).  Norm arithmetic is fp32; the block output is fp16 under `stream16`.
             dma16 = (w16_0 is not None and w16_1 is not None and self.conv_mode == 1
                      and lib.ds_conv_f16dma_supported(n, Ho, Ho, cin, 0, cout)
                      and lib.ds_conv_f16dma_supported(n, Ho, Ho, cout, cin if b.skip_conv else 0, cout))

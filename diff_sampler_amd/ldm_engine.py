@@ -32,9 +32,11 @@ from .plan import Builder, Plan, ptr
 
 class LDMUNetEngine:
     def __init__(self, spec: ldm_arch.LDMUNetSpec, params: Dict[str, torch.Tensor], device='cuda', use_fp16=False):
-        """use_fp16: the reference samples this U-Net under ``autocast("cuda")`` (diff-solvers-main/sample.py:296).  Stage 1 of that
-        mode here: the 3x3 convolutions of the ResBlocks / Upsample layers multiply fp16-rounded operands on the fp16 matrix pipe
-        with fp32 accumulation where the fp16-operand kernel takes the geometry; everything else stays fp32."""
+        """use_fp16: the reference samples this U-Net under ``autocast("cuda")`` (diff-solvers-main/sample.py:296): convolutions and
+        Linear layers multiply fp16 operands (fp32 accumulation here) and emit fp16 tensors.  Here: ResBlock / Upsample convolutions, every
+        projection of the transformer blocks and attention on the fp16 kernels, and the activations between layers -- residual stream,
+        skip stack, the transformer's x -- stored as fp16 rows wherever a layer runs on the fp16-activation kernels (plan(): per layer);
+        norm / softmax arithmetic, q / k / v, the context projections and the time embedding are fp32."""
         self.spec = spec
         self.device = torch.device(device)
         self.use_fp16 = bool(use_fp16)
@@ -236,7 +238,7 @@ class LDMUNetEngine:
             L = ctx_len
             # fp16 mode: tensors that are only the operand of the next projection -- the GroupNorm output, the three LayerNorm outputs,
             # both attention outputs, the GEGLU product -- are stored as fp16 rows and streamed by the fp16-activation GEMM
-            # (csrc/gemm_f16dma.hip); the residual stream t0 .. t3 and q / k / v stay fp32
+            # (csrc/gemm_f16dma.hip); with the fp16 stream (`ts`) so is the transformer's residual stream t0 .. t3; q / k / v stay fp32
             h16 = bool(bd.conv_mode == 1 and lib.ds_attention_f16_supported(d) and lib.ds_gemm_f16dma_supported(M, c, c)
                        and lib.ds_gemm_f16dma_supported(M, c, 3 * c) and lib.ds_gemm_f16dma_supported(M, c, 8 * c)
                        and lib.ds_gemm_f16dma_supported(M, 4 * c, c))
