@@ -50,7 +50,7 @@ class AttnArgs(C.Structure):
     _fields_ = [('q', vp), ('k', vp), ('v', vp), ('out', vp), ('ldq', C.c_int), ('ldk', C.c_int), ('ldv', C.c_int),
                 ('ldo', C.c_int), ('q_bs', C.c_longlong), ('k_bs', C.c_longlong), ('v_bs', C.c_longlong),
                 ('o_bs', C.c_longlong), ('batch', C.c_int), ('heads', C.c_int), ('sq', C.c_int), ('skv', C.c_int),
-                ('d', C.c_int), ('scale', C.c_float), ('out_f16', C.c_int)]
+                ('d', C.c_int), ('scale', C.c_float), ('out_f16', C.c_int), ('in_f16', C.c_int)]
 
 
 class GnFinalizeArgs(C.Structure):

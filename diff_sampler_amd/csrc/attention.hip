@@ -229,6 +229,7 @@ extern "C" int ds_attention_supported(int d) {
 
 extern "C" int ds_attention(const ds_attn_args* a, void* stream) {
     (void)hipGetLastError();
+    if (a && (a->out_f16 || a->in_f16)) return DS_E_ARG;          // fp16 tensors: ds_attention_f16 only
     if (!a || !a->q || !a->k || !a->v || !a->out) return DS_E_ARG;
     if (a->batch <= 0 || a->heads <= 0 || a->sq <= 0 || a->skv <= 0 || a->batch > 65535 || a->heads > 65535) return DS_E_ARG;
     if ((a->ldq & 3) || (a->ldk & 3) || (a->ldv & 3) || (a->ldo & 3) || (a->q_bs & 3) || (a->k_bs & 3) || (a->v_bs & 3) || (a->o_bs & 3))

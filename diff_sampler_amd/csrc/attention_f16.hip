@@ -2,8 +2,10 @@
 // mode: networks_edm.py:98-110 (AttentionOp: fp16 q, k multiplied with fp32 accumulation, fp32 softmax, weights cast back to fp16,
 // fp16 w v product) and ldm/modules/attention.py:168-194 under torch.autocast (diff-solvers-main/sample.py:296).
 //
-// q / k / v / out stay fp32 in HBM (the engine's activation format); operands are rounded to fp16 (RNE) while they are staged, the
-// scores, the softmax statistics and both accumulators are fp32.  Same transposed online-softmax formulation as attention.hip
+// q / k / v are fp32 tensors rounded to fp16 (RNE) while they are staged, or -- ds_attn_args.in_f16, the reference's own storage: its
+// qkv projection emits fp16 -- fp16 tensors staged as they are (bit 0: q, bit 1: k and v); the scores, the softmax statistics and both
+// accumulators are fp32.  With fp32 q the factor scale * log2(e) is folded into q before it is rounded; with fp16 q (already rounded by
+// its producer) it multiplies the fp32 scores instead, inside the exponent's fma -- no second rounding of q.  Same transposed online-softmax formulation as attention.hip
 // (a query is a lane; the C/D layout of S^T is directly the B operand of the P V product), re-tiled for the 16-deep fp16 MFMA:
 //   * workgroup = 256 queries of one (image, head), 8 waves x 32 queries; K/V stream through LDS in 64-key tiles, DOUBLE buffered
 //     (one barrier per tile), register-prefetched one tile ahead;
@@ -67,21 +69,29 @@ __global__ void __launch_bounds__(512) flash_attn_f16_kernel(const ds_attn_args 
     }
 
     const float sc = a.scale * 1.4426950408889634f;
+    const bool q16 = a.in_f16 & 1, kv16 = a.in_f16 & 2;          // fp16 sources: leading dimensions / batch strides in halfs
+    const float ss = q16 ? sc : 1.0f;                             // factor applied to the fp32 scores (fp32 q carries it already)
     h8 qf[NKS];
     {
         const int qrow = min(q0 + l31, a.sq - 1);
         const float* qr = qp + (size_t)qrow * a.ldq + 8 * hb;
+        const _Float16* qr16 = reinterpret_cast<const _Float16*>(a.q) + (size_t)b * a.q_bs + h * D + (size_t)qrow * a.ldq + 8 * hb;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             u32x4 w = {0u, 0u, 0u, 0u};
             if (16 * ks + 8 * hb < D) {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(qr + 16 * ks) * sc;
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(qr + 16 * ks + 4) * sc;
-                w = u32x4{pk2(lo[0], lo[1]), pk2(lo[2], lo[3]), pk2(hi[0], hi[1]), pk2(hi[2], hi[3])};
+                if (q16) w = *reinterpret_cast<const u32x4*>(qr16 + 16 * ks);
+                else {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(qr + 16 * ks) * sc;
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(qr + 16 * ks + 4) * sc;
+                    w = u32x4{pk2(lo[0], lo[1]), pk2(lo[2], lo[3]), pk2(hi[0], hi[1]), pk2(hi[2], hi[3])};
+                }
             }
             qf[ks] = __builtin_bit_cast(h8, w);
         }
     }
+    const _Float16* kp16 = reinterpret_cast<const _Float16*>(a.k) + (size_t)b * a.k_bs + h * D;
+    const _Float16* vp16 = reinterpret_cast<const _Float16*>(a.v) + (size_t)b * a.v_bs + h * D;
     f32x16 ot[DB];
 #pragma unroll
     for (int i = 0; i < DB; ++i)
@@ -96,9 +106,12 @@ __global__ void __launch_bounds__(512) flash_attn_f16_kernel(const ds_attn_args 
             const int idx = tid + 512 * j;
             if (NLK * 512 == KCH || idx < KCH) {
                 const int row = idx / D8, c8 = idx - row * D8;
-                const float* p = kp + (size_t)min(t * KT + row, a.skv - 1) * a.ldk + c8 * 8;
-                kr[j][0] = *reinterpret_cast<const f32x4*>(p);
-                kr[j][1] = *reinterpret_cast<const f32x4*>(p + 4);
+                const size_t off = (size_t)min(t * KT + row, a.skv - 1) * a.ldk + c8 * 8;
+                if (kv16) kr[j][0] = *reinterpret_cast<const f32x4*>(kp16 + off);          // eight halfs, staged as they are
+                else {
+                    kr[j][0] = *reinterpret_cast<const f32x4*>(kp + off);
+                    kr[j][1] = *reinterpret_cast<const f32x4*>(kp + off + 4);
+                }
             }
         }
 #pragma unroll
@@ -107,8 +120,14 @@ __global__ void __launch_bounds__(512) flash_attn_f16_kernel(const ds_attn_args 
             if (NLV * 512 == VTS || idx < VTS) {
                 const int g = idx & 15, d4 = idx >> 4;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    vr[j][i] = *reinterpret_cast<const f32x4*>(vp + (size_t)min(t * KT + 4 * g + i, a.skv - 1) * a.ldv + 4 * d4);
+                for (int i = 0; i < 4; ++i) {
+                    const size_t off = (size_t)min(t * KT + 4 * g + i, a.skv - 1) * a.ldv + 4 * d4;
+                    if (kv16) {          // four halfs of one key in the first two dwords
+                        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                        const f32x2_t w = *reinterpret_cast<const f32x2_t*>(vp16 + off);
+                        vr[j][i] = f32x4{w[0], w[1], 0.f, 0.f};
+                    } else vr[j][i] = *reinterpret_cast<const f32x4*>(vp + off);
+                }
             }
         }
     };
@@ -121,7 +140,7 @@ __global__ void __launch_bounds__(512) flash_attn_f16_kernel(const ds_attn_args 
                 const int row = idx / D8, c8 = idx - row * D8;
                 const f32x4 lo = kr[j][0], hi = kr[j][1];
                 *reinterpret_cast<u32x4*>(base + (row * KLD + 8 * c8) * 2) =
-                    u32x4{pk2(lo[0], lo[1]), pk2(lo[2], lo[3]), pk2(hi[0], hi[1]), pk2(hi[2], hi[3])};
+                    kv16 ? __builtin_bit_cast(u32x4, lo) : u32x4{pk2(lo[0], lo[1]), pk2(lo[2], lo[3]), pk2(hi[0], hi[1]), pk2(hi[2], hi[3])};
             }
         }
 #pragma unroll
@@ -130,6 +149,22 @@ __global__ void __launch_bounds__(512) flash_attn_f16_kernel(const ds_attn_args 
             if (NLV * 512 == VTS || idx < VTS) {
                 const int g = idx & 15, d4 = idx >> 4;
                 const int pos = 4 * ((g & ~3) | ((g & 1) << 1) | ((g & 2) >> 1));      // key bits 2 and 3 swapped
+                if (kv16) {          // the same 4-key x 4-channel transposition on halfs: byte permutes of the keys' dwords
+                    unsigned kd[4][2];                                               // key i: dword 0 = channels (0, 1), dword 1 = channels (2, 3)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {          // (through scalars: __builtin_bit_cast of a vector ELEMENT lvalue reads element 0 with this compiler)
+                        const float f0 = vr[j][i][0], f1 = vr[j][i][1];
+                        kd[i][0] = __float_as_uint(f0); kd[i][1] = __float_as_uint(f1);
+                    }
+                    auto lo2 = [](unsigned x, unsigned y) { return (x & 0xffffu) | (y << 16); };          // low halfs of two keys
+                    auto hi2 = [](unsigned x, unsigned y) { return (x >> 16) | (y & 0xffff0000u); };      // high halfs
+                    unsigned char* vt = base + KBYTES + (4 * d4 * VLD + pos) * 2;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        *reinterpret_cast<u32x2*>(vt + (2 * e) * VLD * 2) = u32x2{lo2(kd[0][e], kd[1][e]), lo2(kd[2][e], kd[3][e])};
+                        *reinterpret_cast<u32x2*>(vt + (2 * e + 1) * VLD * 2) = u32x2{hi2(kd[0][e], kd[1][e]), hi2(kd[2][e], kd[3][e])};
+                    }
+                } else
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     *reinterpret_cast<u32x2*>(base + KBYTES + ((4 * d4 + c) * VLD + pos) * 2) =
@@ -173,7 +208,7 @@ __global__ void __launch_bounds__(512) flash_attn_f16_kernel(const ds_attn_args 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mn = fmaxf(m, mx);
+            const float mn = fmaxf(m, mx * ss);                  // running maximum in scaled units (ss > 0)
             const bool moved = mn > m;
             const float alpha = __builtin_amdgcn_exp2f(m - mn);
             m = mn;
@@ -181,7 +216,7 @@ __global__ void __launch_bounds__(512) flash_attn_f16_kernel(const ds_attn_args 
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { st[kb][r] = __builtin_amdgcn_exp2f(st[kb][r] - mn); rs += st[kb][r]; }
+                for (int r = 0; r < 16; ++r) { st[kb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], ss, -mn)); rs += st[kb][r]; }
             l = l * alpha + rs;
             if (__any(moved)) {
 #pragma unroll
@@ -271,6 +306,9 @@ extern "C" int ds_attention_f16(const ds_attn_args* a, void* stream) {
     if (a->batch <= 0 || a->heads <= 0 || a->sq <= 0 || a->skv <= 0) return DS_E_ARG;
     if ((a->ldq & 3) || (a->ldk & 3) || (a->ldv & 3) || (a->ldo & 3) || (a->q_bs & 3) || (a->k_bs & 3) || (a->v_bs & 3) || (a->o_bs & 3))
         return DS_E_ALIGN;
+    if (a->in_f16 & ~3) return DS_E_ARG;
+    if ((a->in_f16 & 1) && ((a->ldq & 7) || (a->q_bs & 7))) return DS_E_ALIGN;          // fp16 rows are read in 16-byte (q, k) / 8-byte (v) pieces
+    if ((a->in_f16 & 2) && ((a->ldk & 7) || (a->k_bs & 7))) return DS_E_ALIGN;
     if (!ds_aligned16(a->q) || !ds_aligned16(a->k) || !ds_aligned16(a->v) || !ds_aligned16(a->out)) return DS_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     switch (a->d) {

@@ -176,7 +176,7 @@ class UNetEngine:
         if max_attn:
             n2 = new(B * max_attn // 2); qk = new(B * max_attn // 2 * 3); ao = new(B * max_attn // 2)
             if self.conv_mode == 1:
-                n2_16, ao_16 = bd.new16(B * max_attn // 2), bd.new16(B * max_attn // 2)
+                n2_16, ao_16, qk_16 = bd.new16(B * max_attn // 2), bd.new16(B * max_attn // 2), bd.new16(B * max_attn // 2 * 3)
         bufs.update(act=act, hbuf=hbuf, sres=sres, sproj=sproj)
         # ---- launch emitters: plan.Builder (shared with ldm_engine); thin adapters keep this file's argument names --------------
         f16_level = bd.f16_level
@@ -382,11 +382,13 @@ class UNetEngine:
                 norm('stats', out, cout, cout, n, Ho, Ho, nm + '.norm2.stats', groups=G_out, eps=b.eps)
                 norm('apply', out, cout, cout, n, Ho, Ho, nm + '.norm2', groups=G_out, eps=b.eps, gamma=w[f'{nm}.norm2.g'],
                      beta=w[f'{nm}.norm2.b'], out=n2_, out_ld=cout, out_f16=a16)
-                conv(n2_, cout, cout, n, Ho, Ho, w[f'{nm}.qkv.w'], 3 * cout, qk, 3 * cout, 1, nm + '.qkv', bias=w[f'{nm}.qkv.b'])
+                qk_ = qk_16 if a16 else qk          # fp16 mode: q | k | v are the fp16 rows the reference's qkv projection emits (networks_edm.py:171-173)
+                conv(n2_, cout, cout, n, Ho, Ho, w[f'{nm}.qkv.w'], 3 * cout, qk_, 3 * cout, 1, nm + '.qkv', bias=w[f'{nm}.qkv.b'])
                 # softmax(Q K^T / sqrt(ch)) V per (image, head), scores kept on chip (networks_edm.py:171-176)
-                at = AttnArgs(_ptr(qk), _ptr(qk[cout:]), _ptr(qk[2 * cout:]), _ptr(ao_), 3 * cout, 3 * cout, 3 * cout, cout,
+                at = AttnArgs(_ptr(qk_), _ptr(qk_[cout:]), _ptr(qk_[2 * cout:]), _ptr(ao_), 3 * cout, 3 * cout, 3 * cout, cout,
                               S * 3 * cout, S * 3 * cout, S * 3 * cout, S * cout, B, hd, S, S, ch, 1.0 / math.sqrt(ch))
                 at.out_f16 = 1 if a16 else 0
+                at.in_f16 = 3 if a16 else 0
                 add(lib.ds_attention_f16 if f16_attn else lib.ds_attention, (C.byref(at),), nm + '.attention', keep=(at,))
                 if b.pushes_skip:
                     out2 = bd.new16(M, cout) if f16_out else new(M, cout)

@@ -251,6 +251,9 @@ class Builder:
         if out.dtype == torch.float16:
             assert f16, 'fp16 attention output needs the fp16-operand kernel'
             a.out_f16 = 1
+        # fp16 q / k / v (the projections' outputs in the fp16 stream) are recognised by their dtype: bit 0 = q, bit 1 = k and v
+        a.in_f16 = (1 if q.dtype == torch.float16 else 0) | (2 if k.dtype == torch.float16 else 0)
+        assert k.dtype == v.dtype and (not a.in_f16 or f16), name
         self.add(self.lib.ds_attention_f16 if f16 else self.lib.ds_attention, (C.byref(a),), name, keep=(a,))
 
     def layernorm(self, x, ldx, gamma, beta, eps, y, ldy, rows, cols, name):

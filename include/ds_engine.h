@@ -292,6 +292,9 @@ typedef struct ds_attn_args {
     int batch, heads, sq, skv, d;
     float scale;
     int out_f16;     /* ds_attention_f16 only: `out` is an fp16 tensor (ldo / o_bs in halfs): the operand of the output projection in fp16 mode */
+    int in_f16;      /* ds_attention_f16 only: bit 0: q is an fp16 tensor (ldq / q_bs in halfs, multiples of 8), bit 1: k and v are (ldk, k_bs
+                        multiples of 8; ldv, v_bs of 4) -- the fp16 tensors the reference's qkv projection emits in its fp16 mode
+                        (networks_edm.py:171-173; attention.py:168-176 under autocast); `scale` then multiplies the fp32 scores */
 } ds_attn_args;
 
 int ds_attention(const ds_attn_args* a, void* stream);

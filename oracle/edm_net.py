@@ -134,13 +134,18 @@ def _block(p, prefix, x, emb, *, up, down, adaptive, skip_scale, eps, heads, tap
     x = _stored(prefix + '.conv1', (x + s) * skip_scale)
     if heads:
         n, c = x.shape[0], x.shape[1]
-        qkv = _conv(p, prefix + '.qkv', _gn(p, prefix + '.norm2', x, eps))
+        qkv = _stored(prefix + '.qkv', _conv(p, prefix + '.qkv', _gn(p, prefix + '.norm2', x, eps)))
         q, k, v = qkv.reshape(n * heads, c // heads, 3, -1).unbind(2)
         if _F16_PRED is not None and _F16_PRED(prefix + '.attention'):
             # the fp16-operand attention kernel's arithmetic (see oracle/ldm_net.py:_attn): q * d^-1/2 * log2(e) rounded, k, v rounded,
-            # un-normalised exp2 weights rounded for the P V product, fp32 row sums of the unrounded weights
-            q, k, v = _rnd(prefix + '.attention', q * (math.log2(math.e) / math.sqrt(k.shape[1])), k, v)
-            sc = torch.einsum('ncq,nck->nqk', q, k)
+            # un-normalised exp2 weights rounded for the P V product, fp32 row sums of the unrounded weights.  When q | k | v are stored
+            # fp16 tensors (the qkv projection's output is rounded above) the factor multiplies the fp32 scores instead
+            f = math.log2(math.e) / math.sqrt(k.shape[1])
+            if _F16_STORED is not None and _F16_STORED(prefix + '.qkv'):
+                sc = torch.einsum('ncq,nck->nqk', q, k) * f
+            else:
+                q, k, v = _rnd(prefix + '.attention', q * f, k, v)
+                sc = torch.einsum('ncq,nck->nqk', q, k)
             pw = torch.exp2(sc - sc.max(dim=2, keepdim=True).values)
             a = torch.einsum('nqk,nck->ncq', _rnd(prefix + '.attention', pw)[0] / pw.sum(2, keepdim=True), v)
         else:

@@ -80,9 +80,9 @@ def _res(p, prefix, x, emb):
 
 
 def _attn(p, prefix, x, context, heads):
-    q = _lin(p, prefix + '.to_q', x)
+    q = _stored(prefix + '.to_q', _lin(p, prefix + '.to_q', x))          # fp16 mode: q (and, self-attention, k | v) are stored fp16 tensors
     ctx = x if context is None else context
-    k, v = _lin(p, prefix + '.to_k', ctx), _lin(p, prefix + '.to_v', ctx)
+    k, v = _stored(prefix + '.to_k', _lin(p, prefix + '.to_k', ctx)), _stored(prefix + '.to_v', _lin(p, prefix + '.to_v', ctx))
     b, n, c = q.shape
     d = c // heads
     split = lambda t: t.reshape(b, t.shape[1], heads, d).permute(0, 2, 1, 3).reshape(b * heads, t.shape[1], d)
@@ -91,8 +91,14 @@ def _attn(p, prefix, x, context, heads):
         # the fp16-operand attention kernel's arithmetic: q pre-multiplied by d^-1/2 * log2(e) and THEN rounded, k and v rounded,
         # fp32 scores, un-normalised exp2 weights rounded for the P V product, fp32 row sums of the unrounded weights.  (Where the
         # roundings sit matters: on SD-1.5 two placements differ by 3.5e-3 of the output -- as much as either differs from fp32.)
-        q, k, v = _rnd(prefix, q * (d ** -0.5 * math.log2(math.e)), k, v)
-        sim = torch.einsum('bid,bjd->bij', q, k)
+        if _F16_STORED is not None and _F16_STORED(prefix + '.to_q'):
+            # q is a stored fp16 tensor (rounded by its projection): the factor multiplies the fp32 scores, k / v are rounded while staged
+            # unless they are stored fp16 tensors themselves (rounding is idempotent)
+            q, k, v = _rnd(prefix, q, k, v)
+            sim = torch.einsum('bid,bjd->bij', q, k) * (d ** -0.5 * math.log2(math.e))
+        else:
+            q, k, v = _rnd(prefix, q * (d ** -0.5 * math.log2(math.e)), k, v)
+            sim = torch.einsum('bid,bjd->bij', q, k)
         pw = torch.exp2(sim - sim.max(dim=-1, keepdim=True).values)
         out = torch.einsum('bij,bjd->bid', _rnd(prefix, pw)[0], v) / pw.sum(-1, keepdim=True)
     else:

@@ -62,9 +62,11 @@ def ldm_prefixes(plan):
     return out
 
 
-_LDM_STORED = {'.in_layers': '.in_layers.2', '.out_layers': '.out_layers.3', '.proj_in': '.proj_in', '.proj_out': '.proj_out', '.conv': '.conv',
-               '.attn1.to_out': '.transformer_blocks.0.attn1.to_out.0', '.attn2.to_out': '.transformer_blocks.0.attn2.to_out.0',
-               '.ff.out': '.transformer_blocks.0.ff.net.2'}
+_LDM_STORED = {'.in_layers': ['.in_layers.2'], '.out_layers': ['.out_layers.3'], '.proj_in': ['.proj_in'], '.proj_out': ['.proj_out'], '.conv': ['.conv'],
+               '.attn1.to_out': ['.transformer_blocks.0.attn1.to_out.0'], '.attn2.to_out': ['.transformer_blocks.0.attn2.to_out.0'],
+               '.ff.out': ['.transformer_blocks.0.ff.net.2'],
+               '.attn1.qkv': ['.transformer_blocks.0.attn1.to_q', '.transformer_blocks.0.attn1.to_k', '.transformer_blocks.0.attn1.to_v'],
+               '.attn2.q': ['.transformer_blocks.0.attn2.to_q']}
 
 
 def ldm_stored_prefixes(plan):
@@ -77,7 +79,7 @@ def ldm_stored_prefixes(plan):
         if op.fn is lib.ds_conv2d_nhwc and op.keep[0].out_f16 == 1 and not op.name.endswith('.ff.proj_geglu'):
             for suf in sorted(_LDM_STORED, key=len, reverse=True):
                 if op.name.endswith(suf):
-                    out.add(op.name[:-len(suf)] + _LDM_STORED[suf])
+                    out.update(op.name[:-len(suf)] + t for t in _LDM_STORED[suf])
                     break
             else:
                 raise KeyError(op.name)

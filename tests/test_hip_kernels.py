@@ -1222,3 +1222,40 @@ def test_f16_activation_kernels_with_fp16_residual_and_output_rows(kind, nw):
     assert lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr()) != 0
     a.in_f16, a.res_ld = 1, cout + 4
     assert lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize('d,heads,sq,skv,mask', [(40, 8, 1024, 1024, 3), (64, 6, 256, 256, 3), (40, 8, 300, 77, 1), (160, 2, 64, 64, 3), (80, 4, 512, 77, 1),
+                                                  (64, 3, 130, 130, 2)])
+def test_fused_attention_reads_fp16_q_k_v(d, heads, sq, skv, mask):
+    """ds_attn_args.in_f16 (bit 0: q, bit 1: k and v are fp16 tensors -- the qkv projection's fp16 rows): the operands are staged as they
+    are and `scale` multiplies the fp32 scores.  Against fp64 softmax(q k^T scale) v on the same fp16 values with the softmax weights
+    rounded to fp16 as the kernel does: 1e-3 (the bound of the fp32-input path); self- and cross-attention layouts, ragged lengths."""
+    import ctypes as C
+    from diff_sampler_amd import _lib
+    lib = _lib.load()
+    dev = 'cuda'
+    B, c = 2, heads * d
+    g = torch.Generator().manual_seed(d + sq + mask)
+    q = torch.randn(B * sq, c, generator=g).to(torch.float16)
+    kv = torch.randn(B * skv, 2 * c, generator=g).to(torch.float16)
+    qd = q.to(dev) if mask & 1 else q.float().to(dev)
+    kvd = kv.to(dev) if mask & 2 else kv.float().to(dev)
+    out = torch.full((B * sq, c), float('nan'), device=dev)
+    a = _lib.AttnArgs(qd.data_ptr(), kvd.data_ptr(), kvd[:, c:].data_ptr(), out.data_ptr(), c, 2 * c, 2 * c, c, sq * c, skv * 2 * c, skv * 2 * c,
+                      sq * c, B, heads, sq, skv, d, d ** -0.5)
+    a.in_f16 = mask
+    rc = lib.ds_attention_f16(C.byref(a), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    assert rc == 0, lib.ds_error_string(rc)
+    qq = q.double().reshape(B, sq, heads, d).permute(0, 2, 1, 3)
+    kk = kv[:, :c].double().reshape(B, skv, heads, d).permute(0, 2, 1, 3)
+    vv = kv[:, c:].double().reshape(B, skv, heads, d).permute(0, 2, 1, 3)
+    ref = (torch.softmax(qq @ kk.transpose(-1, -2) * d ** -0.5, -1) @ vv).permute(0, 2, 1, 3).reshape(B * sq, c).float()
+    got = out.cpu()
+    assert torch.isfinite(got).all()
+    assert _rel(got, ref) < 1e-3, _rel(got, ref)
+    # the fp32 kernel does not take fp16 tensors, and misaligned fp16 rows are refused
+    assert lib.ds_attention(C.byref(a), _lib.stream_ptr()) != 0
+    if mask & 1:
+        a.ldq = c + 4
+        assert lib.ds_attention_f16(C.byref(a), _lib.stream_ptr()) != 0

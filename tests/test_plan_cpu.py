@@ -97,7 +97,7 @@ def test_headline_plan_kernel_routing_at_the_benchmark_batch():
 
 def _dtype_lint(P, lib):
     """Every pointer a launch reads or writes as activation rows must point into a plan-owned tensor of the dtype the launch's flags
-    claim (ds_conv_args.in_f16 / out_f16 / res_f16, ds_norm_args.in_f16 bits / out_f16, the LayerNorm entry point, ds_attn_args.out_f16):
+    claim (ds_conv_args.in_f16 / out_f16 / res_f16, ds_norm_args.in_f16 bits / out_f16, the LayerNorm entry point, ds_attn_args.in_f16 / out_f16):
     a mismatch would not crash, it would silently reinterpret fp16 bytes as fp32.  Returns the number of (pointer, flag) pairs checked."""
     import torch
     spans = []
@@ -139,7 +139,9 @@ def _dtype_lint(P, lib):
             check(op.args[5].value, op.fn is not lib.ds_layernorm_rows, op.name + '.y')
         elif op.fn in (lib.ds_attention, lib.ds_attention_f16):
             a = op.keep[0]
-            check(a.q, False, op.name + '.q'); check(a.out, a.out_f16, op.name + '.out')
+            check(a.q, a.in_f16 & 1, op.name + '.q'); check(a.k, a.in_f16 & 2, op.name + '.k'); check(a.v, a.in_f16 & 2, op.name + '.v')
+            check(a.out, a.out_f16, op.name + '.out')
+            assert not a.in_f16 or op.fn is lib.ds_attention_f16, op.name
     return n
 
 
