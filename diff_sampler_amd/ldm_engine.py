@@ -252,14 +252,18 @@ class LDMUNetEngine:
                     out=n2, out_ld=c, out_f16=h16)
             bd.conv(n2, c, c, N, res, res, w[f'{p}.pi.w'], c, t0, c, 1, p + '.proj_in', bias=w[f'{p}.pi.b'])
             # self-attention
-            qkv, t1 = mk(M, 3 * c), ts(M, c)                 # fp16 mode: q | k | v as the fp16 rows the projections emit under autocast
+            # fp16 mode: q | k | v as the fp16 rows the projections emit under autocast -- where the attention kernel is faster on them
+            # (d >= 64: -6 ... -18 %); at d = 40 (S = 4 096) it is 10 % SLOWER than on fp32 rows it converts itself (A/B in one session,
+            # profiles/r3_gemm_f16dma_epilogue.txt section 9), which costs more than the halved projection output saves: fp32 rows there
+            mq = mk if d >= 64 else new
+            qkv, t1 = mq(M, 3 * c), ts(M, c)
             bd.layernorm(t0, c, w[f'{p}.norm1.g'], w[f'{p}.norm1.b'], 1e-5, ln, c, M, c, p + '.norm1')
             bd.linear(ln, c, M, w[f'{p}.qkv1.w'], 3 * c, qkv, p + '.attn1.qkv')
             bd.attention(qkv, qkv[:, c:], qkv[:, 2 * c:], ao, p + '.attn1', batch=N, heads=hd, sq=S, skv=S, d=d, ldq=3 * c, ldk=3 * c,
                          ldv=3 * c, ldo=c, q_bs=S * 3 * c, k_bs=S * 3 * c, v_bs=S * 3 * c, o_bs=S * c, scale=d ** -0.5)
             bd.linear(ao, c, M, w[f'{p}.attn1.o.w'], c, t1, p + '.attn1.to_out', bias=w[f'{p}.attn1.o.b'], res=t0, res_ld=c)
             # cross-attention over the context tokens
-            q2, kv2, t2 = mk(M, c), new(N * L, 2 * c), ts(M, c)          # the context's k | v (fp32 projection of fp32 states, once per context) stay fp32
+            q2, kv2, t2 = mq(M, c), new(N * L, 2 * c), ts(M, c)          # the context's k | v (fp32 projection of fp32 states, once per context) stay fp32
             bd.layernorm(t1, c, w[f'{p}.norm2.g'], w[f'{p}.norm2.b'], 1e-5, ln, c, M, c, p + '.norm2')
             bd.linear(ln, c, M, w[f'{p}.q2.w'], c, q2, p + '.attn2.q')
             bd.linear(bufs['context'], spec.context_dim, N * L, w[f'{p}.kv2.w'], 2 * c, kv2, p + '.attn2.kv')
