@@ -175,7 +175,15 @@ for si, (res, c0, c1, cout, taps) in enumerate(SHAPES):
             ref = (ref + res_t) * 0.70710678
         else:
             ref = ref * 0.70710678
-        err = float((out[:, :cout] - ref).abs().max() / ref.abs().max())
+        got = out16.float() if args.dma16 and a.out_f16 else out[:, :cout]          # fp16 output rows: within one fp16 ulp of the reference
+        if args.dma16:                                                               # the kernel multiplies fp16 operands
+            xin16 = x16.float().reshape(B, res, res, c0 + c1).permute(0, 3, 1, 2)
+            ref = torch.nn.functional.conv2d(xin16, w.half().float(), bias, padding=(1 if taps == 9 else 0)).permute(0, 2, 3, 1).reshape(M, cout)
+            if a.res:
+                ref = (ref + (res16.float() if a.res_f16 else res_t)) * 0.70710678
+            else:
+                ref = ref * 0.70710678
+        err = float((got - ref).abs().max() / ref.abs().max())
         msg += f'  relerr {err:.2e}'
     print(msg, flush=True)
 if tot_t:
