@@ -109,6 +109,26 @@ def test_committed_pmc_summary_names_the_dominant_kernel():
     assert int(m.group(1)) == (lean | ntepi) and 'launch_one<4, true, 2, VAR_TILE_OPTS, 4>' in src
 
 
+def test_bench_defaults_are_the_workloads_the_kept_lines_are_quoted_on():
+    """`python bench.py --config X` without --batch / --solver must be the workload of profiles/r3_bench_X_*_line.json (the driver and a
+    reader re-run it that way): CIFAR-10 DPM-Solver++(2M) B = 256 (BASELINE config 2, the headline), FFHQ-64 B = 128, ImageNet-64 iPNDM-4
+    B = 64 (config 3), SD-1.5 B = 16 (config 5); explicit flags win."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    want = {'cifar10': (256, 'dpmpp'), 'ffhq': (128, 'dpmpp'), 'imagenet64': (64, 'ipndm'), 'sd15': (16, 'dpmpp')}
+    for cfg, (b, solver) in want.items():
+        a = bench.parse(['--config', cfg])
+        assert (a.batch, a.solver) == (b, solver), (cfg, a.batch, a.solver)
+    a = bench.parse(['--config', 'imagenet64', '--batch', '8', '--solver', 'euler'])
+    assert (a.batch, a.solver) == (8, 'euler')
+    assert bench.parse([]).config == 'cifar10' and bench.parse([]).gpus == 1                 # the driver's default call: the headline on one GPU
+    for name, b in (('r3_bench_line.json', 256), ('r3_bench_imagenet64_fp16_line.json', 64), ('r3_bench_sd15_fp16_line.json', 16),
+                    ('r3_bench_ffhq_fp32_line.json', 128)):
+        line = [x for x in open(os.path.join(ROOT, 'profiles', name)).read().splitlines() if x.startswith('{')][-1]
+        assert f'batch {b}/GPU' in json.loads(line)['config']['workload'], name
+
+
 def test_sample_cli_under_two_gloo_ranks_writes_every_seed_exactly_once(tmp_path):
     """`python -m diff_sampler_amd.sample` as the reference launches it (torchrun, one process per device; sample.py:164-169, :268,
     torch_utils/distributed.py:14-31) under 2 gloo ranks on the CPU, in the CLI's launcher self-test mode (--stub: the real seed
