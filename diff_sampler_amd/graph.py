@@ -57,6 +57,7 @@ class GraphedSampler:
         with torch.cuda.graph(self.graph, stream=s):
             self.static_out = self.fn(self.net, self.static_in, class_labels=self.static_labels, **self.kw)
         torch.cuda.synchronize(device)
+        getattr(self.net, 'invalidate_context_cache', lambda: None)()
 
     def __call__(self, latents: torch.Tensor, class_labels: Optional[torch.Tensor] = None, clone: bool = True, condition=None,
                  unconditional_condition=None):
@@ -68,6 +69,9 @@ class GraphedSampler:
         if unconditional_condition is not None:
             self.static_uncond.copy_(unconditional_condition)
         self.graph.replay()
+        # the replay rewrote the denoiser's cross-attention K / V buffers from the static conditions: an eager call that follows must
+        # not believe its own cached context is still there (ldm_engine.CFGDenoiser)
+        getattr(self.net, 'invalidate_context_cache', lambda: None)()
         out = self.static_out
         if clone:
             out = tuple(o.clone() for o in out) if isinstance(out, tuple) else out.clone()

@@ -20,6 +20,7 @@ reference runs this U-Net under autocast; fp32 is the stricter contract -- DESIG
 from __future__ import annotations
 
 import math
+import weakref
 from typing import Dict
 
 import torch
@@ -413,6 +414,12 @@ class CFGDenoiser(CFGSchedule):
     def to(self, *a, **k):
         return self
 
+    def invalidate_context_cache(self):
+        """Forget which context the plans' cross-attention K / V buffers hold.  For callers that write conditions through raw pointers
+        (no `_version` bump) and for graph.GraphedSampler, whose replays overwrite those buffers behind the cache's back."""
+        for P in self.engine._plans.values():
+            P.ctx_key = None
+
     # -- evaluation ----------------------------------------------------------------------------------------------------------
     def raw(self, x, sigma, condition=None, unconditional_condition=None):
         """Runs the plan; returns (F rows NHWC [N*H*W, 4], plan, doubled)."""
@@ -447,12 +454,16 @@ class CFGDenoiser(CFGSchedule):
             bufs['c_noise'].copy_(cn)
         cd = self.spec.context_dim
         parts = [unconditional_condition, cond] if doubled else [cond]
-        # context -> plan buffer and its key / value projections: once per context.  The cache key holds the caller's tensor OBJECTS
-        # (so their storage cannot be recycled under it) and their in-place-modification counters.
-        key = tuple((t, t._version) for t in parts)
+        # context -> plan buffer and its key / value projections: once per context.  The cache key is (weak reference to the caller's
+        # tensor, its address, shape and in-place-modification counter): a weak reference, so the cache pins nothing of the caller's, and a
+        # dead one never matches.  NEVER skipped while the stream is capturing: a hipGraph must contain the copy and the projections (its
+        # replays read whatever the static condition buffers hold THEN), and a capture executes nothing, so afterwards the plan's K / V
+        # buffers are not those of `key` either.
+        capturing = torch.cuda.is_current_stream_capturing()
+        key = tuple((weakref.ref(t), t.data_ptr(), tuple(t.shape), t._version) for t in parts)
         old_key = plan.ctx_key
-        same = (self.cache_context and old_key is not None and len(old_key) == len(key)
-                and all(a[0] is b[0] and a[1] == b[1] for a, b in zip(old_key, key)))
+        same = (self.cache_context and not capturing and old_key is not None and len(old_key) == len(key)
+                and all(a[0]() is t and a[1:] == b[1:] for a, b, t in zip(old_key, key, parts)))
         if not same:
             for i, c_ in enumerate(parts):
                 c_ = c_.to(device=self.device, dtype=torch.float32)
@@ -462,7 +473,7 @@ class CFGDenoiser(CFGSchedule):
                 assert c_.shape == (B, L, cd), (c_.shape, (B, L, cd))
                 _lib.check(lib.ds_copy_rows(ptr(c_), cd, ptr(bufs['context'][i * B * L:]), cd, B * L, cd, st), 'copy context')
             plan.ctx.run(st)
-            plan.ctx_key = key
+            plan.ctx_key = None if capturing else key
         plan.run(st)
         return bufs['out'], plan, doubled
 

@@ -9,7 +9,10 @@
     FFHQ-64 AMED-Solver): whole trajectories;
   * one full-size Stable-Diffusion-v1.5 config-5 trajectory (DPM-Solver++(2M) eps-prediction, discrete rho=1, CFG 7.5).
 
-Tolerances (fp32 path): 2e-4 per evaluation, 5e-4 per EDM trajectory, 1e-3 for the 5-step SD trajectory."""
+Tolerances (fp32 path): 2e-4 per evaluation, 5e-4 per EDM trajectory, 1e-3 for the 5-step SD trajectory.
+Trajectories are bounded PER STEP, each step against its own golden scale (tests/_parity.py: a trajectory runs from scale ~300 at sigma_max
+to an image of scale ~3, so one normalisation over the whole trajectory would leave the final image unconstrained), and the final image
+explicitly.  What every test observed goes to gpurun_out/r4_parity.json (kept copy: profiles/r4_parity.json)."""
 import ctypes as C
 import os
 import sys
@@ -20,6 +23,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+from _parity import per_step_rel, record, step_scales  # noqa: E402  (tests/ is on sys.path under pytest rootdir-less collection)
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(ROOT, 'tests', 'golden')
@@ -121,7 +126,10 @@ def test_config3_imagenet64_trajectory_matches_reference(dev):
                                 t_steps=torch.from_numpy(z['t_steps']).to(dev), num_steps=11, return_inters=True)
     torch.cuda.synchronize()
     assert tuple(out.shape) == tuple(z['traj'].shape)
-    assert _rel(out.cpu(), torch.from_numpy(z['traj'])) < 5e-4
+    gold = torch.from_numpy(z['traj'])
+    errs = per_step_rel(out.cpu(), gold)
+    record('config3_imagenet64_ipndm4_gits_b1_fp32', per_step=errs, final=errs[-1], step_scales=step_scales(gold), bound=5e-4)
+    assert max(errs) < 5e-4 and errs[-1] < 5e-4, errs
 
 
 def test_config4_ffhq64_amed_trajectory_matches_reference(dev):
@@ -140,7 +148,10 @@ def test_config4_ffhq64_amed_trajectory_matches_reference(dev):
                                     schedule_type='time_uniform', schedule_rho=1, afs=True, return_inters=True, AMED_predictor=pred)
     torch.cuda.synchronize()
     assert tuple(out.shape) == tuple(z['traj'].shape)
-    assert _rel(out.cpu(), torch.from_numpy(z['traj'])) < 1e-3
+    gold = torch.from_numpy(z['traj'])
+    errs = per_step_rel(out.cpu(), gold)
+    record('config4_ffhq64_amed_nfe5_b2_fp32', per_step=errs, final=errs[-1], step_scales=step_scales(gold), bound=1e-3)
+    assert max(errs) < 1e-3 and errs[-1] < 1e-3, errs
 
 
 def test_sd15_config5_trajectory_matches_reference(dev):
@@ -155,7 +166,9 @@ def test_sd15_config5_trajectory_matches_reference(dev):
     torch.cuda.synchronize()
     ref = torch.from_numpy(z['traj'])
     assert tr.shape == ref.shape
-    assert _rel(tr.cpu(), ref) < 1e-3
+    errs = per_step_rel(tr.cpu(), ref)
+    record('config5_sd15_dpmpp2m_b_fp32', per_step=errs, final=errs[-1], step_scales=step_scales(ref), bound=1e-3)
+    assert max(errs) < 1e-3 and errs[-1] < 1e-3, errs
 
 
 # ---- the OTHER benchmarked configurations at THEIR bench batches (bench.py --config imagenet64 --batch 64 / --config ffhq --batch 128),
@@ -195,9 +208,13 @@ def test_config3_imagenet64_at_the_benchmark_batch_b64(mode, dev):
     torch.cuda.synchronize()
     assert torch.isfinite(out).all()
     gold = torch.from_numpy(z['traj'])                       # [11, 1, 3, 64, 64]
-    tol = 1e-2 if f16 else 5e-4
+    tol = 1e-2 if f16 else 5e-4                              # of EACH step's own scale; the final image explicitly
+    worst = [0.0] * gold.shape[0]
     for s in slots:
-        assert _rel(out[:, s:s + 1].cpu(), gold) < tol, (mode, s, _rel(out[:, s:s + 1].cpu(), gold))
+        errs = per_step_rel(out[:, s:s + 1].cpu(), gold)
+        worst = [max(a, b) for a, b in zip(worst, errs)]
+    record(f'config3_imagenet64_ipndm4_gits_b64_{mode}', per_step=worst, final=worst[-1], step_scales=step_scales(gold), bound=tol)
+    assert max(worst) < tol and worst[-1] < tol, (mode, worst)
     ids = _conv_kernel_ids(net, B, B)
     if f16:
         assert ids.get(2562, 0) + ids.get(2566, 0) >= 60, ids       # fp16-operand 3x3 kernels (2562: 256 x 128 tiles, 2566: 256 x 256 tiles)
@@ -213,6 +230,7 @@ def test_config3_imagenet64_at_the_benchmark_batch_b64(mode, dev):
     o = netn(x.to(dev), sig.to(dev), class_labels=labels.to(dev)).cpu()
     for s in slots:
         e = _rel(o[s:s + 1], torch.from_numpy(zn['out_vec']))
+        record(f'net_imagenet64_b64_{mode}', **{f'slot{s}': e}, bound=(5e-3 if f16 else 2e-4))
         assert e < (5e-3 if f16 else 2e-4), (mode, s, e)
 
 
@@ -235,8 +253,10 @@ def test_ffhq64_headline_solver_at_the_benchmark_batch_b128(mode, dev):
     torch.cuda.synchronize()
     assert torch.isfinite(out).all()
     gold = torch.from_numpy(z['out'])
-    tol = 1e-2 if f16 else 5e-4
-    assert _rel(out[slots], torch.cat([gold, gold])) < tol, (mode, _rel(out[slots], torch.cat([gold, gold])))
+    tol = 1e-2 if f16 else 5e-4                              # final images against their own scale
+    e = _rel(out[slots], torch.cat([gold, gold]))
+    record(f'ffhq64_dpmpp2m_nfe10_b128_{mode}', final=e, final_scale=float(gold.abs().max()), bound=tol)
+    assert e < tol, (mode, e)
     ids = _conv_kernel_ids(net, B, 1)
     if f16:
         assert ids.get(2562, 0) + ids.get(2566, 0) >= 60, ids
