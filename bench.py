@@ -27,6 +27,11 @@ Prints ONE JSON line on rank 0 with the driver's contract fields plus
   kernels          time share of every kernel class in the instrumented step
   launch_modes     the same sampler call eager vs replayed from one captured hipGraph, at B=8 and at the benchmark batch
   throughput_by_batch  (cifar10) the same call at 1024 images per call next to the benchmark batch (informational)
+  other_configs    (N = 1, default run) the other benchmarked configurations / arithmetic modes, each timed in THIS process under the
+                   driver's clock: ImageNet-64 fp16 B=64 iPNDM-4, SD-1.5 fp16 B=16, FFHQ-64 fp32 B=128, CIFAR-10 fp16x3 B=256 -- value,
+                   ms_per_step (2 timed calls after 1 warm-up), the dominant kernel's own roofline and the whole-application fraction of
+                   the matrix peak of the datatype used (SURVEY 8d FLOPs per evaluation x evaluations / time / peak)
+  latency          small-batch sampler calls (BASELINE config 1 is B = 8): CIFAR-10 B=8 NFE=10 and SD-1.5 fp16 B=1 NFE=10, ms per call
   cpu_baseline     the oracle (CPU restatement of the reference, ``oracle/``; the real reference when /root/reference is
                    importable) timed on this host's cores on a bounded sample of the same workload, at the best of a
                    thread-count sweep (cores = the thread count used)
@@ -51,7 +56,16 @@ PEAK_FP16_MFMA_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak (MI355X_MICROARC
 # mfma16_pattern.hip; profiles/r3_probe_*): informational, `roofline.peak` stays the nominal figure
 SUSTAINED_RANDOM_FP32_TFLOPS, SUSTAINED_RANDOM_FP16_TFLOPS = 145.5, 1720.0
 PEAK_HBM_GBS = 8000.0
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r3_bench_pmc_hbm.json')
+# algorithmic GFLOP per image and network evaluation (2 x MAC; FlopCounterMode on the reference modules)
+GFLOP_PER_EVAL = {'cifar10': 42.38, 'ffhq': 83.73, 'afhqv2': 83.73, 'imagenet64': 219.33, 'sd15': 803.27}
+OTHER_CONFIGS = (('imagenet64', 'fp16', 64), ('sd15', 'fp16', 16), ('ffhq', 'fp32', 128), ('cifar10', 'fp16x3', 256))
+WORKLOAD_NAMES = {'cifar10': 'EDM CIFAR-10 32x32 SongUNet (55.7M params)', 'ffhq': 'EDM FFHQ-64 SongUNet (61.8M params)',
+                  'afhqv2': 'EDM AFHQv2-64 SongUNet', 'imagenet64': 'EDM ImageNet-64 DhariwalUNet (295.9M params)',
+                  'sd15': 'Stable Diffusion v1.5 64x64x4 latent U-Net (859.5M params)'}
+SOLVER_NAMES = {'dpmpp': 'DPM-Solver++(2M) logSNR', 'euler': 'Euler', 'ipndm': 'iPNDM-4', 'heun': 'Heun'}
+LDM_SOLVER_NAME = 'DPM-Solver++(2M) eps-prediction, discrete rho=1, CFG 7.5 (2 U-Net images per latent)'
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r4_bench_pmc_hbm.json')
+PMC_NOTE = {}
 KERNEL_NAMES = {0: 'igemm_f32_kernel<0> (generic gather conv / 1x1 / linear)', 128: 'conv3x3_halo_kernel<2> (128-pixel tiles)',
                 1284: 'conv3x3_halo_kernel<2, WN=4, NT=1> (128-pixel tiles on 8 waves of 64 x 32)',
                 256: 'conv3x3_halo_kernel<4> (256-pixel tiles)', 2561: 'gemm_dma8_kernel (256x128 tiles, LDS-DMA, 1x1 / linear)',
@@ -88,6 +102,7 @@ def parse(argv=None):
     ap.add_argument('--cpu-threads', default='sweep', help="'sweep' (8,16,32; best reported) or a thread count")
     ap.add_argument('--no-launch-modes', action='store_true', help='skip the eager-vs-hipGraph comparison')
     ap.add_argument('--no-batch-sweep', action='store_true', help='skip the extra throughput measurement at 1024 images per call')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the other_configs / latency measurements of the default run')
     ap.add_argument('--stub', action='store_true', help=argparse.SUPPRESS)   # launcher self-test: gloo ranks on CPU, no kernels
     args = ap.parse_args(argv)
     if args.solver is None:
@@ -147,7 +162,7 @@ def instrumented_pass(net, solvers, solver, latents, nfe, ldm=None):
         if op.fn is lib.ds_attention_f16:
             t = op.keep[0]
             return 'flash_attn_f16_kernel (fused attention, fp16 operands)', 4.0 * t.batch * t.heads * t.sq * t.skv * t.d
-        if op.fn is lib.ds_layernorm_rows or op.fn is lib.ds_layernorm_rows_f16:
+        if op.fn is lib.ds_layernorm_rows or op.fn is lib.ds_layernorm_rows_f16 or op.fn is lib.ds_layernorm_rows_f16io:
             return 'layernorm_rows_kernel', 0.0
         if op.fn is lib.ds_gn_stats:
             return 'gn_stats_kernel', 0.0
@@ -182,7 +197,8 @@ def instrumented_pass(net, solvers, solver, latents, nfe, ldm=None):
 
     cfg = ops.cfg_denoise
     x0s = ops.dpmpp_x0_step
-    ops.dpmpp_x0_step = timed_call(X0_KIND, x0s)
+    per_sample = int(latents[0].numel())
+    ops.dpmpp_x0_step = timed_call(X0_KIND if lib.ds_dpmpp_x0_step_in_registers(per_sample) else X0_KIND_LDS, x0s)
     engine._Plan.run = timed_plan_run
     ops.solver_update = timed_call('solver_update_kernel', upd)
     ops.dynamic_threshold = timed_call('dynamic_threshold_kernel', thr)
@@ -200,6 +216,7 @@ def instrumented_pass(net, solvers, solver, latents, nfe, ldm=None):
 
 
 X0_KIND = 'dpmpp_x0_step_reg_kernel (D -> dynamic threshold -> multistep update in one launch, sample held in registers)'
+X0_KIND_LDS = 'dpmpp_x0_step_kernel (D -> dynamic threshold -> multistep update in one launch, |D| staged in LDS)'
 
 
 def update_roofline_large_batch(dev, batch=16384, kind='ipndm'):
@@ -239,12 +256,27 @@ def update_roofline_large_batch(dev, batch=16384, kind='ipndm'):
                 note='micro-benchmark inside bench.py at the batch where the update is bandwidth-bound (every operand is touched once)')
 
 
+KERNEL_TU = {0: 'gemm_conv.hip', 128: 'conv3x3_halo.hip', 1284: 'conv3x3_halo.hip', 256: 'conv3x3_halo.hip', 2565: 'conv3x3_halo.hip',
+             2568: 'conv3x3_halo.hip', 2561: 'gemm_dma8.hip'}
+
+
 def pmc_traffic(kid):
-    """HBM bytes per launch of a conv kernel from the committed rocprofv3 PMC summary (profiles/)."""
+    """(HBM bytes per launch, provenance) of a conv kernel from the committed rocprofv3 PMC summary (profiles/), or None.  The summary
+    records the session it was collected in and the hash of every kernel translation unit at that time (tools/rocprof_summary.py);
+    a kernel whose source changed since then reports null instead of a stale number (PMC_NOTE['why'] says so)."""
     try:
-        k = json.load(open(PMC_FILE))['kernels'][PMC_KEYS[kid]]
-        return 1024.0 * (2.0 * k['FETCH_SIZE_KiB_avg_per_launch'] + k['WRITE_SIZE_KiB_avg_per_launch'])
-    except Exception:
+        from diff_sampler_amd import build
+        z = json.load(open(PMC_FILE))
+        tu = KERNEL_TU[kid]
+        then, now = z['meta']['kernel_source_sha256'][tu], build.source_sha256(tu)
+        if then != now:
+            PMC_NOTE['why'] = f'{os.path.relpath(PMC_FILE, ROOT)} was collected on another build of {tu} ({then[:12]} != {now[:12]}): traffic withheld'
+            return None
+        k = z['kernels'][PMC_KEYS[kid]]
+        byts = 1024.0 * (2.0 * k['FETCH_SIZE_KiB_avg_per_launch'] + k['WRITE_SIZE_KiB_avg_per_launch'])
+        return round(byts), dict(file=os.path.relpath(PMC_FILE, ROOT), session=z['meta']['session'], kernel_source=tu, kernel_source_sha256=now)
+    except Exception as e:
+        PMC_NOTE['why'] = f'no usable PMC summary ({type(e).__name__}: {e})'
         return None
 
 
@@ -400,6 +432,87 @@ def fid_allreduce_timing(dist, dev, world, reps=3):
                 sigma_busbw_GBs=round(alg * 2 * (world - 1) / world, 2), xgmi_link_GBs=153.0, dtype='f64', op='SUM')
 
 
+def build_net(config, dtype, dev):
+    """(net factory, is latent-diffusion) for a named configuration in an arithmetic mode."""
+    import diff_sampler_amd.ldm_arch as ldm_arch
+    if config in ldm_arch.NAMED_LDM_CONFIGS:
+        from diff_sampler_amd.ldm_engine import CFGDenoiser
+        return (lambda: CFGDenoiser.from_config(config, seed=0, device=dev, guidance_rate=7.5, use_fp16=(dtype == 'fp16'))), True
+    from diff_sampler_amd.engine import EDMDenoiser
+    return (lambda: EDMDenoiser.from_config(config, seed=0, device=dev, use_fp16=(dtype == 'fp16'), split_fp16=(dtype == 'fp16x3'))), False
+
+
+def kernel_report(rec):
+    """(kernels table, dominant conv/GEMM kernel's roofline dict) from an instrumented pass."""
+    total_ms = sum(v[0] for v in rec.values())
+    kernels = {(KERNEL_NAMES[k[1]] if isinstance(k, tuple) else k): dict(ms=round(v[0], 2), launches=v[1], share=round(v[0] / total_ms, 4))
+               for k, v in sorted(rec.items(), key=lambda kv: -kv[1][0])}
+    convs = {k: v for k, v in rec.items() if isinstance(k, tuple)}
+    dom, (ms, launches, fl) = max(convs.items(), key=lambda kv: kv[1][0])
+    ach = fl / (ms * 1e-3) / 1e12
+    peak = KERNEL_PEAK.get(dom[1], PEAK_FP32_MFMA_TFLOPS)
+    roof = dict(bound='mfma', kernel=KERNEL_NAMES[dom[1]], achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
+                launches_per_step=launches, avg_launch_ms=round(ms / launches, 4), gflop_per_launch=round(fl / launches / 1e9, 2),
+                share_of_gpu_time=round(ms / total_ms, 4),
+                frac_of_rate_sustained_on_random_operands=round(ach / (SUSTAINED_RANDOM_FP32_TFLOPS if peak == PEAK_FP32_MFMA_TFLOPS else SUSTAINED_RANDOM_FP16_TFLOPS * peak / PEAK_FP16_MFMA_TFLOPS), 4))
+    return kernels, roof, dom[1], total_ms
+
+
+def application_fraction(config, dtype, images_per_sec, nfe):
+    """Whole-application fraction of the matrix peak of the datatype used: SURVEY 8d's algorithmic FLOPs per image and evaluation x the
+    evaluations of one image (NFE; a latent-diffusion latent takes NFE U-Net images: NFE/2 steps x 2 CFG halves) / time / peak.
+    fp16x3 issues three fp16 MFMA products per fp32 product: its ceiling in algorithmic FLOPs is a third of the fp16 peak."""
+    peak = {'fp32': PEAK_FP32_MFMA_TFLOPS, 'fp16': PEAK_FP16_MFMA_TFLOPS, 'fp16x3': PEAK_FP16_MFMA_TFLOPS / 3}[dtype]
+    tf = images_per_sec * GFLOP_PER_EVAL[config] * nfe / 1e3
+    return dict(achieved=round(tf, 1), peak=round(peak, 1), unit='TFLOP/s', frac=round(tf / peak, 4),
+                gflop_per_image=round(GFLOP_PER_EVAL[config] * nfe, 1))
+
+
+def measure_config(config, dtype, batch, nfe, dev, calls=2, latency_batch=None):
+    """One of `other_configs`: build the net, 1 warm-up + `calls` timed sampler calls, one instrumented call for the kernel shares."""
+    from diff_sampler_amd import solvers
+    t_build = time.perf_counter()
+    factory, is_ldm = build_net(config, dtype, dev)
+    net = factory()
+    spec = net.spec
+    solver = 'ipndm' if config == 'imagenet64' else 'dpmpp'
+    g = torch.Generator(device='cpu').manual_seed(4321)
+
+    def inputs(b):
+        lat = torch.randn(b, spec.in_channels, spec.img_resolution, spec.img_resolution, generator=g).to(dev)
+        ldm = (torch.randn(b, 77, spec.context_dim, generator=g).to(dev), torch.randn(b, 77, spec.context_dim, generator=g).to(dev)) if is_ldm else None
+        return lat, ldm
+
+    def timed(lat, ldm, n):
+        sampler_call(solvers, solver, net, lat, nfe, ldm)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = sampler_call(solvers, solver, net, lat, nfe, ldm)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        return (time.perf_counter() - t0) / n
+
+    lat, ldm = inputs(batch)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+    dt = timed(lat, ldm, calls)
+    rec = instrumented_pass(net, solvers, solver, lat, nfe, ldm)
+    kernels, roof, _, _ = kernel_report(rec)
+    top = dict(list(kernels.items())[:5])
+    res = dict(config=dict(workload='%s, %s NFE=%d, batch %d/GPU' % (WORKLOAD_NAMES.get(config, config), LDM_SOLVER_NAME if is_ldm else SOLVER_NAMES[solver], nfe, batch)),
+               dtype=dtype, value=round(batch / dt, 2), unit='images/sec', ms_per_step=round(dt * 1e3, 2), steps=calls, warmup=1,
+               roofline=roof, application=application_fraction(config, dtype, batch / dt, nfe), kernels_top5=top,
+               setup_s=round(t_build, 1))
+    lat_ms = None
+    if latency_batch is not None:
+        l2, ldm2 = inputs(latency_batch)
+        lat_ms = round(timed(l2, ldm2, 3) * 1e3, 2)
+    del net
+    torch.cuda.empty_cache()
+    return res, lat_ms
+
+
 def main(argv=None):
     from diff_sampler_amd import launch
     args = parse(argv)
@@ -434,20 +547,12 @@ def main(argv=None):
         run_step = lambda: time.sleep(0.002 * (1 + rank))
     else:
         from diff_sampler_amd import solvers
-        from diff_sampler_amd.engine import EDMDenoiser
-        import diff_sampler_amd.ldm_arch as ldm_arch
-        if args.config in ldm_arch.NAMED_LDM_CONFIGS:
-            from diff_sampler_amd.ldm_engine import CFGDenoiser
-            net_factory = lambda: CFGDenoiser.from_config(args.config, seed=0, device=dev, guidance_rate=7.5, use_fp16=(args.dtype == 'fp16'))
-            net = net_factory()
-            spec = net.spec
+        net_factory, is_ldm = build_net(args.config, args.dtype, dev)
+        net = net_factory()
+        spec = net.spec
+        if is_ldm:
             ldm = (torch.randn(B, 77, spec.context_dim, generator=g).to(dev), torch.randn(B, 77, spec.context_dim, generator=g).to(dev))
             args.solver = 'dpmpp'
-        else:
-            net_factory = lambda: EDMDenoiser.from_config(args.config, seed=0, device=dev, use_fp16=(args.dtype == 'fp16'),
-                                                          split_fp16=(args.dtype == 'fp16x3'))
-            net = net_factory()
-            spec = net.spec
         latents = torch.randn(B, spec.in_channels, spec.img_resolution, spec.img_resolution, generator=g).to(dev)
 
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -497,20 +602,11 @@ def main(argv=None):
     roof = roof_u = kernels = None
     if rank == 0 and not stub:
         rec = instrumented_pass(net, solvers, args.solver, latents, args.nfe, ldm)
-        total_ms = sum(v[0] for v in rec.values())
-        kernels = {(KERNEL_NAMES[k[1]] if isinstance(k, tuple) else k): dict(ms=round(v[0], 2), launches=v[1], share=round(v[0] / total_ms, 4))
-                   for k, v in sorted(rec.items(), key=lambda kv: -kv[1][0])}
-        convs = {k: v for k, v in rec.items() if isinstance(k, tuple)}
-        dom, (ms, launches, fl) = max(convs.items(), key=lambda kv: kv[1][0])
-        ach = fl / (ms * 1e-3) / 1e12
-        traffic = pmc_traffic(dom[1]) if (args.config == 'cifar10' and B == 256 and args.dtype == 'fp32') else None   # the PMC pass is of the default workload
-        peak = KERNEL_PEAK.get(dom[1], PEAK_FP32_MFMA_TFLOPS)
-        roof = dict(bound='mfma', kernel=KERNEL_NAMES[dom[1]], achieved=round(ach, 2), peak=peak, unit='TFLOP/s',
-                    frac=round(ach / peak, 4), traffic=(round(traffic) if traffic else None),
-                    traffic_unit='HBM bytes per launch (rocprofv3 PMC, %s)' % os.path.relpath(PMC_FILE, ROOT),
-                    launches_per_step=launches, avg_launch_ms=round(ms / launches, 4), gflop_per_launch=round(fl / launches / 1e9, 2),
-                    share_of_gpu_time=round(ms / total_ms, 4),
-                    frac_of_rate_sustained_on_random_operands=round(ach / (SUSTAINED_RANDOM_FP32_TFLOPS if peak == PEAK_FP32_MFMA_TFLOPS else SUSTAINED_RANDOM_FP16_TFLOPS * peak / PEAK_FP16_MFMA_TFLOPS), 4))
+        kernels, roof, dom_id, total_ms = kernel_report(rec)
+        traffic = pmc_traffic(dom_id) if (args.config == 'cifar10' and B == 256 and args.dtype == 'fp32') else None   # the PMC pass is of the default workload
+        roof['traffic'] = traffic[0] if traffic else None
+        roof['traffic_unit'] = 'HBM bytes per launch (rocprofv3 PMC: FETCH_SIZE x 2 + WRITE_SIZE)'
+        roof['traffic_source'] = traffic[1] if traffic else PMC_NOTE.get('why')
         per = spec.in_channels * spec.img_resolution ** 2 * 4
         if X0_KIND in rec and ldm is None:
             # the headline solver's update: ONE ds_dpmpp_x0_step launch per evaluation.  Algorithmic bytes of the fused launch: x, F read;
@@ -553,10 +649,31 @@ def main(argv=None):
                 sync()
                 by_batch[str(b2)] = round(2 * b2 / (time.perf_counter() - t1), 2)
                 del lat2
+    others = latency = None
+    if (rank == 0 and world == 1 and not stub and not args.no_other_configs and not args.graph
+            and (args.config, args.dtype, B, args.solver, args.nfe) == ('cifar10', 'fp32', 256, 'dpmpp', 10)):
+        # the default run: the other benchmarked configurations / modes and the small-batch latencies, under the same clock
+        latency = {}
+        l8 = torch.randn(8, spec.in_channels, spec.img_resolution, spec.img_resolution, device=dev)
+        sampler_call(solvers, args.solver, net, l8, args.nfe); sync()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            sampler_call(solvers, args.solver, net, l8, args.nfe)
+        sync()
+        latency['cifar10_fp32_B8_nfe10_ms'] = round((time.perf_counter() - t1) / 5 * 1e3, 2)
+        del net, latents, l8, out
+        torch.cuda.empty_cache()
+        others = []
+        for cfg_, dt_, b_ in OTHER_CONFIGS:
+            try:
+                res, lat_ms = measure_config(cfg_, dt_, b_, args.nfe, dev, latency_batch=(1 if cfg_ == 'sd15' else None))
+                others.append(res)
+                if lat_ms is not None:
+                    latency['sd15_fp16_B1_nfe10_ms'] = lat_ms
+            except Exception as e:                                   # a failing side measurement must not take the headline line with it
+                others.append(dict(config=dict(workload=f'{cfg_} {dt_} batch {b_}'), error=f'{type(e).__name__}: {e}'))
     if rank == 0:
-        workload_name = {'cifar10': 'EDM CIFAR-10 32x32 SongUNet (55.7M params)', 'ffhq': 'EDM FFHQ-64 SongUNet (61.8M params)',
-                         'afhqv2': 'EDM AFHQv2-64 SongUNet', 'imagenet64': 'EDM ImageNet-64 DhariwalUNet (295.9M params)',
-                         'sd15': 'Stable Diffusion v1.5 64x64x4 latent U-Net (859.5M params)'}.get(args.config, args.config)
+        workload_name = WORKLOAD_NAMES.get(args.config, args.config)
         total_images = B * world * args.steps
         line = {
             'metric': 'images/sec (whole node) at NFE=%d, %s' % (args.nfe, 'EDM CIFAR-10' if args.config == 'cifar10' else workload_name.split(' (')[0]),
@@ -566,12 +683,13 @@ def main(argv=None):
                       'fp16x3': 'fp16x3 (fp32-emulated: split fp16 hi/lo operands, 3 MFMA products, fp32 accumulate) in the 3x3 convolutions, rest fp32'}[args.dtype],
             'data': 'synthetic N(0,1) latents, random-init (signal-carrying) weights',
             'config': {'workload': '%s, %s NFE=%d, batch %d/GPU' %
-                       (workload_name, 'DPM-Solver++(2M) eps-prediction, discrete rho=1, CFG 7.5 (2 U-Net images per latent)' if ldm is not None else
-                        {'dpmpp': 'DPM-Solver++(2M) logSNR', 'euler': 'Euler', 'ipndm': 'iPNDM-4', 'heun': 'Heun'}[args.solver], args.nfe, B),
+                       (workload_name, LDM_SOLVER_NAME if ldm is not None else SOLVER_NAMES[args.solver], args.nfe, B),
                        'images_per_step': B * world, 'sharding': 'independent image batches per rank, no collective',
                        'launch': 'hipGraph replay' if args.graph else 'eager'},
             'roofline': roof, 'roofline_update': roof_u, 'roofline_update_large_batch': roof_ul, 'roofline_update_large_batch_other_solver': roof_ul_other, 'kernels': kernels,
             'launch_modes': modes, 'throughput_by_batch': by_batch, 'cpu_baseline': cpu, 'multi_gpu': multi,
+            'application': (application_fraction(args.config, args.dtype, total_images / dt / world, args.nfe) if not stub and args.config in GFLOP_PER_EVAL else None),
+            'other_configs': others, 'latency': latency,
         }
         if stub:
             line['stub'] = True

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libdsamd.so')
@@ -19,7 +20,52 @@ DS_RESAMPLE_NONE, DS_RESAMPLE_DOWN, DS_RESAMPLE_UP = 0, 1, 2
 DS_GN_MAX_CHUNKS = 32
 
 
+class ConvTune(C.Structure):
+    """ds_conv_tune: per-call kernel selection overrides (include/ds_engine.h); all zero = the library's own choice."""
+    _fields_ = [('mode', C.c_int), ('variant', C.c_int), ('splits', C.c_int), ('f16dma_nb', C.c_int), ('f16dma_nw', C.c_int),
+                ('ablate', C.c_int)]
+
+
+_tune_state = threading.local()
+
+
+class tuning:
+    """``with _lib.tuning(variant=3, mode=256): ...`` -- every ConvArgs CONSTRUCTED on this thread inside the block carries these
+    ds_conv_tune overrides (benchmarks, A/B runs, tests).  The state is this thread's default for argument construction on the Python
+    side; libdsamd.so itself is stateless: the overrides travel inside each call's (or plan entry's) argument struct."""
+
+    def __init__(self, **kw):
+        bad = set(kw) - {f for f, _ in ConvTune._fields_}
+        if bad:
+            raise TypeError(f'unknown ds_conv_tune fields {sorted(bad)}')
+        self.kw = kw
+
+    def __enter__(self):
+        self.prev = getattr(_tune_state, 'kw', None)
+        _tune_state.kw = dict(self.prev or {}, **self.kw)
+        return self
+
+    def __exit__(self, *exc):
+        _tune_state.kw = self.prev
+        return False
+
+
+def current_tuning():
+    kw = dict(_ENV_TUNE)
+    kw.update(getattr(_tune_state, 'kw', None) or {})
+    return kw
+
+
+# benchmarks / A-B runs of whole programs: DS_CONV_VARIANT / DS_CONV (= tune.mode) in the environment become the default overrides
+_ENV_TUNE = {k: int(os.environ[e]) for k, e in (('variant', 'DS_CONV_VARIANT'), ('mode', 'DS_CONV')) if os.environ.get(e)}
+
+
 class ConvArgs(C.Structure):
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        for f, v in current_tuning().items():
+            setattr(self.tune, f, int(v))
+
     _fields_ = [('x0', vp), ('x1', vp), ('c0', C.c_int), ('c1', C.c_int), ('ld0', C.c_int), ('ld1', C.c_int),
                 ('n', C.c_int), ('h', C.c_int), ('w', C.c_int), ('taps', C.c_int), ('wgt', vp), ('cout', C.c_int),
                 ('bias', vp), ('cbias', vp), ('cbias_ld', C.c_int), ('cbias_rows', C.c_int), ('res', vp),
@@ -27,7 +73,7 @@ class ConvArgs(C.Structure):
                 ('norm_coefs', vp), ('norm_act', C.c_int),
                 ('e0', vp), ('e1', vp), ('ec0', C.c_int), ('ec1', C.c_int), ('eld0', C.c_int), ('eld1', C.c_int),
                 ('stride', C.c_int), ('workspace', vp), ('workspace_floats', C.c_longlong),
-                ('out_nchw', C.c_int), ('stats_out', vp), ('wgt_f16', C.c_int), ('wgt_shift', C.c_int), ('in_f16', C.c_int), ('out_f16', C.c_int), ('res_f16', C.c_int)]
+                ('out_nchw', C.c_int), ('stats_out', vp), ('wgt_f16', C.c_int), ('wgt_shift', C.c_int), ('in_f16', C.c_int), ('out_f16', C.c_int), ('res_f16', C.c_int), ('tune', ConvTune)]
 
 
 class GemmArgs(C.Structure):
@@ -63,7 +109,7 @@ class UpdateArgs(C.Structure):
     _fields_ = [('xe', vp), ('xb', vp), ('f', vp), ('raw', C.c_int), ('f_ld', C.c_int), ('hist', vp * 3),
                 ('coefs', vp), ('coef_rows', C.c_int), ('hcoefs', C.c_float * 8), ('afs', C.c_int),
                 ('sigma_data', C.c_float), ('m_out', vp), ('store_d', C.c_int), ('x_out', vp),
-                ('n', C.c_int), ('c', C.c_int), ('h', C.c_int), ('w', C.c_int)]
+                ('n', C.c_int), ('c', C.c_int), ('h', C.c_int), ('w', C.c_int), ('variant', C.c_int)]
 
 
 class AmedPredictor(C.Structure):
@@ -104,18 +150,11 @@ _SIGNATURES = {
     'ds_version': (C.c_int, []),
     'ds_error_string': (C.c_char_p, [C.c_int]),
     'ds_conv2d_nhwc': (C.c_int, [C.POINTER(ConvArgs), vp]),
-    'ds_debug_force_generic_conv': (C.c_int, [C.c_int]),
-    'ds_debug_force_splits': (C.c_int, [C.c_int]),
-    'ds_debug_conv_variant': (C.c_int, [C.c_int]),
-    'ds_debug_conv_halo2_launches': (C.c_longlong, []),
     'ds_conv_kernel_id': (C.c_int, [C.POINTER(ConvArgs)]),
     'ds_conv3x3_halo_supported': (C.c_int, [C.c_int, C.c_int]),
     'ds_conv_f16_supported': (C.c_int, [C.c_int] * 7),
     'ds_conv_f16dma_supported': (C.c_int, [C.c_int] * 6),
     'ds_gemm_f16dma_supported': (C.c_int, [C.c_longlong, C.c_int, C.c_int]),
-    'ds_debug_f16dma_nb': (C.c_int, [C.c_int]),
-    'ds_debug_f16dma_nw': (C.c_int, [C.c_int]),
-    'ds_debug_f16dma_ablate': (C.c_int, [C.c_int]),
     'ds_conv_split_supported': (C.c_int, [C.c_int] * 7),
     'ds_gemm_f16_supported': (C.c_int, [C.c_longlong, C.c_int, C.c_int]),
     'ds_gemm_nt_batched': (C.c_int, [C.POINTER(GemmArgs), vp]),
@@ -137,7 +176,6 @@ _SIGNATURES = {
     'ds_solver_update': (C.c_int, [C.POINTER(UpdateArgs), vp]),
     'ds_dpmpp_x0_step': (C.c_int, [C.POINTER(UpdateArgs), C.c_float, vp]),
     'ds_dpmpp_x0_step_in_registers': (C.c_int, [C.c_longlong]),
-    'ds_debug_dpmpp_variant': (C.c_int, [C.c_int]),
     'ds_table_select': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp]),
     'ds_dynamic_threshold': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp]),
     'ds_scale': (C.c_int, [vp, C.c_float, vp, C.c_longlong, vp]),
@@ -149,7 +187,7 @@ _SIGNATURES = {
     'ds_traj_moments': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     'ds_traj_pair_cost': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     'ds_philox_randn': (C.c_int, [vp, C.c_ulonglong, vp, C.c_int, C.c_longlong, C.c_longlong, vp]),
-    'ds_debug_philox_probe': (C.c_int, [C.c_ulonglong, C.c_ulonglong, vp, C.c_int, C.c_int, vp]),
+    'ds_philox_probe': (C.c_int, [C.c_ulonglong, C.c_ulonglong, vp, C.c_int, C.c_int, vp]),
     'ds_philox_randint': (C.c_int, [vp, C.c_ulonglong, C.c_uint, vp, C.c_int, vp]),
     'ds_channel_mean': (C.c_int, [vp, C.c_int, C.c_int, C.c_longlong, vp, vp]),
     'ds_plan_create': (C.c_int, [C.POINTER(vp)]),
@@ -186,8 +224,6 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
     _lib = lib
-    if os.environ.get('DS_CONV_VARIANT'):          # benchmarks / A-B test runs: kernel variant of the halo convolution
-        lib.ds_debug_conv_variant(int(os.environ['DS_CONV_VARIANT']))
     return lib
 
 

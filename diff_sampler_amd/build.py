@@ -25,6 +25,26 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def headers():
+    return sorted(glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(HERE, '..', 'include', '*.h')))
+
+
+def source_sha256(tu):
+    """Hash of what a translation unit of csrc/ is compiled from: its .hip source and every header of csrc/ and include/ (a superset of
+    what it includes).  bench.py ties profiler-derived numbers (profiles/*pmc*.json) to the kernel source they were measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in [os.path.join(CSRC, tu)] + headers():
+        h.update(os.path.basename(f).encode() + b'\0')
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def source_hashes():
+    return {os.path.basename(s): source_sha256(os.path.basename(s)) for s in sources()}
+
+
 def build_lib(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
@@ -33,8 +53,12 @@ def build_lib(force=False, verbose=True):
         raise RuntimeError('hipcc not found: libdsamd.so cannot be built on this machine')
     from concurrent.futures import ThreadPoolExecutor
 
+    newest_header = max([os.path.getmtime(h) for h in headers()] or [0.0])
+
     def compile_one(src):
         obj = src[:-4] + '.o'
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
+            return obj                                          # this translation unit is up to date
         cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC'] + EXTRA_FLAGS + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)

@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
     const int nextra = p.ec0 / 64;                             // appended 1x1 slabs (centre tap only)
     const int NCH = nchunks + nextra;
     const int KT = nchunks * 9 + nextra;
-    const int abl = p.coef_lds;                                 // timing ablations (ds_debug_f16dma_ablate; results are wrong when set)
+    const int abl = p.coef_lds;                                 // timing ablations (ds_conv_args.tune.ablate; results are wrong when set)
     auto halo_dma = [&](int chunk, int hbuf, auto jc) {          // DMA round j of slab `chunk` into halo buffer hbuf
         constexpr int j = decltype(jc)::value;
         if ((abl & 2) && chunk > 0) return;
@@ -257,10 +257,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
     epilogue_pipe<0, true, (NB == 1 ? 32 : 64), (NB == 3 ? 32 : (NB == 4 ? 64 : 0))>(p, accA, accB, stage, lane, m0 + wr * 64, wn0, p.out);
 }
 
-}  // namespace
-int g_f16dma_ablate = 0;        // benchmarks only: bit 0 = no weight DMA after the prologue, 1 = no halo DMA after slab 0, 2 = no epilogue,
-                                // 4 = no per-tap barrier, 5 = no fragment reads
-namespace {
+// p.t_ablate (ds_conv_args.tune.ablate), benchmarks only: bit 0 = no weight DMA after the prologue, 1 = no halo DMA after slab 0,
+// 2 = no epilogue, 4 = no per-tap barrier, 5 = no fragment reads
 
 template <int W, int NB>
 int launch_w_nb(KParams p, int n_begin, int ntiles, hipStream_t stream) {
@@ -268,7 +266,7 @@ int launch_w_nb(KParams p, int n_begin, int ntiles, hipStream_t stream) {
     p.ntiles = ntiles;
     p.n_begin = n_begin;
     p.splits = 1;
-    p.coef_lds = g_f16dma_ablate;
+    p.coef_lds = p.t_ablate;
     int smem = (int)f16dma_smem<W, NB>();
     const int epi = 8 * 32 * EPI_LD * (int)sizeof(float);
     if (smem < epi) smem = epi;
@@ -292,8 +290,7 @@ int launch_w(const KParams& p, int nb, int n_begin, int ntiles, hipStream_t stre
 
 }  // namespace
 
-int g_f16dma_nb = 0;            // benchmarks / tests: > 0 forces the column-tile width of the main launch (64 * nb columns)
-int g_f16dma_nw = 0;            // benchmarks / tests: 4 / 8 forces the wave count of gemm_f16dma_kernel (128- / 256-row tiles); 0 = by K
+// p.t_nb (ds_conv_args.tune.f16dma_nb), benchmarks / tests: > 0 forces the column-tile width of the main launch (64 * nb columns)
 
 // widest column tile the LDS holds next to two halo buffers
 static int max_nb(int W) { return (W == 16 || W == 32) ? 4 : 3; }
@@ -329,7 +326,7 @@ static int tiling(const KParams& p, int nb0, int (*out)[3], int* cost) {
 int conv3x3_f16dma_plan(const KParams& p, int (*out)[3]) {
     const int cap = max_nb(p.W);
     int cost;
-    if (g_f16dma_nb > 0) return tiling(p, g_f16dma_nb < cap ? g_f16dma_nb : cap, out, &cost);
+    if (p.t_nb > 0) return tiling(p, p.t_nb < cap ? p.t_nb : cap, out, &cost);
     int best_nb = cap, best_cost = 0x7fffffff, best_n = 99;
     for (int nb = cap; nb >= 1; --nb) {
         int tmp[4][3];

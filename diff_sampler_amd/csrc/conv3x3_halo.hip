@@ -66,13 +66,13 @@ __device__ __forceinline__ unsigned lds_addr(const float* p) {
 }
 
 
-// Kernel variants (template VAR, selected at run time by ds_debug_conv_variant; 0 = the round-1 kernel, 1 = PIPE).  The other
+// Kernel variants (template VAR, selected per call by ds_conv_args.tune.variant; 0 = the round-1 kernel, 1 = PIPE).  The other
 // bits are TIMING ABLATIONS that produce wrong results on purpose (tools/bench_conv.py --variants): 2 = no GroupNorm/SiLU
 // arithmetic in the halo writer, 4 = the halo is staged once and never again, 8 = the weight DMA is issued once and never
 // again, 16 = the epilogue stores nothing.
 constexpr int VAR_PIPE = 1, VAR_NO_NORM = 2, VAR_NO_HALO = 4, VAR_NO_DMA = 8, VAR_NO_EPI = 16;
 // Round-2 options of the 256 x 256 tile (NT = 4).  VAR_LEAN | VAR_NTEPI is the DEFAULT kernel of that tile (+1.3 % on the main
-// shapes, +0.7 ... 1.1 % on the headline, profiles/r2_conv_tile_options.txt); ds_debug_conv_variant(256) selects the plain one (A/B runs):
+// shapes, +0.7 ... 1.1 % on the headline, profiles/r2_conv_tile_options.txt); tune.variant = 256 selects the plain one (A/B runs):
 //   VAR_LEAN  the weight DMA of a tap is addressed as (uniform SGPR base of the tap and row group) + (ONE constant 32-bit per-lane
 //             offset) with the LDS destination computed on the scalar unit: the compiled loop otherwise spends 22 VALU instructions
 //             per tap on 64-bit pointer arithmetic, zero-page selects and v_readfirstlane of a wave-uniform value, and on this chip
@@ -524,20 +524,21 @@ Geo geometry(const KParams& p, int tbm, int wn = 2) {
     return g;
 }
 
-int g_tile_override = 0;       // 0 = heuristic, 128 / 256 = forced (benchmarks)
-
-int g_glds = 1;                // weight staging: 1 = LDS-DMA, 0 = through registers (A/B switch)
-int g_variant = 0;             // kernel variant of the 128-column LDS-DMA tiles (see VAR_*; benchmarks / ablations)
-int g_tail64 = 1;              // 64-column tiles for a ragged last column tile (A/B switch)
+// Per-call overrides (ds_conv_args.tune -> KParams.t_mode / t_variant; 0 = the library's choice):
+//   t_mode 128 / 256 = forced M tile, 2 = weights staged through registers instead of LDS-DMA, 4 = no 64-column tail tiles (A/B switches)
+//   t_variant        = kernel variant of the LDS-DMA tiles (see VAR_*; benchmarks / ablations)
+inline int tile_override(const KParams& p) { return (p.t_mode == 128 || p.t_mode == 256) ? p.t_mode : 0; }
+inline bool use_glds(const KParams& p) { return p.t_mode != 2; }
+inline bool use_tail64(const KParams& p) { return p.t_mode != 4; }
 
 // 256-pixel x 256-channel tiles (64 x 128 per wave, NT = 4) instead of 256 x 128: taken where the channel count reaches 256, the
 // tile lies in one image (16-, 32- or 64-column images: at most 7 halo slots per thread -- the kernel sits at 256 VGPRs), there is
 // no split-K, and the tiles still give every CU a workgroup.  Measured +4.1 ... +4.5 % on the CIFAR-10 / FFHQ 32x32 and 16x16 layers (129 -> 136 TFLOP/s
-// network average, profiles/r2_conv_wide_n.txt).  g_variant 7 switches it off (A/B runs), 6 forces it regardless of the tile count.
+// network average, profiles/r2_conv_wide_n.txt).  p.t_variant 7 switches it off (A/B runs), 6 forces it regardless of the tile count.
 bool wide_n_tiles(const KParams& p, const Geo& g) {
-    const int v = g_variant & 31;                    // bits 5.. select options of the 256 x 256 tile itself
+    const int v = p.t_variant & 31;                    // bits 5.. select options of the 256 x 256 tile itself
 #ifdef DS_CONV_ABLATIONS
-    if (g_variant & 0x10000) { if (p.splits != 1 || p.N < 256 || g.NP * 8 > 7 * 512 || g.nimg != 1) return false; return true; }
+    if (p.t_variant & 0x10000) { if (p.splits != 1 || p.N < 256 || g.NP * 8 > 7 * 512 || g.nimg != 1) return false; return true; }
 #endif
     if (v != 0 && v != 6) return false;
     if (p.splits != 1 || p.N < 256 || g.NP * 8 > 7 * 512 || g.nimg != 1 || p.nrows_b < (p.N / 256) * 256) return false;
@@ -546,9 +547,9 @@ bool wide_n_tiles(const KParams& p, const Geo& g) {
 }
 
 bool wide192_tiles(const KParams& p, const Geo& g) {
-    if ((g_variant & 31) != 0 || (g_variant & 8192)) return false;
+    if ((p.t_variant & 31) != 0 || (p.t_variant & 8192)) return false;
     if (p.splits != 1 || p.N % 192 || p.N % 256 == 0 || g.NP * 8 > 7 * 512 || g.nimg != 1 || p.nrows_b < p.N || !p.vec_ok || p.out_planar) return false;
-    return (g_variant & 16384) || (long long)((p.M + 255) / 256) * (p.N / 192) >= 256;          // the tiles still cover the 256 CUs (bit 14: forced, tests)
+    return (p.t_variant & 16384) || (long long)((p.M + 255) / 256) * (p.N / 192) >= 256;          // the tiles still cover the 256 CUs (bit 14: forced, tests)
 }
 
 template <int WM, bool GLDS, int WN, int VAR = 0, int NT = 2>
@@ -563,7 +564,7 @@ int launch_one(KParams p, const Geo& g, int n_begin, int ntiles, hipStream_t str
     // coefficient planes of a multi-image tile's images in LDS, where they fit without costing the 4-wave shape its second
     // workgroup per CU (80 KB each) or the 8-wave shape the 128 KB it may ask for; otherwise halo_store reads them from global memory
     const int coef_bytes = (p.norm && g.nimg > 1) ? g.nimg * 3 * (p.c0 + p.c1) * (int)sizeof(float) : 0;
-    p.coef_lds = coef_bytes > 0 && smem + coef_bytes <= (WM == 2 ? 80 : 128) * 1024 && !(g_variant & 512);     // 512: A/B switch
+    p.coef_lds = coef_bytes > 0 && smem + coef_bytes <= (WM == 2 ? 80 : 128) * 1024 && !(p.t_variant & 512);     // 512: A/B switch
     if (p.coef_lds) smem += coef_bytes;
     const int epi = 4 * 64 * EPI_LD * (int)sizeof(float);       // = 8 x 32 x EPI_LD for the 8-wave shape
     if (smem < epi) smem = epi;
@@ -577,7 +578,7 @@ int launch_one(KParams p, const Geo& g, int n_begin, int ntiles, hipStream_t str
 // where the whole launch is at most one workgroup per CU (with more, two 4-wave workgroups share a CU and every SIMD has its two waves
 // anyway), the float4 epilogue is legal and every one of those tiles is complete.  Variant bit 11: off (A/B runs).
 bool half_wave_tiles(const KParams& p, int n_begin, int wide) {
-    if ((g_variant & 31) != 0 || (g_variant & 2048) || !g_glds || wide < 1) return false;
+    if ((p.t_variant & 31) != 0 || (p.t_variant & 2048) || !use_glds(p) || wide < 1) return false;
     if (!p.vec_ok || p.out_planar || p.act == DS_ACT_GEGLU || n_begin + wide * BN > p.N || p.nrows_b < n_begin + wide * BN) return false;
     if (p.splits > 1 && !p.vec_part) return false;
     if ((long long)((p.M + 127) / 128) * wide * p.splits > 256) return false;
@@ -606,8 +607,8 @@ int launch_wm(KParams& p, hipStream_t stream) {
             KParams q = p;
             int rc;
 #ifdef DS_CONV_ABLATIONS
-            if (g_variant & 0x10000) {                 // timing ablations of the 256 x 256 tile (wrong results on purpose)
-                switch (g_variant & 31) {
+            if (p.t_variant & 0x10000) {                 // timing ablations of the 256 x 256 tile (wrong results on purpose)
+                switch (p.t_variant & 31) {
                     case 4: rc = launch_one<4, true, 2, 4, 4>(q, g4, 0, n256 / 256, stream); break;
                     case 16: rc = launch_one<4, true, 2, 16, 4>(q, g4, 0, n256 / 256, stream); break;
                     case 20: rc = launch_one<4, true, 2, 20, 4>(q, g4, 0, n256 / 256, stream); break;
@@ -618,7 +619,7 @@ int launch_wm(KParams& p, hipStream_t stream) {
             } else
 #endif
             {
-            if (g_variant & 256) rc = launch_one<4, true, 2, 0, 4>(q, g4, 0, n256 / 256, stream);                  // plain (A/B)
+            if (p.t_variant & 256) rc = launch_one<4, true, 2, 0, 4>(q, g4, 0, n256 / 256, stream);                  // plain (A/B)
             else rc = launch_one<4, true, 2, VAR_TILE_OPTS, 4>(q, g4, 0, n256 / 256, stream);
             if (rc) return rc;
             }
@@ -626,12 +627,12 @@ int launch_wm(KParams& p, hipStream_t stream) {
     }
     const int nrest = p.N - n256;
     const int full = nrest / BN, rem = nrest - full * BN;
-    const bool tail64 = rem > 0 && rem <= 64 && geometry(p, 64 * WM, 1).ok && g_tail64;
+    const bool tail64 = rem > 0 && rem <= 64 && geometry(p, 64 * WM, 1).ok && use_tail64(p);
     const int wide = tail64 ? full : (nrest + BN - 1) / BN;
     if (wide > 0) {
         const Geo g = geometry(p, 64 * WM, 2);
         int rc;
-        if (WM == 4 && GLDS && (g_variant & 31) == 3 && p.splits == 1 && n256 == 0 && conv3x3_halo2_applicable(p, wide, 0)) {
+        if (WM == 4 && GLDS && (p.t_variant & 31) == 3 && p.splits == 1 && n256 == 0 && conv3x3_halo2_applicable(p, wide, 0)) {
             KParams q = p;
             rc = launch_conv3x3_halo2(q, wide, 0, stream);
         } else if (WM == 2 && GLDS && half_wave_tiles(p, n256, wide)) {
@@ -640,7 +641,7 @@ int launch_wm(KParams& p, hipStream_t stream) {
         } else if constexpr (GLDS) {
             // (routing the layers that leave a SIMD with ONE wave -- 8x8 layers at the benchmark batch -- to the software-pipelined
             // VAR_PIPE kernel gains 2.8 % on those layers in isolation and nothing measurable on the network: not done)
-            switch (g_variant & 31) {
+            switch (p.t_variant & 31) {
                 case 1: rc = launch_one<WM, GLDS, 2, 1>(p, g, n256, wide, stream); break;
 #ifdef DS_CONV_ABLATIONS
                 case 2: rc = launch_one<WM, GLDS, 2, 2>(p, g, 0, wide, stream); break;
@@ -655,7 +656,7 @@ int launch_wm(KParams& p, hipStream_t stream) {
                 default:
                     // round 3: the 128-column tiles take the 256 x 256 tile's scalar-addressed weight DMA and non-temporal epilogue
                     // (every weight row of a full tile exists: rows are padded to 128); variant bit 12 switches it off (A/B runs)
-                    if (p.splits == 1 && !(g_variant & 4096) && n256 + wide * BN <= p.nrows_b)
+                    if (p.splits == 1 && !(p.t_variant & 4096) && n256 + wide * BN <= p.nrows_b)
                         rc = launch_one<WM, GLDS, 2, VAR_LEAN | VAR_NTEPI>(p, g, n256, wide, stream);
                     else
                         rc = launch_one<WM, GLDS, 2, 0>(p, g, n256, wide, stream);
@@ -678,10 +679,6 @@ int launch_wm(KParams& p, hipStream_t stream) {
 
 bool conv3x3_halo_supported(const KParams& p) { return geometry(p, 128).ok; }
 
-void conv3x3_halo_set_tile(int tile) { g_tile_override = tile; }
-void conv3x3_halo_set_glds(int on) { g_glds = on; }
-void conv3x3_halo_set_variant(int v) { g_variant = v; }
-void conv3x3_halo_set_tail64(int on) { g_tail64 = on; }
 
 // Tile shape and split-K factor of a layer: the cheaper of the two tile shapes under the cost model (igemm_common.h); the
 // 256-pixel tile gets a 3 % bonus where both fill the chip (weights shared by twice the pixels).
@@ -695,31 +692,36 @@ HaloPlan plan_halo(const KParams& p) {
     const int units = (p.c0 + p.c1 + p.ec0 + p.ec1) / BK;
     const long long mn = (long long)p.M * p.N, cap = p.part ? p.part_cap : 0;
     double c128 = 0.0, c256 = 0.0;
-    const int s128 = choose_splits((long long)((p.M + 127) / 128) * nt, false, units, 9, cap, mn, &c128);
+    const int s128 = choose_splits((long long)((p.M + 127) / 128) * nt, false, units, 9, cap, mn, &c128, p.t_splits);
     hp.tile = 128; hp.splits = s128;
     const long long blocks256 = (long long)((p.M + 255) / 256) * nt;
     // the 8-wave shape only where its tiles alone cover the 256 CUs twice (below that the model is optimistic about it)
-    if (g256.ok && g_tile_override != 128 && (blocks256 >= 512 || g_tile_override == 256)) {
-        const int s256 = choose_splits(blocks256, true, units, 9, cap, mn, &c256);
-        if (g_tile_override == 256 || 0.97 * c256 < c128) { hp.tile = 256; hp.splits = s256; }
+    if (g256.ok && tile_override(p) != 128 && (blocks256 >= 512 || tile_override(p) == 256)) {
+        const int s256 = choose_splits(blocks256, true, units, 9, cap, mn, &c256, p.t_splits);
+        if (tile_override(p) == 256 || 0.97 * c256 < c128) { hp.tile = 256; hp.splits = s256; }
     }
-    if (((g_variant & 31) == 6 || (g_variant & 16384)) && hp.tile == 256) hp.splits = 1;      // forced wide tiles (tests at small sizes): no split-K
+    if (((p.t_variant & 31) == 6 || (p.t_variant & 16384)) && hp.tile == 256) hp.splits = 1;      // forced wide tiles (tests at small sizes): no split-K
     return hp;
 }
 
 // 0 = unsupported, 128 / 256 = M tile of the 128-column kernels, 2565 = the 256 x 256-tile kernel, 1284 = 128-pixel tiles on 8 half-size waves
 int conv3x3_halo_choice(const KParams& p) {
     const HaloPlan hp = plan_halo(p);
-    if (hp.tile == 128 && g_glds) {
+    if (hp.tile == 128 && use_glds(p)) {
         KParams q = p;
         q.splits = hp.splits;
         const int full = p.N / BN, rem = p.N - full * BN;
-        const bool tail64 = rem > 0 && rem <= 64 && geometry(p, 128, 1).ok && g_tail64;
+        const bool tail64 = rem > 0 && rem <= 64 && geometry(p, 128, 1).ok && use_tail64(p);
         if (half_wave_tiles(q, 0, tail64 ? full : (p.N + BN - 1) / BN)) return 1284;
     }
-    if (hp.tile == 256 && g_glds) {
+    if (hp.tile == 256 && use_glds(p)) {
         KParams q = p;
         q.splits = hp.splits;
+        if ((p.t_variant & 31) == 3 && hp.splits == 1) {          // tune.variant 3: the second-generation 256 x 128 kernel where it applies
+            const int full = p.N / BN, rem = p.N - full * BN;
+            const bool tail64 = rem > 0 && rem <= 64 && geometry(p, 256, 1).ok && use_tail64(p);
+            if (conv3x3_halo2_applicable(q, tail64 ? full : (p.N + BN - 1) / BN, 0)) return 2560;
+        }
         if (wide192_tiles(q, geometry(p, 256, 2))) return 2568;        // 192-column tiles for every column (ADM channel counts)
         if (wide_n_tiles(q, geometry(p, 256, 2))) return 2565;         // (its first N / 256 column tiles; a remainder stays on 128 / 64 columns)
     }
@@ -729,8 +731,8 @@ int conv3x3_halo_choice(const KParams& p) {
 int launch_conv3x3_halo(KParams& p, hipStream_t stream) {
     const HaloPlan hp = plan_halo(p);
     p.splits = hp.splits;
-    if (hp.tile == 256) return g_glds ? launch_wm<4, true>(p, stream) : launch_wm<4, false>(p, stream);
-    return g_glds ? launch_wm<2, true>(p, stream) : launch_wm<2, false>(p, stream);
+    if (hp.tile == 256) return use_glds(p) ? launch_wm<4, true>(p, stream) : launch_wm<4, false>(p, stream);
+    return use_glds(p) ? launch_wm<2, true>(p, stream) : launch_wm<2, false>(p, stream);
 }
 
 }  // namespace igemm

@@ -522,8 +522,6 @@ bool conv3x3_halo2_applicable(const KParams& p, int wide, int mode) {
     return true;
 }
 
-long long g_halo2_launches = 0;     // how many launches went to this kernel (tests assert the routing)
-
 template <int MODE>
 static int launch_mode(KParams& p, int wide, hipStream_t stream) {
     switch (p.W) {
@@ -536,7 +534,6 @@ static int launch_mode(KParams& p, int wide, hipStream_t stream) {
 
 // mode: 0 = fp32 operands, 1 = fp16 operands (64-channel slabs), 2 = split fp16 hi/lo operands (fp32-emulated, 32-channel slabs)
 int launch_conv3x3_halo2(KParams& p, int wide, int mode, hipStream_t stream) {
-    ++g_halo2_launches;
     if (mode == 1) return launch_mode<1>(p, wide, stream);
     if (mode == 2) return launch_mode<2>(p, wide, stream);
     return launch_mode<0>(p, wide, stream);

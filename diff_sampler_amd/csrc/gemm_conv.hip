@@ -206,7 +206,7 @@ int launch(KParams& p, int batch, hipStream_t stream) {
     p.ntiles = (p.N + BN - 1) / BN;
     dim3 grid;
     if (MODE == 0) {
-        p.splits = choose_splits((long long)p.mtiles * p.ntiles, false, p.K / BK, 1, p.part ? p.part_cap : 0, (long long)p.M * p.N);
+        p.splits = choose_splits((long long)p.mtiles * p.ntiles, false, p.K / BK, 1, p.part ? p.part_cap : 0, (long long)p.M * p.N, nullptr, p.t_splits);
         grid = dim3(grid_1d(p.mtiles, p.ntiles), p.splits, 1);
     } else {
         p.splits = 1;
@@ -227,12 +227,7 @@ bool vec_epilogue_ok(const KParams& p) {
     return true;
 }
 
-int g_force_generic = 0;
-
 }  // namespace
-
-int g_force_splits = 0;
-int g_use_dma8 = 1;
 
 namespace {
 // Column statistics of a finished output tensor in the epilogue's partial format (split-K layers: their epilogue runs in
@@ -272,27 +267,10 @@ int launch_splitk_reduce(const KParams& p, hipStream_t stream) {
 
 using namespace igemm;
 
-// Debug/benchmark switch: 1 = route 3x3 convolutions through the generic gather kernel instead of the halo kernel.
-// v = 128 / 256 keeps the halo kernel but forces its M tile; v = 0 restores the defaults.
-extern "C" int ds_debug_force_generic_conv(int v) {
-    g_force_generic = (v == 1);
-    conv3x3_halo_set_tile((v == 128 || v == 256) ? v : 0);
-    conv3x3_halo_set_glds(v == 2 ? 0 : 1);           // v = 2: halo kernel with register-staged weights
-    conv3x3_halo_set_tail64(v == 4 ? 0 : 1);
-    g_use_dma8 = (v == 6) ? 0 : 1;                   // v = 6: no 8-wave DMA kernel for 1x1 / Linear layers (A/B measurements)         // v = 4: no 64-column tail tiles (A/B measurements)
-    return DS_OK;
-}
-
-extern "C" int ds_debug_conv_variant(int v) {
-    conv3x3_halo_set_variant(v);
-    return DS_OK;
-}
-
-extern "C" long long ds_debug_conv_halo2_launches(void) { return g_halo2_launches; }
-
-extern "C" int ds_debug_force_splits(int s) {
-    g_force_splits = s > 0 ? s : 0;
-    return DS_OK;
+// ds_conv_args.tune -> KParams: per-call kernel selection overrides (include/ds_engine.h); the library keeps no selection state.
+static void set_tune(KParams& p, const ds_conv_args* a) {
+    p.t_mode = a->tune.mode; p.t_variant = a->tune.variant; p.t_splits = a->tune.splits > 0 ? a->tune.splits : 0;
+    p.t_nb = a->tune.f16dma_nb; p.t_nw = a->tune.f16dma_nw; p.t_ablate = a->tune.ablate;
 }
 
 extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
@@ -314,6 +292,7 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     const long long M = (long long)a->n * a->h * a->w;
     if (M > 0x7fffffffLL - BM) return DS_E_SHAPE;
     KParams p{};
+    set_tune(p, a);
     p.a0 = a->x0; p.a1 = a->x1; p.c0 = a->c0; p.c1 = a->c1; p.lda0 = a->ld0; p.lda1 = a->ld1;
     p.H = a->h; p.W = a->w; p.HW = a->h * a->w; p.taps = a->taps;
     const int stride = a->stride ? a->stride : 1;
@@ -386,15 +365,17 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
         if (!conv3x3_halo2_applicable(p, wide, a->wgt_f16)) return DS_E_SHAPE;
         return launch_conv3x3_halo2(p, wide, a->wgt_f16, (hipStream_t)stream);
     }
-    if (!g_force_generic && stride == 1 && conv3x3_halo_supported(p)) return launch_conv3x3_halo(p, (hipStream_t)stream);
+    const bool generic = p.t_mode == 1;                    // tune.mode 1: the generic gather kernel (A/B runs, cross-checks)
+    if (!generic && stride == 1 && conv3x3_halo_supported(p)) return launch_conv3x3_halo(p, (hipStream_t)stream);
     if (p.norm) return DS_E_SHAPE;           // fused input normalisation exists only in the halo kernel
-    if (!g_force_generic && g_use_dma8 && gemm_dma8_applicable(p)) return launch_gemm_dma8(p, (hipStream_t)stream);
+    if (!generic && p.t_mode != 6 && gemm_dma8_applicable(p)) return launch_gemm_dma8(p, (hipStream_t)stream);     // mode 6: no 8-wave DMA kernel
     return launch<0>(p, 1, (hipStream_t)stream);
 }
 
 extern "C" int ds_conv_kernel_id(const ds_conv_args* a) {
     if (!a) return DS_E_ARG;
     KParams p{};
+    set_tune(p, a);
     p.taps = a->taps; p.H = a->h; p.W = a->w; p.HW = a->h * a->w; p.M = a->n * a->h * a->w; p.N = a->cout;
     p.c0 = a->c0; p.c1 = a->c1; p.ec0 = a->ec0; p.ec1 = a->ec1;
     if (a->workspace && a->workspace_floats > 0 && ds_aligned16(a->workspace) && a->act != DS_ACT_GEGLU) {
@@ -408,8 +389,8 @@ extern "C" int ds_conv_kernel_id(const ds_conv_args* a) {
     p.nrows_b = ((a->cout + BN - 1) / BN) * BN;                                     // weights are row-padded, as in ds_conv2d_nhwc
     if (a->wgt_f16 == 1 && a->in_f16) return a->taps == 1 ? 2567 : 2566;
     if (a->wgt_f16) return a->wgt_f16 == 2 ? 2563 : (a->taps == 1 ? 2564 : 2562);
-    if (g_force_generic) return 0;
-    if (a->taps != 9 || a->stride > 1) return (g_use_dma8 && gemm_dma8_applicable(p)) ? 2561 : 0;
+    if (p.t_mode == 1) return 0;
+    if (a->taps != 9 || a->stride > 1) return (p.t_mode != 6 && gemm_dma8_applicable(p)) ? 2561 : 0;
     return conv3x3_halo_choice(p);
 }
 
@@ -433,9 +414,6 @@ extern "C" int ds_gemm_f16dma_supported(long long rows, int k, int cout) {
     p.taps = 1; p.stride = 1; p.M = (int)rows; p.N = cout; p.K = k; p.c0 = k; p.vec_ok = 1; p.nrows_b = ((cout + BN - 1) / BN) * BN;
     return gemm_f16dma_applicable(p) ? 1 : 0;
 }
-extern "C" int ds_debug_f16dma_nb(int nb) { const int o = g_f16dma_nb; g_f16dma_nb = nb; return o; }
-extern "C" int ds_debug_f16dma_nw(int nw) { const int o = g_f16dma_nw; g_f16dma_nw = nw; return o; }
-extern "C" int ds_debug_f16dma_ablate(int mask) { const int o = g_f16dma_ablate; g_f16dma_ablate = mask; return o; }
 extern "C" int ds_gemm_f16_supported(long long rows, int c0, int c1) {
     KParams p{};
     if (rows > 0x7fffffffLL) return 0;

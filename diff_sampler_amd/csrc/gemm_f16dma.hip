@@ -150,7 +150,7 @@ int launch_nb(KParams p, int n_begin, int ntiles, hipStream_t stream) {
     p.ntiles = ntiles;
     p.n_begin = n_begin;
     p.splits = 1;
-    p.coef_lds = g_f16dma_ablate;
+    p.coef_lds = p.t_ablate;
     int smem = (int)gemm16_smem<NB, NW>();
     const int epi = NW * 32 * EPI_LD * (int)sizeof(float);
     if (smem < epi) smem = epi;
@@ -171,12 +171,12 @@ bool gemm_f16dma_applicable(const KParams& p) {
 // Column tiling as in conv3x3_f16dma.hip (cost 1 + nb per round of resident workgroups); the GEGLU epilogue pairs 32 value columns with
 // their 32 gate columns inside a 64-column half of a wave tile, so it takes even widths only.  Projections with K <= 2 560 and N <= 1 280
 // take the four-wave, 128-row variant (two workgroups per CU, NB <= 3): 5 - 10 % faster there, slower on wide outputs (A/B per shape in
-// profiles/r3_gemm_f16dma_epilogue.txt); g_f16dma_nw (benchmarks) forces 4 or 8.
+// profiles/r3_gemm_f16dma_epilogue.txt); ds_conv_args.tune.f16dma_nw (benchmarks) forces 4 or 8.
 int launch_gemm_f16dma(KParams& p, hipStream_t stream) {
     const bool geglu = p.act == DS_ACT_GEGLU;
     if (geglu && (p.N % 128)) return DS_E_SHAPE;
     int nw = (p.K <= 2560 && p.N <= 1280) ? 4 : 8;
-    if (g_f16dma_nw == 4 || g_f16dma_nw == 8) nw = g_f16dma_nw;
+    if (p.t_nw == 4 || p.t_nw == 8) nw = p.t_nw;
     const int mtiles = (p.M + nw * 32 - 1) / (nw * 32), slots = nw == 4 ? 512 : 256, max_nb = nw == 4 ? 3 : 4;
     auto tiling = [&](int nb0, int (*out)[3], int* cost) {
         int n = 0, col = 0, c = 0;
@@ -194,7 +194,7 @@ int launch_gemm_f16dma(KParams& p, hipStream_t stream) {
         const int n = tiling(nb, tmp, &cost);
         if (cost < best_cost || (cost == best_cost && n < best_n)) { best_cost = cost; best_n = n; best_nb = nb; }
     }
-    if (g_f16dma_nb > 0 && !(geglu && (g_f16dma_nb & 1))) best_nb = g_f16dma_nb < max_nb ? g_f16dma_nb : max_nb;
+    if (p.t_nb > 0 && !(geglu && (p.t_nb & 1))) best_nb = p.t_nb < max_nb ? p.t_nb : max_nb;
     int plan[4][3];
     const int n = tiling(best_nb, plan, &cost);
     for (int i = 0; i < n; ++i) {

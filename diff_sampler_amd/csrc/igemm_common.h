@@ -45,6 +45,9 @@ struct KParams {
     // split-K (small-M layers): blockIdx.y = split; each split contracts a contiguous range of K slabs / tiles and writes
     // its raw partial tile to part[split][M][N]; splitk_reduce_kernel sums them and applies the epilogue
     int splits; float* part; int vec_part; long long part_cap;     // part_cap: workspace capacity in floats (host side only)
+    // per-call kernel selection overrides (ds_conv_args.tune, all 0 = the library's own choice; host side only).  There is no process-wide
+    // selection state: two threads / streams may run layers with different overrides at the same time.
+    int t_mode, t_variant, t_splits, t_nb, t_nw, t_ablate;
 };
 
 // Fused epilogue of one wave's 64x64 accumulator tile (2x2 MFMA 32x32 tiles).
@@ -462,7 +465,7 @@ __device__ __forceinline__ void epilogue_pipe(const KParams& p, const f32x16 (&a
     const int colA = wn0 + (lane & (WA / 8 - 1)) * 8;
     const int colB = wn0 + WA + (lane & (WBB / 8 - 1)) * 8;
     EpiRows e0, e1;
-    if (p.res && p.res_f16 && !(p.coef_lds & 1024)) {             // the fp16 residual stream: raw rows, requested early (see epi_block); bit 10 of ds_debug_f16dma_ablate = A/B switch
+    if (p.res && p.res_f16 && !(p.coef_lds & 1024)) {             // the fp16 residual stream: raw rows, requested early (see epi_block); bit 10 of ds_conv_args.tune.ablate = A/B switch
         EpiRes16 a0, a1, b0, b1;
         epi_request_res16<WA>(p, wm0, colA, lane, a0);
         epi_request_res16<WA>(p, wm0 + 32, colA, lane, a1);
@@ -530,10 +533,9 @@ inline double layer_cost_us(long long blocks, bool big_tile, int ktiles, int s, 
     if (s > 1) t += 8.0 + (double)s * (double)mn * 8.0 / 2.0e6;
     return t;
 }
-extern int g_force_splits;      // benchmarks: > 0 overrides the heuristic (ds_debug_force_splits)
 // Best split count for a layer of `blocks` tiles whose K loop has `units` splittable units of `tiles_per_unit` K tiles.
 inline int choose_splits(long long blocks, bool big_tile, int units, int tiles_per_unit, long long part_capacity_floats,
-                         long long mn, double* cost_out = nullptr) {
+                         long long mn, double* cost_out = nullptr, int forced = 0) {     // forced > 0: ds_conv_args.tune.splits
     const int ktiles = units * tiles_per_unit;
     double best_c = layer_cost_us(blocks, big_tile, ktiles, 1, mn);
     int best = 1;
@@ -541,8 +543,8 @@ inline int choose_splits(long long blocks, bool big_tile, int units, int tiles_p
     if (smax > 16) smax = 16;
     if (mn > 0 && smax * mn > part_capacity_floats) smax = part_capacity_floats / mn;
     if (units >= 4 && mn > 0) {
-        if (g_force_splits > 0) {
-            best = (int)(g_force_splits < smax ? g_force_splits : smax);
+        if (forced > 0) {
+            best = (int)(forced < smax ? forced : smax);
             if (best < 1) best = 1;
             best_c = layer_cost_us(blocks, big_tile, ((units + best - 1) / best) * tiles_per_unit * best, best, mn);
         } else {
@@ -560,26 +562,19 @@ int launch_splitk_reduce(const KParams& p, hipStream_t stream);   // gemm_conv.h
 // gemm_dma8.hip
 bool gemm_dma8_applicable(const KParams& p);
 int launch_gemm_dma8(KParams& p, hipStream_t stream);
-extern int g_use_dma8;
 
 // conv3x3_halo.hip
 bool conv3x3_halo_supported(const KParams& p);
 int launch_conv3x3_halo(KParams& p, hipStream_t stream);
 int conv3x3_halo_choice(const KParams& p);   // 0 / 128 / 256: which halo tile shape the launcher picks
-void conv3x3_halo_set_tile(int tile);     // 0 = heuristic, 128 / 256 = forced M tile (benchmarks)
-void conv3x3_halo_set_glds(int on);       // weight staging by LDS-DMA (default) or through registers
-void conv3x3_halo_set_variant(int v);     // kernel variant of the 128-column LDS-DMA tiles (conv3x3_halo.hip: VAR_*)
-void conv3x3_halo_set_tail64(int on);     // 64-column tiles for the ragged last column tile (default on)
 
 // conv3x3_halo2.hip: second-generation 256 x 128 tile (static tap schedule, double halo buffer)
 bool conv3x3_halo2_applicable(const KParams& p, int wide, int mode);   // mode 0 fp32 / 1 fp16 / 2 split-fp16
 int launch_conv3x3_halo2(KParams& p, int wide, int mode, hipStream_t stream);
-extern long long g_halo2_launches;
 
 // conv3x3_f16dma.hip: 3x3 on fp16 activations, both operands by LDS-DMA, 256-pixel x 64/128/192/256-channel tiles
 bool conv3x3_f16dma_applicable(const KParams& p);
 int launch_conv3x3_f16dma(KParams& p, hipStream_t stream);
-extern int g_f16dma_nb, g_f16dma_nw, g_f16dma_ablate;
 
 // gemm_f16dma.hip: 1x1 / Linear on fp16 activations (both operands by LDS-DMA)
 bool gemm_f16dma_applicable(const KParams& p);

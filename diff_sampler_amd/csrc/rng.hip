@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) philox_probe_kernel(unsigned long long se
 
 }  // namespace
 
-extern "C" int ds_debug_philox_probe(unsigned long long seed, unsigned long long offset, float* out, int n, int variant, void* stream) {
+extern "C" int ds_philox_probe(unsigned long long seed, unsigned long long offset, float* out, int n, int variant, void* stream) {
     if (!out || n < 1 || variant < 0 || variant >= 96) return DS_E_ARG;
     hipLaunchKernelGGL(philox_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, offset, out, n, variant);
     DS_CHECK_LAUNCH();

@@ -555,8 +555,6 @@ extern "C" int ds_dynamic_threshold(const float* x0, float* out, int n, int per,
     return DS_OK;
 }
 
-static int g_dpmpp_variant = 0;      // 0 = register kernel where the sample size has one, 1 = always the LDS kernel (tests compare the two)
-extern "C" int ds_debug_dpmpp_variant(int v) { const int o = g_dpmpp_variant; g_dpmpp_variant = v; return o; }
 
 // 1 when ds_dpmpp_x0_step runs a sample of `per` values on the register-resident kernel (given 16-B aligned tensors)
 extern "C" int ds_dpmpp_x0_step_in_registers(long long per) {
@@ -574,7 +572,7 @@ extern "C" int ds_dpmpp_x0_step(const ds_update_args* a, float p, void* stream) 
     bool al = ds_aligned16(a->xe) && ds_aligned16(a->xb) && (a->afs || ds_aligned16(a->f)) && (!a->x_out || ds_aligned16(a->x_out)) &&
               (!a->m_out || ds_aligned16(a->m_out)) && !a->hist[2];
     for (int i = 0; i < 2; ++i) if (a->hist[i] && !ds_aligned16(a->hist[i])) al = false;
-    if (g_dpmpp_variant == 0 && al && ds_dpmpp_x0_step_in_registers(per)) {
+    if (a->variant == 0 && al && ds_dpmpp_x0_step_in_registers(per)) {
         const dim3 grid(a->n);
         if (per == 64 * 12) hipLaunchKernelGGL((dpmpp_x0_step_reg_kernel<64, 12>), grid, dim3(64), 0, (hipStream_t)stream, *a, p);
         else if (per == 256 * 12) hipLaunchKernelGGL((dpmpp_x0_step_reg_kernel<256, 12>), grid, dim3(256), 0, (hipStream_t)stream, *a, p);

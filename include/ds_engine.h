@@ -58,6 +58,29 @@ const char* ds_error_string(int code);
  * Constraints: c0 % 32 == 0, c1 % 32 == 0, all leading dimensions % 4 == 0, pointers 16-byte aligned,
  * W has ceil(cout/128)*128 rows (zero padded).
  */
+typedef struct ds_conv_tune {
+    /* 1 = generic gather kernel instead of the LDS-halo / LDS-DMA kernels (both exact fp32: cross-check), 128 / 256 = forced M tile of
+     * the halo kernel, 2 = halo kernel with register-staged weights, 4 = no 64-column tail tiles, 6 = no 8-wave DMA kernel for 1x1 /
+     * Linear layers. */
+    int mode;
+    /* Kernel variant of the LDS-halo 3x3 convolution.  Low five bits: 0 = default, 1 = software-pipelined tap loop of the 128-column
+     * tiles, 3 = second-generation kernel (conv3x3_halo2.hip) where it applies, 6 / 7 = 256 x 256 tiles forced (tests at small sizes)
+     * / switched off, other values = timing ablations compiled only with -DDS_CONV_ABLATIONS (wrong results on purpose; + 0x10000:
+     * ablations of the 256 x 256 tile).  Bit 8 (256): the 256 x 256 tile's plain kernel instead of its default (scalar-addressed weight
+     * DMA + non-temporal epilogue); bit 9 (512): multi-image tiles read their GroupNorm coefficient planes from global memory instead of
+     * LDS; bit 11 (2048): the four-wave 128 x 128 tile also where the default is eight half-size waves; bit 12 (4096): the 128-column
+     * tiles without the scalar-addressed weight DMA / non-temporal epilogue; bit 13 (8192): no 256 x 192 tiles for the 192-multiples
+     * (ADM channel counts); bit 14 (16384): force them regardless of the tile count (tests). */
+    int variant;
+    int splits;        /* > 0: split-K factor of a convolution that has a workspace (clamped to what the layer allows) */
+    int f16dma_nb;     /* fp16-activation kernels: column-tile width 64 * nb, nb = 1..4 */
+    int f16dma_nw;     /* fp16-activation GEMM: 4 / 8 = 128- / 256-row variant */
+    /* fp16-activation kernels, benchmarks only (results are WRONG when bits 0 - 5 are set): bit 0: no weight DMA after the prologue,
+     * bit 1: no halo DMA after the first slab, bit 2: no epilogue, bit 4: no per-tap barrier, bit 5: no LDS fragment reads; bit 10
+     * (results stay correct): fp16 residual rows requested one group ahead instead of early (profiles/r3_gemm_f16dma_epilogue.txt). */
+    int ablate;
+} ds_conv_tune;
+
 typedef struct ds_conv_args {
     const float* x0; const float* x1;      /* sources; x1 may be NULL when c1 == 0                               */
     int c0, c1;                            /* channels taken from each source                                   */
@@ -127,13 +150,17 @@ typedef struct ds_conv_args {
     int out_f16;
     /* 1 (with in_f16): `res` is an fp16 tensor [M][res_ld halfs] (res_ld % 8 == 0, 16-byte aligned) -- the fp16 residual stream; added in fp32. */
     int res_f16;
+    /* Per-call kernel selection overrides for benchmarks, A/B measurements and tests; all zero = the library's own choice (what the
+     * engines pass).  They travel with the call (and with a ds_plan entry): the library keeps NO process-wide selection state, so two
+     * threads / streams can run layers under different overrides at the same time (tests/test_hip_kernels.py: two-thread test). */
+    ds_conv_tune tune;
 } ds_conv_args;
 
 int ds_conv2d_nhwc(const ds_conv_args* a, void* stream);
 
 /* Which kernel ds_conv2d_nhwc dispatches this call to: 0 = generic gather kernel (igemm_f32_kernel<0>), 128 / 256 =
  * LDS-halo kernel with that M tile (conv3x3_halo_kernel<2> / <4>), 2561 = 8-wave LDS-DMA 1x1 / Linear kernel
- * (gemm_dma8_kernel), 2562 = fp16-operand halo kernel (conv3x3_halo2_kernel<W, 1>), 2563 = split-fp16 (fp32-emulated) halo kernel
+ * (gemm_dma8_kernel), 2562 = fp16-operand halo kernel (conv3x3_halo2_kernel<W, 1>), 2560 = the same kernel on fp32 operands (tune.variant 3), 2563 = split-fp16 (fp32-emulated) halo kernel
  * (conv3x3_halo2_kernel<W, 2>), 2564 = fp16-operand 1x1 / Linear kernel (gemm_f16_kernel), 2565 = LDS-halo kernel <4> with
  * 256-pixel x 256-channel tiles (64 x 128 per wave; channel counts that are multiples of 256 on 16-, 32- and 64-column images), 1284 =
  * LDS-halo kernel with 128-pixel tiles on eight waves of 64 x 32 (layers with at most one tile per CU).  Used by bench.py to
@@ -151,14 +178,6 @@ int ds_conv_f16_supported(int n, int h, int w, int c0, int c1, int ec0, int ec1)
 int ds_conv_f16dma_supported(int n, int h, int w, int c0, int ec0, int cout);
 /* 1 when a 1x1 / Linear layer [rows][k] -> [rows][cout] runs on the fp16-activation GEMM (in_f16 with taps == 1, csrc/gemm_f16dma.hip). */
 int ds_gemm_f16dma_supported(long long rows, int k, int cout);
-/* benchmarks / tests: force the column-tile width (64 * nb columns, nb = 1..4; 0 = cost model) of the fp16-activation kernel; returns the previous value */
-int ds_debug_f16dma_nb(int nb);
-int ds_debug_f16dma_nw(int nw);   /* benchmarks / tests: 4 / 8 forces the 128- / 256-row variant of the fp16-activation GEMM, 0 = by K (returns the old value) */
-/* benchmarks only (results are WRONG when bits 0 - 5 are set): timing ablations of the fp16-activation convolution -- bit 0: no weight
- * DMA after the prologue, bit 1: no halo DMA after the first slab, bit 2: no epilogue, bit 4: no per-tap barrier, bit 5: no LDS fragment
- * reads; bit 10 (convolution and GEMM; results stay correct): fp16 residual rows requested one group ahead instead of early -- the A/B
- * switch of profiles/r3_gemm_f16dma_epilogue.txt; returns the previous mask */
-int ds_debug_f16dma_ablate(int mask);
 
 /* 1x1 convolution / Linear with fp16 operands (wgt_f16 == 1 and taps == 1: `wgt` = [cout_pad][K] halfs in plain K order; the fp32
  * input rows are rounded to fp16 while they are staged): 1 if rows % 256 == 0 and every source is a multiple of 64 channels. */
@@ -175,35 +194,14 @@ int ds_conv_split_supported(int n, int h, int w, int c0, int c1, int ec0, int ec
 int ds_philox_randn(const unsigned long long* seeds, unsigned long long offset, float* out, int batch, long long n,
                     long long threads_total, void* stream);
 
-/* Diagnostic (tools/probe_rng.py): element i = first Box-Muller output of Philox (seed, subsequence i, offset) with a selectable
- * build of log / sqrt / sin (variant in [0, 96)), to identify which one the installed torch's randn was compiled with. */
-int ds_debug_philox_probe(unsigned long long seed, unsigned long long offset, float* out, int n, int variant, void* stream);
+/* Diagnostic, stateless (tools/probe_rng.py): element i = first Box-Muller output of Philox (seed, subsequence i, offset) with a
+ * selectable build of log / sqrt / sin (variant in [0, 96)), to identify which one the installed torch's randn was compiled with. */
+int ds_philox_probe(unsigned long long seed, unsigned long long offset, float* out, int n, int variant, void* stream);
 
 /* out[b] = `torch.randint(range, size=[], generator=g_b)` at Philox offset `offset` (sample.py:283: class labels); range < 2**32;
  * the offset then advances by 4. */
 int ds_philox_randint(const unsigned long long* seeds, unsigned long long offset, unsigned int range, int* out, int batch, void* stream);
 
-/* Benchmark/debug switch: v != 0 routes 3x3 convolutions through the generic gather kernel instead of the
- * LDS-halo kernel (both are exact fp32; used for A/B measurements and as a cross-check in the tests). */
-int ds_debug_force_generic_conv(int v);
-
-/* Benchmark switch: s > 0 forces the split-K factor of every convolution that has a workspace (clamped to what the layer
- * allows); 0 restores the heuristic. */
-int ds_debug_force_splits(int s);
-
-/* Benchmark switch: kernel variant of the LDS-halo 3x3 convolution.  Low five bits: 0 = default (set by the library),
- * 1 = software-pipelined tap loop of the 128-column tiles (LDS fragment reads of K step g+1 in flight under the MFMAs of step g),
- * 3 = second-generation kernel (conv3x3_halo2.hip: static tap schedule, double halo buffer) where it applies, 6 / 7 = 256 x 256
- * tiles forced (tests at small sizes) / switched off, other values = timing ablations compiled only with -DDS_CONV_ABLATIONS (they
- * compute wrong results on purpose; + 0x10000: ablations of the 256 x 256 tile).  Bit 8 (256): the 256 x 256 tile's plain kernel
- * instead of its default (scalar-addressed weight DMA + non-temporal epilogue); bit 9 (512): tiles of several images read their
- * GroupNorm coefficient planes from global memory instead of LDS; bit 11 (2048): the four-wave 128 x 128 tile also where the default
- * is eight half-size waves; bit 12 (4096): the 128-column tiles without the scalar-addressed weight DMA / non-temporal epilogue; bit 13
- * (8192): no 256 x 192 tiles for the 192-multiples (ADM channel counts); bit 14 (16384): force them regardless of the tile count (tests). */
-int ds_debug_conv_variant(int v);
-
-/* Number of convolution launches routed to the second-generation 256 x 128 halo kernel so far (tests assert the routing). */
-long long ds_debug_conv_halo2_launches(void);
 
 /* Batched C[z] = act(alpha * A[z] * B[z]^T + rowbias + colbias) on the same MFMA core ("NT": both operands have k
  * contiguous).  Used for attention: S = Q K^T / sqrt(C) and O = P V (networks_edm.py:108, :176) and the transposed
@@ -369,6 +367,7 @@ typedef struct ds_update_args {
     int store_d;
     float* x_out;
     int n, c, h, w;
+    int variant;                           /* ds_dpmpp_x0_step only: 0 = the library's choice, 1 = always the LDS kernel (tests compare the two) */
 } ds_update_args;
 
 int ds_solver_update(const ds_update_args* a, void* stream);
@@ -381,11 +380,10 @@ int ds_solver_update(const ds_update_args* a, void* stream);
  * c * h * w <= ~38 000 elements per sample (LDS); f_ld must be 0 (channel-planar F).
  * Samples of 3x32x32, 3x64x64, 4x64x64 (and 3x16x16) values with 16-B aligned tensors and at most two history tensors run on the
  * register-resident kernel (every operand touched once: 3-4 R + 2 W passes, HBM-bound from a few thousand images per launch);
- * ds_dpmpp_x0_step_in_registers(c*h*w) tells which, ds_debug_dpmpp_variant(1) forces the LDS kernel (returns the previous setting).
+ * ds_dpmpp_x0_step_in_registers(c*h*w) tells which, ds_update_args.variant = 1 forces the LDS kernel.
  * Both kernels return the exact order statistics, so their results are bit-identical. */
 int ds_dpmpp_x0_step(const ds_update_args* a, float p, void* stream);
 int ds_dpmpp_x0_step_in_registers(long long per_sample);
-int ds_debug_dpmpp_variant(int variant);
 
 /* dst[0..row_floats) = table[(*step) * row_floats ...]; then optionally (*step)++ when advance != 0.  The only
  * per-step state of a captured sampler step: every kernel of the step reads its scalars (sigma, coefficients) from

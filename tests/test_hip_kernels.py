@@ -101,12 +101,9 @@ def test_conv2d_nhwc_matches_aten(case, force, ws):
     biasd, cbd, resd = bias.to(dev), cb.to(dev), _nhwc(res).to(dev)
     a.bias, a.cbias, a.res = biasd.data_ptr(), cbd.data_ptr(), resd.data_ptr()
     import ctypes as C
-    lib.ds_debug_force_generic_conv(force)
-    try:
-        rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
-        torch.cuda.synchronize()
-    finally:
-        lib.ds_debug_force_generic_conv(0)
+    a.tune.mode = force                    # ds_conv_tune: 1 = generic gather kernel, 128 / 256 = forced halo M tile (per call, no global state)
+    rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
+    torch.cuda.synchronize()
     assert rc == 0, lib.ds_error_string(rc)
     got = out[:, :cout].cpu()
     assert _rel(got, _nhwc(ref)) < TOL
@@ -468,19 +465,13 @@ def _run_halo_case(case, variant, workspace=False, tile=256, want_kid=None):
     if workspace:                          # split-K scratch
         scratch = torch.full((20 << 20,), float('nan'), device=dev)
         a.workspace, a.workspace_floats = scratch.data_ptr(), scratch.numel()
-    before = lib.ds_debug_conv_halo2_launches()
-    lib.ds_debug_force_generic_conv(tile)
-    lib.ds_debug_conv_variant(variant)
-    try:
-        kid = lib.ds_conv_kernel_id(C.byref(a))
-        rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
-        torch.cuda.synchronize()
-    finally:
-        lib.ds_debug_force_generic_conv(0)
-        lib.ds_debug_conv_variant(0)
+    a.tune.mode, a.tune.variant = tile, variant
+    kid = lib.ds_conv_kernel_id(C.byref(a))
+    rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
+    torch.cuda.synchronize()
     assert rc == 0, lib.ds_error_string(rc)
     if variant == 3:
-        assert lib.ds_debug_conv_halo2_launches() == before + 1, 'the layer was not routed to the second-generation kernel'
+        assert kid == 2560, 'the layer was not routed to the second-generation kernel'
     if want_kid is not None:
         assert kid == want_kid, (kid, want_kid)
     if (variant & 31) == 6:
@@ -497,7 +488,7 @@ def _run_halo_case(case, variant, workspace=False, tile=256, want_kid=None):
 
 @pytest.mark.parametrize('case', HALO2_CASES)
 def test_conv_halo2_kernel_matches_aten(case):
-    """Second-generation 256 x 128 halo kernel (conv3x3_halo2.hip), routed by ds_debug_conv_variant(3) with the 256-pixel tile
+    """Second-generation 256 x 128 halo kernel (conv3x3_halo2.hip), routed by ds_conv_tune.variant = 3 with the 256-pixel tile
     forced; the routing itself is asserted through the launch counter."""
     _run_halo_case(case, 3)
 
@@ -517,7 +508,7 @@ WIDE_N_CASES = [
 @pytest.mark.parametrize('case', WIDE_N_CASES)
 def test_conv_wide_n_tiles_match_aten(case):
     """conv3x3_halo_kernel<4, NT = 4>: 256-pixel x 256-channel tiles (64 x 128 per wave) for the 256-multiples of the channel
-    count, the remainder on 128- / 64-column tiles of the same layer (ds_debug_conv_variant(6) forces the shape at test sizes)."""
+    count, the remainder on 128- / 64-column tiles of the same layer (ds_conv_tune.variant = 6 forces the shape at test sizes)."""
     _run_halo_case(case, 6)
 
 
@@ -534,7 +525,7 @@ WIDE192_CASES = [
 def test_conv_192_column_tiles_match_aten(case):
     """conv3x3_halo_kernel<4, NT = 3>: 256-pixel x 192-channel tiles (64 x 96 per wave) for channel counts that are multiples of 192 but not
     of 256 (ADM: 192 / 384 / 576) -- all columns of the layer in one launch instead of 256- / 128-column tiles plus a 64-column tail
-    (ds_debug_conv_variant bit 14 forces the shape at test sizes)."""
+    (ds_conv_tune.variant bit 14 forces the shape at test sizes)."""
     _run_halo_case(case, 16384)
 
 
@@ -639,11 +630,10 @@ def test_conv_f16_operands_matches_fp16_rounded_reference(case):
                       coefs.data_ptr() if use_norm else None, 1 if act else 0,
                       e0.data_ptr() if ec0 else None, e1.data_ptr() if ec1 else None, ec0, ec1, ec0, ec1)
     a.wgt_f16 = 1
-    before = lib.ds_debug_conv_halo2_launches()
+    assert lib.ds_conv_kernel_id(C.byref(a)) == 2562          # conv3x3_halo2_kernel<W, fp16 operands>
     rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
     torch.cuda.synchronize()
     assert rc == 0, lib.ds_error_string(rc)
-    assert lib.ds_debug_conv_halo2_launches() == before + 1
     got = out[:, :cout].cpu()
     assert _rel(got, _nhwc(ref16)) < 2e-3
     assert _rel(got, _nhwc(ref32)) < 3e-3
@@ -722,11 +712,10 @@ def test_conv_split_fp16_emulates_fp32_within_the_fp32_tolerance(case):
                       coefs.data_ptr() if use_norm else None, 1 if act else 0,
                       e0.data_ptr() if ec0 else None, e1.data_ptr() if ec1 else None, ec0, ec1, ec0, ec1)
     a.wgt_f16, a.wgt_shift = 2, shift
-    before = lib.ds_debug_conv_halo2_launches()
+    assert lib.ds_conv_kernel_id(C.byref(a)) == 2563          # conv3x3_halo2_kernel<W, split fp16 operands>
     rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
     torch.cuda.synchronize()
     assert rc == 0, lib.ds_error_string(rc)
-    assert lib.ds_debug_conv_halo2_launches() == before + 1
     assert _rel(out[:, :cout].cpu(), _nhwc(ref)) < TOL
 
 
@@ -916,12 +905,9 @@ def test_conv_f16_activations_dma_kernel(case):
     if with_stats:
         a.stats_out = stats.data_ptr()
     assert lib.ds_conv_kernel_id(C.byref(a)) == 2566
-    prev = lib.ds_debug_f16dma_nb(nb)
-    try:
-        rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
-        torch.cuda.synchronize()
-    finally:
-        lib.ds_debug_f16dma_nb(prev)
+    a.tune.f16dma_nb = nb
+    rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
+    torch.cuda.synchronize()
     assert rc == 0, lib.ds_error_string(rc)
     got = out.cpu()
     assert torch.isfinite(got).all()
@@ -1059,12 +1045,9 @@ def test_gemm_f16_activations_dma_kernel(case):
     if stats is not None:
         a.stats_out = stats.data_ptr()
     assert lib.ds_conv_kernel_id(C.byref(a)) == 2567
-    prev = lib.ds_debug_f16dma_nb(nb)
-    try:
-        rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
-        torch.cuda.synchronize()
-    finally:
-        lib.ds_debug_f16dma_nb(prev)
+    a.tune.f16dma_nb = nb
+    rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
+    torch.cuda.synchronize()
     assert rc == 0, lib.ds_error_string(rc)
     got = out.float().cpu()
     assert torch.isfinite(got).all()
@@ -1204,12 +1187,9 @@ def test_f16_activation_kernels_with_fp16_residual_and_output_rows(kind, nw):
             a = _lib.ConvArgs(xd.data_ptr(), None, cin, 0, cin, 0, n, h, h, taps, wp.data_ptr(), cout, bd_.data_ptr(), None, 0, 1, rd.data_ptr(), cout,
                               0.7071, 0, out.data_ptr(), cout)
             a.wgt_f16, a.in_f16, a.out_f16, a.res_f16, a.stats_out = 1, 1, 1, 1, stats.data_ptr()
-            p_nb, p_nw = lib.ds_debug_f16dma_nb(nb), lib.ds_debug_f16dma_nw(nw)
-            try:
-                rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
-                torch.cuda.synchronize()
-            finally:
-                lib.ds_debug_f16dma_nb(p_nb); lib.ds_debug_f16dma_nw(p_nw)
+            a.tune.f16dma_nb, a.tune.f16dma_nw = nb, nw
+            rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
+            torch.cuda.synchronize()
             assert rc == 0, (shp, nb, lib.ds_error_string(rc))
             got = out.float().cpu()
             assert torch.isfinite(got).all(), (shp, nb)

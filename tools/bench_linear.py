@@ -26,7 +26,7 @@ for label, M, K, N in SHAPES:
     row = []
     outs = []
     for force in (0, 1):
-        lib.ds_debug_force_generic_conv(force)
+        a.tune.mode = force                   # ds_conv_tune.mode 1: the generic gather kernel
         kid = lib.ds_conv_kernel_id(C.byref(a))
         assert lib.ds_conv2d_nhwc(C.byref(a), st) == 0
         torch.cuda.synchronize()
@@ -38,6 +38,6 @@ for label, M, K, N in SHAPES:
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
         row.append(f'{("dma8" if kid == 2561 else "generic") if force == 0 else "generic (forced)"}: {ms*1e3:7.0f} us {2.0*M*K*N/ms/1e9:6.1f} TF')
-    lib.ds_debug_force_generic_conv(0)
+    a.tune.mode = 0
     err = float((outs[0] - outs[1]).abs().max() / outs[1].abs().max())
     print(f'{label:24s} M={M:6d} K={K:5d} N={N:5d}  ' + '   '.join(row) + f'   rel diff {err:.1e}', flush=True)

@@ -38,7 +38,7 @@ ref = torch.randn(n, generator=torch.Generator(dev).manual_seed(0), device=dev)
 out = torch.empty(n, device=dev)
 match = {}
 for variant in range(96):
-    lib.ds_debug_philox_probe(0, 0, C.c_void_p(out.data_ptr()), n, variant, _lib.stream_ptr())
+    lib.ds_philox_probe(0, 0, C.c_void_p(out.data_ptr()), n, variant, _lib.stream_ptr())
     torch.cuda.synchronize()
     mism = int((out != ref).sum())
     match[variant] = mism

@@ -4,8 +4,11 @@
     python tools/rocprof_summary.py pmc    gpurun_out/pmc_fetch/bench_results.db gpurun_out/pmc_write/bench_results.db profiles/r1_bench_pmc_hbm.json
 """
 import json
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def short(name):
@@ -36,7 +39,11 @@ def pmc(db_fetch, db_write, out):
             r[key + '_launches'] = c
             r[key + '_KiB_total'] = s
             r[key + '_KiB_avg_per_launch'] = a
-    json.dump({'note': 'raw rocprofv3 values in KiB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x '
+    from diff_sampler_amd import build
+    json.dump({'meta': {'session': os.path.dirname(db_fetch), 'kernel_source_sha256': build.source_hashes(),
+                        'note': 'hashes of csrc/<tu>.hip + all headers at collection time: bench.py reports a kernel\'s traffic only while '
+                                'the hash of its translation unit is unchanged'},
+               'note': 'raw rocprofv3 values in KiB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x '
                        '(MI355X_MICROARCH.md, HBM section): double it before comparing with byte counts',
                'kernels': res}, open(out, 'w'), indent=1)
     for k, v in list(res.items())[:8]:

@@ -39,12 +39,11 @@ for label, n, res, cin, cout, taps in SHAPES:
     rows = []
     for tile in ((128, 256) if taps == 9 else (0,)):
         for s in (0, 1, 2, 3, 4, 5, 6, 8, 12, 16, 24, 32):
-            lib.ds_debug_force_generic_conv(tile)
-            lib.ds_debug_force_splits(s if s else 0)
+            a.tune.mode, a.tune.splits = tile, (s if s else 0)
             if s == 0 and tile != (128 if taps == 9 else 0):
                 continue
             if s == 0:
-                lib.ds_debug_force_generic_conv(0)        # pure heuristic (tile and splits)
+                a.tune.mode = 0                           # pure heuristic (tile and splits)
             rc = lib.ds_conv2d_nhwc(C.byref(a), st)
             assert rc == 0, rc
             torch.cuda.synchronize()
@@ -55,7 +54,6 @@ for label, n, res, cin, cout, taps in SHAPES:
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 5
             rows.append((('heur' if s == 0 else f't{tile}/s{s}'), ms))
-    lib.ds_debug_force_generic_conv(0); lib.ds_debug_force_splits(0)
     best = min(r[1] for r in rows)
     print(f'{label:26s} M={M:6d} {cin}->{cout}: ' + '  '.join(f'{k}:{ms*1e3:.0f}{"*" if ms == best else ""}' for k, ms in rows) +
           f'   [us; best {fl/best/1e9:.0f} TF]', flush=True)

@@ -17,7 +17,7 @@ ap.add_argument('--batch', type=int, nargs='+', default=[64, 256])
 ap.add_argument('--iters', type=int, default=5)
 ap.add_argument('--breakdown', action='store_true')
 args = ap.parse_args()
-_lib.load().ds_debug_force_generic_conv(int(os.environ.get('DS_CONV', '0')))    # A/B switches of ds_debug_force_generic_conv
+# A/B switches: DS_CONV (= ds_conv_tune.mode) / DS_CONV_VARIANT in the environment apply to every layer of the plans built below (_lib._ENV_TUNE)
 
 import diff_sampler_amd.ldm_arch as ldm_arch  # noqa: E402
 if args.config in ldm_arch.NAMED_LDM_CONFIGS:
