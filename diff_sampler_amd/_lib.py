@@ -184,6 +184,7 @@ _SIGNATURES = {
     'ds_copy_rows': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_longlong, C.c_int, vp]),
     'ds_amed_predict': (C.c_int, [C.POINTER(AmedPredictor), vp, C.c_int, C.c_float, C.c_float, vp, vp]),
     'ds_amed_coefs': (C.c_int, [C.POINTER(AmedCoefArgs), vp]),
+    'ds_fid_moments': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     'ds_traj_moments': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     'ds_traj_pair_cost': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     'ds_philox_randn': (C.c_int, [vp, C.c_ulonglong, vp, C.c_int, C.c_longlong, C.c_longlong, vp]),

@@ -10,8 +10,11 @@ it as stock PyTorch-ROCm.  Everything around it is implemented: image-folder lis
 sharding, the fp64 moment accumulation, the two SUM all-reduces over RCCL, finalisation, the Frechet distance, and the
 ``calc`` / ``ref`` command line (fid.py:92-166).
 
-The fp64 second-moment update is a plain library GEMM (rocBLAS through ``torch.matmul``); the all-reduce goes through
-``torch.distributed`` -- backend ``nccl`` is RCCL over xGMI on ROCm, ``gloo`` in the CPU tests.
+The moment update of a batch on the GPU is ONE launch of ``ds_fid_moments`` (csrc/fid.hip: fp64 MFMA ``f^T f`` + column sums,
+accumulated in place; no fp64 copy of the features, no rocBLAS); there is no fallback when libdsamd.so is missing.  Accumulators
+on the CPU (the gloo tests of the sharding / all-reduce logic, ``bench.py --stub``) use the two torch expressions of fid.py:69-71.
+The all-reduce goes through ``torch.distributed`` -- backend ``nccl`` is RCCL over xGMI on ROCm, ``gloo`` in the CPU tests.
+The detector itself is stock PyTorch: its architecture is not in the reference repository (fid.py:34 downloads a pickle).
 """
 from __future__ import annotations
 
@@ -33,10 +36,23 @@ class MomentAccumulator:
         self.count = 0
 
     def update(self, features: torch.Tensor):
-        f = features.to(torch.float64)
-        self.mu += f.sum(0)
-        self.sigma += f.T @ f
-        self.count += f.shape[0]
+        """fid.py:69-71 for one batch of features [b, feature_dim]."""
+        if self.mu.is_cuda:
+            import ctypes as C
+            from . import _lib
+            f = features.to(self.mu.device)
+            if f.dtype not in (torch.float32, torch.float64):
+                f = f.to(torch.float32)                      # fp16 / bf16 detector outputs widen exactly
+            f = f.contiguous()
+            assert f.dim() == 2 and f.shape[1] == self.mu.numel(), (tuple(f.shape), self.mu.numel())
+            _lib.check(_lib.load().ds_fid_moments(C.c_void_p(f.data_ptr()), int(f.dtype == torch.float64), f.stride(0), f.shape[0],
+                                                  f.shape[1], C.c_void_p(self.mu.data_ptr()), C.c_void_p(self.sigma.data_ptr()),
+                                                  _lib.stream_ptr()), 'ds_fid_moments')
+        else:                                                # host-side accumulators (gloo tests, bench.py --stub): no kernels
+            f = features.to(torch.float64)
+            self.mu += f.sum(0)
+            self.sigma += f.T @ f
+        self.count += features.shape[0]
 
     def all_reduce(self):
         """SUM over ranks (fid.py:74-75).  Returns the wall time of the two collectives in seconds (informational)."""

@@ -476,6 +476,15 @@ int ds_traj_pair_cost(const float* traj, const float* eps, const float* t_steps,
                       double* cost, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * FID moments (diff-solvers-main/fid.py:62-71): one batch of detector features [rows][ld] (fp32 when features_f64 == 0 -- widened to
+ * fp64 exactly, the reference's `.to(torch.float64)` -- or fp64 when 1; the first `dim` columns of each row) accumulated IN PLACE
+ * into the running sums  mu[dim] += features.sum(0)  and  sigma[dim][dim] += features^T features  (row-major, fp64), on the fp64
+ * matrix pipe (v_mfma_f64_16x16x4_f64), one launch per batch; any rows >= 0, any dim >= 1.  The update is bitwise symmetric.
+ * The SUM all-reduce of mu / sigma over ranks (fid.py:74-75) and the finalisation (fid.py:76-78) stay with the caller
+ * (diff_sampler_amd/fid.py: torch.distributed over RCCL). */
+int ds_fid_moments(const void* features, int features_f64, int ld, int rows, int dim, double* mu, double* sigma, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Native launch plans (SURVEY.md section 8b "what a C-ABI engine should export": ds_unet_forward / ds_graph_capture_step).
  *
  * One network evaluation -- EDMPrecond.forward -> SongUNet / DhariwalUNet.forward (networks_edm.py:482-496, :312-355, :427-453) or

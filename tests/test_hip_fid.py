@@ -1,7 +1,8 @@
 """FID moment path on the GPU (reference fid.py:54-87): fp64 first / second moments of [N, 2048] pool features
-accumulated on the device by `fid.MomentAccumulator` (the second-moment update is the library fp64 GEMM), finalised as
-fid.py:76-78, compared with numpy fp64; Frechet distance of two such statistics against the closed form.  Bit-level equality is
-not the bar for an fp64 GEMM with a different summation order: 1e-10 relative (fp64 has 2^-53)."""
+accumulated on the device by `fid.MomentAccumulator` through ds_fid_moments (csrc/fid.hip: v_mfma_f64_16x16x4_f64, in-place
+accumulation), compared with numpy fp64 on the raw sums (1e-12 relative: an fp64 contraction with a different summation order; fp64
+has 2^-53) and after the finalisation of fid.py:76-78 (1e-10: the covariance subtracts two nearly equal numbers); Frechet distance of
+two such statistics against the closed form."""
 import os
 import sys
 
@@ -37,6 +38,37 @@ def test_moments_on_device_match_numpy_fp64(n, d, batch):
     assert np.abs(mu - mu_ref).max() <= 1e-10 * np.abs(mu_ref).max()
     assert np.abs(sigma - sigma_ref).max() <= 1e-10 * np.abs(sigma_ref).max()
     assert np.allclose(sigma_ref, np.cov(f64, rowvar=False), rtol=0, atol=1e-9 * np.abs(sigma_ref).max())
+
+
+@pytest.mark.parametrize('rows,dim,dtype', [(64, 2048, torch.float32), (250, 2048, torch.float32), (7, 64, torch.float32), (33, 96, torch.float64),
+                                            (1, 2048, torch.float32), (5, 50, torch.float32), (130, 200, torch.float64)])
+def test_ds_fid_moments_raw_sums_match_numpy_fp64(rows, dim, dtype):
+    """The kernel itself through the C ABI: mu += f.sum(0), sigma += f^T f IN PLACE on non-zero accumulators, feature rows with a
+    leading dimension larger than dim, ragged dims (not multiples of 16 / 64) and row counts (not multiples of 4); 1e-12 of the
+    result's scale; the update must be exactly symmetric and must not touch memory beyond [dim] / [dim][dim]."""
+    import ctypes as C
+    from diff_sampler_amd import _lib
+    lib = _lib.load()
+    g = np.random.RandomState(rows * 1000 + dim)
+    ld = dim + 8
+    f = (g.randn(rows, ld) * 2.0 + 0.5).astype(np.float32 if dtype == torch.float32 else np.float64)
+    mu0, s0 = g.randn(dim), g.randn(dim, dim)
+    s0 = s0 + s0.T
+    fd = torch.from_numpy(f).cuda()
+    mu = torch.from_numpy(np.concatenate([mu0, [777.0]])).cuda()                 # one guard element behind each accumulator
+    sg = torch.from_numpy(np.concatenate([s0.reshape(-1), [777.0]])).cuda()
+    rc = lib.ds_fid_moments(C.c_void_p(fd.data_ptr()), int(dtype == torch.float64), ld, rows, dim, C.c_void_p(mu.data_ptr()),
+                            C.c_void_p(sg.data_ptr()), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    assert rc == 0, lib.ds_error_string(rc)
+    f64 = f[:, :dim].astype(np.float64)
+    mu_ref, s_ref = mu0 + f64.sum(0), s0 + f64.T @ f64
+    got_mu, got_s = mu.cpu().numpy(), sg.cpu().numpy()
+    assert got_mu[-1] == 777.0 and got_s[-1] == 777.0
+    got_s = got_s[:-1].reshape(dim, dim)
+    assert np.abs(got_mu[:-1] - mu_ref).max() <= 1e-12 * np.abs(mu_ref).max()
+    assert np.abs(got_s - s_ref).max() <= 1e-12 * np.abs(s_ref).max()
+    assert np.array_equal(got_s, got_s.T)
 
 
 def test_calculate_inception_stats_with_a_device_feature_fn_and_frechet_distance():
