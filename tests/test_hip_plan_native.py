@@ -97,8 +97,8 @@ def test_failing_launch_is_reported_with_its_index():
 
 def test_two_threads_run_plans_with_different_kernel_overrides_concurrently():
     """The library keeps no process-wide kernel selection: overrides travel inside each launch's ds_conv_args.tune (include/ds_engine.h).
-    Two plans of the same net -- one built under `_lib.tuning(mode=1)` (every convolution on the generic gather kernel), one with the
-    library's own choices (LDS-halo / LDS-DMA kernels) -- run concurrently from two host threads on two streams; every evaluation of
+    Two plans of the same net -- one built under `_lib.tuning(variant=2048)` (four-wave 128 x 128 tiles where the library would take eight
+    half-size waves), one with the library's own choices -- run concurrently from two host threads on two streams; every evaluation of
     each must be bit-identical to that plan's single-threaded result, and the two routings must really differ."""
     import threading
     from diff_sampler_amd import _lib
@@ -109,7 +109,7 @@ def test_two_threads_run_plans_with_different_kernel_overrides_concurrently():
     x = torch.randn(8, 3, 32, 32, generator=g).to(dev)
     sig = (torch.rand(8, generator=g) * 3 + 0.1).to(dev)
     nets, plans, want = {}, {}, {}
-    for name, tune in (('generic', dict(mode=1)), ('default', {})):
+    for name, tune in (('tuned', dict(variant=2048)), ('default', {})):
         with _lib.tuning(**tune):
             nets[name] = EDMDenoiser.from_config('cifar10', seed=3)
             want[name] = nets[name](x, sig).clone()                 # builds the plan inside the override scope
@@ -118,9 +118,11 @@ def test_two_threads_run_plans_with_different_kernel_overrides_concurrently():
 
     def kernel_ids(plan):
         return [lib.ds_conv_kernel_id(C.byref(op.keep[0])) for op in plan.ops if op.fn is lib.ds_conv2d_nhwc and op.keep[0].taps == 9]
-    ids_g, ids_d = kernel_ids(plans['generic']), kernel_ids(plans['default'])
-    assert len(ids_g) == len(ids_d) > 30 and all(i == 0 for i in ids_g) and sum(i != 0 for i in ids_d) > 30, (ids_g[:5], ids_d[:5])
-    assert _rel(want['generic'].cpu(), want['default'].cpu()) < 2e-5         # two exact-fp32 kernels: same result up to summation order
+    ids_t, ids_d = kernel_ids(plans['tuned']), kernel_ids(plans['default'])
+    # at 8 images most 3x3 layers have at most one 128-pixel tile per CU: 1284 = eight half-size waves by default, 128 = four waves when tuned
+    assert len(ids_t) == len(ids_d) > 30 and sum(i == 1284 for i in ids_d) > 30 and not any(i == 1284 for i in ids_t), (ids_t, ids_d)
+    assert sum(a != b for a, b in zip(ids_t, ids_d)) > 30
+    assert _rel(want['tuned'].cpu(), want['default'].cpu()) < 2e-5           # two exact-fp32 kernels: same result up to summation order
     errors = []
 
     def worker(name):
@@ -134,7 +136,7 @@ def test_two_threads_run_plans_with_different_kernel_overrides_concurrently():
                         errors.append((name, i))
         except Exception as e:                                       # noqa: BLE001
             errors.append((name, repr(e)))
-    ts = [threading.Thread(target=worker, args=(n,)) for n in ('generic', 'default')]
+    ts = [threading.Thread(target=worker, args=(n,)) for n in ('tuned', 'default')]
     for t in ts:
         t.start()
     for t in ts:
