@@ -308,36 +308,54 @@ bool conv3x3_f16dma_applicable(const KParams& p) {
 // The starting width is chosen by a small cost model: a launch of t workgroups takes ceil(t / 256) rounds of tiles, and a tile of
 // 64 * nb columns costs about 1 + nb (the halo stream, the A-fragment reads, prologue and epilogue do not shrink with the width), so
 // a layer with few pixel tiles takes narrower column tiles to cover the 256 CUs.
-static int tiling(const KParams& p, int nb0, int (*out)[3], int* cost) {
-    const int mtiles = p.M / 256;
+// `half`: the four-wave half-slab variant (conv3x3_f16dmah.hip): 128-pixel tiles, two workgroups per CU = 512 tile slots per round.
+static int tiling(const KParams& p, int nb0, int (*out)[3], int* cost, bool half = false) {
+    const int mtiles = p.M / (half ? 128 : 256), slots = half ? 512 : 256;
     int n = 0, col = 0, c = 0;
     for (int w = nb0; w >= 1 && col < p.N; --w) {
         const int t = (p.N - col) / (64 * w);
         if (t > 0) {
             out[n][0] = col; out[n][1] = t; out[n][2] = w; ++n;
             col += t * 64 * w;
-            c += (int)(((long long)mtiles * t + 255) / 256) * (1 + w);
+            c += (int)(((long long)mtiles * t + slots - 1) / slots) * (1 + w);
         }
     }
     *cost = c;
     return n;
 }
 
-int conv3x3_f16dma_plan(const KParams& p, int (*out)[3]) {
-    const int cap = max_nb(p.W);
+int conv3x3_f16dma_plan(const KParams& p, int (*out)[3], bool half = false) {
+    const int cap = half ? conv3x3_f16dmah_max_nb(p.W) : max_nb(p.W);
     int cost;
-    if (p.t_nb > 0) return tiling(p, p.t_nb < cap ? p.t_nb : cap, out, &cost);
+    if (p.t_nb > 0) return tiling(p, p.t_nb < cap ? p.t_nb : cap, out, &cost, half);
     int best_nb = cap, best_cost = 0x7fffffff, best_n = 99;
     for (int nb = cap; nb >= 1; --nb) {
         int tmp[4][3];
-        const int n = tiling(p, nb, tmp, &cost);
+        const int n = tiling(p, nb, tmp, &cost, half);
         if (cost < best_cost || (cost == best_cost && n < best_n)) { best_cost = cost; best_n = n; best_nb = nb; }
     }
-    return tiling(p, best_nb, out, &cost);
+    return tiling(p, best_nb, out, &cost, half);
+}
+
+// Which layers take the four-wave half-slab variant (two workgroups per CU, conv3x3_f16dmah.hip).  ds_conv_args.tune.f16dma_nw forces it
+// (4) or the eight-wave kernel (8); otherwise by layer class, from the A/B of profiles/r4_conv_f16dmah_ab.txt.
+bool conv3x3_f16dma_use_half(const KParams& p) {
+    if (!conv3x3_f16dmah_applicable(p)) return false;
+    if (p.t_nw == 4) return true;
+    if (p.t_nw == 8) return false;
+    return false;
 }
 
 int launch_conv3x3_f16dma(KParams& p, hipStream_t stream) {
     int plan[4][3];
+    if (conv3x3_f16dma_use_half(p)) {
+        const int n = conv3x3_f16dma_plan(p, plan, true);
+        for (int i = 0; i < n; ++i) {
+            const int rc = launch_conv3x3_f16dmah_tiles(p, plan[i][2], plan[i][0], plan[i][1], stream);
+            if (rc) return rc;
+        }
+        return DS_OK;
+    }
     const int n = conv3x3_f16dma_plan(p, plan);
     for (int i = 0; i < n; ++i) {
         int rc;

@@ -251,7 +251,54 @@ __global__ void __launch_bounds__(256) colstats_kernel(const KParams p) {
 }
 }  // namespace
 
+namespace {
+// Split-K reduce of a layer whose output feeds a GroupNorm (p.stats), in ONE launch: a block owns a 64-row x 64-column block of the output
+// -- exactly one (row block, column chunk) cell of the statistics -- sums the partial planes in split order (float4 rows), applies the
+// epilogue, stores the rows and leaves the cell's column sums / sums of squares behind.  Replaces splitk_reduce_kernel + colstats_kernel
+// (one dependent launch less per split layer: at 8 images per call two thirds of the CIFAR-10 net's convolutions are split).
+// thread = (column quad: tid & 15, row lane: tid >> 4; rows lane, lane + 16, lane + 32, lane + 48).  Requires N % 64 == 0, float4-aligned
+// output / residual / bias rows (p.vec_ok) and float4 partial planes (p.vec_part).
+__global__ void __launch_bounds__(256) splitk_reduce_stats_kernel(const KParams p) {
+    __shared__ f32x4 sh[2][16][16];
+    const int rb = blockIdx.x, cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int col = blockIdx.y * 64 + cq * 4;
+    const size_t plane = (size_t)p.M * p.N;
+    f32x4 cb = {0.f, 0.f, 0.f, 0.f}, s4 = cb, q4 = cb;
+    if (p.colbias) cb = *reinterpret_cast<const f32x4*>(p.colbias + col);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int row = rb * 64 + rl + 16 * k;
+        if (row >= p.M) break;
+        f32x4 v = *reinterpret_cast<const f32x4*>(p.part + (size_t)row * p.N + col);
+        for (int sp = 1; sp < p.splits; ++sp) v += *reinterpret_cast<const f32x4*>(p.part + sp * plane + (size_t)row * p.N + col);
+        v += cb;
+        if (p.cbias) v += *reinterpret_cast<const f32x4*>(p.cbias + (size_t)(p.cbias_bcast ? 0 : row / p.HW) * p.cbias_ld + col);
+        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.res_ld + col);
+        v *= p.scale;
+        if (p.act == DS_ACT_SILU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ds_silu(v[j]);
+        }
+        *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.ldo + col) = v;
+        s4 += v; q4 += v * v;
+    }
+    sh[0][rl][cq] = s4; sh[1][rl][cq] = q4;
+    __syncthreads();
+    if (rl < 2) {                                   // rl = 0: sums, 1: sums of squares; fixed order over the 16 row lanes
+        f32x4 t = sh[rl][0][cq];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += sh[rl][k][cq];
+        *reinterpret_cast<f32x4*>(p.stats + ((size_t)rb * 2 + rl) * p.N + col) = t;
+    }
+}
+}  // namespace
+
 int launch_splitk_reduce(const KParams& p, hipStream_t stream) {
+    if (p.stats && p.vec_ok && p.vec_part && !p.out_planar && (p.N & 63) == 0 && p.act != DS_ACT_GEGLU) {
+        hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((p.M + 63) / 64, p.N / 64), dim3(256), 0, stream, p);
+        DS_CHECK_LAUNCH();
+        return DS_OK;
+    }
     long long blocks = ((long long)p.M * ((p.N + 3) / 4) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
@@ -387,7 +434,7 @@ extern "C" int ds_conv_kernel_id(const ds_conv_args* a) {
     p.vec_ok = (vec_epilogue_ok(p) && !a->out_nchw) ? 1 : 0;
     p.stride = a->stride ? a->stride : 1; p.K = a->taps * (a->c0 + a->c1) + a->ec0 + a->ec1; p.norm = a->norm_coefs;
     p.nrows_b = ((a->cout + BN - 1) / BN) * BN;                                     // weights are row-padded, as in ds_conv2d_nhwc
-    if (a->wgt_f16 == 1 && a->in_f16) return a->taps == 1 ? 2567 : 2566;
+    if (a->wgt_f16 == 1 && a->in_f16) return a->taps == 1 ? 2567 : (conv3x3_f16dma_use_half(p) ? 2569 : 2566);
     if (a->wgt_f16) return a->wgt_f16 == 2 ? 2563 : (a->taps == 1 ? 2564 : 2562);
     if (p.t_mode == 1) return 0;
     if (a->taps != 9 || a->stride > 1) return (p.t_mode != 6 && gemm_dma8_applicable(p)) ? 2561 : 0;

@@ -539,7 +539,9 @@ inline int choose_splits(long long blocks, bool big_tile, int units, int tiles_p
     const int ktiles = units * tiles_per_unit;
     double best_c = layer_cost_us(blocks, big_tile, ktiles, 1, mn);
     int best = 1;
-    long long smax = units / 2;
+    // down to ONE unit per split (round 4; until then units / 2): the layers this matters for are the 8x8 / 16x16 layers of small batches
+    // (CIFAR-10 at 8 images: 8 slabs -> 8 splits of one slab = 9 K tiles each instead of 4 x 18), where every serial K tile is ~2 us
+    long long smax = units;
     if (smax > 16) smax = 16;
     if (mn > 0 && smax * mn > part_capacity_floats) smax = part_capacity_floats / mn;
     if (units >= 4 && mn > 0) {
@@ -575,6 +577,12 @@ int launch_conv3x3_halo2(KParams& p, int wide, int mode, hipStream_t stream);
 // conv3x3_f16dma.hip: 3x3 on fp16 activations, both operands by LDS-DMA, 256-pixel x 64/128/192/256-channel tiles
 bool conv3x3_f16dma_applicable(const KParams& p);
 int launch_conv3x3_f16dma(KParams& p, hipStream_t stream);
+
+bool conv3x3_f16dma_use_half(const KParams& p);   // true: the layer runs on conv3x3_f16dmah_kernel (four waves, two workgroups per CU)
+// conv3x3_f16dmah.hip: the same convolution on 128-pixel tiles with 32-channel half slabs, four waves, two workgroups per CU
+bool conv3x3_f16dmah_applicable(const KParams& p);
+int conv3x3_f16dmah_max_nb(int W);
+int launch_conv3x3_f16dmah_tiles(const KParams& p, int nb, int n_begin, int ntiles, hipStream_t stream);
 
 // gemm_f16dma.hip: 1x1 / Linear on fp16 activations (both operands by LDS-DMA)
 bool gemm_f16dma_applicable(const KParams& p);

@@ -74,7 +74,8 @@ typedef struct ds_conv_tune {
     int variant;
     int splits;        /* > 0: split-K factor of a convolution that has a workspace (clamped to what the layer allows) */
     int f16dma_nb;     /* fp16-activation kernels: column-tile width 64 * nb, nb = 1..4 */
-    int f16dma_nw;     /* fp16-activation GEMM: 4 / 8 = 128- / 256-row variant */
+    int f16dma_nw;     /* fp16-activation GEMM: 4 / 8 = 128- / 256-row variant; fp16-activation 3x3: 4 = the four-wave half-slab kernel on
+                        * 128-pixel tiles (two workgroups per CU, kernel id 2569), 8 = the eight-wave kernel on 256-pixel tiles (2566) */
     /* fp16-activation kernels, benchmarks only (results are WRONG when bits 0 - 5 are set): bit 0: no weight DMA after the prologue,
      * bit 1: no halo DMA after the first slab, bit 2: no epilogue, bit 4: no per-tap barrier, bit 5: no LDS fragment reads; bit 10
      * (results stay correct): fp16 residual rows requested one group ahead instead of early (profiles/r3_gemm_f16dma_epilogue.txt). */

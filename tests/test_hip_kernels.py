@@ -868,11 +868,14 @@ F16DMA_CASES = [
 ]
 
 
+@pytest.mark.parametrize('nw', [8, 4])
 @pytest.mark.parametrize('case', F16DMA_CASES)
-def test_conv_f16_activations_dma_kernel(case):
+def test_conv_f16_activations_dma_kernel(case, nw):
     """ds_conv2d_nhwc with in_f16 (csrc/conv3x3_f16dma.hip): the input is an fp16 NHWC tensor, both operands go to LDS by DMA, column tiles
     of 64 / 128 / 192 / 256 channels.  Reference = the same arithmetic on the CPU (fp16 operands, products summed in fp64): 2e-5 of the
-    output scale -- only the fp32 accumulation order differs; the GroupNorm column sums the epilogue leaves are checked too."""
+    output scale -- only the fp32 accumulation order differs; the GroupNorm column sums the epilogue leaves are checked too.
+    nw = 8: the eight-wave kernel on 256-pixel tiles (kernel id 2566); nw = 4: the four-wave half-slab variant on 128-pixel tiles, two
+    workgroups per CU (csrc/conv3x3_f16dmah.hip, kernel id 2569) -- forced per call through ds_conv_tune.f16dma_nw."""
     import ctypes as C
     from diff_sampler_amd import _lib, ops
     B, H, cin, cout, ec0, nb, with_stats = case
@@ -904,8 +907,8 @@ def test_conv_f16_activations_dma_kernel(case):
     a.wgt_f16, a.in_f16 = 1, 1
     if with_stats:
         a.stats_out = stats.data_ptr()
-    assert lib.ds_conv_kernel_id(C.byref(a)) == 2566
-    a.tune.f16dma_nb = nb
+    a.tune.f16dma_nb, a.tune.f16dma_nw = nb, nw
+    assert lib.ds_conv_kernel_id(C.byref(a)) == (2566 if nw == 8 else 2569)
     rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
     torch.cuda.synchronize()
     assert rc == 0, lib.ds_error_string(rc)

@@ -16,6 +16,8 @@ ap.add_argument('--config', default='cifar10')
 ap.add_argument('--batch', type=int, nargs='+', default=[64, 256])
 ap.add_argument('--iters', type=int, default=5)
 ap.add_argument('--breakdown', action='store_true')
+ap.add_argument('--per-op', action='store_true', help='with --breakdown: one line per convolution launch (geometry, kernel id, time, TFLOP/s)')
+ap.add_argument('--fp16', action='store_true', help="the reference's use_fp16 mode")
 args = ap.parse_args()
 # A/B switches: DS_CONV (= ds_conv_tune.mode) / DS_CONV_VARIANT in the environment apply to every layer of the plans built below (_lib._ENV_TUNE)
 
@@ -52,7 +54,16 @@ if args.config in ldm_arch.NAMED_LDM_CONFIGS:
             for k, v in sorted(tot.items(), key=lambda kv: -kv[1]):
                 print(f'   {k:20s} {v:8.2f} ms')
     sys.exit(0)
-net = EDMDenoiser.from_config(args.config, seed=0)
+lib = _lib.load()
+
+
+def _again(op, st):
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(); op.fn(*op.args, st); e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1)
+
+
+net = EDMDenoiser.from_config(args.config, seed=0, use_fp16=args.fp16)
 spec = net.spec
 for B in args.batch:
     x = torch.randn(B, spec.in_channels, spec.img_resolution, spec.img_resolution, device='cuda')
@@ -77,6 +88,13 @@ for B in args.batch:
             op.fn(*op.args, st)
             e1.record(); torch.cuda.synchronize()
             kind = op.name.split('.')[-1]
-            tot[kind] = tot.get(kind, 0.0) + e0.elapsed_time(e1)
+            ms = min(e0.elapsed_time(e1), _again(op, st))
+            tot[kind] = tot.get(kind, 0.0) + ms
+            if args.per_op and op.fn is lib.ds_conv2d_nhwc:
+                import ctypes as C
+                a = op.keep[0]
+                fl = 2.0 * a.n * a.h * a.w * a.cout * (a.taps * (a.c0 + a.c1) + a.ec0 + a.ec1)
+                print(f'      {op.name:34s} {a.h:2d}x{a.w:<2d} taps={a.taps} cin={a.c0 + a.c1:4d}+{a.ec0 + a.ec1:<4d} cout={a.cout:4d} kid={lib.ds_conv_kernel_id(C.byref(a)):4d} '
+                      f'{ms * 1e3:7.1f} us {fl / ms / 1e9:6.1f} TF', flush=True)
         for k, v in sorted(tot.items(), key=lambda kv: -kv[1]):
             print(f'   {k:16s} {v:8.2f} ms')
