@@ -14,9 +14,10 @@
 // staged 16 at a time as fp64 in LDS ([16][128 + 16] doubles per operand; the 16-double pad puts consecutive rows 32 banks apart, so the
 // 2 rows x 16 doubles a ds_read_b64 lane group touches are conflict free), coalesced 4-byte loads, widened once per element; the next 16
 // rows are requested into registers before the 64 MFMAs of the current ones.  Per 16 rows a wave issues 32 ds_read_b64 for 64 MFMAs
-// (4 096 matrix cycles): the loop is matrix-bound by construction.  Diagonal workgroups stage one operand tile, not two.
-// sigma[i][j] and sigma[j][i] add the same products in the same order: the update is bitwise symmetric.
+// (4 096 matrix cycles): the loop is matrix-bound by construction.  // sigma[i][j] and sigma[j][i] add the same products in the same order: the update is bitwise symmetric.
 // Workgroups of block column 0 also add the column sums of their 128 features to mu (rows in order, fp64, from the staged tile).
+#include <type_traits>
+
 #include "ds_common.h"
 
 namespace {
@@ -39,37 +40,41 @@ __global__ void __launch_bounds__(256) fid_moments_kernel(const void* __restrict
     __shared__ double tile[2][FR][FP];                          // [operand: 0 = i side, 1 = j side][row][feature]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bi = blockIdx.y * FT, bj = blockIdx.x * FT;
-    const bool diag = blockIdx.x == blockIdx.y;
     const int wi = (wave >> 1) * 64, wj = (wave & 1) * 64;       // this wave's 64 x 64 corner inside the tile
     const int lc = lane & 15, lk = lane >> 4;
     const int sc = tid & (FT - 1), sr = tid >> 7;                // staging: feature column, first row (rows sr, sr + 2, ...)
 
-    double pre[2][FR / 2];
-    auto request = [&](int r0) {                                // 16 rows x 128 features per operand -> registers (zeros outside)
+    // Requests are UNCONDITIONAL loads from clamped (always valid) addresses, zeroed by a select when they are staged: a predicated load
+    // compiles to a branch with a full vmcnt(0) behind each of the 16 loads of a chunk (first version: 14 -> 22 TFLOP/s only).  The raw
+    // values stay in registers as loaded (fp32 features: widened when they are written to LDS).
+    typedef typename std::conditional<F64, double, float>::type raw_t;
+    raw_t pre[2][FR / 2];
+    const raw_t* fsrc = reinterpret_cast<const raw_t*>(feat);
+    const int ci_ = min(bi + sc, dim - 1), cj_ = min(bj + sc, dim - 1);
+    const bool vi = bi + sc < dim, vj = bj + sc < dim;
+    auto request = [&](int r0) {                                // 16 rows x 128 features per operand -> registers
 #pragma unroll
-        for (int o = 0; o < 2; ++o) {
-            if (o == 1 && diag) break;
-            const int c = (o ? bj : bi) + sc;
-#pragma unroll
-            for (int u = 0; u < FR / 2; ++u) {
-                const int r = r0 + sr + 2 * u;
-                pre[o][u] = (r < rows && c < dim) ? feat_at<F64>(feat, (size_t)r * ld + c) : 0.0;
-            }
+        for (int u = 0; u < FR / 2; ++u) {
+            const size_t ro = (size_t)min(r0 + sr + 2 * u, rows - 1) * ld;
+            pre[0][u] = fsrc[ro + ci_];
+            pre[1][u] = fsrc[ro + cj_];                          // (diagonal workgroups: the same addresses again -- L1 hits, no branch)
         }
+    };
+    auto staged = [&](int o, int u, int r0) -> double {         // the value of row r0 + sr + 2u as staged: zero outside [rows) x [dim)
+        const bool ok = (r0 + sr + 2 * u < rows) && (o ? vj : vi);
+        return ok ? (double)pre[o][u] : 0.0;
     };
     f64x4 acc[4][4] = {};
     double colsum = 0.0;
     const double* ta = &tile[0][0][0];
-    const double* tb = diag ? ta : &tile[1][0][0];
+    const double* tb = &tile[1][0][0];
     request(0);
     for (int r0 = 0; r0 < rows; r0 += FR) {
         __syncthreads();                                        // the previous chunk's reads are done
 #pragma unroll
-        for (int o = 0; o < 2; ++o) {
-            if (o == 1 && diag) break;
+        for (int o = 0; o < 2; ++o)
 #pragma unroll
-            for (int u = 0; u < FR / 2; ++u) tile[o][sr + 2 * u][sc] = pre[o][u];
-        }
+            for (int u = 0; u < FR / 2; ++u) tile[o][sr + 2 * u][sc] = staged(o, u, r0);
         __syncthreads();
         if (r0 + FR < rows) request(r0 + FR);                    // in flight under this chunk's MFMAs
         if (blockIdx.x == 0 && tid < FT) {                      // mu: column sums of the i-side tile, rows in order
