@@ -17,13 +17,8 @@
 
 namespace {
 
-// NW = waves per workgroup = 32-query blocks per workgroup: 4 (128 queries, the K / V tile staged once for four waves) or 1 (32 queries)
-// for launches that would leave most of the chip idle -- CIFAR-10's 16x16 attention at 8 images is 16 workgroups of 128 queries, each a
-// serial walk over the keys on ONE CU (78 us for 0.5 GFLOP); 32-query workgroups put it on 64 CUs.  A wave's arithmetic does not depend
-// on NW: results are bit-identical.
-template <int D, int NW>
-__global__ void __launch_bounds__(64 * NW) flash_attn_kernel(const ds_attn_args a) {
-    constexpr int T = 64 * NW;
+template <int D>
+__global__ void __launch_bounds__(256) flash_attn_kernel(const ds_attn_args a) {
     // A head size that leaves 8 channels beyond the last full 32-row block of O^T (d = 40: SD-1.5's 64x64 stage) would spend
     // a whole MFMA block (16 MFMAs per key tile) on 8 useful rows; those VREM channels are accumulated by the vector ALU
     // instead (16 keys x 8 channels = 128 FMAs per lane and tile, V read as LDS broadcasts), in the shadow of the MFMAs.
@@ -33,15 +28,13 @@ __global__ void __launch_bounds__(64 * NW) flash_attn_kernel(const ds_attn_args 
     constexpr int VLD = DB * 32 + 8;         // rows 4 apart land 32 banks apart (and room for the VREM channels)
     constexpr int NQ4 = D / 8;
     constexpr int D4 = D / 4;
-    constexpr bool PREFETCH = D <= 96 && NW == 4;   // larger heads: the O^T / Q registers leave no room for a staged tile (nor does a
-                                                    // one-wave workgroup, whose 64 threads would hold a whole tile)
+    constexpr bool PREFETCH = D <= 96;       // larger heads: the O^T / Q registers leave no room for a staged tile
     // 32-key blocks per K/V tile: 64-key tiles halve the barriers and the per-tile softmax bookkeeping (max / rescale) where
     // the registers still allow two waves per SIMD (d = 64: 7.07 -> 6.85 ms on ImageNet-64; d = 40 with 64-key tiles needs
     // 288 registers, drops to one wave per SIMD and loses 13 %)
     constexpr int KB = (D <= 64 && VREM == 0) ? 2 : 1;
     constexpr int KT = 32 * KB;
-    constexpr int TOT = KT / 4 * D;          // 16-B units of a K (or V) tile
-    constexpr int NLD = (TOT + T - 1) / T;
+    constexpr int NLD = (KT / 4 * D + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;
     float* Vs = smem + KT * KLD;
@@ -50,7 +43,7 @@ __global__ void __launch_bounds__(64 * NW) flash_attn_kernel(const ds_attn_args 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hb = lane >> 5, l31 = lane & 31;
     const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+    const int q0 = blockIdx.x * 128 + wave * 32;
     const bool active = q0 < a.sq;
     const float* qp = a.q + (size_t)b * a.q_bs + h * D;
     const float* kp = a.k + (size_t)b * a.k_bs + h * D;
@@ -74,12 +67,12 @@ __global__ void __launch_bounds__(64 * NW) flash_attn_kernel(const ds_attn_args 
 #pragma unroll
     for (int j = 0; j < (VREM ? VREM : 1); ++j) oe[j] = 0.f;
 
-    f32x4 kr[PREFETCH ? NLD : 1], vr[PREFETCH ? NLD : 1];
-    auto gload = [&](int t) {                // (PREFETCH only) the whole tile into registers
+    f32x4 kr[NLD], vr[NLD];
+    auto gload = [&](int t) {
 #pragma unroll
-        for (int j = 0; j < (PREFETCH ? NLD : 0); ++j) {
-            const int idx = tid + T * j;
-            if (NLD * T == TOT || idx < TOT) {
+        for (int j = 0; j < NLD; ++j) {
+            const int idx = tid + 256 * j;
+            if (NLD * 256 == KT / 4 * D || idx < KT / 4 * D) {
                 const int row = idx / D4, c4 = idx - row * D4;
                 const int key = min(t * KT + row, a.skv - 1);
                 kr[j] = *reinterpret_cast<const f32x4*>(kp + (size_t)key * a.ldk + c4 * 4);
@@ -89,37 +82,12 @@ __global__ void __launch_bounds__(64 * NW) flash_attn_kernel(const ds_attn_args 
     };
     auto sstore = [&]() {
 #pragma unroll
-        for (int j = 0; j < (PREFETCH ? NLD : 0); ++j) {
-            const int idx = tid + T * j;
-            if (NLD * T == TOT || idx < TOT) {
+        for (int j = 0; j < NLD; ++j) {
+            const int idx = tid + 256 * j;
+            if (NLD * 256 == KT / 4 * D || idx < KT / 4 * D) {
                 const int row = idx / D4, c4 = idx - row * D4;
                 *reinterpret_cast<f32x4*>(Ks + row * KLD + c4 * 4) = kr[j];
                 *reinterpret_cast<f32x4*>(Vs + row * VLD + c4 * 4) = vr[j];
-            }
-        }
-    };
-    auto stage_direct = [&](int t) {         // (no PREFETCH) global -> LDS in chunks of four 16-B units per thread and operand
-        constexpr int CH = 4;
-        for (int j0 = 0; j0 < NLD; j0 += CH) {
-            f32x4 kc[CH], vc[CH];
-#pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                const int idx = tid + T * (j0 + j);
-                if (idx < TOT) {
-                    const int row = idx / D4, c4 = idx - row * D4;
-                    const int key = min(t * KT + row, a.skv - 1);
-                    kc[j] = *reinterpret_cast<const f32x4*>(kp + (size_t)key * a.ldk + c4 * 4);
-                    vc[j] = *reinterpret_cast<const f32x4*>(vp + (size_t)key * a.ldv + c4 * 4);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                const int idx = tid + T * (j0 + j);
-                if (idx < TOT) {
-                    const int row = idx / D4, c4 = idx - row * D4;
-                    *reinterpret_cast<f32x4*>(Ks + row * KLD + c4 * 4) = kc[j];
-                    *reinterpret_cast<f32x4*>(Vs + row * VLD + c4 * 4) = vc[j];
-                }
             }
         }
     };
@@ -128,8 +96,9 @@ __global__ void __launch_bounds__(64 * NW) flash_attn_kernel(const ds_attn_args 
     if (PREFETCH) gload(0);
     const float* kfrag = Ks + l31 * KLD + 4 * hb;
     for (int t = 0; t < ntiles; ++t) {
+        if (!PREFETCH) gload(t);
         __syncthreads();                     // every wave is done with the previous tile
-        if (PREFETCH) sstore(); else stage_direct(t);
+        sstore();
         __syncthreads();
         if (PREFETCH && t + 1 < ntiles) gload(t + 1);    // in flight during the MFMAs below
         if (!active) continue;
@@ -237,24 +206,16 @@ __global__ void __launch_bounds__(64 * NW) flash_attn_kernel(const ds_attn_args 
     }
 }
 
-template <int D, int NW>
-int launch_nw(const ds_attn_args* a, hipStream_t stream) {
-    constexpr int DB = (D > 32 && (D % 32) == 8) ? D / 32 : (D + 31) / 32;
-    constexpr int KT = (D <= 64 && !(D > 32 && (D % 32) == 8)) ? 64 : 32;
-    constexpr int bytes = (KT * (D + 4) + KT * (DB * 32 + 8) + 32 + NW * 32 * 33) * (int)sizeof(float);
-    DS_ENSURE_DYN_LDS((&flash_attn_kernel<D, NW>), bytes);
-    dim3 grid((a->sq + 32 * NW - 1) / (32 * NW), a->heads, a->batch);
-    hipLaunchKernelGGL((flash_attn_kernel<D, NW>), grid, dim3(64 * NW), bytes, stream, *a);
-    DS_CHECK_LAUNCH();
-    return DS_OK;
-}
-
-// 128-query workgroups unless they would cover less than half of the 256 CUs: then 32-query workgroups (four times as many)
 template <int D>
 int launch(const ds_attn_args* a, hipStream_t stream) {
-    const long long blocks128 = (long long)((a->sq + 127) / 128) * a->heads * a->batch;
-    if (blocks128 < 128 && a->sq > 32) return launch_nw<D, 1>(a, stream);
-    return launch_nw<D, 4>(a, stream);
+    constexpr int DB = (D > 32 && (D % 32) == 8) ? D / 32 : (D + 31) / 32;
+    constexpr int KT = (D <= 64 && !(D > 32 && (D % 32) == 8)) ? 64 : 32;
+    constexpr int bytes = (KT * (D + 4) + KT * (DB * 32 + 8) + 32 + 4 * 32 * 33) * (int)sizeof(float);
+    DS_ENSURE_DYN_LDS((&flash_attn_kernel<D>), bytes);
+    dim3 grid((a->sq + 127) / 128, a->heads, a->batch);
+    hipLaunchKernelGGL(flash_attn_kernel<D>, grid, dim3(256), bytes, stream, *a);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
 }
 
 }  // namespace

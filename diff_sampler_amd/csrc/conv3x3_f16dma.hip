@@ -40,7 +40,9 @@ struct GeoD {
 template <int W, int NB>
 constexpr unsigned f16dma_smem() { return 2u * NB * 8192u + 2u * GeoD<W>::HALO_B; }
 
-template <int W, int NB>
+// ILV: the DMA requests of a tap are issued between the MFMAs of its last K step (round 4) instead of behind them (round 3; kept as the
+// A/B partner, ds_conv_tune.ablate bit 11 -- a template parameter, because both orders in one kernel body spill)
+template <int W, int NB, bool ILV>
 __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p) {
     using G = GeoD<W>;
     constexpr int WP = G::WP, HP = G::HP, TH = G::TH, NIMG = G::NIMG, NP = G::NP, NDMA = G::NDMA;
@@ -99,6 +101,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
         for (int i = 0; i < NB; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (size_t)i * 64 * ldbh + (size_t)kt * 64),
                                              (lptr_t)(lds + wbuf * WB + (i * 64 + wave * 8) * 128), 16, 0, 0);
+    };
+    auto w_dma_row = [&](int kt, int wbuf, auto ic) {            // one 64-row block of it (issued between MFMAs, see the tap)
+        constexpr int i = decltype(ic)::value;
+        if ((abl & 1) && kt > 1) return;
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (size_t)i * 64 * ldbh + (size_t)kt * 64),
+                                         (lptr_t)(lds + wbuf * WB + (i * 64 + wave * 8) * 128), 16, 0, 0);
     };
 
     // ---- fragment addresses (LDS byte addresses relative to a halo buffer / a weight buffer) ------------------------------------------
@@ -220,15 +228,41 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
                 frag_read(P, a_addr(0, T9 + 1) + hoff, a_addr(1, T9 + 1) + hoff, bbase + nwoff);
             }
         }
-        DS2_FENCE(); mfma_group(Q); DS2_FENCE();      // (A/B in one session, profiles/r3_conv_f16dma_ablations.txt: +2 % over issuing the DMA first)
-        if (kt + 2 < KT) w_dma(kt + 2, kt & 1);
-        if constexpr (SLAB_END) {
-            if (chunk + 2 < NCH) {
-                if (chunk + 1 >= nchunks) static_for<NDMA>([&](auto jc) { halo_dma(chunk + 2, chunk & 1, jc); });   // next slab has one tap
-                else halo_dma(chunk + 2, chunk & 1, IC<0>{});
+        auto halo_issue = [&]() {
+            if constexpr (SLAB_END) {
+                if (chunk + 2 < NCH) {
+                    if (chunk + 1 >= nchunks) static_for<NDMA>([&](auto jc) { halo_dma(chunk + 2, chunk & 1, jc); });   // next slab has one tap
+                    else halo_dma(chunk + 2, chunk & 1, IC<0>{});
+                }
+            } else if constexpr (T9 + 1 < NDMA) {
+                if (chunk + 1 < NCH) halo_dma(chunk + 1, (chunk + 1) & 1, IC<T9 + 1>{});
             }
-        } else if constexpr (T9 + 1 < NDMA) {
-            if (chunk + 1 < NCH) halo_dma(chunk + 1, (chunk + 1) & 1, IC<T9 + 1>{});
+        };
+        if constexpr (!ILV) {                         // round-3 order (A/B switch, tune.ablate bit 11): the whole MFMA group, then every request
+            DS2_FENCE(); mfma_group(Q); DS2_FENCE();      // (A/B in one session, profiles/r3_conv_f16dma_ablations.txt: +2 % over issuing the DMA first)
+            if (kt + 2 < KT) w_dma(kt + 2, kt & 1);
+            halo_issue();
+        } else {
+            // Round 4: the requests are issued BETWEEN the MFMAs of the group.  A wave issues in order: behind the group's last MFMA only
+            // its own 32 cycles shelter anything, and both waves of a SIMD reach this point together (they left the same barrier), so the
+            // 150 - 300 cycles of address arithmetic, M0 writes and LDS-DMA issue left the matrix pipe idle.  Behind MFMA pair i go weight
+            // rows [i * 64, i * 64 + 64) of tap kt + 2; the halo round goes behind the first pair.
+            const bool wd = kt + 2 < KT;
+            DS2_FENCE();
+            DSD_MM(accA[0][0], Q.a0, Q.b0); DSD_MM(accA[1][0], Q.a1, Q.b0);
+            DS2_FENCE(); halo_issue(); if (wd) w_dma_row(kt + 2, kt & 1, IC<0>{}); DS2_FENCE();
+            if constexpr (NB > 1) {
+                DSD_MM(accA[0][1], Q.a0, Q.b1); DSD_MM(accA[1][1], Q.a1, Q.b1);
+                DS2_FENCE(); if (wd) w_dma_row(kt + 2, kt & 1, IC<1>{}); DS2_FENCE();
+            }
+            if constexpr (NB > 2) {
+                DSD_MM(accB[0][0], Q.a0, Q.b2); DSD_MM(accB[1][0], Q.a1, Q.b2);
+                DS2_FENCE(); if (wd) w_dma_row(kt + 2, kt & 1, IC<2>{}); DS2_FENCE();
+            }
+            if constexpr (NB > 3) {
+                DSD_MM(accB[0][1], Q.a0, Q.b3); DSD_MM(accB[1][1], Q.a1, Q.b3);
+                DS2_FENCE(); if (wd) w_dma_row(kt + 2, kt & 1, IC<3>{}); DS2_FENCE();
+            }
         }
         DS2_FENCE();
         ++kt;
@@ -270,8 +304,13 @@ int launch_w_nb(KParams p, int n_begin, int ntiles, hipStream_t stream) {
     int smem = (int)f16dma_smem<W, NB>();
     const int epi = 8 * 32 * EPI_LD * (int)sizeof(float);
     if (smem < epi) smem = epi;
-    DS_ENSURE_DYN_LDS((&conv3x3_f16dma_kernel<W, NB>), 160 * 1024);
-    hipLaunchKernelGGL((conv3x3_f16dma_kernel<W, NB>), dim3(grid_1d(p.mtiles, p.ntiles), 1), dim3(512), smem, stream, p);
+    if (p.t_ablate & 2048) {
+        DS_ENSURE_DYN_LDS((&conv3x3_f16dma_kernel<W, NB, false>), 160 * 1024);
+        hipLaunchKernelGGL((conv3x3_f16dma_kernel<W, NB, false>), dim3(grid_1d(p.mtiles, p.ntiles), 1), dim3(512), smem, stream, p);
+    } else {
+        DS_ENSURE_DYN_LDS((&conv3x3_f16dma_kernel<W, NB, true>), 160 * 1024);
+        hipLaunchKernelGGL((conv3x3_f16dma_kernel<W, NB, true>), dim3(grid_1d(p.mtiles, p.ntiles), 1), dim3(512), smem, stream, p);
+    }
     DS_CHECK_LAUNCH();
     return DS_OK;
 }

@@ -90,6 +90,14 @@ for B in args.batch:
             kind = op.name.split('.')[-1]
             ms = min(e0.elapsed_time(e1), _again(op, st))
             tot[kind] = tot.get(kind, 0.0) + ms
+            if args.per_op and op.fn is lib.ds_norm_act:
+                a = op.keep[0]
+                up = 4 if a.resample == 2 else 1
+                pix = a.n * a.h * a.w
+                byts = pix * (a.c0 * (2 if a.in_f16 & 1 else 4) + a.c1 * (2 if a.in_f16 & 2 else 4)) + \
+                    pix * up // (4 if a.resample == 1 else 1) * (a.c0 + a.c1) * ((2 if a.out_f16 else 4) + (2 if a.raw_out else 0))
+                print(f'      {op.name:34s} {a.h:2d}x{a.w:<2d} norm c={a.c0:4d}+{a.c1:<4d} resample={a.resample} in16={a.in_f16} out16={a.out_f16} raw={int(bool(a.raw_out))} '
+                      f'{ms * 1e3:7.1f} us {byts / ms / 1e9:6.0f} GB/s', flush=True)
             if args.per_op and op.fn is lib.ds_conv2d_nhwc:
                 import ctypes as C
                 a = op.keep[0]
