@@ -517,7 +517,7 @@ extern "C" int ds_norm_act(const ds_norm_args* a, void* stream) {
         // (8x8 / 16x16 stages: a few MB, the whole pass is one or two memory round trips) 4 pixels per thread = one round of four loads and
         // four times the workgroups -- the 16-pixel geometry left them at 13 - 19 us per launch, ~1 TB/s (profiles/r4_norm_small.txt)
         const long long elems = (long long)a->n * OH * OW * (a->c0 + a->c1);
-        const int ppt = elems < (8ll << 20) ? 4 : 16;
+        const int ppt = elems < (16ll << 20) ? 4 : 16;
         const int by_work = (OH * OW + ppt * PL - 1) / (ppt * PL);
         if (max_chunks > by_work) max_chunks = by_work;
     }
