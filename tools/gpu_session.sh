@@ -15,7 +15,7 @@ set -x
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 TAG=$1; shift
 O=gpurun_out/$TAG; mkdir -p $O
-QUICK="--no-cpu-baseline --no-launch-modes --no-batch-sweep"
+QUICK="--no-cpu-baseline --no-launch-modes --no-batch-sweep --no-other-configs"
 n=0
 for step in "$@"; do
   n=$((n+1)); kind=${step%%:*}; arg=""; [ "$kind" != "$step" ] && arg=${step#*:}
