@@ -10,7 +10,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libdsamd.so')
+LIB_PATH = os.environ.get('DS_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libdsamd.so')      # DS_LIB_PATH: an alternative build (A/B runs of tools/)
 
 c_float_p = C.POINTER(C.c_float)
 vp = C.c_void_p

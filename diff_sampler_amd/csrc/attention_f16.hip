@@ -35,7 +35,17 @@ __device__ __forceinline__ unsigned pk2(float x, float y) {          // two fp32
 }
 
 template <int D>
-__global__ void __launch_bounds__(512) flash_attn_f16_kernel(const ds_attn_args a, const int qblocks, const int pairs) {
+// Waves per SIMD the register allocation must leave room for.  Head sizes <= 64 at 4: TWO 512-thread workgroups per CU.  With one (the
+// round-3 allocation: 144 / 147 VGPRs at d = 40 / 64) the two waves of a SIMD belong to the same workgroup and leave the same per-tile
+// barrier together: they run their MFMA segments (Q K^T, P V) and their VALU segment (softmax: ~207 VALU per 14 MFMAs, SQ counters in
+// profiles/r4_attn_f16_counters.json) in lockstep, so the matrix pipe idles while both do softmax and vice versa.  A second, independent
+// workgroup on the CU is out of phase with the first.  (-DDS_ATTN_OCC2 builds the round-3 allocation: A/B runs.)
+#ifdef DS_ATTN_OCC2
+#define DS_ATTN_WAVES(D) 2
+#else
+#define DS_ATTN_WAVES(D) ((D) <= 64 ? 4 : 2)
+#endif
+__global__ void __launch_bounds__(512, DS_ATTN_WAVES(D)) flash_attn_f16_kernel(const ds_attn_args a, const int qblocks, const int pairs) {
     constexpr int DP = (D + 15) / 16 * 16;           // contraction length of S^T, zero padded
     constexpr int NKS = DP / 16;
     constexpr int DB = (D + 31) / 32;                // 32-row blocks of O^T
@@ -49,6 +59,8 @@ __global__ void __launch_bounds__(512) flash_attn_f16_kernel(const ds_attn_args 
     constexpr int VTS = (KT / 4) * D4;               // (4 keys, 4 channels) patches of a V tile
     constexpr int NLV = (VTS + 511) / 512;
     constexpr bool PREFETCH = D <= 96;               // larger heads: no registers left to hold a staged tile across the MFMAs
+                                                     // (dropping the prefetch at d <= 64 to avoid the 10 - 23 spilled registers of the
+                                                     // four-waves-per-SIMD allocation: 3 - 6 % slower, profiles/r4_attn_f16_occupancy_ab.txt)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     float* Es = reinterpret_cast<float*>(smem_b + 2 * TILE_B);      // epilogue transposition patches, 32 x 33 floats per wave
 

@@ -168,6 +168,14 @@ def test_bench_defaults_are_the_workloads_the_kept_lines_are_quoted_on():
                     ('r3_bench_ffhq_fp32_line.json', 128)):
         line = [x for x in open(os.path.join(ROOT, 'profiles', name)).read().splitlines() if x.startswith('{')][-1]
         assert f'batch {b}/GPU' in json.loads(line)['config']['workload'], name
+    # round 4: ONE default run carries the headline and, under the same clock, the other configurations (`other_configs`) + `latency`
+    line = json.loads([x for x in open(os.path.join(ROOT, 'profiles', 'r4_bench_line.json')).read().splitlines() if x.startswith('{')][-1])
+    assert 'batch 256/GPU' in line['config']['workload'] and line['dtype'] == 'fp32'
+    got = [(o['config']['workload'], o['dtype']) for o in line['other_configs']]
+    for (cfg, dt, b), (wl, odt) in zip(bench.OTHER_CONFIGS, got):
+        assert f'batch {b}/GPU' in wl and odt == dt and bench.WORKLOAD_NAMES[cfg].split(' (')[0] in wl, (cfg, wl)
+    assert all('error' not in o and o['roofline']['frac'] > 0 and 0 < o['application']['frac'] < 1 for o in line['other_configs'])
+    assert set(line['latency']) == {'cifar10_fp32_B8_nfe10_ms', 'sd15_fp16_B1_nfe10_ms'}
 
 
 def test_sample_cli_under_two_gloo_ranks_writes_every_seed_exactly_once(tmp_path):
