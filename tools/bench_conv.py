@@ -38,6 +38,7 @@ SHAPES_SD15_GEMM = [  # SD-1.5 transformer projections / 1x1s on the image rows 
     (64, 320, 0, 320, 1), (64, 320, 0, 960, 1), (64, 1280, 0, 320, 1), (32, 640, 0, 640, 1), (32, 640, 0, 1920, 1), (32, 2560, 0, 640, 1),
     (16, 1280, 0, 1280, 1), (16, 1280, 0, 3840, 1), (16, 5120, 0, 1280, 1),
     (64, 320, 0, 256, 1), (64, 320, 0, 64, 1), (64, 320, 0, 128, 1), (64, 320, 0, 192, 1),   # [9..12] locality experiments: N = one tile
+    (64, 320, 0, 2560, 1), (32, 640, 0, 5120, 1), (16, 1280, 0, 10240, 1),                 # [13..15] the GEGLU projections: bench with --geglu
 ]
 
 ap = argparse.ArgumentParser()
@@ -57,6 +58,7 @@ ap.add_argument('--lda', type=int, default=0, help='with --dma16: override the l
 ap.add_argument('--nw', type=int, default=0, help='with --dma16, taps = 1 shapes: force the 4- / 8-wave GEMM variant')
 ap.add_argument('--ablate', type=int, default=0, help='with --dma16: ds_conv_tune.ablate mask (timing only)')
 ap.add_argument('--no-res', action='store_true', help='no residual operand in the epilogue')
+ap.add_argument('--geglu', action='store_true', help='taps = 1 shapes with --dma16: the GEGLU gate in the epilogue (DS_ACT_GEGLU: cout / 2 output columns, no residual)')
 ap.add_argument('--f16out', action='store_true', help='with --dma16: fp16 output rows only')
 ap.add_argument('--f16res', action='store_true', help='with --dma16: fp16 residual rows only')
 ap.add_argument('--f16io', action='store_true', help='with --dma16: fp16 output rows and fp16 residual rows (ds_conv_args.out_f16 / res_f16: the fp16 residual stream)')
@@ -124,6 +126,9 @@ for si, (res, c0, c1, cout, taps) in enumerate(SHAPES):
         if args.lda:
             a.ld0 = args.lda
         a.tune.f16dma_nb, a.tune.f16dma_nw, a.tune.ablate = args.nb, args.nw, args.ablate
+        if args.geglu:
+            assert taps == 1 and cout % 128 == 0
+            a.act, a.res, a.res_f16, a.cbias, a.out_ld, a.out_scale = 2, None, 0, None, cout // 2, 1.0
     if args.norm and taps == 9:
         coefs = torch.randn(B, 3, c0 + c1, device=dev) * 0.1 + torch.tensor([0., 1., 0.], device=dev).reshape(1, 3, 1)
         a.norm_coefs, a.norm_act = coefs.data_ptr(), 1
