@@ -224,6 +224,8 @@ def load():
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
+    if lib.ds_version() != 2:
+        raise DsError(f'{LIB_PATH} reports ABI version {lib.ds_version()}, this binding is written for 2: rebuild it (python diff_sampler_amd/build.py)')
     _lib = lib
     return lib
 

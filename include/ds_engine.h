@@ -43,7 +43,8 @@ extern "C" {
 #define DS_RESAMPLE_DOWN 1  /* 2x2 box filter, stride 2  (networks_edm.py:77 with resample_filter [1,1]) */
 #define DS_RESAMPLE_UP 2    /* nearest neighbour x2      (networks_edm.py:75 with resample_filter [1,1]) */
 
-int ds_version(void);
+int ds_version(void);      /* 2 since round 4: ds_conv_args.tune / ds_update_args.variant appended (struct sizes changed), ds_fid_moments added, the
+                               * process-global ds_debug_* setters removed.  A host must check it before passing argument structs. */
 const char* ds_error_string(int code);
 
 /* ---------------------------------------------------------------------------------------------------------------

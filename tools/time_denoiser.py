@@ -37,11 +37,13 @@ if args.config in ldm_arch.NAMED_LDM_CONFIGS:
         torch.cuda.synchronize()
         dt = (time.time() - t0) / args.iters
         fl = net.engine.flops(2 * B)
-        print(f'{args.config} B={B} (CFG: {2*B} U-Net images): {dt*1e3:.2f} ms/eval  {fl/dt/1e12:.1f} TFLOP/s  {B/dt:.1f} img-evals/s  ({len(plan.ops)} launches)', flush=True)
+        print(f'{args.config} B={B} (CFG: {2*B} U-Net images): {dt*1e3:.2f} ms/eval  {fl/dt/1e12:.1f} TFLOP/s  {B/dt:.1f} img-evals/s  ({len(plan.ops)} launches per evaluation + {len(plan.ctx.ops)} once per context)', flush=True)
         if args.breakdown:
             st = _lib.stream_ptr()
             tot = {}
-            for op in plan.ops:
+            # per-evaluation launches; the cross-attention K / V projections of the context (plan.ctx) run once per context tensor and are
+            # listed separately under 'ctx:' (they are NOT part of the ms/eval above once the context is cached)
+            for op in list(plan.ops) + list(plan.ctx.ops):
                 torch.cuda.synchronize()
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -49,6 +51,7 @@ if args.config in ldm_arch.NAMED_LDM_CONFIGS:
                 e1.record(); torch.cuda.synchronize()
                 parts = op.name.split('.')
                 kind = parts[-1] if parts[-1] not in ('stats',) else '.'.join(parts[-2:])
+                if op in plan.ctx.ops: kind = 'ctx:' + kind
                 if 'attn1' in op.name and kind == 'attn1': kind = 'attn1(self)'
                 tot[kind] = tot.get(kind, 0.0) + e0.elapsed_time(e1)
             for k, v in sorted(tot.items(), key=lambda kv: -kv[1]):
