@@ -29,15 +29,25 @@ def headers():
     return sorted(glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(HERE, '..', 'include', '*.h')))
 
 
+def _code_only(text):
+    """C / C++ source with comments and whitespace runs removed: what the compiler sees, roughly (string literals containing comment
+    markers do not occur in csrc/)."""
+    import re
+    text = re.sub(r'/\*.*?\*/', ' ', text, flags=re.S)
+    text = re.sub(r'//[^\n]*', ' ', text)
+    return re.sub(r'\s+', ' ', text).strip()
+
+
 def source_sha256(tu):
-    """Hash of what a translation unit of csrc/ is compiled from: its .hip source and every header of csrc/ and include/ (a superset of
-    what it includes).  bench.py ties profiler-derived numbers (profiles/*pmc*.json) to the kernel source they were measured on."""
+    """Hash of the CODE a translation unit of csrc/ is compiled from: its .hip source and every header of csrc/ and include/ (a superset
+    of what it includes), comments and whitespace stripped -- a comment edit in a header must not invalidate a measurement.  bench.py ties
+    profiler-derived numbers (profiles/*pmc*.json) to the kernel source they were measured on."""
     import hashlib
     h = hashlib.sha256()
     for f in [os.path.join(CSRC, tu)] + headers():
         h.update(os.path.basename(f).encode() + b'\0')
-        with open(f, 'rb') as fh:
-            h.update(fh.read())
+        with open(f, 'r', encoding='utf-8') as fh:
+            h.update(_code_only(fh.read()).encode())
     return h.hexdigest()
 
 

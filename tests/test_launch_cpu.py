@@ -126,6 +126,9 @@ def test_pmc_traffic_is_tied_to_the_kernel_source_it_was_measured_on(tmp_path, m
     assert bench.pmc_traffic(2565) is None and 'another build' in bench.PMC_NOTE['why']
     f.write_text(json.dumps({'kernels': kern}))                               # a summary without provenance (round 3's) is not trusted
     assert bench.pmc_traffic(2565) is None
+    # the hash is of the CODE: comments and whitespace do not count, a changed token does
+    a = build._code_only('int f(int x) {  // doubles\n  return 2 * x; /* really */ }\n')
+    assert a == build._code_only('int f(int x) {\n\n return 2 * x; }') and a != build._code_only('int f(int x) { return 3 * x; }')
 
 
 def test_committed_pmc_summary_names_the_dominant_kernel():
