@@ -38,7 +38,7 @@ template <int D>
 // Waves per SIMD the register allocation must leave room for.  Head sizes <= 64 at 4: TWO 512-thread workgroups per CU.  With one (the
 // round-3 allocation: 144 / 147 VGPRs at d = 40 / 64) the two waves of a SIMD belong to the same workgroup and leave the same per-tile
 // barrier together: they run their MFMA segments (Q K^T, P V) and their VALU segment (softmax: ~207 VALU per 14 MFMAs, SQ counters in
-// profiles/r4_attn_f16_counters.json) in lockstep, so the matrix pipe idles while both do softmax and vice versa.  A second, independent
+// profiles/r4_attn_f16_counters.json) in lockstep; four waves per SIMD also hide more of each other's latencies.  A second, independent
 // workgroup on the CU is out of phase with the first.  (-DDS_ATTN_OCC2 builds the round-3 allocation: A/B runs.)
 #ifdef DS_ATTN_OCC2
 #define DS_ATTN_WAVES(D) 2
