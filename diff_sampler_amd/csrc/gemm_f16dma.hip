@@ -49,7 +49,10 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_f16dma_kernel(const KParams p
         asrc[j] = row < p.M ? a0 + (size_t)row * p.lda0 + sw : nullptr;
     }
     const _Float16* wsrc = wgt + (size_t)(n0 + (tid >> 3)) * ldbh + sw;
+    const int abl = p.coef_lds;          // timing ablations (ds_conv_args.tune.ablate; results are WRONG when bits 0 / 2 are set): bit 0 = no DMA after
+                                         // the prologue, bit 2 = no epilogue
     auto dma = [&](int kt, int buf) {
+        if ((abl & 1) && kt > 1) return;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const _Float16* g = asrc[j] ? asrc[j] + (size_t)kt * 64 : g_zero_halfs_g;
@@ -139,6 +142,13 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_f16dma_kernel(const KParams p
 #undef DSG16_MM
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
+    if (abl & 4) {                       // no epilogue: every accumulator block (and so every MFMA) is kept alive
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { asm volatile("" :: "v"(accA[i][j])); asm volatile("" :: "v"(accB[i][j])); }
+        return;
+    }
     float* stage = smem + wave * 32 * EPI_LD;
     const int wn0 = n0 + wc * (NB * 32);
     epilogue_pipe<0, false, (NB == 1 ? 32 : 64), (NB == 3 ? 32 : (NB == 4 ? 64 : 0))>(p, accA, accB, stage, lane, m0 + wr * 64, wn0, p.out);

@@ -348,6 +348,13 @@ __device__ __forceinline__ void epi_process(const KParams& p, const float* stage
     const int c8 = (lane & (G::LPR - 1)) * 8, col = bn0 + c8;
     const bool cb_uniform = p.cbias && (p.cbias_bcast || p.HW % 32 == 0);
     const bool geglu = (MODE == 0) && W == 64 && p.act == DS_ACT_GEGLU;
+    // The two scale factors as SCALARS read once (round 4).  `v *= p.acc_scale` on an f32x4 made the compiler fetch the factor with a
+    // <4 x float> load straddling the neighbouring KParams fields, which kept a 28-byte slice of the kernel argument in PRIVATE memory:
+    // every pass of every group then re-read it from scratch (two scratch_load_dwordx4 + s_waitcnt vmcnt(0): a memory round trip per
+    // pass, 16 per wave and tile).  Found with the epilogue ablations of profiles/r4_gemm_f16dma_ablate.txt: the epilogue cost 0.24 ms of
+    // the plain 320 -> 2 560 projection even with its stores AND its staging writes removed.
+    const float acc_scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.acc_scale)));
+    const float scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.scale)));
 #pragma unroll
     for (int pass = 0; pass < G::NP; ++pass) {
         const int rr = pass * G::RPP + lane / G::LPR;
@@ -357,8 +364,8 @@ __device__ __forceinline__ void epi_process(const KParams& p, const float* stage
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             v[h] = *reinterpret_cast<const f32x4*>(stage + rr * EPI_LD + c8 + 4 * h);
-            if (MODE == 0) v[h] *= p.acc_scale;
-            if (MODE == 1) v[h] *= p.scale;
+            if (MODE == 0) v[h] *= acc_scale;
+            if (MODE == 1) v[h] *= scale;
             v[h] += cb[h];
             if (p.rowbias) v[h] += p.rowbias[row];
             if (cb_uniform) v[h] += e.cvu[h];
@@ -369,7 +376,7 @@ __device__ __forceinline__ void epi_process(const KParams& p, const float* stage
                     v[h] += f32x4{(float)hr[4 * h], (float)hr[4 * h + 1], (float)hr[4 * h + 2], (float)hr[4 * h + 3]};
                 } else v[h] += __builtin_bit_cast(f32x4, e.raw[pass][h]);
             }
-            if (MODE == 0) v[h] *= p.scale;
+            if (MODE == 0) v[h] *= scale;
         }
         size_t ocol = (size_t)row * p.ldo + col;
         if (geglu) {
