@@ -355,6 +355,38 @@ __device__ __forceinline__ void epi_process(const KParams& p, const float* stage
     // the plain 320 -> 2 560 projection even with its stores AND its staging writes removed.
     const float acc_scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.acc_scale)));
     const float scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.scale)));
+    if (geglu) {
+        // GEGLU gate (round 4): every lane takes FOUR value columns and their four gate columns (lane & 7 -> columns 4 (lane & 7) .. + 3 and
+        // 32 + the same) instead of lanes 0..3 of a row taking eight values + eight gates while lanes 4..7 idle: the gate is ~25 VALU per
+        // element and the epilogue of the 320 -> 2 560 projection (168 M gates per call) was bound by it at half-empty waves.  Same
+        // arithmetic per element, 8-byte stores (a row's 64 output bytes per 8 lanes, as before).
+        const int c4 = (lane & 7) * 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f}, bg = bv;
+        if (p.colbias) { bv = *reinterpret_cast<const f32x4*>(p.colbias + bn0 + c4); bg = *reinterpret_cast<const f32x4*>(p.colbias + bn0 + 32 + c4); }
+#pragma unroll
+        for (int pass = 0; pass < G::NP; ++pass) {
+            const int rr = pass * G::RPP + lane / G::LPR;
+            const int row = rbase + rr;
+            if (row >= p.M) continue;
+            f32x4 val = *reinterpret_cast<const f32x4*>(stage + rr * EPI_LD + c4);
+            f32x4 gt = *reinterpret_cast<const f32x4*>(stage + rr * EPI_LD + 32 + c4);
+            val = (val * acc_scale + bv) * scale;           // (no row / per-image bias, no residual: the launcher rejects them with GEGLU)
+            gt += bg;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) val[q] *= ds_gelu_gate_fast(gt[q]);
+            const size_t ocol = (size_t)row * p.ldo + (bn0 >> 1) + c4;
+            if (p.out_f16) {
+                typedef _Float16 epi_h4 __attribute__((ext_vector_type(4)));
+                const epi_h4 hv = {(_Float16)val[0], (_Float16)val[1], (_Float16)val[2], (_Float16)val[3]};
+                epi_h4* op = reinterpret_cast<epi_h4*>(reinterpret_cast<_Float16*>(o_base) + ocol);
+                if (NTS) __builtin_nontemporal_store(hv, op); else *op = hv;
+            } else {
+                f32x4* op = reinterpret_cast<f32x4*>(o_base + ocol);
+                if (NTS) __builtin_nontemporal_store(val, op); else *op = val;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int pass = 0; pass < G::NP; ++pass) {
         const int rr = pass * G::RPP + lane / G::LPR;
@@ -379,17 +411,7 @@ __device__ __forceinline__ void epi_process(const KParams& p, const float* stage
             if (MODE == 0) v[h] *= scale;
         }
         size_t ocol = (size_t)row * p.ldo + col;
-        if (geglu) {
-            if (c8 >= 32) continue;                                 // gate columns: consumed by the value lanes
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                f32x4 gt = *reinterpret_cast<const f32x4*>(stage + rr * EPI_LD + c8 + 32 + 4 * h);
-                if (p.colbias) gt += *reinterpret_cast<const f32x4*>(p.colbias + col + 32 + 4 * h);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[h][q] *= ds_gelu_gate_fast(gt[q]);
-            }
-            ocol = (size_t)row * p.ldo + (bn0 >> 1) + c8;
-        } else if (p.act == DS_ACT_SILU) {
+        if (p.act == DS_ACT_SILU) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll

@@ -54,3 +54,24 @@ def test_native_plan_records_every_launch_and_checks_argument_sizes():
     assert lib.ds_plan_size(h) == len(P.ops)
     P.close()
     assert P._native is None
+
+
+def test_fp16_activation_gemm_epilogue_keeps_the_kernel_argument_out_of_private_memory():
+    """Round-4 regression guard (no GPU needed: hipcc cross-compiles).  The fused epilogue of the fp16-activation kernels
+    (igemm_common.h: epi_process) once fetched `p.acc_scale` with a <4 x float> load straddling neighbouring KParams fields, which kept a
+    28-byte slice of the kernel argument in PRIVATE memory -- re-read from scratch in every pass of every tile -- and its GEGLU branch
+    pushed the 192-column tiles into register spills.  Every instantiation of gemm_f16dma_kernel with column tiles of at most 192 channels
+    must need no scratch at all (the 256-column tile keeps its known accumulator spills in the epilogue)."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    src = os.path.join(ROOT, 'diff_sampler_amd', 'csrc', 'gemm_f16dma.hip')
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-c', src, '-o', os.devnull, '-Rpass-analysis=kernel-resource-usage'],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    found = re.findall(r'Function Name: (\S*gemm_f16dma_kernelILi(\d)ELi(\d)E\S*).*?ScratchSize \[bytes/lane\]: (\d+)', r.stderr, flags=re.S)
+    assert len(found) >= 7, r.stderr[-1500:]
+    for name, nb, nw, scratch in found:
+        if int(nb) <= 3:
+            assert int(scratch) == 0, (name, scratch)
