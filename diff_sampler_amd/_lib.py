@@ -56,8 +56,9 @@ def current_tuning():
     return kw
 
 
-# benchmarks / A-B runs of whole programs: DS_CONV_VARIANT / DS_CONV (= tune.mode) in the environment become the default overrides
-_ENV_TUNE = {k: int(os.environ[e]) for k, e in (('variant', 'DS_CONV_VARIANT'), ('mode', 'DS_CONV')) if os.environ.get(e)}
+# benchmarks / A-B runs of whole programs: DS_CONV_VARIANT / DS_CONV (= tune.mode) / DS_CONV_ABLATE (= tune.ablate, e.g. 4096: the staged
+# epilogue of the fp16-activation kernels) in the environment become the default overrides
+_ENV_TUNE = {k: int(os.environ[e]) for k, e in (('variant', 'DS_CONV_VARIANT'), ('mode', 'DS_CONV'), ('ablate', 'DS_CONV_ABLATE')) if os.environ.get(e)}
 
 
 class ConvArgs(C.Structure):

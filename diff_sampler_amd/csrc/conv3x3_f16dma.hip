@@ -23,6 +23,7 @@
 // optional fused 1x1 skip projection on ONE fp16 source [M][ec0], square power-of-two images W in {8, 16, 32, 64} with 256-pixel
 // tiles (one image per tile, or four 8x8 images), cout % 64 == 0, no split-K.
 #include "pipe_common.h"
+#include "epi_direct.h"
 
 namespace igemm {
 namespace {
@@ -40,9 +41,11 @@ struct GeoD {
 template <int W, int NB>
 constexpr unsigned f16dma_smem() { return 2u * NB * 8192u + 2u * GeoD<W>::HALO_B; }
 
-// ILV: the DMA requests of a tap are issued between the MFMAs of its last K step (round 4) instead of behind them (round 3; kept as the
-// A/B partner, ds_conv_tune.ablate bit 11 -- a template parameter, because both orders in one kernel body spill)
-template <int W, int NB, bool ILV>
+// DIRECT: the epilogue that stores straight from the accumulators (epi_direct.h) or the staged one (epilogue_pipe) -- one instantiation
+// each, chosen by the launcher (epi_direct_ok): a kernel body holding both allocates registers for the worse of the two.
+// (The DMA requests of a tap are issued between the MFMAs of its last K step, round 4; the round-3 order "behind them" was kept as an
+// A/B instantiation until the comparison was recorded in docs/HISTORY.md section E.6.)
+template <int W, int NB, bool DIRECT>
 __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p) {
     using G = GeoD<W>;
     constexpr int WP = G::WP, HP = G::HP, TH = G::TH, NIMG = G::NIMG, NP = G::NP, NDMA = G::NDMA;
@@ -157,7 +160,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
         if constexpr (NB == 4)
             asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f.a0), "+v"(f.a1), "+v"(f.b0), "+v"(f.b1), "+v"(f.b2), "+v"(f.b3) : "n"(N));
     };
-#define DSD_MM(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a_), __builtin_bit_cast(h8, b_), acc_, 0, 0, 0)
+    // SWAPPED product (round 4): the weight fragment is the MFMA's first operand, so an accumulator block holds lane = pixel, registers =
+    // channels -- what epilogue_direct (igemm_common.h) stores without an LDS transpose
+#define DSD_MM(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, b_), __builtin_bit_cast(h8, a_), acc_, 0, 0, 0)
     auto mfma_group = [&](Frag& f) {                           // consecutive MFMAs never touch the same accumulator
         DSD_MM(accA[0][0], f.a0, f.b0); DSD_MM(accA[1][0], f.a1, f.b0);
         if constexpr (NB > 1) { DSD_MM(accA[0][1], f.a0, f.b1); DSD_MM(accA[1][1], f.a1, f.b1); }
@@ -238,11 +243,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
                 if (chunk + 1 < NCH) halo_dma(chunk + 1, (chunk + 1) & 1, IC<T9 + 1>{});
             }
         };
-        if constexpr (!ILV) {                         // round-3 order (A/B switch, tune.ablate bit 11): the whole MFMA group, then every request
-            DS2_FENCE(); mfma_group(Q); DS2_FENCE();      // (A/B in one session, profiles/r3_conv_f16dma_ablations.txt: +2 % over issuing the DMA first)
-            if (kt + 2 < KT) w_dma(kt + 2, kt & 1);
-            halo_issue();
-        } else {
+        {
             // Round 4: the requests are issued BETWEEN the MFMAs of the group.  A wave issues in order: behind the group's last MFMA only
             // its own 32 cycles shelter anything, and both waves of a SIMD reach this point together (they left the same barrier), so the
             // 150 - 300 cycles of address arithmetic, M0 writes and LDS-DMA issue left the matrix pipe idle.  Behind MFMA pair i go weight
@@ -288,7 +289,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
     const int wn0 = n0 + wc * (NB * 32);
     // non-temporal residual loads / output stores: +1 ... 2 % (A/B, profiles/r3_conv_f16dma_ablations.txt); the launcher only takes this
     // kernel on the vector path (vec_ok, cout a multiple of the tile width)
-    epilogue_pipe<0, true, (NB == 1 ? 32 : 64), (NB == 3 ? 32 : (NB == 4 ? 64 : 0))>(p, accA, accB, stage, lane, m0 + wr * 64, wn0, p.out);
+    if constexpr (DIRECT) epilogue_direct<false, NB, true>(p, accA, accB, lane, m0 + wr * 64, wn0);
+    else epilogue_pipe<0, true, (NB == 1 ? 32 : 64), (NB == 3 ? 32 : (NB == 4 ? 64 : 0)), true>(p, accA, accB, stage, lane, m0 + wr * 64, wn0, p.out);
 }
 
 // p.t_ablate (ds_conv_args.tune.ablate), benchmarks only: bit 0 = no weight DMA after the prologue, 1 = no halo DMA after slab 0,
@@ -304,7 +306,7 @@ int launch_w_nb(KParams p, int n_begin, int ntiles, hipStream_t stream) {
     int smem = (int)f16dma_smem<W, NB>();
     const int epi = 8 * 32 * EPI_LD * (int)sizeof(float);
     if (smem < epi) smem = epi;
-    if (p.t_ablate & 2048) {
+    if (!epi_direct_ok(p, true, NB)) {
         DS_ENSURE_DYN_LDS((&conv3x3_f16dma_kernel<W, NB, false>), 160 * 1024);
         hipLaunchKernelGGL((conv3x3_f16dma_kernel<W, NB, false>), dim3(grid_1d(p.mtiles, p.ntiles), 1), dim3(512), smem, stream, p);
     } else {

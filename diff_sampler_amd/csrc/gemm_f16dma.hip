@@ -10,6 +10,7 @@
 // Scope: taps == 1, ONE fp16 source [M][K] (K % 64 == 0, ld % 8 == 0), cout % 64 == 0 (GEGLU: NB in {2, 4}), any M (tail rows read a
 // zero page and are masked by the epilogue).
 #include "pipe_common.h"
+#include "epi_direct.h"
 
 namespace igemm {
 namespace {
@@ -22,7 +23,7 @@ __device__ __attribute__((aligned(128))) _Float16 g_zero_halfs_g[64];
 template <int NB, int NW>
 constexpr unsigned gemm16_smem() { return 2u * (NW * 4096u + NB * 8192u); }
 
-template <int NB, int NW>
+template <int NB, int NW, bool DIRECT>
 __global__ void __launch_bounds__(NW * 64, 2) gemm_f16dma_kernel(const KParams p) {
     constexpr unsigned AB = NW * 4096u, WB = NB * 8192u;       // bytes of one A / W stage
     constexpr int BM = NW * 32, NT = NW * 64;                  // rows per tile, threads
@@ -100,7 +101,9 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_f16dma_kernel(const KParams p
         if constexpr (NB == 4)
             asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f.a0), "+v"(f.a1), "+v"(f.b0), "+v"(f.b1), "+v"(f.b2), "+v"(f.b3) : "n"(N));
     };
-#define DSG16_MM(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a_), __builtin_bit_cast(h8, b_), acc_, 0, 0, 0)
+    // SWAPPED product (round 4): the weight fragment is the MFMA's first operand, so an accumulator block holds lane = row (pixel), registers =
+    // columns (channels) -- what epilogue_direct (igemm_common.h) stores without an LDS transpose
+#define DSG16_MM(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, b_), __builtin_bit_cast(h8, a_), acc_, 0, 0, 0)
     auto mfma_group = [&](Frag& f) {
         DSG16_MM(accA[0][0], f.a0, f.b0); DSG16_MM(accA[1][0], f.a1, f.b0);
         if constexpr (NB > 1) { DSG16_MM(accA[0][1], f.a0, f.b1); DSG16_MM(accA[1][1], f.a1, f.b1); }
@@ -151,7 +154,8 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_f16dma_kernel(const KParams p
     }
     float* stage = smem + wave * 32 * EPI_LD;
     const int wn0 = n0 + wc * (NB * 32);
-    epilogue_pipe<0, false, (NB == 1 ? 32 : 64), (NB == 3 ? 32 : (NB == 4 ? 64 : 0))>(p, accA, accB, stage, lane, m0 + wr * 64, wn0, p.out);
+    if constexpr (DIRECT) epilogue_direct<false, NB, false>(p, accA, accB, lane, m0 + wr * 64, wn0);
+    else epilogue_pipe<0, false, (NB == 1 ? 32 : 64), (NB == 3 ? 32 : (NB == 4 ? 64 : 0)), true>(p, accA, accB, stage, lane, m0 + wr * 64, wn0, p.out);
 }
 
 template <int NB, int NW>
@@ -164,8 +168,13 @@ int launch_nb(KParams p, int n_begin, int ntiles, hipStream_t stream) {
     int smem = (int)gemm16_smem<NB, NW>();
     const int epi = NW * 32 * EPI_LD * (int)sizeof(float);
     if (smem < epi) smem = epi;
-    DS_ENSURE_DYN_LDS((&gemm_f16dma_kernel<NB, NW>), 160 * 1024);
-    hipLaunchKernelGGL((gemm_f16dma_kernel<NB, NW>), dim3(grid_1d(p.mtiles, p.ntiles), 1), dim3(NW * 64), smem, stream, p);
+    if (epi_direct_ok(p, false, NB)) {
+        DS_ENSURE_DYN_LDS((&gemm_f16dma_kernel<NB, NW, true>), 160 * 1024);
+        hipLaunchKernelGGL((gemm_f16dma_kernel<NB, NW, true>), dim3(grid_1d(p.mtiles, p.ntiles), 1), dim3(NW * 64), smem, stream, p);
+    } else {
+        DS_ENSURE_DYN_LDS((&gemm_f16dma_kernel<NB, NW, false>), 160 * 1024);
+        hipLaunchKernelGGL((gemm_f16dma_kernel<NB, NW, false>), dim3(grid_1d(p.mtiles, p.ntiles), 1), dim3(NW * 64), smem, stream, p);
+    }
     DS_CHECK_LAUNCH();
     return DS_OK;
 }

@@ -330,8 +330,19 @@ __device__ __forceinline__ void epi_request(const KParams& p, int rbase, int col
 }
 
 // a0 / a1: the group's accumulators of columns [0, 32) / [32, 64) of the block (a1 unused for W = 32) -> the wave's 32 staging rows
-template <int W>
+// TR: the accumulators of a SWAPPED product (weights as the MFMA's first operand: lane = pixel lane & 31, register r = channel
+// 8 (r >> 2) + 4 (lane >> 5) + (r & 3); see epilogue_direct) -- four consecutive channels per 16-byte write.
+template <int W, bool TR = false>
 __device__ __forceinline__ void epi_stage(const f32x16& a0, const f32x16& a1, float* stage, int lane) {
+    if constexpr (TR) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float* sp = stage + (lane & 31) * EPI_LD + 8 * q + 4 * (lane >> 5);
+            *reinterpret_cast<f32x4*>(sp) = f32x4{a0[4 * q], a0[4 * q + 1], a0[4 * q + 2], a0[4 * q + 3]};
+            if (W == 64) *reinterpret_cast<f32x4*>(sp + 32) = f32x4{a1[4 * q], a1[4 * q + 1], a1[4 * q + 2], a1[4 * q + 3]};
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int sr = ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_LD + (lane & 31);
@@ -466,7 +477,7 @@ __device__ __forceinline__ void epi_stats(const KParams& p, int lane, int wm0, i
 // groups (n0 / n1) are requested here as soon as a group's accumulators are staged and dead -- two groups ahead of their use, and with
 // the first block's rows requested before anything else every residual row of the tile is in flight early, without ever holding more
 // than three groups' rows next to the live accumulators.  The EpiRows requests then fetch the per-image bias rows only.
-template <int MODE, bool NTS, int W, int NEXT_W, bool R16>
+template <int MODE, bool NTS, int W, int NEXT_W, bool R16, bool TR = false>
 __device__ __forceinline__ void epi_block(const KParams& p, const f32x16 (&acc)[2][2], float* stage, int lane, int wm0, int bn0, int next_col,
                                           float* o_base, EpiRows& cur, EpiRows& oth, const EpiRes16& r0, const EpiRes16& r1, EpiRes16& n0,
                                           EpiRes16& n1) {
@@ -475,11 +486,11 @@ __device__ __forceinline__ void epi_block(const KParams& p, const f32x16 (&acc)[
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 cb[2] = {zero, zero}, st_s[2] = {zero, zero}, st_q[2] = {zero, zero};
     if (p.colbias) { const f32x4* c = reinterpret_cast<const f32x4*>(p.colbias + col); cb[0] = c[0]; cb[1] = c[1]; }
-    epi_stage<W>(acc[0][0], acc[0][1], stage, lane);
+    epi_stage<W, TR>(acc[0][0], acc[0][1], stage, lane);
     if constexpr (R16 && NEXT_W != 0) epi_request_res16<NW_>(p, wm0, next_col, lane, n0);
     epi_request<W, NTS, R16>(p, wm0 + 32, col, lane, oth);
     epi_process<MODE, W, NTS, R16>(p, stage, wm0, cur, r0, lane, bn0, o_base, cb, st_s, st_q);
-    epi_stage<W>(acc[1][0], acc[1][1], stage, lane);
+    epi_stage<W, TR>(acc[1][0], acc[1][1], stage, lane);
     if constexpr (R16 && NEXT_W != 0) epi_request_res16<NW_>(p, wm0 + 32, next_col, lane, n1);
     if constexpr (NEXT_W != 0) epi_request<NW_, NTS, R16>(p, wm0, next_col, lane, cur);
     epi_process<MODE, W, NTS, R16>(p, stage, wm0 + 32, oth, r1, lane, bn0, o_base, cb, st_s, st_q);
@@ -487,7 +498,7 @@ __device__ __forceinline__ void epi_block(const KParams& p, const f32x16 (&acc)[
 }
 
 // stage: 32 x EPI_LD floats owned by the wave.  The caller guarantees the vector path (p.vec_ok, whole blocks inside N, no split).
-template <int MODE, bool NTS, int WA, int WB>
+template <int MODE, bool NTS, int WA, int WB, bool TR = false>
 __device__ __forceinline__ void epilogue_pipe(const KParams& p, const f32x16 (&accA)[2][2], const f32x16 (&accB)[2][2], float* stage, int lane,
                                               int wm0, int wn0, float* o_base) {
     constexpr int WBB = WB ? WB : 32;
@@ -499,14 +510,14 @@ __device__ __forceinline__ void epilogue_pipe(const KParams& p, const f32x16 (&a
         epi_request_res16<WA>(p, wm0, colA, lane, a0);
         epi_request_res16<WA>(p, wm0 + 32, colA, lane, a1);
         epi_request<WA, NTS, true>(p, wm0, colA, lane, e0);
-        epi_block<MODE, NTS, WA, WB, true>(p, accA, stage, lane, wm0, wn0, colB, o_base, e0, e1, a0, a1, b0, b1);
-        if constexpr (WB != 0) epi_block<MODE, NTS, WBB, 0, true>(p, accB, stage, lane, wm0, wn0 + WA, 0, o_base, e0, e1, b0, b1, a0, a1);
+        epi_block<MODE, NTS, WA, WB, true, TR>(p, accA, stage, lane, wm0, wn0, colB, o_base, e0, e1, a0, a1, b0, b1);
+        if constexpr (WB != 0) epi_block<MODE, NTS, WBB, 0, true, TR>(p, accB, stage, lane, wm0, wn0 + WA, 0, o_base, e0, e1, b0, b1, a0, a1);
         return;
     }
     EpiRes16 none;
     epi_request<WA, NTS>(p, wm0, colA, lane, e0);
-    epi_block<MODE, NTS, WA, WB, false>(p, accA, stage, lane, wm0, wn0, colB, o_base, e0, e1, none, none, none, none);
-    if constexpr (WB != 0) epi_block<MODE, NTS, WBB, 0, false>(p, accB, stage, lane, wm0, wn0 + WA, 0, o_base, e0, e1, none, none, none, none);
+    epi_block<MODE, NTS, WA, WB, false, TR>(p, accA, stage, lane, wm0, wn0, colB, o_base, e0, e1, none, none, none, none);
+    if constexpr (WB != 0) epi_block<MODE, NTS, WBB, 0, false, TR>(p, accB, stage, lane, wm0, wn0 + WA, 0, o_base, e0, e1, none, none, none, none);
 }
 
 // XCD-aware decode of a 1-D workgroup id into (m tile, n tile): the dispatcher places workgroup b on XCD b % 8, so

@@ -1207,6 +1207,109 @@ def test_f16_activation_kernels_with_fp16_residual_and_output_rows(kind, nw):
     assert lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr()) != 0
 
 
+DIRECT_EPILOGUE_CASES = [
+    # kind, wave count (GEMM), shape, forced nb, epilogue
+    ('gemm', 4, (1000, 320, 320), 0, 'bias'),                # ragged rows
+    ('gemm', 4, (512, 320, 960), 3, 'silu'),
+    ('gemm', 8, (640, 640, 1280), 4, 'res'),
+    ('gemm', 4, (300, 1280, 320), 2, 'res'),
+    ('gemm', 8, (777, 64, 64), 1, 'none'),
+    ('gemm', 8, (2048, 320, 2560), 4, 'geglu'),
+    ('gemm', 4, (1000, 320, 2560), 2, 'geglu'),
+    ('gemm', 8, (4096, 640, 640), 4, 'stats'),               # column sums on the GEMM: falls back to the staged epilogue, still correct
+    ('conv', 0, (4, 16, 192, 192), 3, 'cbias_silu_stats'),
+    ('conv', 0, (2, 32, 128, 320), 0, 'res_stats'),
+    ('conv', 0, (2, 32, 64, 256), 4, 'cbias_stats'),
+    ('conv', 0, (8, 8, 256, 64), 1, 'res'),
+    ('conv', 0, (1, 64, 64, 128), 2, 'bias_stats'),
+    ('conv', 0, (2, 16, 128, 256), 4, 'bcast_stats'),        # one per-image bias row for every image (cbias_rows = 1)
+]
+
+
+@pytest.mark.parametrize('case', DIRECT_EPILOGUE_CASES)
+def test_f16_epilogue_without_the_lds_transpose_equals_the_staged_one(case):
+    """csrc/epi_direct.h (round 4): conv3x3_f16dma / gemm_f16dma multiply with swapped MFMA operands (lane = output row, registers = channels)
+    and store fp16 rows straight from the accumulators -- no staging through LDS.  Same operations in the same order on the same values as
+    epilogue_pipe: the output rows must be BIT-IDENTICAL to the staged epilogue's (ds_conv_tune.ablate bit 12 forces it), the GroupNorm
+    column sums equal up to the order of the fp32 additions, and both agree with the CPU reference (fp16 operands, fp64 sums)."""
+    import ctypes as C
+    from diff_sampler_amd import _lib, ops
+    kind, nw, shp, nb, mode = case
+    lib = _lib.load()
+    dev = 'cuda'
+    g = torch.Generator().manual_seed(sum(shp) + nb + len(mode))
+    if kind == 'gemm':
+        rows, k, cout = shp
+        n, h, taps, cin = rows, 1, 1, k
+        x = torch.randn(rows, k, generator=g).to(torch.float16)
+        wt = torch.randn(cout, k, generator=g) / k ** 0.5
+        y = x.double() @ wt.to(torch.float16).double().t()
+    else:
+        n, h, cin, cout = shp
+        rows, taps = n * h * h, 9
+        assert lib.ds_conv_f16dma_supported(n, h, h, cin, 0, cout) == 1
+        x = torch.randn(rows, cin, generator=g).to(torch.float16)
+        wt = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+        y = F.conv2d(x.double().reshape(n, h, h, cin).permute(0, 3, 1, 2), wt.to(torch.float16).double(), padding=1)
+        y = y.permute(0, 2, 3, 1).reshape(rows, cout)
+    bias = torch.randn(cout, generator=g)
+    geglu = mode == 'geglu'
+    if geglu:
+        inner = cout // 2
+        val = torch.arange(inner).reshape(-1, 32)
+        perm = torch.stack([val, val + inner], 1).reshape(-1)
+        wp = ops.pack_linear_weight_f16(ops.pack_linear_weight(wt[perm].to(dev)))
+        biasd = bias[perm].contiguous().to(dev)
+        yb = y + bias.double()
+        ref = yb[:, :inner] * F.gelu(yb[:, inner:])
+        ocols = inner
+    else:
+        wp = ops.pack_linear_weight_f16(ops.pack_linear_weight(wt.to(dev))) if kind == 'gemm' else ops.pack_conv_weight_f16(wt.to(dev))
+        biasd = bias.to(dev)
+        ref = y + bias.double() if mode != 'none' else y
+        ocols = cout
+    cb = res16 = None
+    scale = 1.0
+    if 'cbias' in mode or 'bcast' in mode:
+        cb = torch.randn(1 if 'bcast' in mode else n, cout, generator=g)
+        ref = ref + (cb.double()[:, None, :].expand(-1, h * h, -1).reshape(-1, cout) if 'bcast' not in mode else cb.double())
+    if 'res' in mode:
+        res16 = torch.randn(rows, cout, generator=g).to(torch.float16)
+        ref, scale = (ref + res16.double()) * 0.7071, 0.7071
+    if 'silu' in mode:
+        ref = F.silu(ref)
+    ref = ref.float().to(torch.float16).float()
+    xd = x.to(dev)
+    cbd = cb.to(dev) if cb is not None else None
+    rd = res16.to(dev) if res16 is not None else None
+    with_stats = 'stats' in mode
+    outs, sts = [], []
+    for ablate in (0, 4096):
+        out = torch.full((rows, ocols), float('nan'), dtype=torch.float16, device=dev)
+        stats = torch.full((-(-rows // 64) * 2 * cout,), float('nan'), device=dev) if with_stats else None
+        a = _lib.ConvArgs(xd.data_ptr(), None, cin, 0, cin, 0, n, h, h, taps, wp.data_ptr(), cout, biasd.data_ptr() if mode != 'none' else None,
+                          cbd.data_ptr() if cb is not None else None, cout if cb is not None else 0, cb.shape[0] if cb is not None else 1,
+                          rd.data_ptr() if rd is not None else None, cout, scale, 2 if geglu else (1 if 'silu' in mode else 0), out.data_ptr(), ocols)
+        a.wgt_f16, a.in_f16, a.out_f16, a.res_f16 = 1, 1, 1, int(rd is not None)
+        if with_stats:
+            a.stats_out = stats.data_ptr()
+        a.tune.f16dma_nb, a.tune.f16dma_nw, a.tune.ablate = nb, nw, ablate
+        assert lib.ds_conv_kernel_id(C.byref(a)) == (2567 if kind == 'gemm' else 2566)
+        rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
+        torch.cuda.synchronize()
+        assert rc == 0, lib.ds_error_string(rc)
+        outs.append(out.cpu())
+        sts.append(stats.cpu() if with_stats else None)
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1])
+    assert _rel(outs[0].float(), ref) < 1.5e-3
+    if with_stats and rows % 64 == 0:
+        got = outs[0].float()
+        for st in sts:
+            st = st.reshape(-1, 2, cout)
+            assert _rel(st[:, 0], got.reshape(-1, 64, cout).sum(1)) < 1e-5 and _rel(st[:, 1], (got * got).reshape(-1, 64, cout).sum(1)) < 1e-5
+
+
 @pytest.mark.parametrize('d,heads,sq,skv,mask', [(40, 8, 1024, 1024, 3), (64, 6, 256, 256, 3), (40, 8, 300, 77, 1), (160, 2, 64, 64, 3), (80, 4, 512, 77, 1),
                                                   (64, 3, 130, 130, 2)])
 def test_fused_attention_reads_fp16_q_k_v(d, heads, sq, skv, mask):

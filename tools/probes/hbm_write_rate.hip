@@ -7,6 +7,9 @@
 //   mode 1: 8 rows x 128 B per wave instruction, rows ld bytes apart, column blocks swept row-tile by row-tile (the GEMM's order)
 //   mode 2: 8 rows x  64 B per wave instruction (half lines), the other half written by a LATER sweep
 //   mode 3: as 2, but both halves written back to back by the same wave (what a fused two-block GEGLU pass would do)
+//   mode 4: 32 rows x 32 B per wave instruction (lane = row, lane half = 16-B piece): what an epilogue WITHOUT the LDS transpose would
+//           store if the MFMA operands are swapped (lane = pixel, registers = channels; v_permlane32_swap pairs the quads) -- and `rd<4>`
+//           the residual rows it would load in the same pattern
 //   hipcc --offload-arch=gfx950 -O3 -o tools/probes/hbm_write_rate tools/probes/hbm_write_rate.hip && tools/probes/hbm_write_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -40,6 +43,9 @@ __global__ void __launch_bounds__(256) wr(char* out, long long rows, long long l
 #pragma unroll
                 for (int pass = 0; pass < 2; ++pass)
                     st(base + (long long)(pass * 16 + (lane >> 2)) * ld + blk * 128 + half * 64 + (lane & 3) * 16);
+    } else if (MODE == 4) {                          // lane = row (32 rows), lane half = which 16 B of a 32-B piece; 16 pieces per 512-B row
+#pragma unroll
+        for (int piece = 0; piece < 16; ++piece) st(base + (long long)(lane & 31) * ld + piece * 32 + (lane >> 5) * 16);
     } else {                                         // both halves of a line back to back
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk)
@@ -49,6 +55,44 @@ __global__ void __launch_bounds__(256) wr(char* out, long long rows, long long l
                 for (int half = 0; half < 2; ++half)
                     st(base + (long long)(pass * 16 + (lane >> 2)) * ld + blk * 128 + half * 64 + (lane & 3) * 16);
     }
+}
+
+// the same tiles READ (residual rows): mode 1 = 8 rows x 128 B per instruction, mode 4 = 32 rows x 32 B
+template <int MODE, bool NT>
+__global__ void __launch_bounds__(256) rd(const char* in, long long rows, long long ld, int col_tiles, float* sink) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long long tile = blockIdx.x;
+    const long long rt = tile / col_tiles, ct = tile % col_tiles;
+    const char* base = in + (rt * 128 + wave * 32) * ld + ct * 512;
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto ldv = [&](const char* p) { return NT ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(p)) : *reinterpret_cast<const f4*>(p); };
+    if (MODE == 1) {
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) acc += ldv(base + (long long)(pass * 8 + (lane >> 3)) * ld + blk * 128 + (lane & 7) * 16);
+    } else {
+#pragma unroll
+        for (int piece = 0; piece < 16; ++piece) acc += ldv(base + (long long)(lane & 31) * ld + piece * 32 + (lane >> 5) * 16);
+    }
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) sink[tid] = acc[0];
+}
+
+template <int MODE, bool NT>
+void run_rd(const char* label, const char* in, long long rows, long long ld, float* sink) {
+    const int col_tiles = (int)(ld / 512);
+    const long long tiles = rows / 128 * col_tiles;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    rd<MODE, NT><<<(unsigned)tiles, 256>>>(in, rows, ld, col_tiles, sink);
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(e0);
+        rd<MODE, NT><<<(unsigned)tiles, 256>>>(in, rows, ld, col_tiles, sink);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    printf("%-72s %8.3f ms  %6.2f TB/s\n", label, best, (double)rows * ld / best / 1e9);
 }
 
 template <int MODE, bool NT>
@@ -80,6 +124,14 @@ int main() {
     run<2, true>("16 rows x 64 B per instruction, other half later, nontemporal", out, rows, ld);
     run<3, false>("16 rows x 64 B per instruction, both halves back to back", out, rows, ld);
     run<3, true>("16 rows x 64 B per instruction, both halves back to back, nontemporal", out, rows, ld);
+    run<4, false>("32 rows x 32 B per instruction (lane = row; no-transpose epilogue)", out, rows, ld);
+    run<4, true>("32 rows x 32 B per instruction, nontemporal", out, rows, ld);
+    float* sink; (void)hipMalloc(&sink, 4096);
+    run_rd<1, false>("READ  8 rows x 128 B per instruction", out, rows, ld, sink);
+    run_rd<1, true>("READ  8 rows x 128 B per instruction, nontemporal", out, rows, ld, sink);
+    run_rd<4, false>("READ 32 rows x 32 B per instruction", out, rows, ld, sink);
+    run_rd<4, true>("READ 32 rows x 32 B per instruction, nontemporal", out, rows, ld, sink);
+    (void)hipFree(sink);
     (void)hipFree(out);
     return 0;
 }
