@@ -413,6 +413,8 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
         return launch_conv3x3_halo2(p, wide, a->wgt_f16, (hipStream_t)stream);
     }
     const bool generic = p.t_mode == 1;                    // tune.mode 1: the generic gather kernel (A/B runs, cross-checks)
+    // network heads (cout <= 4): VALU kernel instead of a 64- / 128-column matrix tile (tune.mode != 0 keeps the matrix kernels: 8 = just that)
+    if (p.t_mode == 0 && p.t_variant == 0 && conv3x3_thin_applicable(p)) return launch_conv3x3_thin(p, (hipStream_t)stream);
     if (!generic && stride == 1 && conv3x3_halo_supported(p)) return launch_conv3x3_halo(p, (hipStream_t)stream);
     if (p.norm) return DS_E_SHAPE;           // fused input normalisation exists only in the halo kernel
     if (!generic && p.t_mode != 6 && gemm_dma8_applicable(p)) return launch_gemm_dma8(p, (hipStream_t)stream);     // mode 6: no 8-wave DMA kernel
@@ -437,6 +439,10 @@ extern "C" int ds_conv_kernel_id(const ds_conv_args* a) {
     if (a->wgt_f16 == 1 && a->in_f16) return a->taps == 1 ? 2567 : (conv3x3_f16dma_use_half(p) ? 2569 : 2566);
     if (a->wgt_f16) return a->wgt_f16 == 2 ? 2563 : (a->taps == 1 ? 2564 : 2562);
     if (p.t_mode == 1) return 0;
+    if (p.t_mode == 0 && p.t_variant == 0 && !a->res && !a->cbias && !a->stats_out) {
+        KParams q = p; q.HW = p.HW; q.res = nullptr; q.cbias = nullptr; q.stats = nullptr; q.splits = 1; q.norm_act = a->norm_act;
+        if (conv3x3_thin_applicable(q)) return 2570;
+    }
     if (a->taps != 9 || a->stride > 1) return (p.t_mode != 6 && gemm_dma8_applicable(p)) ? 2561 : 0;
     return conv3x3_halo_choice(p);
 }

@@ -615,6 +615,9 @@ bool conv3x3_halo2_applicable(const KParams& p, int wide, int mode);   // mode 0
 int launch_conv3x3_halo2(KParams& p, int wide, int mode, hipStream_t stream);
 
 // conv3x3_f16dma.hip: 3x3 on fp16 activations, both operands by LDS-DMA, 256-pixel x 64/128/192/256-channel tiles
+// conv3x3_thin.hip: 3x3 layers with at most four output channels (the network heads)
+bool conv3x3_thin_applicable(const KParams& p);
+int launch_conv3x3_thin(KParams& p, hipStream_t stream);
 bool conv3x3_f16dma_applicable(const KParams& p);
 int launch_conv3x3_f16dma(KParams& p, hipStream_t stream);
 

@@ -62,7 +62,8 @@ const char* ds_error_string(int code);
 typedef struct ds_conv_tune {
     /* 1 = generic gather kernel instead of the LDS-halo / LDS-DMA kernels (both exact fp32: cross-check), 128 / 256 = forced M tile of
      * the halo kernel, 2 = halo kernel with register-staged weights, 4 = no 64-column tail tiles, 6 = no 8-wave DMA kernel for 1x1 /
-     * Linear layers. */
+     * Linear layers, 8 = no thin-output kernel (conv3x3_thin.hip, kernel id 2570) for 3x3 layers with cout <= 4: the matrix kernels as for
+     * any other layer.  (Any non-zero mode or variant keeps the matrix kernels.) */
     int mode;
     /* Kernel variant of the LDS-halo 3x3 convolution.  Low five bits: 0 = default, 1 = software-pipelined tap loop of the 128-column
      * tiles, 3 = second-generation kernel (conv3x3_halo2.hip) where it applies, 6 / 7 = 256 x 256 tiles forced (tests at small sizes)
@@ -165,7 +166,8 @@ int ds_conv2d_nhwc(const ds_conv_args* a, void* stream);
  * (gemm_dma8_kernel), 2562 = fp16-operand halo kernel (conv3x3_halo2_kernel<W, 1>), 2560 = the same kernel on fp32 operands (tune.variant 3), 2563 = split-fp16 (fp32-emulated) halo kernel
  * (conv3x3_halo2_kernel<W, 2>), 2564 = fp16-operand 1x1 / Linear kernel (gemm_f16_kernel), 2565 = LDS-halo kernel <4> with
  * 256-pixel x 256-channel tiles (64 x 128 per wave; channel counts that are multiples of 256 on 16-, 32- and 64-column images), 1284 =
- * LDS-halo kernel with 128-pixel tiles on eight waves of 64 x 32 (layers with at most one tile per CU).  Used by bench.py to
+ * LDS-halo kernel with 128-pixel tiles on eight waves of 64 x 32 (layers with at most one tile per CU), 2570 = the thin-output 3x3 kernel
+ * of the network heads (conv3x3_thin_kernel: cout <= 4, one fp32 source, no residual / per-image bias / statistics).  Used by bench.py to
  * attribute time per kernel. */
 int ds_conv_kernel_id(const ds_conv_args* a);
 

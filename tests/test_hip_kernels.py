@@ -315,6 +315,65 @@ def test_conv_planar_output(B, H, cin, cout, ws):
     assert _rel(out.cpu(), F.conv2d(x, wt, bias, padding=1)) < TOL
 
 
+THIN_CASES = [
+    # B, H, W, cin, cout, norm (0 none / 1 affine / 2 affine + SiLU), planar output, bias
+    (2, 32, 32, 256, 3, 2, True, True),          # EDM CIFAR-10 head: GroupNorm + SiLU fused, NCHW output
+    (1, 64, 64, 192, 3, 2, True, True),          # ImageNet-64 head
+    (2, 64, 64, 320, 4, 0, False, True),         # SD-1.5 head on the normalised tensor, rows with out_ld = 4
+    (3, 8, 8, 64, 1, 1, False, False),           # one output, 8x8 images (a wave = one image), no bias
+    (2, 16, 32, 96, 2, 2, True, False),          # non-square
+    (5, 16, 16, 32, 4, 0, True, True),           # one 32-channel step, five images (M = 1 280: the last workgroup is ragged)
+]
+
+
+@pytest.mark.parametrize('case', THIN_CASES)
+def test_conv_thin_output_kernel_matches_the_matrix_kernels(case):
+    """csrc/conv3x3_thin.hip (kernel id 2570): 3x3 layers with at most four output channels -- the network heads -- as VALU work on 8 pixels x
+    32 channels per wave instruction instead of a 64- / 128-column matrix tile.  Against ATen in fp64 (the fp32 bound of the other kernels)
+    and against the matrix kernel the same call takes with ds_conv_tune.mode = 8."""
+    import ctypes as C
+    from diff_sampler_amd import _lib, ops
+    B, H, W, cin, cout, norm, planar, with_bias = case
+    lib = _lib.load()
+    dev = 'cuda'
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = torch.randn(B, cin, H, W, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    mu = torch.randn(B, cin, generator=g) * 0.3
+    ga = 1 + 0.2 * torch.randn(B, cin, generator=g)
+    be = 0.2 * torch.randn(B, cin, generator=g)
+    xin = x.double()
+    if norm:
+        xin = (xin - mu.double()[:, :, None, None]) * ga.double()[:, :, None, None] + be.double()[:, :, None, None]
+        if norm == 2:
+            xin = F.silu(xin)
+    ref = F.conv2d(xin, wt.double(), bias.double() if with_bias else None, padding=1) * 0.5
+    xn, wp, bd = _nhwc(x).to(dev), ops.pack_conv_weight(wt).to(dev), bias.to(dev)
+    coefs = torch.stack([mu, ga, be], 1).contiguous().to(dev)
+    outs = []
+    for mode in (0, 8):
+        out = torch.full((B, cout, H, W) if planar else (B * H * W, 4), float('nan'), device=dev)
+        a = _lib.ConvArgs(xn.data_ptr(), None, cin, 0, cin, 0, B, H, W, 9, wp.data_ptr(), cout, bd.data_ptr() if with_bias else None, None, 0, 1,
+                          None, 0, 0.5, 0, out.data_ptr(), 4, coefs.data_ptr() if norm else None, 1 if norm == 2 else 0)
+        a.out_nchw = int(planar)
+        a.tune.mode = mode
+        kid = lib.ds_conv_kernel_id(C.byref(a))
+        assert (kid == 2570) == (mode == 0), kid
+        rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
+        torch.cuda.synchronize()
+        if mode == 8 and rc != 0 and norm:
+            continue                              # (fused normalisation outside the halo kernel's geometries: no matrix kernel to compare with)
+        assert rc == 0, lib.ds_error_string(rc)
+        got = out.cpu() if planar else out[:, :cout].cpu()
+        assert torch.isfinite(got).all()
+        want = ref.float() if planar else _nhwc(ref.float())
+        assert _rel(got, want) < TOL, mode
+        outs.append(got)
+    if len(outs) == 2:
+        assert _rel(outs[0], outs[1]) < TOL
+
+
 @pytest.mark.parametrize('B,H,cin,cout,taps,ws', [(3, 16, 64, 128, 9, False), (2, 8, 256, 320, 9, True), (2, 32, 32, 192, 9, False),
                                                    (16, 32, 640, 1024, 1, False), (4, 8, 64, 64, 1, False), (2, 64, 32, 64, 9, False)])
 def test_conv_epilogue_statistics_feed_groupnorm(B, H, cin, cout, taps, ws):
