@@ -13,7 +13,7 @@
 //     involution on the DMA source address and on the fragment read: 16 consecutive pixels of one chunk hit 16 different bank
 //     quads); out-of-image pixels fetch a zero page.  Two halo buffers: slab s+1 streams in (one 8-KB DMA round per tap) while slab s
 //     is multiplied;
-//   * weights of a tap: NB * 64 rows x 128 B, swizzled the same way, double-buffered, one tap ahead;
+//   * weights of a tap: NB * 64 rows x 128 B, swizzled the same way, in a ring of D = 2 .. 4 buffers (f16dma_ring), D - 1 taps ahead;
 //   * per tap: one barrier; the A-fragment addresses of the 9 taps are 18 precomputed registers, a K step is `base ^ (ks << 5)`;
 //   * 192-channel layers (ADM: 192 / 384 / 576 / 768) get 192-column tiles (NB = 3), 256-multiples NB = 4 where two halo
 //     buffers + 64 KB of weights fit the 160 KB LDS (images of at most 32 columns), tails NB = 2 / 1;
@@ -38,8 +38,21 @@ struct GeoD {
     static constexpr unsigned HALO_B = NDMA * 8192u;
 };
 
+// Weight ring depth (round 4): a tap's weights are requested D - 1 taps ahead.  D = 2 is the double buffer of round 3 -- enough for NB >= 3,
+// where a tap holds >= 24 MFMAs per wave (1.2 us at the clock the part sustains) and the request of tap kt + 2 has that long to land.  A
+// 64-column tile (NB = 1: every layer of the 8x8 stages, 10 % of ImageNet-64 fp16 and 6 % of SD-1.5 fp16, and the tail tiles) holds 8 MFMAs
+// per tap: 0.4 us of work against ~1 us of L2 -> LDS latency, measured 1.05 us per tap = 0.2 of the matrix rate of the wide tiles.  Such
+// tiles leave LDS unused, so the ring takes what fits next to the two halo buffers, at most four taps.  Measured (session gpurun_out/r6e,
+// against the same library with D = 2 everywhere): nothing on a layer benchmarked alone, where the weights stay in L2 / MALL between
+// launches (8x8 768 -> 768: 0.077 - 0.086 ms both ways), but +2.5 % on ImageNet-64 fp16 and +1.5 % on SD-1.5 fp16 as samplers, where every
+// layer's weights come from HBM: profiles/r4_conv_f16dma_ring_ab.txt.
 template <int W, int NB>
-constexpr unsigned f16dma_smem() { return 2u * NB * 8192u + 2u * GeoD<W>::HALO_B; }
+constexpr int f16dma_ring() {
+    const int fit = (int)((160u * 1024u - 2u * GeoD<W>::HALO_B) / (NB * 8192u));
+    return NB >= 3 ? 2 : (fit > 4 ? 4 : (fit < 2 ? 2 : fit));
+}
+template <int W, int NB>
+constexpr unsigned f16dma_smem() { return (unsigned)f16dma_ring<W, NB>() * NB * 8192u + 2u * GeoD<W>::HALO_B; }
 
 // DIRECT: the epilogue that stores straight from the accumulators (epi_direct.h) or the staged one (epilogue_pipe) -- one instantiation
 // each, chosen by the launcher (epi_direct_ok): a kernel body holding both allocates registers for the worse of the two.
@@ -50,9 +63,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
     using G = GeoD<W>;
     constexpr int WP = G::WP, HP = G::HP, TH = G::TH, NIMG = G::NIMG, NP = G::NP, NDMA = G::NDMA;
     constexpr unsigned WB = NB * 8192u, HB = G::HALO_B;
+    constexpr int D = f16dma_ring<W, NB>();                    // weight ring: taps kt .. kt + D - 1 are in LDS or in flight
     static_assert(f16dma_smem<W, NB>() <= 160u * 1024u, "LDS");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* lds = reinterpret_cast<char*>(smem);                 // [weights 0 | weights 1 | halo 0 | halo 1]
+    char* lds = reinterpret_cast<char*>(smem);                 // [weights 0 | ... | weights D - 1 | halo 0 | halo 1]
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -94,12 +108,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
         const _Float16* base = extra ? e0 + (size_t)(chunk - nchunks) * 64 : a0 + (size_t)chunk * 64;
         const int ld = extra ? p.elda0 : p.lda0;
         const _Float16* g = hpix[j] >= 0 ? base + (size_t)hpix[j] * ld + hch : g_zero_halfs;
-        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + 2 * WB + hbuf * HB + (j * 512 + wave * 64) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + D * WB + hbuf * HB + (j * 512 + wave * 64) * 16), 16, 0, 0);
     };
     // ---- weight DMA of K tile (tap) kt: rows i * 64 + (tid >> 3), i < NB; the source chunk is pre-swizzled -----------------------
     const _Float16* wsrc = wgt + (size_t)(n0 + (tid >> 3)) * ldbh + (((tid & 7) ^ ((tid >> 4) & 7)) * 8);
     auto w_dma = [&](int kt, int wbuf) {
-        if ((abl & 1) && kt > 1) return;
+        if ((abl & 1) && kt >= D) return;
 #pragma unroll
         for (int i = 0; i < NB; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (size_t)i * 64 * ldbh + (size_t)kt * 64),
@@ -107,7 +121,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
     };
     auto w_dma_row = [&](int kt, int wbuf, auto ic) {            // one 64-row block of it (issued between MFMAs, see the tap)
         constexpr int i = decltype(ic)::value;
-        if ((abl & 1) && kt > 1) return;
+        if ((abl & 1) && kt >= D) return;
         __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (size_t)i * 64 * ldbh + (size_t)kt * 64),
                                          (lptr_t)(lds + wbuf * WB + (i * 64 + wave * 8) * 128), 16, 0, 0);
     };
@@ -170,7 +184,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
         if constexpr (NB > 3) { DSD_MM(accB[0][1], f.a0, f.b3); DSD_MM(accB[1][1], f.a1, f.b3); }
     };
     constexpr int NR = 2 + NB;                                 // LDS reads per fragment set
-    const unsigned halo0 = lds0 + 2 * WB;
+    const unsigned halo0 = lds0 + D * WB;
 
     // ---- prologue: halo of slab 0, the part of slab 1's halo that is due (see the tap), weights of taps 0 and 1 -------------------
     static_for<NDMA>([&](auto jc) { halo_dma(0, 0, jc); });
@@ -178,8 +192,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
         if (nchunks == 0) static_for<NDMA>([&](auto jc) { halo_dma(1, 1, jc); });      // slab 0 is a one-tap slab
         else halo_dma(1, 1, IC<0>{});
     }
-    w_dma(0, 0);
-    if (KT > 1) w_dma(1, 1);
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < KT) w_dma(d, d);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     Frag P_, Q_;
@@ -188,11 +203,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
         frag_read(P_, halo0 + a_addr(0, (int)ctr), halo0 + a_addr(1, (int)ctr), bbase);
     }
 
-    int kt = 0;
+    int kt = 0, slot = 0;                                      // slot = kt % D: the ring buffer of tap kt
     // One tap: T9 = tap of a 3x3 slab (0..8) or 9 = the centre tap of an appended 1x1 slab.  P holds the fragments of its K step 0
     // (read after the previous tap's barrier).
     //   K steps 0..2 : reads of step k+1 in flight under the MFMAs of step k
-    //   then         : all reads of this tap done, own DMAs landed (vmcnt(0)), barrier: buffer kt & 1 -- and, at a slab end, the
+    //   then         : all reads of this tap done, own DMAs landed (counted, see below), barrier: ring buffer kt % D -- and, at a slab end, the
     //                  halo buffer -- are free and the operands of tap kt+1 are in LDS
     //   K step 3     : behind the barrier: the first fragment reads of tap kt+1, the step's MFMAs, then -- in their shadow -- the DMA
     //                  issue of tap kt+2's weights and of the next halo round
@@ -205,7 +220,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
         constexpr int TT = X ? 4 : T9;
         constexpr bool SLAB_END = X || T9 == 8;
         const unsigned hoff = halo0 + (unsigned)(chunk & 1) * HB;
-        const unsigned woff = (unsigned)(kt & 1) * WB;
+        const unsigned woff = (unsigned)slot * WB;
+        const int nslot = slot + 1 == D ? 0 : slot + 1;
         const unsigned a_0 = a_addr(0, TT) + hoff, a_1 = a_addr(1, TT) + hoff;
         const unsigned vb = bbase + woff;
         frag_read(Q, a_0 ^ 32u, a_1 ^ 32u, vb ^ 32u);
@@ -218,13 +234,17 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
         frag_wait(P, IC<NR>{});
         DS2_FENCE(); mfma_group(P); DS2_FENCE();
         frag_wait(Q, IC<0>{});
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // own DMAs landed: everything at a slab end (the next slab's halo) and in the last D - 1 taps; otherwise all but the youngest
+        // (D - 2) * NB requests -- the weights of taps kt + 2 .. kt + D - 1 (loads complete in order; halo rounds issued in between only
+        // make this wait for more than it needs)
+        if (D == 2 || SLAB_END || kt + D > KT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * NB) : "memory");
         if (!(abl & 16)) __builtin_amdgcn_s_barrier();         // (timing ablation: no per-tap barrier)
         DS2_FENCE();
         // ---- behind the barrier: first the fragment reads of tap kt+1 and the last K step's MFMAs, THEN the DMA issue (address
         // arithmetic, M0 writes, NB + 1 LDS-DMA instructions: ~150-300 cycles per wave) in the shadow of those MFMAs -------------------
         if (kt + 1 < KT) {
-            const unsigned nwoff = (unsigned)((kt + 1) & 1) * WB;
+            const unsigned nwoff = (unsigned)nslot * WB;
             if constexpr (SLAB_END) {
                 const unsigned nh = halo0 + (unsigned)((chunk + 1) & 1) * HB;
                 const int nt9 = chunk + 1 >= nchunks ? 4 : 0;
@@ -247,26 +267,26 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
             // Round 4: the requests are issued BETWEEN the MFMAs of the group.  A wave issues in order: behind the group's last MFMA only
             // its own 32 cycles shelter anything, and both waves of a SIMD reach this point together (they left the same barrier), so the
             // 150 - 300 cycles of address arithmetic, M0 writes and LDS-DMA issue left the matrix pipe idle.  Behind MFMA pair i go weight
-            // rows [i * 64, i * 64 + 64) of tap kt + 2; the halo round goes behind the first pair.
-            const bool wd = kt + 2 < KT;
+            // rows [i * 64, i * 64 + 64) of tap kt + D; the halo round goes behind the first pair.
+            const bool wd = kt + D < KT;
             DS2_FENCE();
             DSD_MM(accA[0][0], Q.a0, Q.b0); DSD_MM(accA[1][0], Q.a1, Q.b0);
-            DS2_FENCE(); halo_issue(); if (wd) w_dma_row(kt + 2, kt & 1, IC<0>{}); DS2_FENCE();
+            DS2_FENCE(); halo_issue(); if (wd) w_dma_row(kt + D, slot, IC<0>{}); DS2_FENCE();
             if constexpr (NB > 1) {
                 DSD_MM(accA[0][1], Q.a0, Q.b1); DSD_MM(accA[1][1], Q.a1, Q.b1);
-                DS2_FENCE(); if (wd) w_dma_row(kt + 2, kt & 1, IC<1>{}); DS2_FENCE();
+                DS2_FENCE(); if (wd) w_dma_row(kt + D, slot, IC<1>{}); DS2_FENCE();
             }
             if constexpr (NB > 2) {
                 DSD_MM(accB[0][0], Q.a0, Q.b2); DSD_MM(accB[1][0], Q.a1, Q.b2);
-                DS2_FENCE(); if (wd) w_dma_row(kt + 2, kt & 1, IC<2>{}); DS2_FENCE();
+                DS2_FENCE(); if (wd) w_dma_row(kt + D, slot, IC<2>{}); DS2_FENCE();
             }
             if constexpr (NB > 3) {
                 DSD_MM(accB[0][1], Q.a0, Q.b3); DSD_MM(accB[1][1], Q.a1, Q.b3);
-                DS2_FENCE(); if (wd) w_dma_row(kt + 2, kt & 1, IC<3>{}); DS2_FENCE();
+                DS2_FENCE(); if (wd) w_dma_row(kt + D, slot, IC<3>{}); DS2_FENCE();
             }
         }
         DS2_FENCE();
-        ++kt;
+        ++kt; slot = nslot;
     };
     int chunk = 0;
     for (; chunk < nchunks; ++chunk) {

@@ -32,6 +32,7 @@ SHAPES_FFHQ = [  # FFHQ-64 SongUNet (128 / 256 channels at 64 / 32 / 16 / 8): be
 ]
 SHAPES_SD15 = [  # SD-1.5 latent U-Net 3x3 convs (320 / 640 / 1280 channels at 64 / 32 / 16 / 8): bench with --batch 32
     (64, 320, 0, 320, 9), (64, 320, 320, 320, 9), (32, 640, 0, 640, 9), (32, 640, 640, 640, 9), (16, 1280, 0, 1280, 9), (16, 1280, 1280, 1280, 9),
+    (8, 1280, 0, 1280, 9), (8, 1280, 1280, 1280, 9),                                       # [6], [7]: the 8x8 stage (64-column tiles)
 ]
 
 SHAPES_SD15_GEMM = [  # SD-1.5 transformer projections / 1x1s on the image rows (taps = 1): bench with --batch 32 --f16 --dma16 [--f16io]
