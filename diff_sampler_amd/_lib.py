@@ -156,6 +156,7 @@ _SIGNATURES = {
     'ds_conv_f16_supported': (C.c_int, [C.c_int] * 7),
     'ds_conv_f16dma_supported': (C.c_int, [C.c_int] * 6),
     'ds_gemm_f16dma_supported': (C.c_int, [C.c_longlong, C.c_int, C.c_int]),
+    'ds_conv_f16dma_stride2_supported': (C.c_int, [C.c_int] * 5),
     'ds_conv_split_supported': (C.c_int, [C.c_int] * 7),
     'ds_gemm_f16_supported': (C.c_int, [C.c_longlong, C.c_int, C.c_int]),
     'ds_gemm_nt_batched': (C.c_int, [C.POINTER(GemmArgs), vp]),

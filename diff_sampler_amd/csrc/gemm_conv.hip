@@ -329,7 +329,8 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     if (a->out_f16 && (!a->in_f16 || (a->cout & 63) || (a->out_ld & 7) || !ds_aligned16(a->out))) return DS_E_ARG;   // fp16 output rows: the fp16-activation kernels only
     if (a->res_f16 && (!a->in_f16 || !a->res || (a->res_ld & 7) || !ds_aligned16(a->res))) return DS_E_ARG;          // fp16 residual rows: the same kernels
     if (a->in_f16) {          // fp16 activations: pure matrix kernels (conv3x3_f16dma.hip / gemm_f16dma.hip); ld in halfs, 16-byte chunks
-        if (a->wgt_f16 != 1 || a->c1 || a->ec1 || a->norm_coefs || a->out_nchw || (a->stride && a->stride != 1)) return DS_E_ARG;
+        if (a->wgt_f16 != 1 || a->c1 || a->ec1 || a->norm_coefs || a->out_nchw) return DS_E_ARG;
+        if (a->stride > 1 && (a->stride != 2 || a->taps != 9 || a->ec0 || a->res)) return DS_E_ARG;      // stride 2: the Downsample convolution, csrc/gemm_f16dma.hip (gather)
         if (a->taps == 1 && a->ec0) return DS_E_ARG;
         if ((a->ld0 & 7) || (a->ec0 && ((a->eld0 & 7) || !a->e0 || !ds_aligned16(a->e0)))) return DS_E_ALIGN;
     }
@@ -395,6 +396,15 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
             if (!gemm_f16_applicable(p)) return DS_E_SHAPE;
             return launch_gemm_f16(p, (hipStream_t)stream);
         }
+        if (a->wgt_f16 == 1 && a->in_f16 && a->taps == 9 && stride == 2) {
+            // the latent-diffusion Downsample on fp16 rows: the fp16-activation GEMM with a gathered A tile (weights packed like the stride-1 kernel's)
+            if (a->wgt_shift) return DS_E_ARG;
+            p.ldb = p.K / 2;
+            p.out_f16 = a->out_f16 ? 1 : 0; p.res_f16 = 0;
+            p.part = nullptr; p.part_cap = 0; p.splits = 1;
+            if (!gemm_f16dma_gather_applicable(p)) return DS_E_SHAPE;
+            return launch_gemm_f16dma(p, (hipStream_t)stream, true);
+        }
         if (a->taps != 9 || stride != 1 || (a->wgt_f16 != 1 && a->wgt_f16 != 2)) return DS_E_ARG;
         if (a->wgt_shift < 0 || a->wgt_shift > 24 || (a->wgt_f16 == 1 && a->wgt_shift)) return DS_E_ARG;
         if (a->in_f16) {
@@ -436,6 +446,7 @@ extern "C" int ds_conv_kernel_id(const ds_conv_args* a) {
     p.vec_ok = (vec_epilogue_ok(p) && !a->out_nchw) ? 1 : 0;
     p.stride = a->stride ? a->stride : 1; p.K = a->taps * (a->c0 + a->c1) + a->ec0 + a->ec1; p.norm = a->norm_coefs;
     p.nrows_b = ((a->cout + BN - 1) / BN) * BN;                                     // weights are row-padded, as in ds_conv2d_nhwc
+    if (a->wgt_f16 == 1 && a->in_f16 && a->taps == 9 && p.stride == 2) return 2571;
     if (a->wgt_f16 == 1 && a->in_f16) return a->taps == 1 ? 2567 : (conv3x3_f16dma_use_half(p) ? 2569 : 2566);
     if (a->wgt_f16) return a->wgt_f16 == 2 ? 2563 : (a->taps == 1 ? 2564 : 2562);
     if (p.t_mode == 1) return 0;
@@ -466,6 +477,14 @@ extern "C" int ds_gemm_f16dma_supported(long long rows, int k, int cout) {
     if (rows > 0x7fffffffLL || rows < 1) return 0;
     p.taps = 1; p.stride = 1; p.M = (int)rows; p.N = cout; p.K = k; p.c0 = k; p.vec_ok = 1; p.nrows_b = ((cout + BN - 1) / BN) * BN;
     return gemm_f16dma_applicable(p) ? 1 : 0;
+}
+extern "C" int ds_conv_f16dma_stride2_supported(int n, int h, int w, int c0, int cout) {
+    KParams p{};
+    const long long M = (long long)n * h * w;
+    if (n < 1 || h < 1 || w < 1 || M > 0x7fffffffLL / 4) return 0;
+    p.taps = 9; p.stride = 2; p.H = h; p.W = w; p.HW = h * w; p.IH = 2 * h; p.IW = 2 * w; p.M = (int)M; p.N = cout; p.c0 = c0; p.K = 9 * c0;
+    p.vec_ok = 1; p.nrows_b = ((cout + BN - 1) / BN) * BN;
+    return gemm_f16dma_gather_applicable(p) ? 1 : 0;
 }
 extern "C" int ds_gemm_f16_supported(long long rows, int c0, int c1) {
     KParams p{};

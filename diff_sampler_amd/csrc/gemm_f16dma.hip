@@ -9,6 +9,11 @@
 // attention output and the GEGLU gate write fp16 rows, and this kernel streams them.
 // Scope: taps == 1, ONE fp16 source [M][K] (K % 64 == 0, ld % 8 == 0), cout % 64 == 0 (GEGLU: NB in {2, 4}), any M (tail rows read a
 // zero page and are masked by the epilogue).
+// GATHER (round 4): the same kernel as the latent-diffusion `Downsample` -- a 3x3, stride-2, pad-1 convolution (openaimodel.py:146-148) on the
+// fp16 residual stream.  The A tile of K tile kt = (64-channel slab, tap) is then a GATHER of 128-byte row pieces: output pixel (img, oy, ox)
+// reads input pixel (img, 2 oy + ty - 1, 2 ox + tx - 1), channels [64 slab, 64 slab + 64), or the zero page outside the image -- the LDS-DMA
+// takes a per-lane global address, so the gather costs a handful of VALU per K tile and nothing else; weights are the [slab][tap][64] packing of
+// the stride-1 kernel (ops.pack_conv_weight_f16), so the weight stream is unchanged.  Replaces widen-to-fp32 + igemm_f32_kernel<0> in fp16 mode.
 #include "pipe_common.h"
 #include "epi_direct.h"
 
@@ -23,7 +28,7 @@ __device__ __attribute__((aligned(128))) _Float16 g_zero_halfs_g[64];
 template <int NB, int NW>
 constexpr unsigned gemm16_smem() { return 2u * (NW * 4096u + NB * 8192u); }
 
-template <int NB, int NW, bool DIRECT>
+template <int NB, int NW, bool DIRECT, bool GATHER = false>
 __global__ void __launch_bounds__(NW * 64, 2) gemm_f16dma_kernel(const KParams p) {
     constexpr unsigned AB = NW * 4096u, WB = NB * 8192u;       // bytes of one A / W stage
     constexpr int BM = NW * 32, NT = NW * 64;                  // rows per tile, threads
@@ -44,19 +49,46 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_f16dma_kernel(const KParams p
     // DMA: thread tid owns 16-B unit j * NT + tid of round j: row j * (NT / 8) + (tid >> 3), LDS chunk slot tid & 7 = source chunk ^ ((row >> 1) & 7)
     const int sw = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;
     const _Float16* asrc[4];
+    int pixb[4];                         // GATHER: input pixel index of tap (0, 0) of the row's output pixel (may lie outside the image)
+    unsigned vmask[4];                   // GATHER: bit t = tap t of this row reads inside the image (0 for rows >= M)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int row = m0 + j * (NT / 8) + (tid >> 3);
-        asrc[j] = row < p.M ? a0 + (size_t)row * p.lda0 + sw : nullptr;
+        if constexpr (GATHER) {
+            asrc[j] = nullptr; pixb[j] = 0; vmask[j] = 0u;
+            if (row < p.M) {
+                const int img = row / p.HW, rem = row - img * p.HW;
+                const int oy = rem / p.W, ox = rem - oy * p.W;
+                const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;
+                pixb[j] = (img * p.IH + iy0) * p.IW + ix0;
+                unsigned m = 0u;
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    if ((unsigned)(iy0 + t / 3) < (unsigned)p.IH && (unsigned)(ix0 + t % 3) < (unsigned)p.IW) m |= 1u << t;
+                vmask[j] = m;
+            }
+        } else {
+            asrc[j] = row < p.M ? a0 + (size_t)row * p.lda0 + sw : nullptr;
+        }
     }
     const _Float16* wsrc = wgt + (size_t)(n0 + (tid >> 3)) * ldbh + sw;
     const int abl = p.coef_lds;          // timing ablations (ds_conv_args.tune.ablate; results are WRONG when bits 0 / 2 are set): bit 0 = no DMA after
                                          // the prologue, bit 2 = no epilogue
     auto dma = [&](int kt, int buf) {
         if ((abl & 1) && kt > 1) return;
+        int slab = 0, tap = 0, toff = 0;                       // GATHER: K tile kt = (slab, tap), tap-minor like the weight packing
+        if constexpr (GATHER) {
+            slab = kt / 9; tap = kt - slab * 9;
+            const int ty = tap / 3;
+            toff = ty * p.IW + (tap - ty * 3);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const _Float16* g = asrc[j] ? asrc[j] + (size_t)kt * 64 : g_zero_halfs_g;
+            const _Float16* g;
+            if constexpr (GATHER)
+                g = ((vmask[j] >> tap) & 1u) ? a0 + (size_t)(pixb[j] + toff) * p.lda0 + (slab * 64 + sw) : g_zero_halfs_g;
+            else
+                g = asrc[j] ? asrc[j] + (size_t)kt * 64 : g_zero_halfs_g;
             __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + buf * AB + (j * NT + wave * 64) * 16), 16, 0, 0);
         }
 #pragma unroll
@@ -154,11 +186,11 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_f16dma_kernel(const KParams p
     }
     float* stage = smem + wave * 32 * EPI_LD;
     const int wn0 = n0 + wc * (NB * 32);
-    if constexpr (DIRECT) epilogue_direct<false, NB, false>(p, accA, accB, lane, m0 + wr * 64, wn0);
+    if constexpr (DIRECT) epilogue_direct<false, NB, GATHER>(p, accA, accB, lane, m0 + wr * 64, wn0);      // GATHER layers carry GroupNorm column sums
     else epilogue_pipe<0, false, (NB == 1 ? 32 : 64), (NB == 3 ? 32 : (NB == 4 ? 64 : 0)), true>(p, accA, accB, stage, lane, m0 + wr * 64, wn0, p.out);
 }
 
-template <int NB, int NW>
+template <int NB, int NW, bool GATHER = false>
 int launch_nb(KParams p, int n_begin, int ntiles, hipStream_t stream) {
     p.mtiles = (p.M + NW * 32 - 1) / (NW * 32);
     p.ntiles = ntiles;
@@ -168,12 +200,12 @@ int launch_nb(KParams p, int n_begin, int ntiles, hipStream_t stream) {
     int smem = (int)gemm16_smem<NB, NW>();
     const int epi = NW * 32 * EPI_LD * (int)sizeof(float);
     if (smem < epi) smem = epi;
-    if (epi_direct_ok(p, false, NB)) {
-        DS_ENSURE_DYN_LDS((&gemm_f16dma_kernel<NB, NW, true>), 160 * 1024);
-        hipLaunchKernelGGL((gemm_f16dma_kernel<NB, NW, true>), dim3(grid_1d(p.mtiles, p.ntiles), 1), dim3(NW * 64), smem, stream, p);
+    if (epi_direct_ok(p, GATHER, NB)) {
+        DS_ENSURE_DYN_LDS((&gemm_f16dma_kernel<NB, NW, true, GATHER>), 160 * 1024);
+        hipLaunchKernelGGL((gemm_f16dma_kernel<NB, NW, true, GATHER>), dim3(grid_1d(p.mtiles, p.ntiles), 1), dim3(NW * 64), smem, stream, p);
     } else {
-        DS_ENSURE_DYN_LDS((&gemm_f16dma_kernel<NB, NW, false>), 160 * 1024);
-        hipLaunchKernelGGL((gemm_f16dma_kernel<NB, NW, false>), dim3(grid_1d(p.mtiles, p.ntiles), 1), dim3(NW * 64), smem, stream, p);
+        DS_ENSURE_DYN_LDS((&gemm_f16dma_kernel<NB, NW, false, GATHER>), 160 * 1024);
+        hipLaunchKernelGGL((gemm_f16dma_kernel<NB, NW, false, GATHER>), dim3(grid_1d(p.mtiles, p.ntiles), 1), dim3(NW * 64), smem, stream, p);
     }
     DS_CHECK_LAUNCH();
     return DS_OK;
@@ -187,15 +219,26 @@ bool gemm_f16dma_applicable(const KParams& p) {
     return true;
 }
 
+// The strided 3x3 convolution on fp16 rows (GATHER): H, W = OUTPUT size, IH = 2 H, IW = 2 W; bias / per-image bias / column sums / fp16 or fp32
+// output rows through the family's epilogues, no residual, no extra 1x1 sources.
+bool gemm_f16dma_gather_applicable(const KParams& p) {
+    if (p.taps != 9 || p.stride != 2 || p.norm != nullptr || p.ec0 || p.ec1 || p.c1 || p.res || p.act == DS_ACT_GEGLU) return false;
+    if (p.c0 < 64 || p.c0 % 64 || p.K != 9 * p.c0 || p.N % 64 || !p.vec_ok || p.nrows_b < p.N || p.M < 1) return false;
+    if (p.IH != 2 * p.H || p.IW != 2 * p.W || p.HW != p.H * p.W || p.M % p.HW) return false;
+    if ((long long)p.M * 4 > 0x7fffffffLL) return false;
+    return true;
+}
+
 // Column tiling as in conv3x3_f16dma.hip (cost 1 + nb per round of resident workgroups); the GEGLU epilogue pairs 32 value columns with
 // their 32 gate columns inside a 64-column half of a wave tile, so it takes even widths only.  Projections with K <= 2 560 and N <= 1 280
 // take the four-wave, 128-row variant (two workgroups per CU, NB <= 3): 5 - 10 % faster there, slower on wide outputs (A/B per shape in
 // profiles/r3_gemm_f16dma_epilogue.txt); ds_conv_args.tune.f16dma_nw (benchmarks) forces 4 or 8.
-int launch_gemm_f16dma(KParams& p, hipStream_t stream) {
+int launch_gemm_f16dma(KParams& p, hipStream_t stream, bool gather) {
     const bool geglu = p.act == DS_ACT_GEGLU;
     if (geglu && (p.N % 128)) return DS_E_SHAPE;
     int nw = (p.K <= 2560 && p.N <= 1280) ? 4 : 8;
     if (p.t_nw == 4 || p.t_nw == 8) nw = p.t_nw;
+    if (gather) nw = 8;                                        // the gather is instantiated for the eight-wave tile only
     const int mtiles = (p.M + nw * 32 - 1) / (nw * 32), slots = nw == 4 ? 512 : 256, max_nb = nw == 4 ? 3 : 4;
     auto tiling = [&](int nb0, int (*out)[3], int* cost) {
         int n = 0, col = 0, c = 0;
@@ -218,7 +261,11 @@ int launch_gemm_f16dma(KParams& p, hipStream_t stream) {
     const int n = tiling(best_nb, plan, &cost);
     for (int i = 0; i < n; ++i) {
         int rc;
-        switch (plan[i][2] + (nw == 4 ? 10 : 0)) {
+        switch (plan[i][2] + (nw == 4 ? 10 : 0) + (gather ? 20 : 0)) {
+            case 21: rc = launch_nb<1, 8, true>(p, plan[i][0], plan[i][1], stream); break;
+            case 22: rc = launch_nb<2, 8, true>(p, plan[i][0], plan[i][1], stream); break;
+            case 23: rc = launch_nb<3, 8, true>(p, plan[i][0], plan[i][1], stream); break;
+            case 24: rc = launch_nb<4, 8, true>(p, plan[i][0], plan[i][1], stream); break;
             case 1: rc = launch_nb<1, 8>(p, plan[i][0], plan[i][1], stream); break;
             case 2: rc = launch_nb<2, 8>(p, plan[i][0], plan[i][1], stream); break;
             case 3: rc = launch_nb<3, 8>(p, plan[i][0], plan[i][1], stream); break;

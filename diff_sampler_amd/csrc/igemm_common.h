@@ -629,7 +629,8 @@ int launch_conv3x3_f16dmah_tiles(const KParams& p, int nb, int n_begin, int ntil
 
 // gemm_f16dma.hip: 1x1 / Linear on fp16 activations (both operands by LDS-DMA)
 bool gemm_f16dma_applicable(const KParams& p);
-int launch_gemm_f16dma(KParams& p, hipStream_t stream);
+bool gemm_f16dma_gather_applicable(const KParams& p);                 // 3x3 stride-2 convolution on fp16 rows (the gather form of the same kernel)
+int launch_gemm_f16dma(KParams& p, hipStream_t stream, bool gather = false);
 
 // gemm_f16.hip: 1x1 / Linear with fp16 operands (A rounded while staged, W packed fp16)
 bool gemm_f16_applicable(const KParams& p);

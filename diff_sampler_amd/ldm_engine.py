@@ -32,12 +32,15 @@ from .plan import Builder, Plan, ptr
 
 
 class LDMUNetEngine:
-    def __init__(self, spec: ldm_arch.LDMUNetSpec, params: Dict[str, torch.Tensor], device='cuda', use_fp16=False):
+    def __init__(self, spec: ldm_arch.LDMUNetSpec, params: Dict[str, torch.Tensor], device='cuda', use_fp16=False, qkv_f16_min_head=40):
         """use_fp16: the reference samples this U-Net under ``autocast("cuda")`` (diff-solvers-main/sample.py:296): convolutions and
         Linear layers multiply fp16 operands (fp32 accumulation here) and emit fp16 tensors.  Here: ResBlock / Upsample convolutions, every
         projection of the transformer blocks and attention on the fp16 kernels, and the activations between layers -- residual stream,
         skip stack, the transformer's x -- stored as fp16 rows wherever a layer runs on the fp16-activation kernels (plan(): per layer);
-        norm / softmax arithmetic, q / k / v, the context projections and the time embedding are fp32."""
+        norm / softmax arithmetic, the context projections and the time embedding are fp32.  qkv_f16_min_head: q / k / v of the attention
+        layers with at least this head size are the fp16 rows their projections emit under autocast (smaller heads: fp32 rows the attention
+        kernel rounds itself) -- an A/B knob of benchmarks; the default is every head size of SD-1.5."""
+        self.qkv_f16_min_head = int(qkv_f16_min_head)
         self.spec = spec
         self.device = torch.device(device)
         self.use_fp16 = bool(use_fp16)
@@ -107,6 +110,9 @@ class LDMUNetEngine:
                         w[f'{p}.{n_}.g'], w[f'{p}.{n_}.b'] = g(f'{t}.{n_}.weight'), g(f'{t}.{n_}.bias')
                 elif l.kind == 'down':
                     w[f'{p}.w'], w[f'{p}.b'] = pack_conv_weight(g(f'{p}.op.weight')), g(f'{p}.op.bias')
+                    if self.use_fp16 and l.cin % 64 == 0 and l.cout % 64 == 0:
+                        from .ops import pack_conv_weight_f16
+                        w[f'{p}.w16'] = (pack_conv_weight_f16(g(f'{p}.op.weight')), 0)     # [slab][tap][64]: the stride-1 packing, gathered by the GEMM
                 elif l.kind == 'up':
                     w[f'{p}.w'], w[f'{p}.b'] = pack_conv_weight(g(f'{p}.conv.weight')), g(f'{p}.conv.bias')
                     if self.use_fp16 and l.cin % 64 == 0:
@@ -253,10 +259,11 @@ class LDMUNetEngine:
                     out=n2, out_ld=c, out_f16=h16)
             bd.conv(n2, c, c, N, res, res, w[f'{p}.pi.w'], c, t0, c, 1, p + '.proj_in', bias=w[f'{p}.pi.b'])
             # self-attention
-            # fp16 mode: q | k | v as the fp16 rows the projections emit under autocast -- where the attention kernel is faster on them
-            # (d >= 64: -6 ... -18 %); at d = 40 (S = 4 096) it is 10 % SLOWER than on fp32 rows it converts itself (A/B in one session,
-            # profiles/r3_gemm_f16dma_epilogue.txt section 9), which costs more than the halved projection output saves: fp32 rows there
-            mq = mk if d >= 64 else new
+            # fp16 mode: q | k | v as the fp16 rows the projections emit under autocast.  Round 3 kept fp32 rows at d = 40 (S = 4 096), where the
+            # attention kernel was 10 % slower on fp16 rows; that was the lockstep of a lone workgroup per CU, removed in round 4
+            # (profiles/r4_attn_f16_occupancy_ab.txt: 1.73 vs 1.70 ms at 32 images), and the halved output of the 320 -> 960 projection (HBM-bound:
+            # 503 -> 252 MB at 32 images) is worth more than that
+            mq = mk if d >= self.qkv_f16_min_head else new
             qkv, t1 = mq(M, 3 * c), ts(M, c)
             bd.layernorm(t0, c, w[f'{p}.norm1.g'], w[f'{p}.norm1.b'], 1e-5, ln, c, M, c, p + '.norm1')
             bd.linear(ln, c, M, w[f'{p}.qkv1.w'], 3 * c, qkv, p + '.attn1.qkv')
@@ -303,10 +310,20 @@ class LDMUNetEngine:
                 elif l.kind == 'st':
                     cur = st_layer(l, cur[0], cur[1])
                 elif l.kind == 'down':
-                    out = new(N * l.res_out ** 2, l.cout)
-                    cur = (widen(cur[0], l.cin, l.res_in, p), l.cin)      # the strided convolution reads fp32 rows
-                    bd.conv(cur[0], l.cin, l.cin, N, l.res_out, l.res_out, w[f'{p}.w'], l.cout, out, l.cout, 9, p + '.op',
-                            bias=w[f'{p}.b'], stride=2, stats=True)
+                    # fp16 mode, input on the fp16 stream: the strided convolution is the fp16-activation GEMM with a gathered A tile
+                    # (csrc/gemm_f16dma.hip, GATHER) and its output joins the fp16 stream (under autocast the reference's Downsample
+                    # conv emits fp16, openaimodel.py:146-148); otherwise an fp32 copy of the input and the generic fp32 kernel
+                    f16dn = bool(w.get(f'{p}.w16') is not None and stream16 and cur[0].dtype == torch.float16
+                                 and lib.ds_conv_f16dma_stride2_supported(N, l.res_out, l.res_out, l.cin, l.cout))
+                    if f16dn:
+                        out = new_act(N * l.res_out ** 2, l.cout)
+                        bd.conv(cur[0], l.cin, l.cin, N, l.res_out, l.res_out, w[f'{p}.w'], l.cout, out, l.cout, 9, p + '.op',
+                                bias=w[f'{p}.b'], stride=2, stats=True, w16=w[f'{p}.w16'], in_f16=True)
+                    else:
+                        out = new(N * l.res_out ** 2, l.cout)
+                        cur = (widen(cur[0], l.cin, l.res_in, p), l.cin)      # the strided convolution reads fp32 rows
+                        bd.conv(cur[0], l.cin, l.cin, N, l.res_out, l.res_out, w[f'{p}.w'], l.cout, out, l.cout, 9, p + '.op',
+                                bias=w[f'{p}.b'], stride=2, stats=True)
                     cur = (out, l.cout)
                 elif l.kind == 'up':
                     f16up = bool(w.get(f'{p}.w16') is not None and bd.conv_mode == 1 and lib.ds_conv_f16dma_supported(N, l.res_out, l.res_out, l.cin, 0, l.cout))
@@ -391,9 +408,9 @@ class CFGDenoiser(CFGSchedule):
     host_sigma_ok = True       # solvers._Run: pass sigma as a Python float (c_noise is host math; nothing to copy or sync)
 
     def __init__(self, spec: ldm_arch.LDMUNetSpec, params: Dict[str, torch.Tensor], device='cuda', guidance_rate=None,
-                 guidance_type=None, use_fp16=False):
+                 guidance_type=None, use_fp16=False, **engine_kw):
         self.spec = spec
-        self.engine = LDMUNetEngine(spec, params, device, use_fp16=use_fp16)
+        self.engine = LDMUNetEngine(spec, params, device, use_fp16=use_fp16, **engine_kw)
         self.device = self.engine.device
         self.guidance_rate = spec.guidance_rate if guidance_rate is None else guidance_rate
         self.guidance_type = spec.guidance_type if guidance_type is None else guidance_type

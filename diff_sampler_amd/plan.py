@@ -156,7 +156,9 @@ class Builder:
             assert ok, (name, 'no fp16-activation GEMM for this shape')
             w16, in_f16 = (wgt, 0), True
         elif in_f16:
-            assert w16 is not None and taps == 9 and stride == 1 and x1 is None and e1 is None and norm_coefs is None and not out_nchw
+            # stride 2 (the LDM Downsample on the fp16 stream): the gather form of the fp16-activation GEMM; no extras, no residual
+            assert w16 is not None and taps == 9 and stride in (1, 2) and x1 is None and e1 is None and norm_coefs is None and not out_nchw
+            assert stride == 1 or (not ec0 and res is None and self.lib.ds_conv_f16dma_stride2_supported(n, h, w, c0, cout)), name
         f16 = in_f16 or w16 is not None and taps == 9 and stride == 1 and self.f16_level(n, h, w, c0, c1, ec0, ec1) >= (2 if norm_coefs is not None else 1)
         shift = 0
         if f16:

@@ -110,7 +110,8 @@ typedef struct ds_conv_args {
     const float* e0; const float* e1; int ec0, ec1; int eld0, eld1;
     /* Output stride of a 3x3 convolution: 0 or 1 = dense; 2 = the LDM `Downsample` convolution (stride 2, pad 1,
      * ldm/modules/diffusionmodules/openaimodel.py:146-148): h, w are then the OUTPUT size and the input is 2h x 2w.
-     * stride 2 excludes norm_coefs and the e0/e1 extras. */
+     * stride 2 excludes norm_coefs and the e0/e1 extras.  With in_f16 (fp16 rows in, `wgt` in the [slab64][tap][64] fp16 packing of the
+     * stride-1 kernel) it also excludes `res`; availability: ds_conv_f16dma_stride2_supported(). */
     int stride;
     /* Optional split-K scratch (floats): layers whose output has too few tiles to fill the 256 CUs (small batch, 8x8 /
      * 16x16 stages) split the K loop over up to 64 workgroups per tile, each writing a raw partial tile here; a second
@@ -167,7 +168,8 @@ int ds_conv2d_nhwc(const ds_conv_args* a, void* stream);
  * (conv3x3_halo2_kernel<W, 2>), 2564 = fp16-operand 1x1 / Linear kernel (gemm_f16_kernel), 2565 = LDS-halo kernel <4> with
  * 256-pixel x 256-channel tiles (64 x 128 per wave; channel counts that are multiples of 256 on 16-, 32- and 64-column images), 1284 =
  * LDS-halo kernel with 128-pixel tiles on eight waves of 64 x 32 (layers with at most one tile per CU), 2570 = the thin-output 3x3 kernel
- * of the network heads (conv3x3_thin_kernel: cout <= 4, one fp32 source, no residual / per-image bias / statistics).  Used by bench.py to
+ * of the network heads (conv3x3_thin_kernel: cout <= 4, one fp32 source, no residual / per-image bias / statistics), 2571 = the stride-2
+ * 3x3 convolution on fp16 rows (gemm_f16dma_kernel<.., GATHER>).  Used by bench.py to
  * attribute time per kernel. */
 int ds_conv_kernel_id(const ds_conv_args* a);
 
@@ -182,6 +184,11 @@ int ds_conv_f16_supported(int n, int h, int w, int c0, int c1, int ec0, int ec1)
 int ds_conv_f16dma_supported(int n, int h, int w, int c0, int ec0, int cout);
 /* 1 when a 1x1 / Linear layer [rows][k] -> [rows][cout] runs on the fp16-activation GEMM (in_f16 with taps == 1, csrc/gemm_f16dma.hip). */
 int ds_gemm_f16dma_supported(long long rows, int k, int cout);
+/* 1 when the latent-diffusion `Downsample` (3x3, stride 2, pad 1; ldm/modules/diffusionmodules/openaimodel.py:146-148) with n images of
+ * OUTPUT size h x w (input 2h x 2w), c0 input and cout output channels runs on the fp16-activation GEMM in its gather form
+ * (ds_conv_args.in_f16 = 1, wgt_f16 = 1, taps = 9, stride = 2; csrc/gemm_f16dma.hip).  Replaces, in fp16 mode, an fp32 copy of the
+ * fp16 residual stream + the generic fp32 kernel. */
+int ds_conv_f16dma_stride2_supported(int n, int h, int w, int c0, int cout);
 
 /* 1x1 convolution / Linear with fp16 operands (wgt_f16 == 1 and taps == 1: `wgt` = [cout_pad][K] halfs in plain K order; the fp32
  * input rows are rounded to fp16 while they are staged): 1 if rows % 256 == 0 and every source is a multiple of 64 channels. */

@@ -132,7 +132,7 @@ def _block(p, name, h, emb, context, heads, taps):
         elif (q + '.proj_in.weight') in p:
             h = _st(p, q, h, context, heads)
         elif (q + '.op.weight') in p:
-            h = _conv(p, q + '.op', h, stride=2)
+            h = _stored(q + '.op', _conv(p, q + '.op', h, stride=2))
         elif (q + '.conv.weight') in p:
             h = _stored(q + '.conv', _conv(p, q + '.conv', F.interpolate(h, scale_factor=2, mode='nearest')))
         elif (q + '.weight') in p and p[q + '.weight'].dim() == 4:

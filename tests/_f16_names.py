@@ -63,6 +63,7 @@ def ldm_prefixes(plan):
 
 
 _LDM_STORED = {'.in_layers': ['.in_layers.2'], '.out_layers': ['.out_layers.3'], '.proj_in': ['.proj_in'], '.proj_out': ['.proj_out'], '.conv': ['.conv'],
+               '.op': ['.op'],
                '.attn1.to_out': ['.transformer_blocks.0.attn1.to_out.0'], '.attn2.to_out': ['.transformer_blocks.0.attn2.to_out.0'],
                '.ff.out': ['.transformer_blocks.0.ff.net.2'],
                '.attn1.qkv': ['.transformer_blocks.0.attn1.to_q', '.transformer_blocks.0.attn1.to_k', '.transformer_blocks.0.attn1.to_v'],

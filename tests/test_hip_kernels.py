@@ -1122,6 +1122,68 @@ def test_gemm_f16_activations_dma_kernel(case):
         assert _rel(st[:, 0], got.reshape(-1, 64, cout).sum(1)) < 1e-5
 
 
+CONV_F16_STRIDE2_CASES = [
+    # images, OUTPUT side, cin, cout, forced nb, epilogue ('f16out' | 'f32out' | 'staged')
+    (1, 8, 64, 64, 0, 'f16out'),             # 64 output rows: less than one row tile (tail rows read the zero page)
+    (3, 8, 128, 192, 0, 'f16out'),           # 192 rows, 192 columns (NB = 3)
+    (2, 16, 320, 320, 0, 'f16out'),          # SD-1.5 input_blocks.3 at a small batch: 320 = 256 + 64 columns
+    (5, 16, 64, 128, 1, 'f32out'),           # 1 280 rows = five row tiles, fp32 output rows (staged epilogue)
+    (2, 32, 64, 256, 4, 'staged'),           # NB = 4, fp16 rows through the staged epilogue (tune.ablate bit 12)
+    (4, 4, 640, 640, 2, 'f16out'),           # 4x4 output images: every output pixel touches a border
+]
+
+
+@pytest.mark.parametrize('case', CONV_F16_STRIDE2_CASES)
+def test_conv3x3_stride2_f16_activations_gather_kernel(case):
+    """The latent-diffusion Downsample (3x3, stride 2, pad 1, openaimodel.py:146-148) on fp16 rows: ds_conv_args.in_f16 with taps == 9,
+    stride == 2 = the fp16-activation GEMM with a gathered A tile (csrc/gemm_f16dma.hip, GATHER) against F.conv2d on the same fp16 operands in
+    fp64: 2e-5 of the output scale for fp32 rows, one fp16 ulp for fp16 rows; the GroupNorm column sums are those of the stored tensor."""
+    import ctypes as C
+    from diff_sampler_amd import _lib, ops
+    n, side, cin, cout, nb, mode = case
+    lib = _lib.load()
+    assert lib.ds_conv_f16dma_stride2_supported(n, side, side, cin, cout) == 1
+    g = torch.Generator().manual_seed(n * 1000 + side * 100 + cin + cout)
+    x = torch.randn(n, cin, 2 * side, 2 * side, generator=g).to(torch.float16)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(x.double(), wt.to(torch.float16).double(), bias.double(), stride=2, padding=1)         # [n, cout, side, side]
+    ref = ref.permute(0, 2, 3, 1).reshape(n * side * side, cout).float()
+    dev = 'cuda'
+    xd = x.permute(0, 2, 3, 1).contiguous().reshape(-1, cin).to(dev)                                      # NHWC fp16 rows of the INPUT
+    wp = ops.pack_conv_weight_f16(wt.to(dev))
+    bd_ = bias.to(dev)
+    M = n * side * side
+    f16out = mode != 'f32out'
+    out = torch.full((M, cout), float('nan'), dtype=torch.float16 if f16out else torch.float32, device=dev)
+    stats = torch.full((-(-M // 64) * 2 * cout,), float('nan'), device=dev)
+    a = _lib.ConvArgs(xd.data_ptr(), None, cin, 0, cin, 0, n, side, side, 9, wp.data_ptr(), cout, bd_.data_ptr(), None, 0, 1,
+                      None, 0, 1.0, 0, out.data_ptr(), cout)
+    a.stride = 2
+    a.wgt_f16, a.in_f16, a.out_f16 = 1, 1, int(f16out)
+    a.stats_out = stats.data_ptr()
+    assert lib.ds_conv_kernel_id(C.byref(a)) == 2571
+    a.tune.f16dma_nb = nb
+    if mode == 'staged':
+        a.tune.ablate = 4096
+    rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    assert rc == 0, lib.ds_error_string(rc)
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    if f16out:
+        assert _rel(got, ref.to(torch.float16).float()) < 1.5e-3
+    else:
+        assert _rel(got, ref) < 2e-5
+    if M % 64 == 0:
+        st = stats.cpu().reshape(-1, 2, cout)
+        blocks = got.reshape(-1, 64, cout)
+        assert _rel(st[:, 0], blocks.sum(1)) < 1e-5 and _rel(st[:, 1], (blocks * blocks).sum(1)) < 1e-5
+    # a residual operand is not part of this path: refused, not ignored
+    a.res, a.res_ld = out.data_ptr(), cout
+    assert lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr()) != 0
+
+
 def test_layernorm_and_attention_fp16_outputs():
     """ds_layernorm_rows_f16 and ds_attention_f16 with out_f16: the fp32 results rounded to nearest even."""
     import ctypes as C
