@@ -21,7 +21,11 @@
 //     outputs, norms and the residual stream stay fp32.
 // Scope: taps == 9, stride 1, ONE fp16 source [M][c0] (c0 % 64 == 0; the decoder's concatenation is materialised by the norm pass),
 // optional fused 1x1 skip projection on ONE fp16 source [M][ec0], square power-of-two images W in {8, 16, 32, 64} with 256-pixel
-// tiles (one image per tile, or four 8x8 images), cout % 64 == 0, no split-K.
+// tiles (one image per tile, or four 8x8 images), cout % 64 == 0.
+// Split-K (round 4, second part): layers whose widest tiling leaves half of the chip idle (the 8x8 stages: 56 - 64 tiles of 108 - 220 serial
+// taps at the bench batches) contract S contiguous ranges of 64-channel slabs in S workgroups per tile (blockIdx.y), each writing its raw
+// fp32 partial tile to the caller's workspace; splitk_reduce_f16_kernel (gemm_conv.hip) sums them in split order and applies the epilogue
+// (bias, per-image bias, fp16 / fp32 residual, activation, fp16 / fp32 rows, GroupNorm column sums of the stored values).
 #include "pipe_common.h"
 #include "epi_direct.h"
 
@@ -98,8 +102,20 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
     }
     const int nchunks = p.c0 / 64;                             // 3x3 slabs (9 taps each)
     const int nextra = p.ec0 / 64;                             // appended 1x1 slabs (centre tap only)
-    const int NCH = nchunks + nextra;
-    const int KT = nchunks * 9 + nextra;
+    // This workgroup contracts slabs [cb, NCH) = taps [kt0, KT) of the layer's K: everything, or -- split-K, blockIdx.y = split -- the
+    // range whose boundaries are the slab boundaries nearest to the equal-tap cuts (a 3x3 slab weighs nine taps, an appended 1x1 slab one)
+    int cb = 0, NCH = nchunks + nextra;
+    if (p.splits > 1) {
+        const int kt_all = nchunks * 9 + nextra, sp = (int)blockIdx.y;
+        auto cut = [&](int i) {
+            const int t = (int)(((long long)kt_all * i) / p.splits);
+            return t <= nchunks * 9 ? (t + 4) / 9 : nchunks + (t - nchunks * 9);
+        };
+        cb = cut(sp);
+        if (sp + 1 < p.splits) NCH = cut(sp + 1);
+    }
+    const int kt0 = cb <= nchunks ? cb * 9 : nchunks * 9 + (cb - nchunks);
+    const int KT = NCH <= nchunks ? NCH * 9 : nchunks * 9 + (NCH - nchunks);
     const int abl = p.coef_lds;                                 // timing ablations (ds_conv_args.tune.ablate; results are wrong when set)
     auto halo_dma = [&](int chunk, int hbuf, auto jc) {          // DMA round j of slab `chunk` into halo buffer hbuf
         constexpr int j = decltype(jc)::value;
@@ -187,23 +203,24 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
     const unsigned halo0 = lds0 + D * WB;
 
     // ---- prologue: halo of slab 0, the part of slab 1's halo that is due (see the tap), weights of taps 0 and 1 -------------------
-    static_for<NDMA>([&](auto jc) { halo_dma(0, 0, jc); });
-    if (NCH > 1) {
-        if (nchunks == 0) static_for<NDMA>([&](auto jc) { halo_dma(1, 1, jc); });      // slab 0 is a one-tap slab
-        else halo_dma(1, 1, IC<0>{});
+    static_for<NDMA>([&](auto jc) { halo_dma(cb, cb & 1, jc); });
+    if (cb + 1 < NCH) {
+        if (cb >= nchunks) static_for<NDMA>([&](auto jc) { halo_dma(cb + 1, (cb + 1) & 1, jc); });      // the first slab is a one-tap slab
+        else halo_dma(cb + 1, (cb + 1) & 1, IC<0>{});
     }
 #pragma unroll
     for (int d = 0; d < D; ++d)
-        if (d < KT) w_dma(d, d);
+        if (kt0 + d < KT) w_dma(kt0 + d, d);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     Frag P_, Q_;
     {
-        const unsigned ctr = nchunks > 0 ? 0u : 4u;            // first tap: (0, 0) of a 3x3 slab, or the centre tap of a 1x1 slab
-        frag_read(P_, halo0 + a_addr(0, (int)ctr), halo0 + a_addr(1, (int)ctr), bbase);
+        const unsigned ctr = cb < nchunks ? 0u : 4u;           // first tap: (0, 0) of a 3x3 slab, or the centre tap of a 1x1 slab
+        const unsigned h0 = halo0 + (unsigned)(cb & 1) * HB;
+        frag_read(P_, h0 + a_addr(0, (int)ctr), h0 + a_addr(1, (int)ctr), bbase);
     }
 
-    int kt = 0, slot = 0;                                      // slot = kt % D: the ring buffer of tap kt
+    int kt = kt0, slot = 0;                                    // slot = (kt - kt0) % D: the ring buffer of tap kt
     // One tap: T9 = tap of a 3x3 slab (0..8) or 9 = the centre tap of an appended 1x1 slab.  P holds the fragments of its K step 0
     // (read after the previous tap's barrier).
     //   K steps 0..2 : reads of step k+1 in flight under the MFMAs of step k
@@ -288,8 +305,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
         DS2_FENCE();
         ++kt; slot = nslot;
     };
-    int chunk = 0;
-    for (; chunk < nchunks; ++chunk) {
+    int chunk = cb;
+    const int n33 = nchunks < NCH ? nchunks : NCH;             // end of this range's 3x3 slabs
+    for (; chunk < n33; ++chunk) {
         tap(IC<0>{}, chunk); tap(IC<1>{}, chunk); tap(IC<2>{}, chunk);
         tap(IC<3>{}, chunk); tap(IC<4>{}, chunk); tap(IC<5>{}, chunk);
         tap(IC<6>{}, chunk); tap(IC<7>{}, chunk); tap(IC<8>{}, chunk);
@@ -307,6 +325,16 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
     }
     float* stage = smem + wave * 32 * EPI_LD;
     const int wn0 = n0 + wc * (NB * 32);
+    if (p.splits > 1) {                                        // split-K: the raw partial tile, fp32 rows of plane blockIdx.y (staged instantiation only)
+        if constexpr (!DIRECT) {
+            KParams q = p;
+            q.out = p.part + (size_t)blockIdx.y * p.M * p.N; q.ldo = p.N;
+            q.colbias = nullptr; q.rowbias = nullptr; q.cbias = nullptr; q.res = nullptr; q.scale = 1.f; q.act = DS_ACT_NONE;
+            q.stats = nullptr; q.out_f16 = 0; q.res_f16 = 0; q.out_planar = 0;
+            epilogue_pipe<0, true, (NB == 1 ? 32 : 64), (NB == 3 ? 32 : (NB == 4 ? 64 : 0)), true>(q, accA, accB, stage, lane, m0 + wr * 64, wn0, q.out);
+        }
+        return;
+    }
     // non-temporal residual loads / output stores: +1 ... 2 % (A/B, profiles/r3_conv_f16dma_ablations.txt); the launcher only takes this
     // kernel on the vector path (vec_ok, cout a multiple of the tile width)
     if constexpr (DIRECT) epilogue_direct<false, NB, true>(p, accA, accB, lane, m0 + wr * 64, wn0);
@@ -321,14 +349,14 @@ int launch_w_nb(KParams p, int n_begin, int ntiles, hipStream_t stream) {
     p.mtiles = p.M / 256;
     p.ntiles = ntiles;
     p.n_begin = n_begin;
-    p.splits = 1;
+    if (p.splits < 1) p.splits = 1;                            // > 1: set by launch_conv3x3_f16dma (the reduce follows the last column range)
     p.coef_lds = p.t_ablate;
     int smem = (int)f16dma_smem<W, NB>();
     const int epi = 8 * 32 * EPI_LD * (int)sizeof(float);
     if (smem < epi) smem = epi;
-    if (!epi_direct_ok(p, true, NB)) {
+    if (p.splits > 1 || !epi_direct_ok(p, true, NB)) {         // partial tiles leave through the staged epilogue
         DS_ENSURE_DYN_LDS((&conv3x3_f16dma_kernel<W, NB, false>), 160 * 1024);
-        hipLaunchKernelGGL((conv3x3_f16dma_kernel<W, NB, false>), dim3(grid_1d(p.mtiles, p.ntiles), 1), dim3(512), smem, stream, p);
+        hipLaunchKernelGGL((conv3x3_f16dma_kernel<W, NB, false>), dim3(grid_1d(p.mtiles, p.ntiles), p.splits), dim3(512), smem, stream, p);
     } else {
         DS_ENSURE_DYN_LDS((&conv3x3_f16dma_kernel<W, NB, true>), 160 * 1024);
         hipLaunchKernelGGL((conv3x3_f16dma_kernel<W, NB, true>), dim3(grid_1d(p.mtiles, p.ntiles), 1), dim3(512), smem, stream, p);
@@ -398,6 +426,30 @@ int conv3x3_f16dma_plan(const KParams& p, int (*out)[3], bool half = false) {
     return tiling(p, best_nb, out, &cost, half);
 }
 
+// Split-K (see the header): S > 1 when the WIDEST tiling of the layer (fewest LDS operand bytes per MFMA) fills at most half of the 256 CUs and
+// every split keeps at least two 3x3 slabs' worth of taps (18): S = 256 / tiles, at most 16, within the workspace.  `plan` / `n` are then
+// replaced by that widest tiling (ds_conv_args.tune.f16dma_nb keeps the forced one); ds_conv_args.tune.splits forces S (1 = never).
+static int conv3x3_f16dma_splits(const KParams& p, int (*plan)[3], int* n) {
+    if (!p.part || !p.vec_part || p.t_splits == 1) return 1;
+    int wide[4][3], cost;
+    const int nw = p.t_nb > 0 ? 0 : tiling(p, max_nb(p.W), wide, &cost);
+    int (*cand)[3] = nw ? wide : plan;
+    const int nc = nw ? nw : *n;
+    long long tiles = 0;
+    for (int i = 0; i < nc; ++i) tiles += (long long)(p.M / 256) * cand[i][1];
+    long long s = p.t_splits > 1 ? p.t_splits : (tiles <= 128 ? 256 / tiles : 1);
+    const long long kt_all = (long long)(p.c0 / 64) * 9 + p.ec0 / 64, mn = (long long)p.M * p.N;
+    if (s > 16) s = 16;
+    if (s > kt_all / 18) s = kt_all / 18;
+    if (s * mn > p.part_cap) s = p.part_cap / mn;
+    if (s < 2) return 1;
+    if (nw) {
+        for (int i = 0; i < nw; ++i) { plan[i][0] = wide[i][0]; plan[i][1] = wide[i][1]; plan[i][2] = wide[i][2]; }
+        *n = nw;
+    }
+    return (int)s;
+}
+
 // Which layers take the four-wave half-slab variant (two workgroups per CU, conv3x3_f16dmah.hip).  ds_conv_args.tune.f16dma_nw forces it
 // (4) or the eight-wave kernel (8); otherwise by layer class, from the A/B of profiles/r4_conv_f16dmah_ab.txt.
 bool conv3x3_f16dma_use_half(const KParams& p) {
@@ -417,7 +469,8 @@ int launch_conv3x3_f16dma(KParams& p, hipStream_t stream) {
         }
         return DS_OK;
     }
-    const int n = conv3x3_f16dma_plan(p, plan);
+    int n = conv3x3_f16dma_plan(p, plan);
+    p.splits = conv3x3_f16dma_splits(p, plan, &n);
     for (int i = 0; i < n; ++i) {
         int rc;
         switch (p.W) {
@@ -428,6 +481,7 @@ int launch_conv3x3_f16dma(KParams& p, hipStream_t stream) {
         }
         if (rc) return rc;
     }
+    if (p.splits > 1) return launch_splitk_reduce_f16(p, stream);
     return DS_OK;
 }
 

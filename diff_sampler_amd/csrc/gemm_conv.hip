@@ -293,6 +293,68 @@ __global__ void __launch_bounds__(256) splitk_reduce_stats_kernel(const KParams 
 }
 }  // namespace
 
+namespace {
+// Split-K reduce of the fp16-activation convolution (conv3x3_f16dma.hip): splitk_reduce_stats_kernel with the fp16 residual stream and fp16
+// output rows of that family -- out = act((sum over splits, in split order + colbias + cbias[img] + res) * scale), rounded to nearest even
+// when the rows are fp16; the column sums left for the consumer's GroupNorm are those of the values as STORED, like the fused epilogues'.
+// Block = 64 rows x 64 columns = one cell of the statistics; thread = (column quad, row lane; rows lane + 16 k).  N % 64 == 0.
+__global__ void __launch_bounds__(256) splitk_reduce_f16_kernel(const KParams p) {
+    __shared__ f32x4 sh[2][16][16];
+    typedef _Float16 rh4 __attribute__((ext_vector_type(4)));
+    const int rb = blockIdx.x, cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int col = blockIdx.y * 64 + cq * 4;
+    const size_t plane = (size_t)p.M * p.N;
+    f32x4 cb = {0.f, 0.f, 0.f, 0.f}, s4 = cb, q4 = cb;
+    if (p.colbias) cb = *reinterpret_cast<const f32x4*>(p.colbias + col);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int row = rb * 64 + rl + 16 * k;
+        if (row >= p.M) break;
+        f32x4 v = *reinterpret_cast<const f32x4*>(p.part + (size_t)row * p.N + col);
+        for (int sp = 1; sp < p.splits; ++sp) v += *reinterpret_cast<const f32x4*>(p.part + sp * plane + (size_t)row * p.N + col);
+        v += cb;
+        if (p.cbias) v += *reinterpret_cast<const f32x4*>(p.cbias + (size_t)(p.cbias_bcast ? 0 : row / p.HW) * p.cbias_ld + col);
+        if (p.res) {
+            if (p.res_f16) {
+                const rh4 r = *reinterpret_cast<const rh4*>(reinterpret_cast<const _Float16*>(p.res) + (size_t)row * p.res_ld + col);
+                v += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+            } else {
+                v += *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.res_ld + col);
+            }
+        }
+        v *= p.scale;
+        if (p.act == DS_ACT_SILU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ds_silu(v[j]);
+        }
+        if (p.out_f16) {
+            const rh4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            *reinterpret_cast<rh4*>(reinterpret_cast<_Float16*>(p.out) + (size_t)row * p.ldo + col) = h;
+            v = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        } else {
+            *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.ldo + col) = v;
+        }
+        s4 += v; q4 += v * v;
+    }
+    if (!p.stats) return;
+    sh[0][rl][cq] = s4; sh[1][rl][cq] = q4;
+    __syncthreads();
+    if (rl < 2) {                                   // rl = 0: sums, 1: sums of squares; fixed order over the 16 row lanes
+        f32x4 t = sh[rl][0][cq];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += sh[rl][k][cq];
+        *reinterpret_cast<f32x4*>(p.stats + ((size_t)rb * 2 + rl) * p.N + col) = t;
+    }
+}
+}  // namespace
+
+int launch_splitk_reduce_f16(const KParams& p, hipStream_t stream) {
+    if ((p.N & 63) || !p.vec_ok || !p.vec_part || p.out_planar || p.act == DS_ACT_GEGLU || p.splits < 2) return DS_E_SHAPE;
+    hipLaunchKernelGGL(splitk_reduce_f16_kernel, dim3((p.M + 63) / 64, p.N / 64), dim3(256), 0, stream, p);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+
 int launch_splitk_reduce(const KParams& p, hipStream_t stream) {
     if (p.stats && p.vec_ok && p.vec_part && !p.out_planar && (p.N & 63) == 0 && p.act != DS_ACT_GEGLU) {
         hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((p.M + 63) / 64, p.N / 64), dim3(256), 0, stream, p);
@@ -410,7 +472,7 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
         if (a->in_f16) {
             p.ldb = p.K / 2;
             p.out_f16 = a->out_f16 ? 1 : 0; p.res_f16 = a->res_f16 ? 1 : 0;
-            p.part = nullptr; p.part_cap = 0; p.splits = 1;
+            p.splits = 1;                                   // p.part stays: under-filled layers split K (conv3x3_f16dma_splits)
             if (!conv3x3_f16dma_applicable(p)) return DS_E_SHAPE;
             return launch_conv3x3_f16dma(p, (hipStream_t)stream);
         }

@@ -600,6 +600,7 @@ inline int choose_splits(long long blocks, bool big_tile, int units, int tiles_p
     return best;
 }
 int launch_splitk_reduce(const KParams& p, hipStream_t stream);   // gemm_conv.hip (also fills p.stats when requested)
+int launch_splitk_reduce_f16(const KParams& p, hipStream_t stream);   // the same for the fp16-activation convolution (fp16 / fp32 residual and output rows)
 
 // gemm_dma8.hip
 bool gemm_dma8_applicable(const KParams& p);

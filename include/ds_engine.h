@@ -74,7 +74,8 @@ typedef struct ds_conv_tune {
      * tiles without the scalar-addressed weight DMA / non-temporal epilogue; bit 13 (8192): no 256 x 192 tiles for the 192-multiples
      * (ADM channel counts); bit 14 (16384): force them regardless of the tile count (tests). */
     int variant;
-    int splits;        /* > 0: split-K factor of a convolution that has a workspace (clamped to what the layer allows) */
+    int splits;        /* > 0: split-K factor of a convolution that has a workspace (clamped to what the layer allows; 1 = never split).  The
+                        * fp16-activation 3x3 kernel (in_f16) splits on its own where its widest tiling covers at most half of the CUs */
     int f16dma_nb;     /* fp16-activation kernels: column-tile width 64 * nb, nb = 1..4 */
     int f16dma_nw;     /* fp16-activation GEMM: 4 / 8 = 128- / 256-row variant; fp16-activation 3x3: 4 = the four-wave half-slab kernel on
                         * 128-pixel tiles (two workgroups per CU, kernel id 2569), 8 = the eight-wave kernel on 256-pixel tiles (2566) */

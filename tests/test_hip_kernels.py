@@ -980,6 +980,87 @@ def test_conv_f16_activations_dma_kernel(case, nw):
         assert _rel(st[:, 0], blocks.sum(1)) < 1e-5 and _rel(st[:, 1], (blocks * blocks).sum(1)) < 1e-5
 
 
+F16DMA_SPLIT_CASES = [
+    # B, H(=W), cin, cout, ec0, forced nb, tune.splits (0 = the library's choice), fp16 residual + output rows, splits expected (None = any > 1)
+    (4, 8, 256, 192, 0, 0, 2, False, 2),             # 36 taps: two splits of two slabs
+    (8, 8, 768, 768, 0, 0, 0, False, None),          # ADM 8x8 layer at a small batch: 8 tiles -> the chooser splits (108 taps -> 6)
+    (4, 8, 256, 128, 512, 0, 2, False, 2),           # 44 taps: [two 3x3 slabs | two 3x3 slabs + eight 1x1 slabs]
+    (4, 8, 128, 192, 2560, 3, 3, True, 3),           # 58 taps: the middle and the last split are 1x1 slabs only (prologue of a one-tap first slab)
+    (2, 16, 512, 256, 0, 4, 2, False, 2),            # 256-column tiles through the staged epilogue
+    (4, 8, 512, 192, 0, 0, 3, True, 3),              # fp16 residual stream and fp16 rows out of the reduce kernel
+    (4, 8, 128, 64, 0, 0, 4, False, 1),              # 18 taps: too short to split -- forced count clamped to 1
+]
+
+
+@pytest.mark.parametrize('case', F16DMA_SPLIT_CASES)
+def test_conv_f16_activations_split_k(case):
+    """Split-K of the fp16-activation convolution (csrc/conv3x3_f16dma.hip + splitk_reduce_f16_kernel): S workgroups per tile contract
+    contiguous slab ranges, a reduce launch applies the epilogue.  Same reference and tolerances as the unsplit kernel; the split count the
+    launcher takes is read back through the partial planes (plane S - 1 written, plane S untouched)."""
+    import ctypes as C
+    from diff_sampler_amd import _lib, ops
+    B, H, cin, cout, ec0, nb, splits, f16io, expect = case
+    lib = _lib.load()
+    assert lib.ds_conv_f16dma_supported(B, H, H, cin, ec0, cout) == 1
+    g = torch.Generator().manual_seed(sum(case[:7]) + 11)
+    x = torch.randn(B, cin, H, H, generator=g).to(torch.float16)
+    e = torch.randn(B, ec0, H, H, generator=g).to(torch.float16) if ec0 else None
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    we = torch.randn(cout, ec0, 1, 1, generator=g) / ec0 ** 0.5 if ec0 else None
+    bias = torch.randn(cout, generator=g)
+    cb = torch.randn(B, cout, generator=g)
+    res = torch.randn(B, cout, H, H, generator=g)
+    if f16io:
+        res = res.to(torch.float16).float()
+    h16 = lambda t: t.to(torch.float16).to(torch.float64)
+    ref = F.conv2d(x.double(), h16(w), padding=1)
+    if ec0:
+        ref = ref + F.conv2d(e.double(), h16(we))
+    ref = _nhwc(((ref + (bias[None, :, None, None] + cb[:, :, None, None] + res).double()) * 0.7071).float())
+    dev = 'cuda'
+    xn = x.permute(0, 2, 3, 1).reshape(-1, cin).contiguous().to(dev)
+    en = e.permute(0, 2, 3, 1).reshape(-1, ec0).contiguous().to(dev) if ec0 else None
+    wp = ops.pack_conv_weight_f16(w.to(dev), we.to(dev) if ec0 else None)
+    M = B * H * H
+    out = torch.full((M, cout), float('nan'), dtype=torch.float16 if f16io else torch.float32, device=dev)
+    stats = torch.full((-(-M // 64) * 2 * cout,), float('nan'), device=dev)
+    planes = 17
+    ws = torch.full((planes * M * cout,), float('nan'), device=dev)
+    biasd, cbd = bias.to(dev), cb.to(dev)
+    resd = _nhwc(res).to(dev).to(torch.float16 if f16io else torch.float32).contiguous()
+    a = _lib.ConvArgs(xn.data_ptr(), None, cin, 0, cin, 0, B, H, H, 9, wp.data_ptr(), cout, biasd.data_ptr(), cbd.data_ptr(), cout, B,
+                      resd.data_ptr(), cout, 0.7071, 0, out.data_ptr(), cout, None, 0, en.data_ptr() if ec0 else None, None, ec0, 0, ec0, 0)
+    a.wgt_f16, a.in_f16, a.out_f16, a.res_f16 = 1, 1, int(f16io), int(f16io)
+    a.stats_out = stats.data_ptr()
+    a.workspace, a.workspace_floats = ws.data_ptr(), ws.numel()
+    a.tune.f16dma_nb, a.tune.splits = nb, splits
+    rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    assert rc == 0, lib.ds_error_string(rc)
+    written = torch.isfinite(ws.reshape(planes, -1)).all(dim=1).cpu()
+    used = int(written.sum())
+    assert bool(written[:used].all()) and not bool(torch.isfinite(ws.reshape(planes, -1)[used:]).any())     # whole planes 0 .. S - 1, nothing else
+    S = used if used else 1
+    assert (S == expect) if expect is not None else (S > 1), S
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    if f16io:
+        assert _rel(got, ref.to(torch.float16).float()) < 1.5e-3
+    else:
+        assert _rel(got, ref) < 2e-5
+    st = stats.cpu().reshape(-1, 2, cout)
+    blocks = got.reshape(-1, 64, cout)
+    assert _rel(st[:, 0], blocks.sum(1)) < 1e-5 and _rel(st[:, 1], (blocks * blocks).sum(1)) < 1e-5
+    # tune.splits = 1 = never: the unsplit kernel, same result class, no partial plane touched
+    ws.fill_(float('nan')); out.fill_(float('nan'))
+    a.tune.splits = 1
+    assert lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert not bool(torch.isfinite(ws).any())
+    one = out.float().cpu()
+    assert _rel(one, got) < (1.5e-3 if f16io else 2e-5)
+
+
 def test_conv_f16_activations_rejects_what_it_does_not_cover():
     import ctypes as C
     from diff_sampler_amd import _lib
