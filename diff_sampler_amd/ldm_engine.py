@@ -32,15 +32,17 @@ from .plan import Builder, Plan, ptr
 
 
 class LDMUNetEngine:
-    def __init__(self, spec: ldm_arch.LDMUNetSpec, params: Dict[str, torch.Tensor], device='cuda', use_fp16=False, qkv_f16_min_head=40):
+    def __init__(self, spec: ldm_arch.LDMUNetSpec, params: Dict[str, torch.Tensor], device='cuda', use_fp16=False, qkv_f16_min_head=40, f16_downsample=True):
         """use_fp16: the reference samples this U-Net under ``autocast("cuda")`` (diff-solvers-main/sample.py:296): convolutions and
         Linear layers multiply fp16 operands (fp32 accumulation here) and emit fp16 tensors.  Here: ResBlock / Upsample convolutions, every
         projection of the transformer blocks and attention on the fp16 kernels, and the activations between layers -- residual stream,
         skip stack, the transformer's x -- stored as fp16 rows wherever a layer runs on the fp16-activation kernels (plan(): per layer);
         norm / softmax arithmetic, the context projections and the time embedding are fp32.  qkv_f16_min_head: q / k / v of the attention
         layers with at least this head size are the fp16 rows their projections emit under autocast (smaller heads: fp32 rows the attention
-        kernel rounds itself) -- an A/B knob of benchmarks; the default is every head size of SD-1.5."""
+        kernel rounds itself); f16_downsample: the strided Downsample convolutions read and write the fp16 stream (False: an fp32 copy and the
+        generic fp32 kernel, the round-3 routing) -- A/B knobs of benchmarks, the defaults are what the parity goldens were made with."""
         self.qkv_f16_min_head = int(qkv_f16_min_head)
+        self.f16_downsample = bool(f16_downsample)
         self.spec = spec
         self.device = torch.device(device)
         self.use_fp16 = bool(use_fp16)
@@ -313,7 +315,7 @@ class LDMUNetEngine:
                     # fp16 mode, input on the fp16 stream: the strided convolution is the fp16-activation GEMM with a gathered A tile
                     # (csrc/gemm_f16dma.hip, GATHER) and its output joins the fp16 stream (under autocast the reference's Downsample
                     # conv emits fp16, openaimodel.py:146-148); otherwise an fp32 copy of the input and the generic fp32 kernel
-                    f16dn = bool(w.get(f'{p}.w16') is not None and stream16 and cur[0].dtype == torch.float16
+                    f16dn = bool(self.f16_downsample and w.get(f'{p}.w16') is not None and stream16 and cur[0].dtype == torch.float16
                                  and lib.ds_conv_f16dma_stride2_supported(N, l.res_out, l.res_out, l.cin, l.cout))
                     if f16dn:
                         out = new_act(N * l.res_out ** 2, l.cout)

@@ -7,6 +7,7 @@ launches; it only marshals arguments -- every operation is a libdsamd kernel.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List
 
 import torch
@@ -16,6 +17,26 @@ from ._lib import AttnArgs, ConvArgs, GemmArgs, GnFinalizeArgs, NormArgs, DS_ACT
 
 
 SPLITK_WORKSPACE_FLOATS = 64 << 20      # 256 MiB per plan
+
+# ---- Tile shapes of the fp16-activation kernels, MEASURED per layer shape when a plan is built on the GPU ------------------------------
+# csrc/conv3x3_f16dma.hip and csrc/gemm_f16dma.hip choose the column-tile width (64 * nb, nb = 1..4) and, for the GEMM, 128- or 256-row
+# tiles (nw = 4 / 8) from a small cost model.  The A/B sessions of rounds 3 and 4 (docs/HISTORY.md D, E.7) found that model wrong by
+# 5 - 10 % on individual SD-1.5 shapes in both directions -- the regime is latency-bound and no static rule survived two boxes.  So the
+# planner measures: the first time a shape is planned in this process, the launch itself (the plan's own buffers, inputs filled with
+# random fp16 values, the L2 / MALL flushed before every timed launch so that weights come from HBM as they do inside a network) is timed
+# under every (nb, nw) candidate, and the winner travels in ds_conv_args.tune -- per call, the library keeps no state.  A candidate must
+# beat the library's own choice by 3 % to replace it.  nb / nw change NOTHING in the arithmetic (every output element is the same
+# K-ordered fp32 sum under any tile shape), so results are bit-identical with or without it; the split-K factor, which does change the
+# order of the fp32 sums, stays rule-based (conv3x3_f16dma_splits).  DS_AUTOTUNE=0 in the environment, or Builder(autotune=False),
+# switches it off; launches whose tune words a test / benchmark has set are left alone; nothing is measured during a stream capture.
+AUTOTUNE = os.environ.get('DS_AUTOTUNE', '1') != '0'
+_TUNE_CACHE: Dict[tuple, tuple] = {}     # layer signature -> (nb, nw, {candidate: ms}) measured in this process
+_FLUSH = []                              # one 512 MiB scratch tensor per process: written before every timed launch
+
+
+def tune_report():
+    """{layer signature: (nb, nw, {(nb, nw): ms})} measured so far in this process (tools / bench.py print it)."""
+    return dict(_TUNE_CACHE)
 
 
 def ptr(t):
@@ -111,9 +132,11 @@ def _native_plan(ops):
 
 
 class Builder:
-    def __init__(self, device, conv_mode=0, w16_cache=None):
+    def __init__(self, device, conv_mode=0, w16_cache=None, autotune=True):
         """w16_cache: dict owned by the engine (it outlives the per-batch plans): data_ptr of a row-padded fp32 1x1 / Linear weight
-        -> its fp16 packing, made on first use when conv_mode == 1."""
+        -> its fp16 packing, made on first use when conv_mode == 1.  autotune: measure the tile shapes of the fp16-activation kernels
+        (see AUTOTUNE above)."""
+        self.autotune = bool(autotune)
         self.w16_cache = w16_cache if w16_cache is not None else {}
         self.P = Plan()
         self.dev = device
@@ -185,7 +208,59 @@ class Builder:
             sb = self.new(-(-(n * h * w) // 64) * 2 * cout)
             a.stats_out = ptr(sb)
             self.stats_of[out.data_ptr()] = (sb, cout)
+        self._autotune(a, (x0, e0 if in_f16 else None))
         self.add(self.lib.ds_conv2d_nhwc, (C.byref(a),), name, keep=(a,))
+
+    def _autotune(self, a, inputs):
+        """Fill a.tune.f16dma_nb / f16dma_nw of an fp16-activation launch with the measured best (module docstring of AUTOTUNE)."""
+        t = a.tune
+        if not (AUTOTUNE and self.autotune and a.in_f16) or not inputs[0].is_cuda:
+            return
+        if t.mode or t.variant or t.f16dma_nb or t.f16dma_nw or t.ablate or torch.cuda.is_current_stream_capturing():
+            return
+        stride = a.stride if a.stride else 1
+        key = (a.taps, stride, a.n, a.h, a.w, a.c0, a.ec0, a.cout, a.act, a.out_f16, a.res_f16, bool(a.res), bool(a.cbias), bool(a.bias),
+               bool(a.stats_out), t.splits)
+        hit = _TUNE_CACHE.get(key)
+        if hit is None:
+            hit = _TUNE_CACHE[key] = self._measure_tiles(a, inputs, stride)
+        t.f16dma_nb, t.f16dma_nw = hit[0], hit[1]
+
+    def _measure_tiles(self, a, inputs, stride):
+        if a.taps == 1:                       # csrc/gemm_f16dma.hip: 128-row tiles hold at most 192 columns; the GEGLU gate pairs even widths
+            cands = [(nb, nw) for nw in (4, 8) for nb in ((2, 4) if a.act == _lib.DS_ACT_GEGLU else (1, 2, 3, 4)) if nw == 8 or nb <= 3]
+        else:                                 # 3x3 (stride 1: conv3x3_f16dma.hip, 256 columns only on 16- / 32-column images; stride 2: the gather GEMM)
+            cands = [(nb, 8) for nb in (1, 2, 3, 4) if nb < 4 or stride == 2 or a.w in (16, 32)]
+        cands = [c for c in cands if 64 * c[0] <= -(-a.cout // 64) * 64]
+        for x in inputs:
+            if x is not None and x.dtype == torch.float16:
+                x.normal_()
+        if not _FLUSH:
+            _FLUSH.append(torch.empty(512 << 20, dtype=torch.uint8, device=inputs[0].device))
+        st = _lib.stream_ptr()
+        t = a.tune
+        times = {}
+        for nb, nw in [(0, 0)] + cands:
+            t.f16dma_nb, t.f16dma_nw = nb, nw
+            if self.lib.ds_conv2d_nhwc(C.byref(a), st):
+                continue
+            ms = []
+            for _ in range(3):
+                _FLUSH[0].fill_(1)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.lib.ds_conv2d_nhwc(C.byref(a), st)
+                e1.record()
+                e1.synchronize()
+                ms.append(e0.elapsed_time(e1))
+            times[(nb, nw)] = sorted(ms)[1]
+        t.f16dma_nb, t.f16dma_nw = 0, 0
+        if (0, 0) not in times:
+            return 0, 0, times
+        best = min(times, key=times.get)
+        if times[best] > 0.97 * times[(0, 0)]:
+            best = (0, 0)
+        return best[0], best[1], times
 
     def linear_w16(self, wgt, rows, c0, c1, dma=False, cout=0):
         """(weights, use the fp16-operand GEMM?) of a 1x1 / Linear layer in fp16 mode: the fp16 packing of `wgt` (cached per weight

@@ -42,8 +42,12 @@ SHAPES_SD15_GEMM = [  # SD-1.5 transformer projections / 1x1s on the image rows 
     (64, 320, 0, 2560, 1), (32, 640, 0, 5120, 1), (16, 1280, 0, 10240, 1),                 # [13..15] the GEGLU projections: bench with --geglu
 ]
 
+SHAPES_SD15_DOWN = [  # SD-1.5 Downsample convolutions (3x3, stride 2; res = OUTPUT size): bench with --batch 32 [--f16 --dma16 --f16out]
+    (32, 320, 0, 320, 9), (16, 640, 0, 640, 9), (8, 1280, 0, 1280, 9),
+]
+
 ap = argparse.ArgumentParser()
-ap.add_argument('--shapes', default='cifar10', choices=['cifar10', 'imagenet64', 'sd15', 'ffhq', 'sd15gemm'])
+ap.add_argument('--shapes', default='cifar10', choices=['cifar10', 'imagenet64', 'sd15', 'ffhq', 'sd15gemm', 'sd15down'])
 ap.add_argument('--batch', type=int, default=256)
 ap.add_argument('--entry', default='ds_conv2d_nhwc')
 ap.add_argument('--iters', type=int, default=10)
@@ -65,9 +69,12 @@ ap.add_argument('--f16res', action='store_true', help='with --dma16: fp16 residu
 ap.add_argument('--f16io', action='store_true', help='with --dma16: fp16 output rows and fp16 residual rows (ds_conv_args.out_f16 / res_f16: the fp16 residual stream)')
 ap.add_argument('--extra', action='store_true', help='append the fused 1x1 skip projection (ec0 = c0 + c1 raw columns) as conv1 of a block with a skip conv has it')
 ap.add_argument('--ws', action='store_true', help='give the launcher a split-K workspace (256 MiB), as the engine plans do (the persistent schedule needs it)')
+ap.add_argument('--splits', type=int, default=0, help='ds_conv_tune.splits (with --ws): force the split-K factor, 1 = never split')
 ap.add_argument('--norm', action='store_true', help='fused GroupNorm affine + SiLU in the halo loader, as the network uses it')
 args = ap.parse_args()
-SHAPES = {'cifar10': SHAPES, 'imagenet64': SHAPES_IMAGENET64, 'sd15': SHAPES_SD15, 'ffhq': SHAPES_FFHQ, 'sd15gemm': SHAPES_SD15_GEMM}[args.shapes]
+STRIDE2 = args.shapes == 'sd15down'
+SHAPES = {'cifar10': SHAPES, 'imagenet64': SHAPES_IMAGENET64, 'sd15': SHAPES_SD15, 'ffhq': SHAPES_FFHQ, 'sd15gemm': SHAPES_SD15_GEMM,
+          'sd15down': SHAPES_SD15_DOWN}[args.shapes]
 
 lib = _lib.load()
 # DS_CONV / DS_CONV_VARIANT in the environment become ds_conv_tune.mode / .variant of every ConvArgs built below (_lib._ENV_TUNE)
@@ -80,7 +87,8 @@ for si, (res, c0, c1, cout, taps) in enumerate(SHAPES):
     if args.only and si not in args.only:
         continue
     M = B * res * res
-    x0 = torch.randn(M, c0, device=dev)
+    MI = 4 * M if STRIDE2 else M                      # input rows (stride 2: the input is 2 res x 2 res)
+    x0 = torch.randn(MI, c0, device=dev)
     x1 = torch.randn(M, c1, device=dev) if c1 else None
     w = torch.randn(cout, c0 + c1, 3 if taps == 9 else 1, 3 if taps == 9 else 1, device=dev) / (taps * (c0 + c1)) ** 0.5
     wp = ops.pack_conv_weight(w)
@@ -90,8 +98,10 @@ for si, (res, c0, c1, cout, taps) in enumerate(SHAPES):
     out = torch.zeros(M, old, device=dev)
     a = ConvArgs(x0.data_ptr(), x1.data_ptr() if c1 else None, c0, c1, c0, c1, B, res, res, taps, wp.data_ptr(), cout, bias.data_ptr(),
                  None, 0, 1, res_t.data_ptr() if cout >= 4 else None, cout, 0.70710678, 0, out.data_ptr(), old)
-    if args.no_res:
+    if args.no_res or STRIDE2:
         a.res = None
+    if STRIDE2:
+        a.stride = 2
     if (args.f16 or args.split) and ((taps != 9 and not args.dma16) or cout < 64 or (args.norm and res < 16)):
         continue
     if args.extra and taps == 9:
@@ -113,7 +123,7 @@ for si, (res, c0, c1, cout, taps) in enumerate(SHAPES):
         a.wgt_f16 = 2 if args.split else 1
     if args.dma16:
         assert args.f16 and not args.norm
-        x16 = torch.randn(M, c0 + c1, device=dev).to(torch.float16)
+        x16 = torch.randn(MI, c0 + c1, device=dev).to(torch.float16)
         a.x0, a.x1, a.c0, a.c1, a.ld0, a.ld1, a.in_f16 = x16.data_ptr(), None, c0 + c1, 0, c0 + c1, 0, 1
         if args.extra and taps == 9:
             e16 = torch.randn(M, c0 + c1, device=dev).to(torch.float16)
@@ -127,6 +137,7 @@ for si, (res, c0, c1, cout, taps) in enumerate(SHAPES):
         if args.lda:
             a.ld0 = args.lda
         a.tune.f16dma_nb, a.tune.f16dma_nw, a.tune.ablate = args.nb, args.nw, args.ablate
+        a.tune.splits = args.splits
         if args.geglu:
             assert taps == 1 and cout % 128 == 0
             a.act, a.res, a.res_f16, a.cbias, a.out_ld, a.out_scale = 2, None, 0, None, cout // 2, 1.0
@@ -168,21 +179,22 @@ for si, (res, c0, c1, cout, taps) in enumerate(SHAPES):
     tot_fl += fl; tot_t += ms
     msg = f'[{si}] {res}x{res} {c0}+{c1}->{cout} taps={taps} M={M}: {ms:8.3f} ms  {fl/ms/1e9:7.1f} TFLOP/s'
     if args.dma16:        # the launch's algorithmic HBM bytes: fp16 activations in, output and residual rows out / in
-        byt = M * (c0 + c1) * 2 + M * cout * (2 if a.out_f16 else 4) + (M * cout * (2 if a.res_f16 else 4) if a.res else 0)
+        byt = MI * (c0 + c1) * 2 + M * cout * (2 if a.out_f16 else 4) + (M * cout * (2 if a.res_f16 else 4) if a.res else 0)
         msg += f'  {byt / ms / 1e6:6.0f} GB/s'
     if args.check:
         xin = torch.cat([x0, x1], 1) if c1 else x0
-        xin = xin.reshape(B, res, res, c0 + c1).permute(0, 3, 1, 2)
-        ref = torch.nn.functional.conv2d(xin, w, bias, padding=(1 if taps == 9 else 0))
+        ri = 2 * res if STRIDE2 else res
+        xin = xin.reshape(B, ri, ri, c0 + c1).permute(0, 3, 1, 2)
+        ref = torch.nn.functional.conv2d(xin, w, bias, stride=(2 if STRIDE2 else 1), padding=(1 if taps == 9 else 0))
         ref = ref.permute(0, 2, 3, 1).reshape(M, cout)
-        if cout >= 4:
+        if cout >= 4 and not STRIDE2:
             ref = (ref + res_t) * 0.70710678
         else:
             ref = ref * 0.70710678
         got = out16.float() if args.dma16 and a.out_f16 else out[:, :cout]          # fp16 output rows: within one fp16 ulp of the reference
         if args.dma16:                                                               # the kernel multiplies fp16 operands
-            xin16 = x16.float().reshape(B, res, res, c0 + c1).permute(0, 3, 1, 2)
-            ref = torch.nn.functional.conv2d(xin16, w.half().float(), bias, padding=(1 if taps == 9 else 0)).permute(0, 2, 3, 1).reshape(M, cout)
+            xin16 = x16.float().reshape(B, ri, ri, c0 + c1).permute(0, 3, 1, 2)
+            ref = torch.nn.functional.conv2d(xin16, w.half().float(), bias, stride=(2 if STRIDE2 else 1), padding=(1 if taps == 9 else 0)).permute(0, 2, 3, 1).reshape(M, cout)
             if a.res:
                 ref = (ref + (res16.float() if a.res_f16 else res_t)) * 0.70710678
             else:
