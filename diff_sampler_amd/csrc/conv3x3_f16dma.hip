@@ -427,23 +427,23 @@ int conv3x3_f16dma_plan(const KParams& p, int (*out)[3], bool half = false) {
 }
 
 // Split-K (see the header): S > 1 when the WIDEST tiling of the layer (fewest LDS operand bytes per MFMA) fills at most half of the 256 CUs and
-// every split keeps at least two 3x3 slabs' worth of taps (18): S = 256 / tiles, at most 16, within the workspace.  `plan` / `n` are then
-// replaced by that widest tiling (ds_conv_args.tune.f16dma_nb keeps the forced one); ds_conv_args.tune.splits forces S (1 = never).
+// every split keeps at least two 3x3 slabs' worth of taps (18): S = 256 / tiles, at most 16, within the workspace.  S is a function of the
+// layer alone -- never of a forced tile width (ds_conv_args.tune.f16dma_nb) -- so the order of the fp32 sums, and with it every output bit,
+// is the same under any tile shape the planner picks; a split layer takes the widest tiling unless the width is forced.
+// ds_conv_args.tune.splits forces S (1 = never).
 static int conv3x3_f16dma_splits(const KParams& p, int (*plan)[3], int* n) {
     if (!p.part || !p.vec_part || p.t_splits == 1) return 1;
     int wide[4][3], cost;
-    const int nw = p.t_nb > 0 ? 0 : tiling(p, max_nb(p.W), wide, &cost);
-    int (*cand)[3] = nw ? wide : plan;
-    const int nc = nw ? nw : *n;
+    const int nw = tiling(p, max_nb(p.W), wide, &cost);
     long long tiles = 0;
-    for (int i = 0; i < nc; ++i) tiles += (long long)(p.M / 256) * cand[i][1];
+    for (int i = 0; i < nw; ++i) tiles += (long long)(p.M / 256) * wide[i][1];
     long long s = p.t_splits > 1 ? p.t_splits : (tiles <= 128 ? 256 / tiles : 1);
     const long long kt_all = (long long)(p.c0 / 64) * 9 + p.ec0 / 64, mn = (long long)p.M * p.N;
     if (s > 16) s = 16;
     if (s > kt_all / 18) s = kt_all / 18;
     if (s * mn > p.part_cap) s = p.part_cap / mn;
     if (s < 2) return 1;
-    if (nw) {
+    if (p.t_nb <= 0) {
         for (int i = 0; i < nw; ++i) { plan[i][0] = wide[i][0]; plan[i][1] = wide[i][1]; plan[i][2] = wide[i][2]; }
         *n = nw;
     }
