@@ -177,3 +177,68 @@ def test_sd15_autocast_mode_pinned_to_reference_golden_and_f16_operand_oracle():
     # transformer blocks, random weights) amplifies such perturbations ~100x -- the same factor that turns fp32 rounding (1e-7) into the
     # 1e-5 agreement of the fp32 mode
     assert e16_eps < 2.5e-3, e16_eps
+
+
+@pytest.mark.parametrize('which', ['imagenet64', 'sd15'])
+def test_measured_tile_shapes_do_not_change_a_bit(which, monkeypatch):
+    """plan.Builder measures the tile shape (nb, nw) of the fp16-activation launches whose output bits cannot depend on it
+    (plan._tile_neutral) when a plan is built on the GPU.  Here the measurement is replaced by a FORCED choice -- the narrowest and then the
+    widest candidate on every eligible launch, both far from the cost model's -- and the network output must equal the cost-model plan's bit
+    for bit (ImageNet-64 ADM at 4 images; the SD-1.5 U-Net at 2 latents under guidance = 4 U-Net images, so that its 8x8 stage, its split-K
+    layers and the strided gather convolutions are on the fp16 kernels too)."""
+    from diff_sampler_amd import _lib, plan as plan_mod
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(5)
+    if which == 'imagenet64':
+        from diff_sampler_amd.engine import EDMDenoiser
+        cfg = dict(arch.NAMED_CONFIGS['imagenet64'])
+        spec = arch.edm_precond_spec(**cfg)
+        params = arch.init_params(spec, seed=9)
+        sig = torch.tensor([30.0, 2.5, 0.3, 0.02]).to(dev)
+        x = (torch.randn(4, 3, 64, 64, generator=g)).to(dev) * sig.reshape(-1, 1, 1, 1)
+        lab = torch.eye(spec.label_dim)[torch.randint(spec.label_dim, (4,), generator=g)].to(dev)
+        make = lambda: EDMDenoiser(spec, params, use_fp16=True)
+        run = lambda net: net(x, sig, class_labels=lab)
+        plan_of = lambda net: net.engine.plan(4, 4)
+    else:
+        import diff_sampler_amd.ldm_arch as la
+        from diff_sampler_amd.ldm_engine import CFGDenoiser
+        spec = la.ldm_unet_spec(**la.NAMED_LDM_CONFIGS['sd15'])
+        params = la.init_ldm_params(spec, seed=3)
+        x = torch.randn(2, 4, 64, 64, generator=g).to(dev) * 3.0
+        cond, uncond = torch.randn(2, 77, 768, generator=g).to(dev), torch.randn(2, 77, 768, generator=g).to(dev)
+        make = lambda: CFGDenoiser(spec, params, dev, guidance_rate=7.5, use_fp16=True)
+        run = lambda net: net(x, 3.0, condition=cond, unconditional_condition=uncond)
+        plan_of = lambda net: next(iter(net.engine._plans.values()))
+
+    def tiles(net):
+        lib = _lib.load()
+        return [(op.keep[0].tune.f16dma_nb, op.keep[0].tune.f16dma_nw) for op in plan_of(net).ops if op.fn is lib.ds_conv2d_nhwc and op.keep[0].in_f16]
+
+    monkeypatch.setattr(plan_mod, 'AUTOTUNE', False)
+    base_net = make()
+    base = run(base_net).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(base).all() and all(t == (0, 0) for t in tiles(base_net))
+    monkeypatch.setattr(plan_mod, 'AUTOTUNE', True)
+    saved = dict(plan_mod._TUNE_CACHE)
+    try:
+        for kind in ('narrow', 'wide'):
+            def forced(self, a, inputs, stride, kind=kind):
+                if a.taps == 1:
+                    pick = ((2, 8) if kind == 'narrow' else (4, 8)) if a.act == _lib.DS_ACT_GEGLU else ((1, 8) if kind == 'narrow' else (3, 4))
+                else:
+                    pick = (1, 8) if kind == 'narrow' else (4, 8)
+                return pick[0], pick[1], {}
+            plan_mod._TUNE_CACHE.clear()
+            monkeypatch.setattr(plan_mod.Builder, '_measure_tiles', forced)
+            net = make()
+            out = run(net)
+            torch.cuda.synchronize()
+            ts = tiles(net)
+            n_forced = sum(1 for t in ts if t != (0, 0))
+            assert n_forced >= 40 and n_forced < len(ts), (kind, n_forced, len(ts))      # most launches forced; the staged-column-sum layers left alone
+            assert torch.equal(out, base), (which, kind, float((out - base).abs().max()))
+    finally:
+        plan_mod._TUNE_CACHE.clear()
+        plan_mod._TUNE_CACHE.update(saved)
