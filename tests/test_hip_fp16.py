@@ -124,7 +124,7 @@ def test_use_fp16_sampler_trajectory_stays_close_to_fp32():
 
 def test_sd15_autocast_mode_pinned_to_reference_golden_and_f16_operand_oracle():
     """SD-1.5 latent U-Net under classifier-free guidance, use_fp16 (the reference's autocast mode, sample.py:293-297), full size:
-    against the REAL reference's fp32 evaluation (tests/golden/ldm_sd15.npz) within 1.5 x the fp16-stream oracle's own distance from it (5.7e-3) and against the oracle evaluated with the
+    against the REAL reference's fp32 evaluation (tests/golden/ldm_sd15.npz) within 1.5 x the fp16-stream oracle's own distance from it (6.2e-3) and against the oracle evaluated with the
     same fp16-rounded operands and stored tensors (tests/golden/ldm_sd15_f16ops.npz): U-Net outputs within 2.5e-3, guided output within
     7.5e-3; the golden's layer lists must be the plan's routing."""
     import numpy as np
@@ -161,8 +161,8 @@ def test_sd15_autocast_mode_pinned_to_reference_golden_and_f16_operand_oracle():
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     json.dump(REPORT, open(os.path.join(ROOT, 'gpurun_out', 'fp16_parity.json'), 'w'), indent=1)
     # Against the REAL reference's fp32 golden.  The bound is derived from the mode's own noise, not picked: the fp16-stream ORACLE (same
-    # tensors rounded, fp64-free CPU arithmetic) is `rel_vs_fp32_golden` = 3.8e-3 away from that golden under 7.5x guidance (stored in the
-    # golden file by oracle/gen_f16_golden.py) -- no kernel that rounds those tensors can be expected closer.  1.5 x that noise (5.7e-3)
+    # tensors rounded, fp64-free CPU arithmetic) is `rel_vs_fp32_golden` = 4.1e-3 away from that golden under 7.5x guidance (stored in the
+    # golden file by oracle/gen_f16_golden.py) -- no kernel that rounds those tensors can be expected closer.  1.5 x that noise (6.2e-3)
     # leaves room for what the kernels legitimately differ by: the order of their fp32 sums moves this number by +-10 % (observed 3.9 -
     # 4.3e-3 over rounds 3 / 4).  The sharp pins are the per-evaluation ones below (kernel vs fp16 oracle, same roundings).
     noise = float(z16['rel_vs_fp32_golden'])
