@@ -186,3 +186,71 @@ def test_ldm_plan_flags_match_the_dtypes_of_the_tensors_they_point_to(N):
     assert all(lib.ds_conv_kernel_id(C.byref(a)) == 2571 for a in down)
     for part in (P.ctx,):
         assert all(op.name.endswith('.attn2.kv') for op in part.ops)
+
+
+def test_sd15_fp16_routing_is_the_autocast_layer_set_minus_the_stated_exceptions():
+    """Routing-independent pin of WHICH layers multiply fp16 operands in the latent-diffusion engine's fp16 mode (the fp16 oracle's predicate is
+    read off the plan, tests/_f16_names.py: that checks the kernels' arithmetic on a given routing, not the routing).  The reference samples
+    this U-Net under torch.autocast (sample.py:293-297), which casts the operands of EVERY nn.Conv2d / nn.Linear: the set of all 4-d / 2-d
+    `.weight` tensors of the state_dict.  The plan's fp16 set must be exactly that set minus what the engine keeps in fp32 on purpose
+    (ldm_engine.LDMUNetEngine docstring): the time embedding (time_embed.*, every ResBlock's emb_layers.1), the context key / value
+    projections (attn2.to_k / to_v: fp32 states, once per context) and the 4-channel head out.2 -- each of them stricter than the reference."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import _f16_names
+    import diff_sampler_amd.ldm_arch as la
+    from diff_sampler_amd.ldm_engine import LDMUNetEngine
+    spec = la.ldm_unet_spec(**la.NAMED_LDM_CONFIGS['sd15'])
+    params = la.init_ldm_params(spec, seed=0)
+    eng = LDMUNetEngine(spec, params, device='cpu', use_fp16=True)
+    for N in (4, 32):                                  # 2 / 16 latents under guidance: the 8x8 stage has its fp16 kernels at both
+        P = eng.plan(N, 1, 77)
+        routed = _f16_names.ldm_prefixes(P)
+        attn = {n for n in routed if n.endswith('.attn1') or n.endswith('.attn2')}
+        assert len(attn) == 32                         # 16 transformer blocks x (self + cross attention) on the fp16 attention kernel
+        routed = {n for n in routed - attn if (n + '.weight') in params}      # (the map names a skip_connection for blocks that have none)
+        autocast = {k[:-len('.weight')] for k, v in params.items() if k.endswith('.weight') and v.dim() in (2, 4)}
+        kept_fp32 = {n for n in autocast if n.startswith('time_embed.') or n.endswith('.emb_layers.1') or n.endswith('.attn2.to_k')
+                     or n.endswith('.attn2.to_v') or n == 'out.2'}
+        assert len(kept_fp32) == 2 + 22 + 32 + 1
+        assert routed == autocast - kept_fp32, (sorted(autocast - kept_fp32 - routed)[:5], sorted(routed - (autocast - kept_fp32))[:5])
+
+
+@pytest.mark.parametrize('name', ['imagenet64', 'cifar10', 'ffhq'])
+def test_edm_fp16_routing_is_every_convolution_of_the_body_but_stem_and_head(name):
+    """The same pin for the EDM nets: with use_fp16 the reference runs the whole U-Net body on x.to(float16) (networks_edm.py:486; every Conv2d
+    multiplies w.to(x.dtype), :79), while the embedding MLP and the affine Linear layers see fp32 inputs.  The plan must route exactly the
+    4-d weights of the state_dict to the fp16-operand kernels, except the 3-channel stem and the 3-channel head (out_conv / aux_conv), which the
+    engine keeps in fp32 (stricter than the reference)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import _f16_names
+    from diff_sampler_amd.engine import EDMDenoiser
+    cfg = dict(arch.NAMED_CONFIGS[name])
+    spec = arch.edm_precond_spec(**cfg)
+    params = arch.init_params(spec, seed=9)
+    net = EDMDenoiser(spec, params, device='cpu', use_fp16=True)
+    routed = _f16_names.edm_prefixes(net.engine.plan(4, 4))
+    routed = {n for n in routed if (n + '.weight') in params}                 # drops the attention launches and skip names of blocks without a skip conv
+    convs = {k[:-len('.weight')] for k, v in params.items() if k.endswith('.weight') and v.dim() == 4}
+    kept_fp32 = {n for n in convs if n.endswith('_conv') and (n.startswith('model.enc.') or n.endswith('aux_conv') or n == 'model.out_conv')}
+    assert len(kept_fp32) == 2, sorted(kept_fp32)
+    assert routed == convs - kept_fp32, (sorted(convs - kept_fp32 - routed)[:5], sorted(routed - (convs - kept_fp32))[:5])
+
+
+def test_planner_tile_measurement_is_off_on_the_cpu_and_for_launches_whose_bits_could_move():
+    """plan.Builder._autotune: nothing is measured for a plan built on the CPU (tune words stay zero), and plan._tile_neutral refuses the
+    launches whose GroupNorm column sums leave through the staged epilogue (1x1 / Linear layers with statistics, fp32 rows, fp32 residual)."""
+    from diff_sampler_amd import plan as plan_mod
+    import diff_sampler_amd.ldm_arch as la
+    from diff_sampler_amd.ldm_engine import LDMUNetEngine
+    lib = _lib.load()
+    spec = la.ldm_unet_spec(**la.NAMED_LDM_CONFIGS['sd15'])
+    P = LDMUNetEngine(spec, la.init_ldm_params(spec, seed=0), device='cpu', use_fp16=True).plan(4, 1, 77)
+    convs = [op.keep[0] for op in P.ops if op.fn is lib.ds_conv2d_nhwc and op.keep[0].in_f16]
+    assert len(convs) > 150 and all(a.tune.f16dma_nb == 0 and a.tune.f16dma_nw == 0 for a in convs)
+    neutral = [plan_mod._tile_neutral(a) for a in convs]
+    assert 0.8 * len(convs) < sum(neutral) < len(convs)
+    for a, ok in zip(convs, neutral):
+        if a.taps == 1 and a.stats_out:
+            assert not ok                              # proj_out: column sums through the staged epilogue
+        if not a.stats_out:
+            assert ok
