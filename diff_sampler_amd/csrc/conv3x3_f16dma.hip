@@ -9,9 +9,14 @@
 // is an fp16 NHWC tensor in HBM (written once per element by ds_norm_act with out_f16 -- the reference's own storage type in this
 // mode, networks_edm.py:486) and the convolution only multiplies:
 //
-//   * halo of a 64-channel slab: NP pixels x 128 B, pixel-major, the 16-B chunk index XOR-swizzled by (pixel >> 1) & 7 (same
-//     involution on the DMA source address and on the fragment read: 16 consecutive pixels of one chunk hit 16 different bank
-//     quads); out-of-image pixels fetch a zero page.  Two halo buffers: slab s+1 streams in (one 8-KB DMA round per tap) while slab s
+//   * halo of a 64-channel slab: NP pixels x 128 B, pixel-major, the 16-B chunk index XOR-swizzled by (v >> 1) & 7 (same
+//     involution on the DMA source address and on the fragment read), v = the halo pixel index on 32- / 64-column images -- the 32
+//     lanes of a fragment read are one image row: 16 consecutive pixels of one chunk hit 16 different bank quads -- and, round 4, the
+//     pixel's COLUMN x in its halo row on 16-column images, x + 8 (row & 1) on 8-column images: there the 32 lanes are two / four image
+//     rows whose halo pitch (18 / 10 pixels) is 2 / 10 mod 16, so a swizzle on the pixel index made every 16-lane group of a
+//     ds_read_b128 hit two (three) addresses in the same bank quad (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.25 - 0.29 resp. 0.43 on
+//     those instantiations, 0 on the others: profiles/r4_*_fp16_sq_counters.json; model: tools/probes/halo_bank_conflicts.py);
+//     out-of-image pixels fetch a zero page.  Two halo buffers: slab s+1 streams in (one 8-KB DMA round per tap) while slab s
 //     is multiplied;
 //   * weights of a tap: NB * 64 rows x 128 B, swizzled the same way, in a ring of D = 2 .. 4 buffers (f16dma_ring), D - 1 taps ahead;
 //   * per tap: one barrier; the A-fragment addresses of the 9 taps are 18 precomputed registers, a K step is `base ^ (ks << 5)`;
@@ -89,7 +94,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
 
     // ---- halo DMA: thread tid owns 16-B unit j * 512 + tid of round j: pixel (unit >> 3), LDS chunk slot tid & 7 -----------------
     int hpix[NDMA];                                            // source pixel (-1: zero page)
-    // source channel offset (halfs): chunk slot ^ ((pixel >> 1) & 7); pixel = j * 64 + (tid >> 3), so the same for every round j
+    // source channel offset (halfs): chunk slot ^ swizzle(pixel).  32- / 64-column images: (pixel >> 1) & 7 with pixel = j * 64 + (tid >> 3),
+    // the same for every round j; 8- / 16-column images: by the pixel's column (and row parity) in the halo, recomputed per round in halo_dma
+    // (a handful of VALU in the shadow of the tap's MFMAs instead of a register kept across the K loop)
     const int hch = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;
 #pragma unroll
     for (int j = 0; j < NDMA; ++j) {
@@ -123,7 +130,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
         const bool extra = chunk >= nchunks;
         const _Float16* base = extra ? e0 + (size_t)(chunk - nchunks) * 64 : a0 + (size_t)chunk * 64;
         const int ld = extra ? p.elda0 : p.lda0;
-        const _Float16* g = hpix[j] >= 0 ? base + (size_t)hpix[j] * ld + hch : g_zero_halfs;
+        int hcj = hch;
+        if constexpr (W <= 16) {                               // halo pixel of this unit: row hp / WP (counted over the tile's image slots), column hp % WP
+            const unsigned hp = (unsigned)(j * 64 + (tid >> 3)), hrow = hp / (unsigned)WP, hcol = hp - hrow * (unsigned)WP;
+            hcj = (int)(((unsigned)(tid & 7) ^ (((hcol + (W == 8 ? 8u * (hrow & 1u) : 0u)) >> 1) & 7u)) * 8u);
+        }
+        const _Float16* g = hpix[j] >= 0 ? base + (size_t)hpix[j] * ld + hcj : g_zero_halfs;
         __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + D * WB + hbuf * HB + (j * 512 + wave * 64) * 16), 16, 0, 0);
     };
     // ---- weight DMA of K tile (tap) kt: rows i * 64 + (tid >> 3), i < NB; the source chunk is pre-swizzled -----------------------
@@ -156,7 +168,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
     const unsigned gsel = (unsigned)(lane >> 5);
     auto a_addr = [&](int i, int tt) -> unsigned {             // byte offset inside a halo buffer, K step 0
         const unsigned hp = (unsigned)(hp0[i] + (tt / 3) * WP + (tt % 3));
-        return hp * 128u + 16u * (((hp >> 1) & 7u) ^ gsel);
+        unsigned sw = (hp >> 1) & 7u;
+        if constexpr (W <= 16) {                               // swizzle by the column (and row parity) of the halo pixel: see the header
+            const unsigned hrow = hp / (unsigned)WP, hcol = hp - hrow * (unsigned)WP;
+            sw = ((hcol + (W == 8 ? 8u * (hrow & 1u) : 0u)) >> 1) & 7u;
+        }
+        return hp * 128u + 16u * (sw ^ gsel);
     };
     const int brow = wc * (NB * 32) + (lane & 31);
     const unsigned lds0 = lds_addr2(smem);
