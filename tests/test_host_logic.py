@@ -418,3 +418,16 @@ def test_gits_warmup_conditioning_by_model_source():
     eng_net = types.SimpleNamespace(label_dim=True, spec=types.SimpleNamespace(context_dim=16))
     cl, c, uc = gits_utils._warmup_conditioning(eng_net, dev, 4, 'ldm', 'ms_coco', dict(prompt=None, guidance_rate=7.5), None)
     assert c.shape == (4, 77, 16) and uc.shape == (4, 77, 16) and torch.equal(uc[0], uc[3])
+
+
+def test_halo_swizzle_of_the_fp16_convolution_is_bank_conflict_free_on_every_image_width():
+    """The LDS layout rule of csrc/conv3x3_f16dma.hip (chunk slot = chunk ^ swizzle(halo pixel)) against the bank model of ds_read_b128
+    (tools/probes/halo_bank_conflicts.py): the column-based swizzle the kernel uses costs no extra LDS cycle on 8-, 16-, 32- and 64-column images;
+    the swizzle on the pixel index it replaced cost one extra cycle per lane group on 16-column images and two on 8-column images -- the
+    ratios the SQ counters showed (profiles/r4_*_fp16_sq_counters.json, docs/HISTORY.md E.21).  The kernel's formula is mirrored by
+    swizzle_by_column; the kernel tests (GPU) check that both sides of the involution agree."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools', 'probes'))
+    import halo_bank_conflicts as hb
+    for W in (8, 16, 32, 64):
+        assert hb.conflicts(W, hb.swizzle_by_column) == (0, 144), W
+    assert [hb.conflicts(W, hb.swizzle_by_index)[0] for W in (64, 32, 16, 8)] == [0, 0, 144, 288]
