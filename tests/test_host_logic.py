@@ -431,3 +431,32 @@ def test_halo_swizzle_of_the_fp16_convolution_is_bank_conflict_free_on_every_ima
     for W in (8, 16, 32, 64):
         assert hb.conflicts(W, hb.swizzle_by_column) == (0, 144), W
     assert [hb.conflicts(W, hb.swizzle_by_index)[0] for W in (64, 32, 16, 8)] == [0, 0, 144, 288]
+
+
+def test_split_k_ranges_of_the_fp16_convolution_partition_the_slabs():
+    """The split-K ranges of csrc/conv3x3_f16dma.hip (`cut`: slab boundaries nearest to the equal-TAP cuts; a 3x3 slab weighs nine taps, an
+    appended 1x1 slab one) mirrored on the host: for every layer shape (3x3 slabs, 1x1 slabs) and every split count the launcher can choose
+    (conv3x3_f16dma_splits: at most 16, at least 18 taps per split) the ranges are non-empty, contiguous and cover every slab exactly once --
+    an empty range would send a workgroup into the K loop with nothing staged.  (The GPU tests run six such shapes; this runs all of them.)"""
+    def ranges(nchunks, nextra, S):
+        kt_all = nchunks * 9 + nextra
+
+        def cut(i):
+            t = (kt_all * i) // S
+            return (t + 4) // 9 if t <= nchunks * 9 else nchunks + (t - nchunks * 9)
+        return [(cut(sp), cut(sp + 1) if sp + 1 < S else nchunks + nextra) for sp in range(S)]
+
+    checked = 0
+    for nchunks in range(0, 48):
+        for nextra in range(0, 100):
+            kt_all = nchunks * 9 + nextra
+            for S in range(2, 17):
+                if S > kt_all // 18:
+                    continue
+                r = ranges(nchunks, nextra, S)
+                assert r[0][0] == 0 and r[-1][1] == nchunks + nextra and all(a < b for a, b in r), (nchunks, nextra, S, r)
+                assert all(r[i][1] == r[i + 1][0] for i in range(S - 1)), (nchunks, nextra, S, r)
+                taps = [(min(b, nchunks) - min(a, nchunks)) * 9 + (max(b, nchunks) - max(a, nchunks)) for a, b in r]
+                assert sum(taps) == kt_all and max(taps) <= kt_all // S + 9 + 1, (nchunks, nextra, S, taps)     # balanced to within one 3x3 slab
+                checked += 1
+    assert checked > 20000
