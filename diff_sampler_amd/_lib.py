@@ -149,6 +149,7 @@ DS_OP_CONV2D, DS_OP_GEMM, DS_OP_GN_STATS, DS_OP_NORM_ACT, DS_OP_GN_FINALIZE, DS_
 
 _SIGNATURES = {
     'ds_version': (C.c_int, []),
+    'ds_build_experiments': (C.c_int, []),
     'ds_error_string': (C.c_char_p, [C.c_int]),
     'ds_conv2d_nhwc': (C.c_int, [C.POINTER(ConvArgs), vp]),
     'ds_conv_kernel_id': (C.c_int, [C.POINTER(ConvArgs)]),

@@ -431,7 +431,11 @@ static int tiling(const KParams& p, int nb0, int (*out)[3], int* cost, bool half
 }
 
 int conv3x3_f16dma_plan(const KParams& p, int (*out)[3], bool half = false) {
+#ifdef DS_BUILD_EXPERIMENTS
     const int cap = half ? conv3x3_f16dmah_max_nb(p.W) : max_nb(p.W);
+#else
+    const int cap = max_nb(p.W);
+#endif
     int cost;
     if (p.t_nb > 0) return tiling(p, p.t_nb < cap ? p.t_nb : cap, out, &cost, half);
     int best_nb = cap, best_cost = 0x7fffffff, best_n = 99;
@@ -470,14 +474,17 @@ static int conv3x3_f16dma_splits(const KParams& p, int (*plan)[3], int* n) {
 // Which layers take the four-wave half-slab variant (two workgroups per CU, conv3x3_f16dmah.hip).  ds_conv_args.tune.f16dma_nw forces it
 // (4) or the eight-wave kernel (8); otherwise by layer class, from the A/B of profiles/r4_conv_f16dmah_ab.txt.
 bool conv3x3_f16dma_use_half(const KParams& p) {
-    if (!conv3x3_f16dmah_applicable(p)) return false;
-    if (p.t_nw == 4) return true;
-    if (p.t_nw == 8) return false;
+#ifdef DS_BUILD_EXPERIMENTS                                    // a recorded negative result: built with DS_BUILD_EXPERIMENTS=1 only, never a default
+    return p.t_nw == 4 && conv3x3_f16dmah_applicable(p);
+#else
+    (void)p;
     return false;
+#endif
 }
 
 int launch_conv3x3_f16dma(KParams& p, hipStream_t stream) {
     int plan[4][3];
+#ifdef DS_BUILD_EXPERIMENTS
     if (conv3x3_f16dma_use_half(p)) {
         const int n = conv3x3_f16dma_plan(p, plan, true);
         for (int i = 0; i < n; ++i) {
@@ -486,6 +493,7 @@ int launch_conv3x3_f16dma(KParams& p, hipStream_t stream) {
         }
         return DS_OK;
     }
+#endif
     int n = conv3x3_f16dma_plan(p, plan);
     p.splits = conv3x3_f16dma_splits(p, plan, &n);
     for (int i = 0; i < n; ++i) {

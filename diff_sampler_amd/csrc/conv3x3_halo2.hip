@@ -510,6 +510,9 @@ int launch_halo2_w(KParams p, int wide, hipStream_t stream) {
 // tiles, a ragged 64-column tail goes to the first-generation kernel; fp16: ALL tiles, a ragged last tile multiplies the zero rows the
 // weight packing pads to 128 and its epilogue guards the columns).  `f16`: the weights at p.b are fp16 in the 64-channel K order.
 bool conv3x3_halo2_applicable(const KParams& p, int wide, int mode) {
+#ifndef DS_BUILD_EXPERIMENTS
+    if (mode != 2) return false;            // modes 0 / 1 are A/B records (docs/HISTORY.md B, D): built with DS_BUILD_EXPERIMENTS=1 only
+#endif
     const int bkc = mode == 1 ? 64 : 32;
     if (p.taps != 9 || wide < 1) return false;
     if (!(p.W == 8 || p.W == 16 || p.W == 32 || p.W == 64)) return false;
@@ -534,9 +537,13 @@ static int launch_mode(KParams& p, int wide, hipStream_t stream) {
 
 // mode: 0 = fp32 operands, 1 = fp16 operands (64-channel slabs), 2 = split fp16 hi/lo operands (fp32-emulated, 32-channel slabs)
 int launch_conv3x3_halo2(KParams& p, int wide, int mode, hipStream_t stream) {
-    if (mode == 1) return launch_mode<1>(p, wide, stream);
     if (mode == 2) return launch_mode<2>(p, wide, stream);
+#ifdef DS_BUILD_EXPERIMENTS
+    if (mode == 1) return launch_mode<1>(p, wide, stream);
     return launch_mode<0>(p, wide, stream);
+#else
+    return DS_E_SHAPE;
+#endif
 }
 
 }  // namespace igemm

@@ -643,6 +643,13 @@ extern "C" int ds_copy_rows(const float* src, int src_ld, float* dst, int dst_ld
     return DS_OK;
 }
 
+extern "C" int ds_build_experiments(void) {
+#ifdef DS_BUILD_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 extern "C" int ds_version(void) { return 2; }      // 2: ds_conv_args.tune, ds_update_args.variant (struct layouts changed), ds_fid_moments; no ds_debug_* entry points
 
 extern "C" const char* ds_error_string(int code) {

@@ -63,6 +63,69 @@ class AMEDPredictor:
         return out
 
 
+# ---- the two public helpers of the reference module (amed-solver-main/solvers_amed.py:7-55).  The reference's samplers call them on every
+# step; here the samplers read the bottleneck from the launch plan directly (_amed_loop), and these shims exist so that code written
+# against the reference module -- `from solvers_amed import init_hook, get_amed_prediction` -- keeps working on an engine net. ----------
+class _BottleneckTap:
+    """What ``init_hook`` hands back as ``unet_enc_out``: the reference appends the hooked block's output on every forward and reads
+    ``unet_enc_out[-1]``; the engine keeps the tap of the LAST evaluation as a plan buffer, so ``[-1]`` fetches it (NCHW, fp32)."""
+
+    def __init__(self, net, name):
+        self.net, self.name, self.active = net, name, True
+
+    def __getitem__(self, i):
+        if i != -1:
+            raise IndexError('only the bottleneck of the last evaluation is kept (unet_enc_out[-1])')
+        if not self.active:
+            raise RuntimeError('the hook was removed')
+        return self.net.block_output(self.name)
+
+    def __len__(self):
+        return 1 if getattr(self.net, '_last', None) is not None else 0
+
+
+class _TapHandle:
+    """The ``hook`` half of ``init_hook``'s return value: ``.remove()`` like a torch RemovableHandle."""
+
+    def __init__(self, tap):
+        self.tap = tap
+
+    def remove(self):
+        self.tap.active = False
+
+
+def init_hook(net, class_labels=None):
+    """``unet_enc_out, hook = init_hook(net, class_labels)`` (solvers_amed.py:7-18): the U-Net bottleneck tap -- ``enc['8x8_block2']`` for
+    class-conditional EDM nets, ``enc['8x8_block3']`` otherwise.  LDM / 256-pixel ADM nets (``middle_block``) are outside the engine's
+    AMED scope and raise."""
+    if hasattr(net, 'guidance_type') or getattr(net, 'img_resolution', 0) == 256 or not hasattr(net, 'block_output'):
+        raise NotImplementedError('init_hook: the engine exposes the AMED bottleneck of EDM nets (engine.EDMDenoiser) only')
+    tap = _BottleneckTap(net, 'enc.8x8_block2' if class_labels is not None else 'enc.8x8_block3')
+    return tap, _TapHandle(tap)
+
+
+def get_amed_prediction(AMED_predictor, t_cur, t_next, net, unet_enc_out, use_afs, batch_size):
+    """``r, scale_dir, scale_time`` as ``[B, 1, 1, 1]`` tensors (solvers_amed.py:22-55): the channel mean of the last bottleneck (zeros
+    under AFS, :27) through the predictor kernel; an absent head yields ones (:43,48,53-54)."""
+    pred = _as_predictor(AMED_predictor, net.device if hasattr(net, 'device') else 'cuda')
+    dev = pred.device
+    if use_afs:
+        bott = torch.zeros(batch_size, 8, 8, dtype=torch.float32, device=dev)
+    elif isinstance(unet_enc_out, _BottleneckTap):                      # the plan's own NHWC buffer: no copy
+        if not unet_enc_out.active:
+            raise RuntimeError('the hook was removed')
+        bott = net.bottleneck_mean(net._last[0], batch_size, class_cond=unet_enc_out.name.endswith('block2'))
+    else:                                                               # any list of [B, C, 8, 8] tensors, as the reference's hook fills
+        t = unet_enc_out[-1].to(dev, torch.float32)
+        nhwc = t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()
+        bott = torch.empty(batch_size, 8, 8, dtype=torch.float32, device=dev)
+        ops.channel_mean(nhwc, t.shape[1], t.shape[1], batch_size * 64, bott)
+    out = torch.empty(batch_size, 4, dtype=torch.float32, device=dev)
+    pred.predict(bott, float(t_cur), float(t_next), out)
+    col = lambda j: out[:, j].reshape(-1, 1, 1, 1).clone()
+    return col(0), col(1), col(2)
+
+
 def _as_predictor(p, device):
     if p is None or isinstance(p, AMEDPredictor):
         return p

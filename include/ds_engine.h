@@ -24,6 +24,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: DS_API marks the entry points declared here as the ONLY exported symbols (the kernels'
+ * C++ launch helpers stay internal to libdsamd.so; tests/test_abi_cpu.py compares the dynamic symbol table with this header). */
+#define DS_API __attribute__((visibility("default")))
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -43,9 +47,13 @@ extern "C" {
 #define DS_RESAMPLE_DOWN 1  /* 2x2 box filter, stride 2  (networks_edm.py:77 with resample_filter [1,1]) */
 #define DS_RESAMPLE_UP 2    /* nearest neighbour x2      (networks_edm.py:75 with resample_filter [1,1]) */
 
-int ds_version(void);      /* 2 since round 4: ds_conv_args.tune / ds_update_args.variant appended (struct sizes changed), ds_fid_moments added, the
+DS_API int ds_version(void);      /* 2 since round 4: ds_conv_args.tune / ds_update_args.variant appended (struct sizes changed), ds_fid_moments added, the
                                * process-global ds_debug_* setters removed.  A host must check it before passing argument structs. */
-const char* ds_error_string(int code);
+DS_API const char* ds_error_string(int code);
+DS_API int ds_build_experiments(void);   /* 1: the library was built with DS_BUILD_EXPERIMENTS=1 and also holds the kernel variants kept as A/B records
+                                          * (conv3x3_f16dmah, conv3x3_halo2 modes 0 / 1: reachable through ds_conv_args.tune only, never chosen by
+                                          * default); 0: the product kernels only -- ds_conv_f16_supported() answers 0 and tune.f16dma_nw = 4 / tune.variant
+                                          * = 3 are ignored for 3x3 layers */
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution / linear layer on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32; exact fp32).
@@ -161,7 +169,7 @@ typedef struct ds_conv_args {
     ds_conv_tune tune;
 } ds_conv_args;
 
-int ds_conv2d_nhwc(const ds_conv_args* a, void* stream);
+DS_API int ds_conv2d_nhwc(const ds_conv_args* a, void* stream);
 
 /* Which kernel ds_conv2d_nhwc dispatches this call to: 0 = generic gather kernel (igemm_f32_kernel<0>), 128 / 256 =
  * LDS-halo kernel with that M tile (conv3x3_halo_kernel<2> / <4>), 2561 = 8-wave LDS-DMA 1x1 / Linear kernel
@@ -172,47 +180,47 @@ int ds_conv2d_nhwc(const ds_conv_args* a, void* stream);
  * of the network heads (conv3x3_thin_kernel: cout <= 4, one fp32 source, no residual / per-image bias / statistics), 2571 = the stride-2
  * 3x3 convolution on fp16 rows (gemm_f16dma_kernel<.., GATHER>).  Used by bench.py to
  * attribute time per kernel. */
-int ds_conv_kernel_id(const ds_conv_args* a);
+DS_API int ds_conv_kernel_id(const ds_conv_args* a);
 
 /* 1 if a 3x3 convolution on h x w images runs on the LDS-halo kernel (needed for norm_coefs), else 0. */
-int ds_conv3x3_halo_supported(int h, int w);
+DS_API int ds_conv3x3_halo_supported(int h, int w);
 
 /* fp16-operand 3x3 convolution (ds_conv_args.wgt_f16): returns 0 = not available for this geometry, 1 = available, 2 = available
  * and the fused input normalisation (norm_coefs) too.  n, h, w: images and size; cin = c0 + c1 and ecin = ec0 + ec1 with every
  * source a multiple of 64 channels. */
-int ds_conv_f16_supported(int n, int h, int w, int c0, int c1, int ec0, int ec1);
+DS_API int ds_conv_f16_supported(int n, int h, int w, int c0, int c1, int ec0, int ec1);
 /* 1 when a 3x3 layer of this geometry runs on the fp16-activation kernel (ds_conv_args.in_f16). */
-int ds_conv_f16dma_supported(int n, int h, int w, int c0, int ec0, int cout);
+DS_API int ds_conv_f16dma_supported(int n, int h, int w, int c0, int ec0, int cout);
 /* 1 when a 1x1 / Linear layer [rows][k] -> [rows][cout] runs on the fp16-activation GEMM (in_f16 with taps == 1, csrc/gemm_f16dma.hip). */
-int ds_gemm_f16dma_supported(long long rows, int k, int cout);
+DS_API int ds_gemm_f16dma_supported(long long rows, int k, int cout);
 /* 1 when the latent-diffusion `Downsample` (3x3, stride 2, pad 1; ldm/modules/diffusionmodules/openaimodel.py:146-148) with n images of
  * OUTPUT size h x w (input 2h x 2w), c0 input and cout output channels runs on the fp16-activation GEMM in its gather form
  * (ds_conv_args.in_f16 = 1, wgt_f16 = 1, taps = 9, stride = 2; csrc/gemm_f16dma.hip).  Replaces, in fp16 mode, an fp32 copy of the
  * fp16 residual stream + the generic fp32 kernel. */
-int ds_conv_f16dma_stride2_supported(int n, int h, int w, int c0, int cout);
+DS_API int ds_conv_f16dma_stride2_supported(int n, int h, int w, int c0, int cout);
 
 /* 1x1 convolution / Linear with fp16 operands (wgt_f16 == 1 and taps == 1: `wgt` = [cout_pad][K] halfs in plain K order; the fp32
  * input rows are rounded to fp16 while they are staged): 1 if rows % 256 == 0 and every source is a multiple of 64 channels. */
-int ds_gemm_f16_supported(long long rows, int c0, int c1);
+DS_API int ds_gemm_f16_supported(long long rows, int c0, int c1);
 
 /* The same for the split-fp16 (fp32-emulated) operands of wgt_f16 == 2; every source a multiple of 32 channels. */
-int ds_conv_split_supported(int n, int h, int w, int c0, int c1, int ec0, int ec1);
+DS_API int ds_conv_split_supported(int n, int h, int w, int c0, int c1, int ec0, int ec1);
 
 /* Batched per-seed latent generator: out[b][i], i < n, = the tensor `torch.randn([n], generator=g_b, device=<this GPU>)` of a generator
  * with `g_b.manual_seed(seeds[b])` whose Philox offset is `offset` (0 for a fresh generator) -- bit for bit, for a whole batch of
  * seeds in one launch.  Replaces B generator constructions + B launches per batch (diff-solvers-main/sample.py:22-36,
  * StackedRandomGenerator.randn).  `threads_total` = 256 * min(CUs * (maxThreadsPerCU / 256), ceil(n / 256)), ATen's execution
  * policy for n elements; afterwards each generator's offset has advanced by ((n - 1) / (threads_total * 4) + 1) * 4. */
-int ds_philox_randn(const unsigned long long* seeds, unsigned long long offset, float* out, int batch, long long n,
+DS_API int ds_philox_randn(const unsigned long long* seeds, unsigned long long offset, float* out, int batch, long long n,
                     long long threads_total, void* stream);
 
 /* Diagnostic, stateless (tools/probe_rng.py): element i = first Box-Muller output of Philox (seed, subsequence i, offset) with a
  * selectable build of log / sqrt / sin (variant in [0, 96)), to identify which one the installed torch's randn was compiled with. */
-int ds_philox_probe(unsigned long long seed, unsigned long long offset, float* out, int n, int variant, void* stream);
+DS_API int ds_philox_probe(unsigned long long seed, unsigned long long offset, float* out, int n, int variant, void* stream);
 
 /* out[b] = `torch.randint(range, size=[], generator=g_b)` at Philox offset `offset` (sample.py:283: class labels); range < 2**32;
  * the offset then advances by 4. */
-int ds_philox_randint(const unsigned long long* seeds, unsigned long long offset, unsigned int range, int* out, int batch, void* stream);
+DS_API int ds_philox_randint(const unsigned long long* seeds, unsigned long long offset, unsigned int range, int* out, int batch, void* stream);
 
 
 /* Batched C[z] = act(alpha * A[z] * B[z]^T + rowbias + colbias) on the same MFMA core ("NT": both operands have k
@@ -230,7 +238,7 @@ typedef struct ds_gemm_args {
     int act;
 } ds_gemm_args;
 
-int ds_gemm_nt_batched(const ds_gemm_args* a, void* stream);
+DS_API int ds_gemm_nt_batched(const ds_gemm_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * GroupNorm statistics + fused normalise / affine / SiLU / resample pass (networks_edm.py:88-98, :160, :165-167).
@@ -269,7 +277,7 @@ typedef struct ds_norm_args {
 } ds_norm_args;
 
 #define DS_GN_MAX_CHUNKS 32
-int ds_gn_stats(const ds_norm_args* a, void* stream);
+DS_API int ds_gn_stats(const ds_norm_args* a, void* stream);
 
 /* GroupNorm statistics from the per-(64-row block, channel) sums the producing convolutions left behind
  * (ds_conv_args.stats_out) instead of a pass over the activations: same outputs as ds_gn_stats (mean / rstd per (image,
@@ -282,11 +290,11 @@ typedef struct ds_gn_finalize_args {
     const float* gamma; const float* beta; const float* scale; const float* shift; int ss_ld; int ss_rows;
     float* mean; float* rstd; float* coefs;     /* as in ds_norm_args                                                   */
 } ds_gn_finalize_args;
-int ds_gn_finalize(const ds_gn_finalize_args* a, void* stream);
-int ds_norm_act(const ds_norm_args* a, void* stream);
+DS_API int ds_gn_finalize(const ds_gn_finalize_args* a, void* stream);
+DS_API int ds_norm_act(const ds_norm_args* a, void* stream);
 
 /* Row softmax, in place or out of place: y[r, :] = softmax(x[r, :cols]) (networks_edm.py:108). */
-int ds_softmax_rows(const float* x, float* y, long long rows, int cols, int ld, void* stream);
+DS_API int ds_softmax_rows(const float* x, float* y, long long rows, int cols, int ld, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused attention  out[b, i, h*d : (h+1)*d] = sum_j softmax_j(scale * q[b,i,h,:] . k[b,j,h,:]) v[b,j,h,:]
@@ -307,32 +315,32 @@ typedef struct ds_attn_args {
                         (networks_edm.py:171-173; attention.py:168-176 under autocast); `scale` then multiplies the fp32 scores */
 } ds_attn_args;
 
-int ds_attention(const ds_attn_args* a, void* stream);
-int ds_attention_supported(int d);
+DS_API int ds_attention(const ds_attn_args* a, void* stream);
+DS_API int ds_attention_supported(int d);
 
 /* The same operation with fp16 operands on the fp16 matrix pipe -- the attention of the reference's fp16 / autocast mode
  * (networks_edm.py:98-110 with use_fp16; ldm/modules/attention.py:168-194 under autocast, sample.py:296): q / k / v / out stay fp32
  * in memory, are rounded to fp16 (nearest even) while staged; scores, softmax statistics and accumulators are fp32; the softmax
  * weights are rounded to fp16 before the P V product as the reference casts them.  Head sizes: ds_attention_f16_supported(d)
  * (d % 8 == 0, d <= 160); otherwise DS_E_SHAPE -- the caller picks ds_attention, there is no silent fallback. */
-int ds_attention_f16(const ds_attn_args* a, void* stream);
-int ds_attention_f16_supported(int d);
+DS_API int ds_attention_f16(const ds_attn_args* a, void* stream);
+DS_API int ds_attention_f16_supported(int d);
 
 /* LayerNorm over the last dimension (ldm/modules/attention.py:206-208): y[r, :] = (x[r, :] - mean) / sqrt(var + eps)
  * * gamma + beta, cols % 4 == 0, cols <= 2048. */
-int ds_layernorm_rows(const float* x, int ldx, const float* gamma, const float* beta, float eps, float* y, int ldy,
+DS_API int ds_layernorm_rows(const float* x, int ldx, const float* gamma, const float* beta, float eps, float* y, int ldy,
                       long long rows, int cols, void* stream);
 /* The same with an fp16 output tensor y16[rows][ldy halfs] (rounded to nearest even): in fp16 / autocast mode the LayerNorm output is only
  * the operand of the following projection (torch.autocast casts nn.Linear inputs to fp16). */
-int ds_layernorm_rows_f16(const float* x, int ldx, const float* gamma, const float* beta, float eps, void* y16, int ldy,
+DS_API int ds_layernorm_rows_f16(const float* x, int ldx, const float* gamma, const float* beta, float eps, void* y16, int ldy,
                           long long rows, int cols, void* stream);
 /* ... and with an fp16 input tensor x16[rows][ldx halfs] as well (a tensor of the fp16 residual stream; statistics and the affine map
  * in fp32 on the widened values). */
-int ds_layernorm_rows_f16io(const void* x16, int ldx, const float* gamma, const float* beta, float eps, void* y16, int ldy,
+DS_API int ds_layernorm_rows_f16io(const void* x16, int ldx, const float* gamma, const float* beta, float eps, void* y16, int ldy,
                             long long rows, int cols, void* stream);
 
 /* GEGLU gate (ldm/modules/attention.py:45-52): y[r, c] = x[r, c] * gelu(x[r, inner + c]) with the exact (erf) GELU. */
-int ds_geglu(const float* x, int ldx, float* y, int ldy, long long rows, int inner, void* stream);
+DS_API int ds_geglu(const float* x, int ldx, float* y, int ldy, long long rows, int inner, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Noise embedding front end (networks_edm.py:185-198, :314-315, :488-491).
@@ -341,12 +349,12 @@ int ds_geglu(const float* x, int ldx, float* y, int ldy, long long rows, int inn
  * swap bit 1 (value 2): `sigma` already holds the embedding argument (c_noise) -- the LDM `timestep_embedding`
  * (ldm/modules/diffusionmodules/util.py:151-171) fed by CFGPrecond's c_noise = M * sigma_inv(sigma) - 1.
  */
-int ds_noise_embed(const float* sigma, int bs, const float* freqs, int nch, int swap, float* out, int out_ld, void* stream);
+DS_API int ds_noise_embed(const float* sigma, int bs, const float* freqs, int nch, int swap, float* out, int out_ld, void* stream);
 
 /* First-layer input: im2col of c_in(sigma) * x for the 3x3 stem conv, written as [n*h*w][kpad] rows with
  * k = tap*c + ch (zero padded to kpad, a multiple of 32), so that the stem runs as a 1x1 on the MFMA kernel.
  * x: NCHW [n][c][h][w]; sigma: [n] or [1] (sigma_rows).  Fuses networks_edm.py:490,493 (c_in * x). */
-int ds_stem_im2col(const float* x, const float* sigma, int sigma_rows, float sigma_data, int n, int c, int h, int w,
+DS_API int ds_stem_im2col(const float* x, const float* sigma, int sigma_rows, float sigma_data, int n, int c, int h, int w,
                    float* out, int kpad, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -382,7 +390,7 @@ typedef struct ds_update_args {
     int variant;                           /* ds_dpmpp_x0_step only: 0 = the library's choice, 1 = always the LDS kernel (tests compare the two) */
 } ds_update_args;
 
-int ds_solver_update(const ds_update_args* a, void* stream);
+DS_API int ds_solver_update(const ds_update_args* a, void* stream);
 
 /* One DPM-Solver++ step in data-prediction form in ONE launch (solvers.py:674-702, solver_utils.py:77-86, :102-163): per sample
  *   D  = as in ds_solver_update (EDM preconditioning of the raw planar network output, a given denoised tensor, or the AFS direction)
@@ -394,39 +402,39 @@ int ds_solver_update(const ds_update_args* a, void* stream);
  * register-resident kernel (every operand touched once: 3-4 R + 2 W passes, HBM-bound from a few thousand images per launch);
  * ds_dpmpp_x0_step_in_registers(c*h*w) tells which, ds_update_args.variant = 1 forces the LDS kernel.
  * Both kernels return the exact order statistics, so their results are bit-identical. */
-int ds_dpmpp_x0_step(const ds_update_args* a, float p, void* stream);
-int ds_dpmpp_x0_step_in_registers(long long per_sample);
+DS_API int ds_dpmpp_x0_step(const ds_update_args* a, float p, void* stream);
+DS_API int ds_dpmpp_x0_step_in_registers(long long per_sample);
 
 /* dst[0..row_floats) = table[(*step) * row_floats ...]; then optionally (*step)++ when advance != 0.  The only
  * per-step state of a captured sampler step: every kernel of the step reads its scalars (sigma, coefficients) from
  * `dst`, so one hipGraph replays for all steps. */
-int ds_table_select(const float* table, int row_floats, int* step, int advance, float* dst, void* stream);
+DS_API int ds_table_select(const float* table, int row_floats, int* step, int advance, float* dst, void* stream);
 
 /* x0 <- clamp(x0, -s, s) / s with s = max(quantile_{0.995}(|x0|) per sample, 1): solver_utils.py:77-86, exact
  * torch.quantile semantics (linear interpolation between the two order statistics around p*(n-1)). */
-int ds_dynamic_threshold(const float* x0, float* out, int n, int per, float p, void* stream);
+DS_API int ds_dynamic_threshold(const float* x0, float* out, int n, int per, float p, void* stream);
 
 /* CFGPrecond epilogue (networks_edm.py:668-690): D = x - sigma * F with, when `doubled`, the classifier-free
  * combination F = F_uncond + guidance * (F_cond - F_uncond) of the two halves of a 2n-image evaluation
  * (rows [0, n*h*w) = unconditional, [n*h*w, 2n*h*w) = conditional).  x / out NCHW [n][c][h][w]; f NHWC rows of f_ld
  * floats; sigma [sigma_rows] (1 = shared). */
-int ds_cfg_denoise(const float* x, const float* f, int f_ld, const float* sigma, int sigma_rows, float guidance, int doubled,
+DS_API int ds_cfg_denoise(const float* x, const float* f, int f_ld, const float* sigma, int sigma_rows, float guidance, int doubled,
                    int n, int c, int h, int w, float* out, void* stream);
 
 /* y = a * x (latents * t_steps[0], solvers.py:68). */
-int ds_scale(const float* x, float a, float* y, long long count, void* stream);
+DS_API int ds_scale(const float* x, float a, float* y, long long count, void* stream);
 
 /* images uint8 NHWC <- clip(x * 127.5 + 128, 0, 255), x NCHW (sample.py:311). */
-int ds_quantize_u8_nhwc(const float* x, uint8_t* out, int n, int c, int h, int w, void* stream);
+DS_API int ds_quantize_u8_nhwc(const float* x, uint8_t* out, int n, int c, int h, int w, void* stream);
 
 /* dst[0..count) = value. */
-int ds_fill(float* dst, float value, long long count, void* stream);
+DS_API int ds_fill(float* dst, float value, long long count, void* stream);
 
 /* dst[r, 0:cols] = src[r, 0:cols] for r < rows (strided 2-D copy; pads/gathers label and sigma rows). */
-int ds_copy_rows(const float* src, int src_ld, float* dst, int dst_ld, long long rows, int cols, void* stream);
+DS_API int ds_copy_rows(const float* src, int src_ld, float* dst, int dst_ld, long long rows, int cols, void* stream);
 
 /* Channel mean of an NHWC tensor: out[n][h*w] = mean_c x[n, hw, c] (AMED bottleneck tap, solvers_amed.py:24-28). */
-int ds_channel_mean(const float* x, int ld, int c, long long rows, float* out, void* stream);
+DS_API int ds_channel_mean(const float* x, int ld, int c, long long rows, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * AMED-Solver (amed-solver-main/solvers_amed.py, amed-solver-main/training/networks.py:56-155).
@@ -447,7 +455,7 @@ typedef struct ds_amed_predictor {
     float scale_dir, scale_time;
 } ds_amed_predictor;
 
-int ds_amed_predict(const ds_amed_predictor* p, const float* bottleneck_mean, int n, float t_cur, float t_next, float* out,
+DS_API int ds_amed_predict(const ds_amed_predictor* p, const float* bottleneck_mean, int n, float t_cur, float t_next, float* out,
                     void* stream);
 
 #define DS_AMED_AMED 0     /* amed_sampler           solvers_amed.py:69-159  */
@@ -470,7 +478,7 @@ typedef struct ds_amed_coef_args {
     int n;
 } ds_amed_coef_args;
 
-int ds_amed_coefs(const ds_amed_coef_args* a, void* stream);
+DS_API int ds_amed_coefs(const ds_amed_coef_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * GITS schedule search (gits-main/gits_utils.py:108-132 cost matrix, :237-255 cal_deviation).
@@ -483,8 +491,8 @@ int ds_amed_coefs(const ds_amed_coef_args* a, void* stream);
  * ds_traj_pair_cost: cost[i*n_pts + j] += sum_b | x_i + (t_j - t_i) d_i - x_j |_p for all i < j (p_norm 1 or 2;
  *   cost must be zeroed by the caller; t_steps is a device array [n_pts]).
  */
-int ds_traj_moments(const float* traj, const float* eps, int n_pts, int batch, int per, double* out, void* stream);
-int ds_traj_pair_cost(const float* traj, const float* eps, const float* t_steps, int n_pts, int batch, int per, int p_norm,
+DS_API int ds_traj_moments(const float* traj, const float* eps, int n_pts, int batch, int per, double* out, void* stream);
+DS_API int ds_traj_pair_cost(const float* traj, const float* eps, const float* t_steps, int n_pts, int batch, int per, int p_norm,
                       double* cost, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -494,7 +502,7 @@ int ds_traj_pair_cost(const float* traj, const float* eps, const float* t_steps,
  * matrix pipe (v_mfma_f64_16x16x4_f64), one launch per batch; any rows >= 0, any dim >= 1.  The update is bitwise symmetric.
  * The SUM all-reduce of mu / sigma over ranks (fid.py:74-75) and the finalisation (fid.py:76-78) stay with the caller
  * (diff_sampler_amd/fid.py: torch.distributed over RCCL). */
-int ds_fid_moments(const void* features, int features_f64, int ld, int rows, int dim, double* mu, double* sigma, void* stream);
+DS_API int ds_fid_moments(const void* features, int features_f64, int ld, int rows, int dim, double* mu, double* sigma, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Native launch plans (SURVEY.md section 8b "what a C-ABI engine should export": ds_unet_forward / ds_graph_capture_step).
@@ -532,19 +540,19 @@ enum { DS_OP_CONV2D = 1,        /* ds_conv_args        -> ds_conv2d_nhwc      */
        DS_OP_LAYERNORM_F16IO = 13 /* ds_layernorm_args -> ds_layernorm_rows_f16io (x and y = fp16 rows) */ };
 
 typedef struct ds_plan ds_plan;
-int ds_plan_create(ds_plan** out);
+DS_API int ds_plan_create(ds_plan** out);
 /* Appends one launch; `args` (the struct named above for `op`, `args_bytes` = its sizeof, checked) is copied.  DS_E_ARG otherwise. */
-int ds_plan_add(ds_plan* plan, int op, const void* args, unsigned long long args_bytes);
-int ds_plan_size(const ds_plan* plan);
+DS_API int ds_plan_add(ds_plan* plan, int op, const void* args, unsigned long long args_bytes);
+DS_API int ds_plan_size(const ds_plan* plan);
 /* Issues every launch of the plan on `stream`, in order.  Returns 0 or the first failing launch's code; ds_plan_last_failed then
  * gives its index (-1 when the last run succeeded). */
-int ds_plan_run(ds_plan* plan, void* stream);
-int ds_plan_last_failed(const ds_plan* plan);
+DS_API int ds_plan_run(ds_plan* plan, void* stream);
+DS_API int ds_plan_last_failed(const ds_plan* plan);
 /* Captures one run of the plan on `stream` (not the legacy default stream) into a hipGraph and instantiates it; a plan holds at most
  * one graph (a second capture replaces it).  ds_plan_graph_launch replays it on `stream`. */
-int ds_plan_graph_capture(ds_plan* plan, void* stream);
-int ds_plan_graph_launch(ds_plan* plan, void* stream);
-void ds_plan_destroy(ds_plan* plan);
+DS_API int ds_plan_graph_capture(ds_plan* plan, void* stream);
+DS_API int ds_plan_graph_launch(ds_plan* plan, void* stream);
+DS_API void ds_plan_destroy(ds_plan* plan);
 
 #ifdef __cplusplus
 }

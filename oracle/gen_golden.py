@@ -30,6 +30,8 @@ Parts
   fullgits  gits-main get_dp_list on the FULL-size CIFAR-10 net (21-step iPNDM-4 teacher, 6-step student, 'dev' metric, 8 warm-up latents)
   full3     BASELINE config 3 at full size through the reference sampler: ImageNet-64 DhariwalUNet (295.9M params, one-hot labels),
             ipndm_sampler max_order=4 on the 11-point GITS-form schedule literal (t_steps), NFE=10, B=1: the whole trajectory
+  full5b    BASELINE config 5 at full size for TWO latents (round 5): the reference's dpm_pp_sampler (eps form, discrete rho=1, num_steps=6,
+            CFG 7.5) on latents / conditions the GPU tests scatter over the BENCHMARK batch of 16 latents (bench.py --config sd15 --batch 16)
   full4     BASELINE config 4 at full size through the reference sampler: FFHQ-64 SongUNet (61.8M params) + AMED_predictor
             (num_steps=4, afs=True, time_uniform rho=1, scale_dir=0.01, scale_time=0; amed-solver-main/launch.sh:21-24), 5 NFE, B=2
 """
@@ -368,6 +370,25 @@ def part_full():
     print('full sd15 config-5 trajectory', tuple(tr.shape), float(tr[-1].abs().max()), flush=True)
 
 
+def part_full5b():
+    """BASELINE config 5 through the REAL reference at B = 2 (4 U-Net images per evaluation under guidance): the whole trajectory.  The GPU
+    test scatters the two latents (with their conditions) over a 16-latent call -- the batch `bench.py --config sd15` times."""
+    sys.path.insert(0, os.path.join(REF, 'diff-solvers-main'))
+    import solvers
+    torch.set_grad_enabled(False)
+    net, unet, kw, spec = _ref_cfg_net('sd15', 23)
+    g = torch.Generator().manual_seed(523)
+    lat = torch.randn(2, 4, 64, 64, generator=g)
+    cond = torch.randn(2, 77, 768, generator=g)
+    uncond = torch.randn(2, 77, 768, generator=g)
+    tr = solvers.dpm_pp_sampler(net, lat, condition=cond, unconditional_condition=uncond, num_steps=6, sigma_min=net.sigma_min,
+                                sigma_max=net.sigma_max, schedule_type='discrete', schedule_rho=1, return_inters=True,
+                                max_order=2, predict_x0=False, lower_order_final=True)
+    np.savez_compressed(os.path.join(OUT, 'ldm_sd15_traj_b2.npz'), seed=23, input_seed=523, latents=lat.numpy(), cond=cond.numpy(),
+                        uncond=uncond.numpy(), traj=tr.numpy())
+    print('full5b sd15 config-5 trajectory, two latents', tuple(tr.shape), float(tr[-1].abs().max()), flush=True)
+
+
 CONFIG3_TSTEPS = [80.0, 31.78, 14.51, 7.42, 3.88, 2.05, 1.06, 0.5666, 0.2531, 0.0631, 0.002]     # 11 points => NFE 10 (GITS form)
 
 
@@ -457,7 +478,7 @@ def part_fullsolv():
     np.savez_compressed(os.path.join(OUT, 'sampler_cifar10_solvers_nfe10_b4.npz'), **d)
 
 
-PARTS = dict(gitsldm=part_gitsldm, fullffhq=part_fullffhq, fullgits=part_fullgits, fullsolv=part_fullsolv, full3=part_full3, full4=part_full4, net=part_net, sched=part_sched, samplers=part_samplers, amed=part_amed, gits=part_gits, ldm=part_ldm, full=part_full)
+PARTS = dict(full5b=part_full5b, gitsldm=part_gitsldm, fullffhq=part_fullffhq, fullgits=part_fullgits, fullsolv=part_fullsolv, full3=part_full3, full4=part_full4, net=part_net, sched=part_sched, samplers=part_samplers, amed=part_amed, gits=part_gits, ldm=part_ldm, full=part_full)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

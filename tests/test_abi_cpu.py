@@ -12,11 +12,19 @@ def test_library_builds_and_exports_header_symbols():
     build.build_lib(verbose=False)
     lib = _lib.load()
     header = open(os.path.join(ROOT, 'include', 'ds_engine.h')).read()
-    declared = set(re.findall(r'^(?:int|long long|const char\*|void)\s+(ds_\w+)\s*\(', header, flags=re.M))
+    declared = set(re.findall(r'^DS_API\s+(?:int|long long|const char\*|void)\s+(ds_\w+)\s*\(', header, flags=re.M))
     assert declared, 'no declarations parsed'
+    assert not re.findall(r'^(?:int|long long|const char\*|void)\s+ds_\w+\s*\(', header, flags=re.M), 'an entry point without DS_API'
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in ds_engine.h but not exported'
     assert set(_lib.EXPORTS) == declared
+    # the ABI surface IS the header: the library is built with -fvisibility=hidden, so its dynamic symbol table must hold exactly the
+    # DS_API functions as code symbols -- no C++ launch helper (igemm::...) leaks out
+    import subprocess
+    nm = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    text = {ln.split()[2] for ln in nm.splitlines() if len(ln.split()) == 3 and ln.split()[1] in 'TtWw'}
+    assert text == declared, (sorted(text - declared), sorted(declared - text))
+    assert lib.ds_build_experiments() in (0, 1)
     assert lib.ds_version() >= 1
     assert lib.ds_error_string(-3) == b'unsupported shape'
 

@@ -111,3 +111,48 @@ def test_block_output_is_the_bottleneck_a_forward_hook_would_see():
         want_tap = ref_net.last_bottleneck                # the oracle's tap of enc.8x8_block3 (no labels), NCHW
     assert _rel(d.cpu(), want_d) < 2e-4
     assert tuple(want_tap.shape) == tuple(tap.shape) and _rel(tap.cpu(), want_tap) < 2e-4
+
+
+@pytest.mark.parametrize('netname', ['tiny_song_amed', 'tiny_song_amed_cond'])
+def test_init_hook_and_get_amed_prediction_shims_follow_the_reference_helpers(netname):
+    """amed-solver-main/solvers_amed.py:7-55: `unet_enc_out, hook = init_hook(net, class_labels)` taps the bottleneck block of the last
+    evaluation and `get_amed_prediction` turns it into [B,1,1,1] tensors r / scale_dir / scale_time.  Checked against the oracle: its
+    bottleneck (oracle.edm_net.OracleNet.last_bottleneck) and its predictor restatement (oracle.solvers_ref.amed_predict)."""
+    import diff_sampler_amd.arch as arch
+    from diff_sampler_amd import solvers_amed
+    from diff_sampler_amd.engine import EDMDenoiser
+    from oracle import solvers_ref
+    from oracle.edm_net import OracleNet
+    dev = torch.device('cuda')
+    kw = dict(arch.NAMED_CONFIGS[netname])
+    spec = arch.edm_precond_spec(**kw)
+    params = arch.init_params(spec, seed=8)
+    net = EDMDenoiser(spec, params)
+    g = torch.Generator().manual_seed(4)
+    B = 3
+    x = torch.randn(B, spec.img_channels, spec.img_resolution, spec.img_resolution, generator=g) * 2.0
+    lab = torch.eye(spec.label_dim)[torch.randint(spec.label_dim, (B,), generator=g)] if spec.label_dim else None
+    tap, hook = solvers_amed.init_hook(net, class_labels=lab)
+    assert len(tap) == 0
+    net(x.to(dev), torch.tensor(2.0, device=dev), class_labels=(lab.to(dev) if lab is not None else None))
+    onet = OracleNet(params, kw)
+    with torch.no_grad():
+        onet(x, torch.tensor(2.0), class_labels=lab)
+    bott = onet.last_bottleneck                                # [B, C, 8, 8] of the block the reference hooks
+    assert len(tap) == 1 and _rel(tap[-1].cpu(), bott) < 2e-4
+    pk = dict(scale_dir=0.05, scale_time=0.05)
+    pp = cases.amed_predictor_params(91, pk['scale_dir'], pk['scale_time'])
+    pred = solvers_amed.AMEDPredictor(pp, device=dev, **pk)
+    for use_afs in (False, True):
+        r, sd, st = solvers_amed.get_amed_prediction(pred, torch.tensor(2.0), torch.tensor(0.7), net, tap, use_afs, B)
+        assert r.shape == sd.shape == st.shape == (B, 1, 1, 1)
+        bm = torch.zeros(B, 8, 8) if use_afs else bott.mean(dim=1)
+        rr, rsd, rst = solvers_ref.amed_predict(pp, pk, bm, torch.tensor(2.0), torch.tensor(0.7))
+        for got, want in ((r, rr), (sd, rsd), (st, rst)):
+            assert torch.allclose(got.cpu().flatten(), want.flatten(), rtol=2e-4, atol=1e-5)
+    # a plain list of NCHW tensors (what the reference's own hook_fn fills) is accepted too
+    r2 = solvers_amed.get_amed_prediction(pred, torch.tensor(2.0), torch.tensor(0.7), net, [tap[-1]], False, B)[0]
+    assert torch.equal(r2, solvers_amed.get_amed_prediction(pred, torch.tensor(2.0), torch.tensor(0.7), net, tap, False, B)[0])
+    hook.remove()
+    with pytest.raises(RuntimeError):
+        tap[-1]
