@@ -63,7 +63,7 @@ WORKLOAD_NAMES = {'cifar10': 'EDM CIFAR-10 32x32 SongUNet (55.7M params)', 'ffhq
                   'afhqv2': 'EDM AFHQv2-64 SongUNet', 'imagenet64': 'EDM ImageNet-64 DhariwalUNet (295.9M params)',
                   'sd15': 'Stable Diffusion v1.5 64x64x4 latent U-Net (859.5M params)'}
 SOLVER_NAMES = {'dpmpp': 'DPM-Solver++(2M) logSNR', 'euler': 'Euler', 'ipndm': 'iPNDM-4', 'heun': 'Heun'}
-LDM_SOLVER_NAME = 'DPM-Solver++(2M) eps-prediction, discrete rho=1, CFG 7.5 (2 U-Net images per latent)'
+LDM_SOLVER_NAME = 'DPM-Solver++(2M) eps-prediction, discrete rho=1, CFG 7.5 (2 U-Net images per latent; new text conditions on every call: the context K / V projections are inside the timed region)'
 PMC_FILE = os.path.join(ROOT, 'profiles', 'r4_bench_pmc_hbm.json')
 PMC_NOTE = {}
 KERNEL_NAMES = {0: 'igemm_f32_kernel<0> (generic gather conv / 1x1 / linear)', 128: 'conv3x3_halo_kernel<2> (128-pixel tiles)',
@@ -116,8 +116,23 @@ def parse(argv=None):
     return args
 
 
+_LDM_CALLS = [0]
+
+
+def _next_conditions(ldm):
+    """`ldm` = a (condition, unconditional_condition) tuple, or a LIST of such tuples used in rotation: every sampler call then sees text
+    conditions different from the previous call's, so the denoiser's per-context cache (ldm_engine.CFGDenoiser: the 32 cross-attention K / V
+    projections of a context are computed once per context tensor) misses on every call and the projections are INSIDE the timed region --
+    what a generation service that receives new prompts per batch pays (sample.py:276-301 encodes the prompts of every batch)."""
+    if isinstance(ldm, list):
+        _LDM_CALLS[0] += 1
+        return ldm[_LDM_CALLS[0] % len(ldm)]
+    return ldm
+
+
 def sampler_call(solvers, solver, net, latents, nfe, ldm=None):
     if ldm is not None:
+        ldm = _next_conditions(ldm)
         # BASELINE config 5: DPM-Solver++(2M) noise prediction, discrete rho=1 schedule; every step is one CFG-doubled
         # evaluation = 2 NFE (sample.py:218), so NFE=10 is num_steps=6
         return solvers.dpm_pp_sampler(net, latents, condition=ldm[0], unconditional_condition=ldm[1], num_steps=nfe // 2 + 1,
@@ -173,7 +188,12 @@ def instrumented_pass(net, solvers, solver, latents, nfe, ldm=None):
         if op.fn is lib.ds_gn_finalize:
             return 'gn_from_partials_kernel (GroupNorm statistics from the conv epilogues)', 0.0
         if op.fn is lib.ds_norm_act:
-            return 'norm_act_kernel', 0.0
+            a = op.keep[0]
+            k = {1: 0.25, 2: 4.0}.get(a.resample, 1.0)           # output pixels per input pixel (2x2 box filter down / nearest x2 up)
+            px = a.n * a.h * a.w
+            byts = px * (a.c0 * (2 if a.in_f16 & 1 else 4) + a.c1 * (2 if a.in_f16 & 2 else 4))
+            byts += px * k * (a.c0 + a.c1) * ((2 if a.out_f16 else 4) + (2 if a.raw_out else 0))
+            return 'norm_act_kernel', float(byts)
         return 'other', 0.0
 
     def timed_plan_run(self, stream):
@@ -261,27 +281,72 @@ def update_roofline_large_batch(dev, batch=16384, kind='ipndm'):
 
 
 KERNEL_TU = {0: 'gemm_conv.hip', 128: 'conv3x3_halo.hip', 1284: 'conv3x3_halo.hip', 256: 'conv3x3_halo.hip', 2565: 'conv3x3_halo.hip',
-             2568: 'conv3x3_halo.hip', 2561: 'gemm_dma8.hip', 2570: 'conv3x3_thin.hip'}
+             2568: 'conv3x3_halo.hip', 2561: 'gemm_dma8.hip', 2570: 'conv3x3_thin.hip', 2563: 'conv3x3_halo2.hip', 2564: 'gemm_f16.hip',
+             2566: 'conv3x3_f16dma.hip', 2567: 'gemm_f16dma.hip', 2571: 'gemm_f16dma.hip', 'norm_act': 'norm_act.hip'}
+# kernel CLASSES of the fp16 engines cover several template instantiations (tile shapes): their PMC rows are matched by pattern and averaged
+# over all launches of the class, exactly as the HIP-event average of the class is taken
+PMC_PATTERNS = {2566: r'conv3x3_f16dma_kernel<', 2567: r'gemm_f16dma_kernel<\d+, \d+, (?:true|false), false>', 2571: r'gemm_f16dma_kernel<\d+, \d+, (?:true|false), true>',
+                2563: r'conv3x3_halo2_kernel<\d+, 2>', 2564: r'gemm_f16_kernel', 'norm_act': r'^norm_act_kernel\('}
+# one PMC summary per benchmarked workload (tools/gpu_session.sh pmc:<bench.py args>): (config, dtype) -> file under profiles/
+PMC_FILES = {('cifar10', 'fp32'): PMC_FILE,
+             ('imagenet64', 'fp16'): os.path.join(ROOT, 'profiles', 'r5_pmc_hbm_imagenet64_fp16.json'),
+             ('sd15', 'fp16'): os.path.join(ROOT, 'profiles', 'r5_pmc_hbm_sd15_fp16.json'),
+             ('ffhq', 'fp32'): os.path.join(ROOT, 'profiles', 'r5_pmc_hbm_ffhq_fp32.json'),
+             ('cifar10', 'fp16x3'): os.path.join(ROOT, 'profiles', 'r5_pmc_hbm_cifar10_fp16x3.json')}
 
 
-def pmc_traffic(kid):
-    """(HBM bytes per launch, provenance) of a conv kernel from the committed rocprofv3 PMC summary (profiles/), or None.  The summary
-    records the session it was collected in and the hash of every kernel translation unit at that time (tools/rocprof_summary.py);
-    a kernel whose source changed since then reports null instead of a stale number (PMC_NOTE['why'] says so)."""
+def pmc_traffic(kid, workload=('cifar10', 'fp32')):
+    """(HBM bytes per launch, provenance) of a kernel (class) from the committed rocprofv3 PMC summary of `workload` (profiles/), or None.
+    The summary records the session it was collected in and the hash of every kernel translation unit at that time
+    (tools/rocprof_summary.py); a kernel whose source changed since then reports null instead of a stale number (PMC_NOTE['why'] says so).
+    Bytes = FETCH_SIZE x 2 (the guide's gfx950 correction) + WRITE_SIZE, averaged over the launches of the class."""
+    import re
+    path = PMC_FILES.get(tuple(workload))
+    if tuple(workload) == ('cifar10', 'fp32'):
+        path = PMC_FILE                                    # (module attribute: the tests point it elsewhere)
     try:
         from diff_sampler_amd import build
-        z = json.load(open(PMC_FILE))
+        z = json.load(open(path))
         tu = KERNEL_TU[kid]
         then, now = z['meta']['kernel_source_sha256'][tu], build.source_sha256(tu)
         if then != now:
-            PMC_NOTE['why'] = f'{os.path.relpath(PMC_FILE, ROOT)} was collected on another build of {tu} ({then[:12]} != {now[:12]}): traffic withheld'
+            PMC_NOTE['why'] = f'{os.path.relpath(path, ROOT)} was collected on another build of {tu} ({then[:12]} != {now[:12]}): traffic withheld'
             return None
-        k = z['kernels'][PMC_KEYS[kid]]
-        byts = 1024.0 * (2.0 * k['FETCH_SIZE_KiB_avg_per_launch'] + k['WRITE_SIZE_KiB_avg_per_launch'])
-        return round(byts), dict(file=os.path.relpath(PMC_FILE, ROOT), session=z['meta']['session'], kernel_source=tu, kernel_source_sha256=now)
+        if kid in PMC_PATTERNS:
+            rows = [v for k, v in z['kernels'].items() if re.search(PMC_PATTERNS[kid], k)]
+        else:
+            rows = [z['kernels'][PMC_KEYS[kid]]]
+        launches = sum(r['FETCH_SIZE_launches'] for r in rows)
+        if not rows or launches <= 0 or launches != sum(r['WRITE_SIZE_launches'] for r in rows):
+            PMC_NOTE['why'] = f'{os.path.relpath(path, ROOT)} holds no consistent rows for kernel class {kid}'
+            return None
+        byts = 1024.0 * (2.0 * sum(r['FETCH_SIZE_KiB_total'] for r in rows) + sum(r['WRITE_SIZE_KiB_total'] for r in rows)) / launches
+        return round(byts), dict(file=os.path.relpath(path, ROOT), session=z['meta']['session'], kernel_source=tu, kernel_source_sha256=now,
+                                 launches_in_pmc_pass=launches, instantiations=len(rows))
     except Exception as e:
         PMC_NOTE['why'] = f'no usable PMC summary ({type(e).__name__}: {e})'
         return None
+
+
+def attach_traffic(roof, kid, workload):
+    t = pmc_traffic(kid, workload)
+    roof['traffic'] = t[0] if t else None
+    roof['traffic_unit'] = 'HBM bytes per launch (rocprofv3 PMC: FETCH_SIZE x 2 + WRITE_SIZE)'
+    roof['traffic_source'] = t[1] if t else PMC_NOTE.get('why')
+    return roof
+
+
+def norm_act_roofline(rec, workload):
+    """HBM roofline of the GroupNorm-apply + SiLU pass of the fp16 engines (norm_act_kernel): algorithmic bytes (every source element read once,
+    every output -- and raw copy -- element written once, at the width it is stored in) over the HIP-event time of its launches."""
+    if 'norm_act_kernel' not in rec or rec['norm_act_kernel'][2] <= 0:
+        return None
+    ms, launches, byts = rec['norm_act_kernel']
+    gbs = byts / (ms * 1e-3) / 1e9
+    r = dict(bound='hbm', kernel='norm_act_kernel (GroupNorm apply + SiLU [+ resample / concatenation] -> fp16 rows)', achieved=round(gbs, 1), peak=PEAK_HBM_GBS,
+             unit='GB/s', frac=round(gbs / PEAK_HBM_GBS, 4), launches_per_step=launches, avg_launch_ms=round(ms / launches, 4),
+             algorithmic_bytes_per_launch=round(byts / launches))
+    return attach_traffic(r, 'norm_act', workload)
 
 
 def cpu_baseline_ldm(args, nfe):
@@ -484,7 +549,9 @@ def measure_config(config, dtype, batch, nfe, dev, calls=2, latency_batch=None):
 
     def inputs(b):
         lat = torch.randn(b, spec.in_channels, spec.img_resolution, spec.img_resolution, generator=g).to(dev)
-        ldm = (torch.randn(b, 77, spec.context_dim, generator=g).to(dev), torch.randn(b, 77, spec.context_dim, generator=g).to(dev)) if is_ldm else None
+        # two condition tuples used in rotation: fresh text conditions on every call (_next_conditions)
+        ldm = [(torch.randn(b, 77, spec.context_dim, generator=g).to(dev), torch.randn(b, 77, spec.context_dim, generator=g).to(dev))
+               for _ in range(2)] if is_ldm else None
         return lat, ldm
 
     def timed(lat, ldm, n):
@@ -502,11 +569,13 @@ def measure_config(config, dtype, batch, nfe, dev, calls=2, latency_batch=None):
     t_build = time.perf_counter() - t_build
     dt = timed(lat, ldm, calls)
     rec = instrumented_pass(net, solvers, solver, lat, nfe, ldm)
-    kernels, roof, _, _ = kernel_report(rec)
+    kernels, roof, dom_id, _ = kernel_report(rec)
+    attach_traffic(roof, dom_id, (config, dtype))
+    roof_norm = norm_act_roofline(rec, (config, dtype)) if dtype == 'fp16' else None
     top = dict(list(kernels.items())[:5])
     res = dict(config=dict(workload='%s, %s NFE=%d, batch %d/GPU' % (WORKLOAD_NAMES.get(config, config), LDM_SOLVER_NAME if is_ldm else SOLVER_NAMES[solver], nfe, batch)),
                dtype=dtype, value=round(batch / dt, 2), unit='images/sec', ms_per_step=round(dt * 1e3, 2), steps=calls, warmup=1,
-               roofline=roof, application=application_fraction(config, dtype, batch / dt, nfe), kernels_top5=top,
+               roofline=roof, roofline_norm_act=roof_norm, application=application_fraction(config, dtype, batch / dt, nfe), kernels_top5=top,
                setup_s=round(t_build, 1))
     lat_ms = None
     if latency_batch is not None:
@@ -555,7 +624,8 @@ def main(argv=None):
         net = net_factory()
         spec = net.spec
         if is_ldm:
-            ldm = (torch.randn(B, 77, spec.context_dim, generator=g).to(dev), torch.randn(B, 77, spec.context_dim, generator=g).to(dev))
+            ldm = [(torch.randn(B, 77, spec.context_dim, generator=g).to(dev), torch.randn(B, 77, spec.context_dim, generator=g).to(dev))
+                   for _ in range(2)]                                # rotated: fresh text conditions on every call (_next_conditions)
             args.solver = 'dpmpp'
         latents = torch.randn(B, spec.in_channels, spec.img_resolution, spec.img_resolution, generator=g).to(dev)
 
@@ -597,20 +667,27 @@ def main(argv=None):
         per = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
         dist.all_gather(per, torch.tensor([dt_local], dtype=torch.float64, device=dev))
         per_ms = [float(t.item()) / args.steps * 1e3 for t in per]
+        per_val = [B / (v * 1e-3) for v in per_ms]          # images / s of each rank's own K steps (before it waits for the others)
         multi = dict(per_rank_ms_per_step_min=round(min(per_ms), 3), per_rank_ms_per_step_max=round(max(per_ms), 3),
-                     per_rank_ms_per_step=[round(v, 3) for v in per_ms], backend='gloo' if stub else 'nccl (RCCL)', communicator=dict(launch.COMM_INFO),
+                     per_rank_ms_per_step=[round(v, 3) for v in per_ms],
+                     per_rank_value_min=round(min(per_val), 2), per_rank_value_max=round(max(per_val), 2), per_rank_value=[round(v, 2) for v in per_val],
+                     per_rank_value_unit='images/sec of one rank over its own timed steps; `value` = all ranks\' images / the slowest rank\'s barrier-bracketed time',
+                     barrier_skew_ms_per_step=round(max(per_ms) - min(per_ms), 3), backend='gloo' if stub else 'nccl (RCCL)', communicator=dict(launch.COMM_INFO),
                      fid_moment_allreduce=fid_allreduce_timing(dist, dev, world))
     if not stub:
         assert torch.isfinite(out).all()
 
-    roof = roof_u = kernels = None
+    roof = roof_u = kernels = roof_norm = None
     if rank == 0 and not stub:
         rec = instrumented_pass(net, solvers, args.solver, latents, args.nfe, ldm)
         kernels, roof, dom_id, total_ms = kernel_report(rec)
-        traffic = pmc_traffic(dom_id) if (args.config == 'cifar10' and B == 256 and args.dtype == 'fp32') else None   # the PMC pass is of the default workload
-        roof['traffic'] = traffic[0] if traffic else None
-        roof['traffic_unit'] = 'HBM bytes per launch (rocprofv3 PMC: FETCH_SIZE x 2 + WRITE_SIZE)'
-        roof['traffic_source'] = traffic[1] if traffic else PMC_NOTE.get('why')
+        if args.dtype == 'fp16':
+            roof_norm = norm_act_roofline(rec, (args.config, args.dtype))
+        default_batch = {'ffhq': 128, 'imagenet64': 64, 'sd15': 16}.get(args.config, 256)      # the PMC passes are of the default workloads
+        if B == default_batch and args.nfe == 10:
+            attach_traffic(roof, dom_id, (args.config, args.dtype))
+        else:
+            roof['traffic'], roof['traffic_source'] = None, 'no PMC pass for this batch / NFE'
         per = spec.in_channels * spec.img_resolution ** 2 * 4
         if X0_KIND in rec and ldm is None:
             # the headline solver's update: ONE ds_dpmpp_x0_step launch per evaluation.  Algorithmic bytes of the fused launch: x, F read;
@@ -690,7 +767,7 @@ def main(argv=None):
                        (workload_name, LDM_SOLVER_NAME if ldm is not None else SOLVER_NAMES[args.solver], args.nfe, B),
                        'images_per_step': B * world, 'sharding': 'independent image batches per rank, no collective',
                        'launch': 'hipGraph replay' if args.graph else 'eager'},
-            'roofline': roof, 'roofline_update': roof_u, 'roofline_update_large_batch': roof_ul, 'roofline_update_large_batch_other_solver': roof_ul_other, 'kernels': kernels,
+            'roofline': roof, 'roofline_norm_act': roof_norm, 'roofline_update': roof_u, 'roofline_update_large_batch': roof_ul, 'roofline_update_large_batch_other_solver': roof_ul_other, 'kernels': kernels,
             'launch_modes': modes, 'throughput_by_batch': by_batch, 'cpu_baseline': cpu, 'multi_gpu': multi,
             'application': (application_fraction(args.config, args.dtype, total_images / dt / world, args.nfe) if not stub and args.config in GFLOP_PER_EVAL else None),
             'other_configs': others, 'latency': latency,

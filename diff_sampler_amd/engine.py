@@ -417,6 +417,8 @@ class UNetEngine:
             norm('apply', xo, co, co, B, R, R, 'out.norm', groups=arch.num_groups(co), eps=spec.out_eps, gamma=w['out.g'],
                  beta=w['out.b'], act_=DS_ACT_SILU, out=act, out_ld=co)
             conv(act, co, co, B, R, R, w['outc.w'], spec.out_channels, bufs['out'], 4, 9, 'out.conv', bias=w['outc.b'], out_nchw=1)
+        from .plan import release_tuning_scratch
+        release_tuning_scratch()            # the tile measurement's 512 MiB flush buffer does not outlive the plan build
         self._plans[key] = P
         return P
 

@@ -45,7 +45,7 @@ class MomentAccumulator:
                 f = f.to(torch.float32)                      # fp16 / bf16 detector outputs widen exactly
             f = f.contiguous()
             assert f.dim() == 2 and f.shape[1] == self.mu.numel(), (tuple(f.shape), self.mu.numel())
-            _lib.check(_lib.load().ds_fid_moments(C.c_void_p(f.data_ptr()), int(f.dtype == torch.float64), f.stride(0), f.shape[0],
+            _lib.check(_lib.load().ds_fid_moments(C.c_void_p(f.data_ptr()), int(f.dtype == torch.float64), max(f.stride(0), f.shape[1]), f.shape[0],
                                                   f.shape[1], C.c_void_p(self.mu.data_ptr()), C.c_void_p(self.sigma.data_ptr()),
                                                   _lib.stream_ptr()), 'ds_fid_moments')
         else:                                                # host-side accumulators (gloo tests, bench.py --stub): no kernels

@@ -357,6 +357,8 @@ class LDMUNetEngine:
         P.ctx.ops = [op for op in P.ops if op.name.endswith('.attn2.kv')]
         P.ops = [op for op in P.ops if not op.name.endswith('.attn2.kv')]
         P.ctx_key = None
+        from .plan import release_tuning_scratch
+        release_tuning_scratch()            # the tile measurement's 512 MiB flush buffer does not outlive the plan build
         self._plans[key] = P
         return P
 
@@ -438,6 +440,7 @@ class CFGDenoiser(CFGSchedule):
         (no `_version` bump) and for graph.GraphedSampler, whose replays overwrite those buffers behind the cache's back."""
         for P in self.engine._plans.values():
             P.ctx_key = None
+            P.ctx_capture_key = None
 
     # -- evaluation ----------------------------------------------------------------------------------------------------------
     def raw(self, x, sigma, condition=None, unconditional_condition=None):
@@ -483,6 +486,14 @@ class CFGDenoiser(CFGSchedule):
         old_key = plan.ctx_key
         same = (self.cache_context and not capturing and old_key is not None and len(old_key) == len(key)
                 and all(a[0]() is t and a[1:] == b[1:] for a, b, t in zip(old_key, key, parts)))
+        if capturing:
+            # inside ONE capture the first evaluation records the context copy and the projections; later evaluations of the same capture
+            # on the same condition tensors skip them -- a replay then pays them once per graph, not once per denoiser evaluation.  The key
+            # is scoped to the capture: invalidate_context_cache() (graph.GraphedSampler calls it right after capturing and after every
+            # replay) clears it, and an eager call never matches it.
+            cap_key = ('capture',) + tuple((t.data_ptr(), tuple(t.shape), t._version) for t in parts)
+            same = self.cache_context and getattr(plan, 'ctx_capture_key', None) == cap_key
+            plan.ctx_capture_key = cap_key
         if not same:
             for i, c_ in enumerate(parts):
                 c_ = c_.to(device=self.device, dtype=torch.float32)

@@ -85,3 +85,48 @@ def ldm_stored_prefixes(plan):
             else:
                 raise KeyError(op.name)
     return out
+
+
+# ---- host mirrors of the tile / split-K rules of csrc/conv3x3_f16dma.hip (tiling, conv3x3_f16dma_plan, conv3x3_f16dma_splits): what a
+# ---- stride-1 fp16-activation 3x3 launch `a` (ds_conv_args) will run as, so that a parity test can assert WHICH tilings it exercised ----
+def _f16dma_tiling(M, N, nb0):
+    out, col, cost = [], 0, 0
+    for w in range(nb0, 0, -1):
+        if col >= N:
+            break
+        t = (N - col) // (64 * w)
+        if t > 0:
+            out.append((col, t, w))
+            col += t * 64 * w
+            cost += -(-(M // 256) * t // 256) * (1 + w)
+    return out, cost
+
+
+def f16dma_splits(a):
+    """Split-K factor of the launch (1 = none): conv3x3_f16dma_splits."""
+    M, N = a.n * a.h * a.w, a.cout
+    if not a.workspace or a.tune.splits == 1:
+        return 1
+    wide, _ = _f16dma_tiling(M, N, 4 if a.w in (16, 32) else 3)
+    tiles = sum((M // 256) * t for _, t, _ in wide)
+    s = a.tune.splits if a.tune.splits > 1 else (256 // tiles if tiles <= 128 else 1)
+    kt_all = (a.c0 // 64) * 9 + a.ec0 // 64
+    s = min(s, 16, kt_all // 18, a.workspace_floats // (M * N))
+    return s if s >= 2 else 1
+
+
+def f16dma_tile_widths(a):
+    """Column-tile widths (in 64-channel units) the launch uses when no width is forced or measured (tune.f16dma_nb == 0): the widest tiling
+    for a split layer, else the cost model's (conv3x3_f16dma_plan)."""
+    M, N = a.n * a.h * a.w, a.cout
+    cap = 4 if a.w in (16, 32) else 3
+    if a.tune.f16dma_nb > 0:
+        return [w for _, _, w in _f16dma_tiling(M, N, min(a.tune.f16dma_nb, cap))[0]]
+    if f16dma_splits(a) > 1:
+        return [w for _, _, w in _f16dma_tiling(M, N, cap)[0]]
+    best = None
+    for nb in range(cap, 0, -1):
+        til, cost = _f16dma_tiling(M, N, nb)
+        if best is None or cost < best[0] or (cost == best[0] and len(til) < best[1]):
+            best = (cost, len(til), til)
+    return [w for _, _, w in best[2]]

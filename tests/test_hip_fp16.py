@@ -167,7 +167,7 @@ def test_sd15_autocast_mode_pinned_to_reference_golden_and_f16_operand_oracle():
     # 4.3e-3 over rounds 3 / 4).  The sharp pins are the per-evaluation ones below (kernel vs fp16 oracle, same roundings).
     noise = float(z16['rel_vs_fp32_golden'])
     assert 3e-3 < noise < 4.5e-3, noise
-    assert e32 < 1.5 * noise, (e32, noise)
+    assert e32 < min(1.5 * noise, 6.5e-3), (e32, noise)       # relative to the mode's noise AND an absolute ceiling (the golden is regenerable)
     # The guided combination against the fp16 oracle: both sides carry their own fp16 rounding noise relative to fp32 (the oracle's is
     # 3.85e-3 on this output, the kernels' 3.9 - 4.3e-3, bounded above), so their distance is bounded by the sum; observed 4.9 - 5.3e-3
     # depending on the order of the fp32 sums in the kernels (any last-bit change moves ~0.2 % of the fp16 roundings across a boundary).
@@ -221,7 +221,8 @@ def test_measured_tile_shapes_do_not_change_a_bit(which, monkeypatch):
     torch.cuda.synchronize()
     assert torch.isfinite(base).all() and all(t == (0, 0) for t in tiles(base_net))
     monkeypatch.setattr(plan_mod, 'AUTOTUNE', True)
-    saved = dict(plan_mod._TUNE_CACHE)
+    monkeypatch.setattr(plan_mod, 'load_tile_table', lambda *a, **k: {})        # the persisted table (profiles/tile_table.json) must not pre-empt the forced choice
+    saved, saved_m = dict(plan_mod._TUNE_CACHE), dict(plan_mod._MEASURED)
     try:
         for kind in ('narrow', 'wide'):
             def forced(self, a, inputs, stride, kind=kind):
@@ -242,3 +243,5 @@ def test_measured_tile_shapes_do_not_change_a_bit(which, monkeypatch):
     finally:
         plan_mod._TUNE_CACHE.clear()
         plan_mod._TUNE_CACHE.update(saved)
+        plan_mod._MEASURED.clear()                                                  # the forced picks are not measurements
+        plan_mod._MEASURED.update(saved_m)

@@ -171,6 +171,82 @@ def test_sd15_config5_trajectory_matches_reference(dev):
     assert max(errs) < 1e-3 and errs[-1] < 1e-3, errs
 
 
+@pytest.mark.parametrize('mode', ['fp32', 'fp16'])
+def test_config5_sd15_at_the_benchmark_batch_b16(mode, dev):
+    """`bench.py --config sd15 --batch 16 [--dtype fp16]` (the SD-1.5 line of the driver's bench): the REAL reference's config-5 trajectory
+    for two latents (oracle/gen_golden.py --part full5b: dpm_pp_sampler eps form, discrete rho = 1, num_steps = 6, CFG 7.5 -- sample.py:293-301,
+    networks_edm.py:688-762) occupies slots 0 / 9 (latent 0) and 6 / 15 (latent 1) of a 16-latent call whose other slots carry other latents
+    and conditions: 32 U-Net images per evaluation, the batch at which the 8x8 stage, the split-K layers, the NB = 4 tiles and the gather
+    `Downsample` GEMM run -- none of which a B = 1 call reaches.  fp32: 1e-3 per step, each step against its own scale.  use_fp16 (the
+    reference's autocast mode): every step within 1.5 x the fp16-stream ORACLE's own distance from the fp32 golden at that step (the noise
+    floor of the mode, stored by oracle/gen_f16_golden.py --traj; absolute ceiling 2e-2) and within 2 x that noise of the oracle's fp16
+    trajectory (two independent roundings of the same tensors); the first evaluation's raw U-Net outputs within 2.5e-3 of the fp16 oracle's (same tensors rounded); the plan must run
+    EVERY body convolution on the fp16 kernels (fp32_convs == 0), split K somewhere, use a 256-column tile and the gather GEMM."""
+    from diff_sampler_amd import _lib, solvers
+    from diff_sampler_amd.ldm_engine import CFGDenoiser
+    z = np.load(os.path.join(G, 'ldm_sd15_traj_b2.npz'))
+    f16 = mode == 'fp16'
+    net = CFGDenoiser.from_config('sd15', seed=int(z['seed']), guidance_rate=7.5, use_fp16=f16)
+    B, slots = 16, [0, 6, 9, 15]                            # golden latent 0 in slots 0 and 9, latent 1 in slots 6 and 15
+    g = torch.Generator().manual_seed(993)
+    lat = torch.randn(B, 4, 64, 64, generator=g)
+    cond = torch.randn(B, 77, 768, generator=g)
+    uncond = torch.randn(B, 77, 768, generator=g)
+    gl, gc, gu = (torch.from_numpy(z[k]) for k in ('latents', 'cond', 'uncond'))
+    lat[slots], cond[slots], uncond[slots] = torch.cat([gl, gl]), torch.cat([gc, gc]), torch.cat([gu, gu])
+    lat, cond, uncond = lat.to(dev), cond.to(dev), uncond.to(dev)
+    tr = solvers.dpm_pp_sampler(net, lat, condition=cond, unconditional_condition=uncond, num_steps=6, sigma_min=net.sigma_min,
+                                sigma_max=net.sigma_max, schedule_type='discrete', schedule_rho=1, return_inters=True,
+                                max_order=2, predict_x0=False, lower_order_final=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(tr).all()
+    gold = torch.from_numpy(z['traj'])                       # [6, 2, 4, 64, 64]
+    gold4 = torch.cat([gold, gold], dim=1)
+    errs = per_step_rel(tr[:, slots].cpu(), gold4)
+    lib = _lib.load()
+    plan = net.engine.plan(2 * B, 1, 77)
+    convs = [op.keep[0] for op in plan.ops if op.fn is lib.ds_conv2d_nhwc]
+    c33 = [a for a in convs if a.taps == 9]
+    ids = [lib.ds_conv_kernel_id(C.byref(a)) for a in c33]
+    if not f16:
+        record('config5_sd15_dpmpp2m_b16_fp32', per_step=errs, final=errs[-1], step_scales=step_scales(gold), bound=1e-3)
+        assert max(errs) < 1e-3 and errs[-1] < 1e-3, errs
+        return
+    z16 = np.load(os.path.join(G, 'ldm_sd15_traj_b2_f16ops.npz'))
+    from _f16_names import ldm_prefixes, ldm_stored_prefixes
+    assert sorted(ldm_prefixes(plan)) == [str(v) for v in z16['f16_layers']]                  # the oracle rounded exactly these layers' operands
+    assert plan.stream16 and sorted(ldm_stored_prefixes(plan)) == [str(v) for v in z16['f16_stored']]
+    # routing at THIS batch: every 3x3 convolution of the body on the fp16-activation kernels (the 4-channel head alone stays fp32, VALU kernel),
+    # the three Downsample convolutions on the gather GEMM, 256-column tiles in use
+    fp32_body = [i for a, i in zip(c33, ids) if not a.wgt_f16 and i != 2570]
+    assert fp32_body == [] and ids.count(2570) == 1, (fp32_body, ids)
+    assert ids.count(2571) == 3 and ids.count(2566) >= 45, ids
+    noise = [float(v) for v in z16['per_step_rel_vs_fp32_golden']]
+    gold16 = torch.from_numpy(z16['traj_f16ops'])
+    errs16 = per_step_rel(tr[:, slots].cpu(), torch.cat([gold16, gold16], dim=1))
+    # the first evaluation alone: raw U-Net outputs (unconditional / conditional halves of the doubled batch) against the fp16 oracle's
+    t0 = solvers.get_schedule(6, net.sigma_min, net.sigma_max, device=dev, schedule_type='discrete', schedule_rho=1, net=net)[0]
+    f_rows = net.raw(lat * t0, float(t0), cond, uncond)[0]
+    torch.cuda.synchronize()
+    eps = f_rows.reshape(2 * B, 64, 64, 4).permute(0, 3, 1, 2).cpu()
+    eps_gold = torch.from_numpy(z16['eps0_f16ops'])          # [uncond 0, uncond 1, cond 0, cond 1]
+    rows = [0, 6, B + 0, B + 6], [9, 15, B + 9, B + 15]
+    e_eps = max(_rel(eps[r], eps_gold) for r in rows)
+    record('config5_sd15_dpmpp2m_b16_fp16', per_step_vs_fp32_golden=errs, per_step_vs_fp16_oracle=errs16, oracle_noise_per_step=noise,
+           first_evaluation_unet_outputs_vs_fp16_oracle=e_eps, step_scales=step_scales(gold), fp32_body_convs=len(fp32_body),
+           conv_kernel_ids={str(k): ids.count(k) for k in sorted(set(ids))})
+    assert errs[0] < 1e-6                                    # step 0 is latents * sigma_max: no network yet
+    for i in range(1, len(errs)):
+        assert errs[i] < min(max(1.5 * noise[i], 2e-3), 2e-2), (i, errs[i], noise[i])
+        assert errs16[i] < max(2.0 * noise[i], 2e-3), (i, errs16[i], noise[i])      # two independent fp16 noises (expected ~1.4 x)
+    assert e_eps < 2.5e-3, e_eps
+    # what only this batch exercises (host mirrors of the launcher's rules, tests/_f16_names.py): split-K on the 8x8 stage, 256-column tiles
+    from _f16_names import f16dma_splits, f16dma_tile_widths
+    s1 = [a for a in c33 if a.in_f16 and (a.stride or 1) == 1]
+    assert sum(1 for a in s1 if a.h == 8 and f16dma_splits(a) > 1) >= 10, [(a.h, a.c0, a.cout, f16dma_splits(a)) for a in s1]
+    assert sum(1 for a in s1 if 4 in f16dma_tile_widths(a)) >= 10
+
+
 # ---- the OTHER benchmarked configurations at THEIR bench batches (bench.py --config imagenet64 --batch 64 / --config ffhq --batch 128),
 # ---- fp32 and the reference's fp16 mode: golden samples of the real reference scattered over the batch, kernel routing asserted --------
 def _conv_kernel_ids(net, B, emb_rows):

@@ -107,6 +107,27 @@ def test_bench_gpus8_self_launch_runs_eight_ranks():
     assert line['other_configs'] is None and line['latency'] is None          # side measurements belong to the N = 1 default run only
 
 
+@pytest.mark.parametrize('config,batch', [('imagenet64', 64), ('sd15', 16)])
+def test_bench_gpus8_fp16_configs_3_and_5(config, batch):
+    """BASELINE configs 3 (ImageNet-64, 8 GPUs) and 5 (SD-1.5, 8 GPUs) are the 8-GPU ones: the driver-form command line of their fp16 benches
+    -- `bench.py --gpus 8 --config <c> --dtype fp16` -- on 8 gloo ranks: default batch and solver of the configuration, whole-job images per
+    step, per-rank value min / max next to the barrier skew."""
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '8', '--stub', '--steps', '2', '--warmup', '1', '--config', config, '--dtype', 'fp16'],
+                       env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _line(r.stdout)
+    assert line['n_gpus'] == 8 and line['stub'] is True and line['scaling'] == 'weak'
+    assert line['config']['images_per_step'] == 8 * batch and f'batch {batch}/GPU' in line['config']['workload']
+    assert ('ImageNet-64' if config == 'imagenet64' else 'Stable Diffusion') in line['config']['workload']
+    assert line['dtype'].startswith('fp16 operands')
+    mg = line['multi_gpu']
+    assert len(mg['per_rank_value']) == 8 and mg['per_rank_value_min'] <= mg['per_rank_value_max']
+    assert mg['per_rank_value'][0] > mg['per_rank_value'][7]                    # the stub makes rank 7 the slowest
+    assert abs(mg['barrier_skew_ms_per_step'] - (mg['per_rank_ms_per_step_max'] - mg['per_rank_ms_per_step_min'])) < 1e-2
+    # whole-job value = all ranks' images over the slowest rank's (barrier-bracketed) time: never above 8 x the slowest rank's own rate
+    assert line['value'] <= 8 * mg['per_rank_value_min'] * 1.01
+
+
 def test_pmc_traffic_is_tied_to_the_kernel_source_it_was_measured_on(tmp_path, monkeypatch):
     """`roofline.traffic` comes from a committed rocprofv3 PMC summary.  The summary carries the session it was collected in and the hash
     of every kernel translation unit at that time (tools/rocprof_summary.py); bench.py reports the bytes with that provenance while the
@@ -115,7 +136,9 @@ def test_pmc_traffic_is_tied_to_the_kernel_source_it_was_measured_on(tmp_path, m
     import bench
     from diff_sampler_amd import build
     name = bench.PMC_KEYS[2565]
-    kern = {name: {'FETCH_SIZE_KiB_avg_per_launch': 200000.0, 'WRITE_SIZE_KiB_avg_per_launch': 160000.0}}
+    row = lambda f, w, n: {'FETCH_SIZE_launches': n, 'FETCH_SIZE_KiB_total': f * n, 'FETCH_SIZE_KiB_avg_per_launch': f, 'WRITE_SIZE_launches': n,
+                           'WRITE_SIZE_KiB_total': w * n, 'WRITE_SIZE_KiB_avg_per_launch': w}       # a row as tools/rocprof_summary.py writes it
+    kern = {name: row(200000.0, 160000.0, 1260)}
     f = tmp_path / 'pmc.json'
     monkeypatch.setattr(bench, 'PMC_FILE', str(f))
     f.write_text(json.dumps({'meta': {'session': 'gpurun_out/x', 'kernel_source_sha256': build.source_hashes()}, 'kernels': kern}))
@@ -126,6 +149,17 @@ def test_pmc_traffic_is_tied_to_the_kernel_source_it_was_measured_on(tmp_path, m
     assert bench.pmc_traffic(2565) is None and 'another build' in bench.PMC_NOTE['why']
     f.write_text(json.dumps({'kernels': kern}))                               # a summary without provenance (round 3's) is not trusted
     assert bench.pmc_traffic(2565) is None
+    # kernel CLASSES of the fp16 engines (other_configs): all instantiations of the class, averaged over their launches
+    kern16 = {'void igemm::(anonymous namespace)::conv3x3_f16dma_kernel<64, 3, true>(igemm::KParams)': row(1000.0, 400.0, 30),
+              'void igemm::(anonymous namespace)::conv3x3_f16dma_kernel<8, 2, false>(igemm::KParams)': row(100.0, 40.0, 10),
+              'norm_act_kernel(ds_norm_args, int, int, int)': row(50.0, 50.0, 7)}
+    f16 = tmp_path / 'pmc16.json'
+    monkeypatch.setitem(bench.PMC_FILES, ('imagenet64', 'fp16'), str(f16))
+    f16.write_text(json.dumps({'meta': {'session': 'gpurun_out/y', 'kernel_source_sha256': build.source_hashes()}, 'kernels': kern16}))
+    byts, src = bench.pmc_traffic(2566, ('imagenet64', 'fp16'))
+    assert byts == round(1024 * (2 * (1000.0 * 30 + 100.0 * 10) + (400.0 * 30 + 40.0 * 10)) / 40) and src['instantiations'] == 2
+    assert bench.pmc_traffic('norm_act', ('imagenet64', 'fp16'))[0] == round(1024 * 150.0)
+    assert bench.pmc_traffic(2567, ('imagenet64', 'fp16')) is None            # no row of that class in the pass
     # the hash is of the CODE: comments and whitespace do not count, a changed token does
     a = build._code_only('int f(int x) {  // doubles\n  return 2 * x; /* really */ }\n')
     assert a == build._code_only('int f(int x) {\n\n return 2 * x; }') and a != build._code_only('int f(int x) { return 3 * x; }')

@@ -74,5 +74,5 @@ for config in args.config:
     del nets
     torch.cuda.empty_cache()
 print('# measured tile shapes (taps, stride, n, h, w, c0, ec0, cout, act, out_f16, res_f16, res, cbias, bias, stats, tune.splits) -> (nb, nw); ms per candidate')
-for key, (nb, nw, times) in sorted(plan_mod.tune_report().items()):
+for (dev_, key), (nb, nw, times) in sorted(plan_mod.tune_report().items()):
     print(key, '->', (nb, nw), ' '.join(f'{c[0]}/{c[1]}:{ms:.3f}' for c, ms in sorted(times.items())), flush=True)
