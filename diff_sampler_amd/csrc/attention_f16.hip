@@ -19,6 +19,16 @@
 //   * the O^T rescale runs only on tiles where some lane's running maximum moved (wave-uniform branch);
 //   * XCD-aware 1-D grid: linear workgroup id % 8 is the XCD, so the (image, head) index is id % 8 + 8 * (...) and all query blocks
 //     of one (image, head) share an L2 (its K/V, <= 1.3 MB at 4096 x 40, are fetched from HBM once, not once per XCD).
+// Round 5 (SQ counters of round 4: 207 VALU per 14 MFMAs per tile, matrix pipe busy 0.25 -- the kernel is VALU-bound, not matrix-bound):
+//   * the softmax DENOMINATOR comes out of the matrix pipe: head sizes that are not a multiple of 32 (d = 40, 80: every SD-1.5 self- and
+//     cross-attention at 64x64 / 32x32) pad O^T to whole 32-row blocks anyway, so row d of V^T is set to ones once and the P V product
+//     accumulates sum_key P[key, q] in that row for free -- the 32 v_add_f32 per tile and lane of the running sum are gone, and the sum is
+//     of the fp16-rounded weights the product actually uses (the reference normalises in fp32 and rounds the weights afterwards,
+//     networks_edm.py:108-109: either way the weights sum to 1 within 2**-11);
+//   * the operand types (fp16 or fp32 q; fp16 or fp32 k / v) are template parameters: the staging code holds no run-time selects and the
+//     registers of the unused path are not allocated (the four-waves-per-SIMD allocation at d <= 64 spilled 10 - 23 registers);
+//   * waves 4 - 7 run at s_setprio 1 (MI355X_MICROARCH.md, "Two waves per SIMD", item 4: the second-dispatched half of an eight-wave
+//     workgroup otherwise loses every VALU arbitration).  -DDS_ATTN_NOPRIO builds without it (A/B runs).
 // Head sizes: d % 8 == 0, d <= 160 (registers / LDS); other sizes keep the fp32 kernel (ds_attention_f16_supported).
 #include "ds_common.h"
 
@@ -34,7 +44,7 @@ __device__ __forceinline__ unsigned pk2(float x, float y) {          // two fp32
     return __builtin_bit_cast(unsigned, p);
 }
 
-template <int D>
+template <int D, int INF16>
 // Waves per SIMD the register allocation must leave room for.  Head sizes <= 64 at 4: TWO 512-thread workgroups per CU.  With one (the
 // round-3 allocation: 144 / 147 VGPRs at d = 40 / 64) the two waves of a SIMD belong to the same workgroup and leave the same per-tile
 // barrier together: they run their MFMA segments (Q K^T, P V) and their VALU segment (softmax: ~207 VALU per 14 MFMAs, SQ counters in
@@ -46,9 +56,12 @@ template <int D>
 #define DS_ATTN_WAVES(D) ((D) <= 64 ? 4 : 2)
 #endif
 __global__ void __launch_bounds__(512, DS_ATTN_WAVES(D)) flash_attn_f16_kernel(const ds_attn_args a, const int qblocks, const int pairs) {
+    static_assert(!(D % 32) || ((D % 32) % 4 == 0), "ones row");
     constexpr int DP = (D + 15) / 16 * 16;           // contraction length of S^T, zero padded
     constexpr int NKS = DP / 16;
     constexpr int DB = (D + 31) / 32;                // 32-row blocks of O^T
+    constexpr bool ONES = (D % 32) != 0;             // row D of V^T is all ones: O^T row D accumulates the softmax denominator
+    constexpr int LB = D / 32, LR = ((D % 32) & 3) + 4 * ((D % 32) >> 3), LH = ((D % 32) >> 2) & 1;   // ... in ot[LB][LR] of lane half LH
     constexpr int KT = 64;                           // keys per tile
     constexpr int KLD = DP + 8;                      // halfs; row stride / 16 B odd: conflict-free ds_read_b128 over 32 rows
     constexpr int VLD = KT + 8;
@@ -79,9 +92,13 @@ __global__ void __launch_bounds__(512, DS_ATTN_WAVES(D)) flash_attn_f16_kernel(c
     if (DP != D) {          // the zero padding of K's contraction columns (never overwritten by the staging below)
         if (tid < 2 * KT) *reinterpret_cast<u32x4*>(smem_b + (tid >> 6) * TILE_B + ((tid & 63) * KLD + D) * 2) = u32x4{0u, 0u, 0u, 0u};
     }
+    if (ONES) {             // V^T row D = 1.0 for all 64 key positions of both tile buffers (the staging writes rows < D only); 16 B per thread
+        if (tid < 16) *reinterpret_cast<u32x4*>(smem_b + (tid >> 3) * TILE_B + KBYTES + (D * VLD + (tid & 7) * 8) * 2) =
+            u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+    }
 
     const float sc = a.scale * 1.4426950408889634f;
-    const bool q16 = a.in_f16 & 1, kv16 = a.in_f16 & 2;          // fp16 sources: leading dimensions / batch strides in halfs
+    constexpr bool q16 = INF16 & 1, kv16 = INF16 & 2;            // fp16 sources: leading dimensions / batch strides in halfs
     const float ss = q16 ? sc : 1.0f;                             // factor applied to the fp32 scores (fp32 q carries it already)
     h8 qf[NKS];
     {
@@ -92,7 +109,7 @@ __global__ void __launch_bounds__(512, DS_ATTN_WAVES(D)) flash_attn_f16_kernel(c
         for (int ks = 0; ks < NKS; ++ks) {
             u32x4 w = {0u, 0u, 0u, 0u};
             if (16 * ks + 8 * hb < D) {
-                if (q16) w = *reinterpret_cast<const u32x4*>(qr16 + 16 * ks);
+                if constexpr (q16) w = *reinterpret_cast<const u32x4*>(qr16 + 16 * ks);
                 else {
                     const f32x4 lo = *reinterpret_cast<const f32x4*>(qr + 16 * ks) * sc;
                     const f32x4 hi = *reinterpret_cast<const f32x4*>(qr + 16 * ks + 4) * sc;
@@ -111,7 +128,7 @@ __global__ void __launch_bounds__(512, DS_ATTN_WAVES(D)) flash_attn_f16_kernel(c
         for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
     float m = -1e30f, l = 0.f;
 
-    f32x4 kr[NLK][2], vr[NLV][4];
+    f32x4 kr[NLK][kv16 ? 1 : 2], vr[NLV][4];
     auto gload = [&](int t) {
 #pragma unroll
         for (int j = 0; j < NLK; ++j) {
@@ -119,7 +136,7 @@ __global__ void __launch_bounds__(512, DS_ATTN_WAVES(D)) flash_attn_f16_kernel(c
             if (NLK * 512 == KCH || idx < KCH) {
                 const int row = idx / D8, c8 = idx - row * D8;
                 const size_t off = (size_t)min(t * KT + row, a.skv - 1) * a.ldk + c8 * 8;
-                if (kv16) kr[j][0] = *reinterpret_cast<const f32x4*>(kp16 + off);          // eight halfs, staged as they are
+                if constexpr (kv16) kr[j][0] = *reinterpret_cast<const f32x4*>(kp16 + off);          // eight halfs, staged as they are
                 else {
                     kr[j][0] = *reinterpret_cast<const f32x4*>(kp + off);
                     kr[j][1] = *reinterpret_cast<const f32x4*>(kp + off + 4);
@@ -134,7 +151,7 @@ __global__ void __launch_bounds__(512, DS_ATTN_WAVES(D)) flash_attn_f16_kernel(c
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const size_t off = (size_t)min(t * KT + 4 * g + i, a.skv - 1) * a.ldv + 4 * d4;
-                    if (kv16) {          // four halfs of one key in the first two dwords
+                    if constexpr (kv16) {          // four halfs of one key in the first two dwords
                         typedef float f32x2_t __attribute__((ext_vector_type(2)));
                         const f32x2_t w = *reinterpret_cast<const f32x2_t*>(vp16 + off);
                         vr[j][i] = f32x4{w[0], w[1], 0.f, 0.f};
@@ -150,9 +167,10 @@ __global__ void __launch_bounds__(512, DS_ATTN_WAVES(D)) flash_attn_f16_kernel(c
             const int idx = tid + 512 * j;
             if (NLK * 512 == KCH || idx < KCH) {
                 const int row = idx / D8, c8 = idx - row * D8;
-                const f32x4 lo = kr[j][0], hi = kr[j][1];
-                *reinterpret_cast<u32x4*>(base + (row * KLD + 8 * c8) * 2) =
-                    kv16 ? __builtin_bit_cast(u32x4, lo) : u32x4{pk2(lo[0], lo[1]), pk2(lo[2], lo[3]), pk2(hi[0], hi[1]), pk2(hi[2], hi[3])};
+                const f32x4 lo = kr[j][0], hi = kr[j][kv16 ? 0 : 1];
+                if constexpr (kv16) *reinterpret_cast<u32x4*>(base + (row * KLD + 8 * c8) * 2) = __builtin_bit_cast(u32x4, lo);
+                else *reinterpret_cast<u32x4*>(base + (row * KLD + 8 * c8) * 2) =
+                    u32x4{pk2(lo[0], lo[1]), pk2(lo[2], lo[3]), pk2(hi[0], hi[1]), pk2(hi[2], hi[3])};
             }
         }
 #pragma unroll
@@ -161,7 +179,7 @@ __global__ void __launch_bounds__(512, DS_ATTN_WAVES(D)) flash_attn_f16_kernel(c
             if (NLV * 512 == VTS || idx < VTS) {
                 const int g = idx & 15, d4 = idx >> 4;
                 const int pos = 4 * ((g & ~3) | ((g & 1) << 1) | ((g & 2) >> 1));      // key bits 2 and 3 swapped
-                if (kv16) {          // the same 4-key x 4-channel transposition on halfs: byte permutes of the keys' dwords
+                if constexpr (kv16) {          // the same 4-key x 4-channel transposition on halfs: byte permutes of the keys' dwords
                     unsigned kd[4][2];                                               // key i: dword 0 = channels (0, 1), dword 1 = channels (2, 3)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {          // (through scalars: __builtin_bit_cast of a vector ELEMENT lvalue reads element 0 with this compiler)
@@ -186,6 +204,9 @@ __global__ void __launch_bounds__(512, DS_ATTN_WAVES(D)) flash_attn_f16_kernel(c
     };
 
     const int ntiles = (a.skv + KT - 1) / KT;
+#ifndef DS_ATTN_NOPRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     gload(0);
     sstore(0);
     if (PREFETCH && ntiles > 1) gload(1);
@@ -228,8 +249,11 @@ __global__ void __launch_bounds__(512, DS_ATTN_WAVES(D)) flash_attn_f16_kernel(c
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { st[kb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], ss, -mn)); rs += st[kb][r]; }
-            l = l * alpha + rs;
+                for (int r = 0; r < 16; ++r) {
+                    st[kb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], ss, -mn));
+                    if (!ONES) rs += st[kb][r];
+                }
+            if (!ONES) l = l * alpha + rs;
             if (__any(moved)) {
 #pragma unroll
                 for (int i = 0; i < DB; ++i) ot[i] *= alpha;
@@ -260,7 +284,10 @@ __global__ void __launch_bounds__(512, DS_ATTN_WAVES(D)) flash_attn_f16_kernel(c
     }
     if (!active) return;
 
-    const float inv = 1.0f / (l + __shfl_xor(l, 32));
+    if (ONES) {             // the denominator sits in O^T row D: register LR of block LB in the lanes of half LH; both halves of a query need it
+        l = __shfl(ot[LB][LR], l31 + 32 * LH);
+    } else l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
     float* patch = Es + wave * (32 * 33);
     float* op = a.out + (size_t)b * a.o_bs + h * D;
 #pragma unroll
@@ -289,18 +316,28 @@ __global__ void __launch_bounds__(512, DS_ATTN_WAVES(D)) flash_attn_f16_kernel(c
     }
 }
 
-template <int D>
-int launch(const ds_attn_args* a, hipStream_t stream) {
+template <int D, int INF16>
+int launch_t(const ds_attn_args* a, hipStream_t stream) {
     constexpr int DP = (D + 15) / 16 * 16, DB = (D + 31) / 32;
     constexpr int bytes = 2 * (64 * (DP + 8) * 2 + DB * 32 * 72 * 2) + 8 * 32 * 33 * (int)sizeof(float);
     static_assert(bytes <= 160 * 1024, "LDS");
-    DS_ENSURE_DYN_LDS((&flash_attn_f16_kernel<D>), bytes);
+    DS_ENSURE_DYN_LDS((&flash_attn_f16_kernel<D, INF16>), bytes);
     const int qblocks = (a->sq + 255) / 256, pairs = a->batch * a->heads;
     const long long blocks = (long long)qblocks * ((pairs + 7) / 8) * 8;
     if (blocks > 0x7fffffffLL) return DS_E_SHAPE;
-    hipLaunchKernelGGL(flash_attn_f16_kernel<D>, dim3((unsigned)blocks), dim3(512), bytes, stream, *a, qblocks, pairs);
+    hipLaunchKernelGGL((flash_attn_f16_kernel<D, INF16>), dim3((unsigned)blocks), dim3(512), bytes, stream, *a, qblocks, pairs);
     DS_CHECK_LAUNCH();
     return DS_OK;
+}
+
+template <int D>
+int launch(const ds_attn_args* a, hipStream_t stream) {
+    switch (a->in_f16 & 3) {           // bit 0: fp16 q, bit 1: fp16 k and v
+        case 0: return launch_t<D, 0>(a, stream);
+        case 1: return launch_t<D, 1>(a, stream);
+        case 2: return launch_t<D, 2>(a, stream);
+        default: return launch_t<D, 3>(a, stream);
+    }
 }
 
 }  // namespace

@@ -31,6 +31,15 @@
 // taps at the bench batches) contract S contiguous ranges of 64-channel slabs in S workgroups per tile (blockIdx.y), each writing its raw
 // fp32 partial tile to the caller's workspace; splitk_reduce_f16_kernel (gemm_conv.hip) sums them in split order and applies the epilogue
 // (bias, per-image bias, fp16 / fp32 residual, activation, fp16 / fp32 rows, GroupNorm column sums of the stored values).
+// Fused input normalisation (round 5; NORM instantiations, ds_conv_args.norm_coefs with in_f16): the operand may be the RAW fp16 tensor
+// (the block input / conv0's output as the producing epilogue stored it) instead of the activated copy a ds_norm_act pass writes.  The raw
+// halo still arrives by LDS-DMA; once a DMA round of slab s + 1 has landed (one tap after it was issued) every thread rewrites the 16-byte
+// unit IT fetched in place: h = silu((x - mu[c]) * A[c] + B[c]) -- the same fp32 expression and the same RNE rounding as norm_act_kernel, so
+// the convolution's output bits equal those of the two-launch form -- while slab s is multiplied.  Out-of-image halo pixels are zero pages
+// and are skipped (they must stay zero AFTER the affine).  The {mu, A, B} rows of the slab's 64 channels (768 B per image of the tile) ride
+// in the unused tail of the halo buffer, fetched by one more LDS-DMA per slab; the appended 1x1 skip slabs stay raw.  With the
+// normalisation in the kernel the decoder's channel concatenation needs no materialising pass either: a slab takes source 0 or source 1
+// (both channel counts multiples of 64).  What it buys and costs per layer class: profiles/r5_conv_f16dma_fused_norm_ab.txt.
 #include "pipe_common.h"
 #include "epi_direct.h"
 
@@ -45,6 +54,9 @@ struct GeoD {
     static constexpr int TH = 256 / (W * NIMG), WP = W + 2, HP = TH + 2, NP = NIMG * HP * WP;
     static constexpr int NDMA = (NP * 8 + 511) / 512;                      // DMA rounds per halo (512 threads x 16 B = 8 KB each)
     static constexpr unsigned HALO_B = NDMA * 8192u;
+    // fused input normalisation: {mu, A, B} x 64 channels x NIMG images in the tail of the halo buffer, behind its NP pixels
+    static constexpr unsigned COEF_OFF = NP * 128u, COEF_UNITS = NIMG * 48u;
+    static_assert(COEF_OFF + NIMG * 768u <= HALO_B, "coefficient rows must fit behind the halo pixels");
 };
 
 // Weight ring depth (round 4): a tap's weights are requested D - 1 taps ahead.  D = 2 is the double buffer of round 3 -- enough for NB >= 3,
@@ -67,7 +79,7 @@ constexpr unsigned f16dma_smem() { return (unsigned)f16dma_ring<W, NB>() * NB * 
 // each, chosen by the launcher (epi_direct_ok): a kernel body holding both allocates registers for the worse of the two.
 // (The DMA requests of a tap are issued between the MFMAs of its last K step, round 4; the round-3 order "behind them" was kept as an
 // A/B instantiation until the comparison was recorded in docs/HISTORY.md section E.6.)
-template <int W, int NB, bool DIRECT>
+template <int W, int NB, bool DIRECT, bool NORM>
 __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p) {
     using G = GeoD<W>;
     constexpr int WP = G::WP, HP = G::HP, TH = G::TH, NIMG = G::NIMG, NP = G::NP, NDMA = G::NDMA;
@@ -106,9 +118,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
         const int y = r0 + hr - 1, x = hc - 1;
         const bool ok = hp < NP && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)W;
         hpix[j] = ok ? ((img0 + sl) * p.H + y) * W + x : -1;
+        if (NORM && hp >= NP) hpix[j] = -2;                    // no such halo pixel: nothing is fetched (the buffer's tail holds the coefficient rows)
     }
-    const int nchunks = p.c0 / 64;                             // 3x3 slabs (9 taps each)
-    const int nextra = p.ec0 / 64;                             // appended 1x1 slabs (centre tap only)
+    const int n0ch = p.c0 / 64, ne0ch = p.ec0 / 64;            // NORM: slabs of source 0; the rest come from source 1
+    const int nchunks = NORM ? (p.c0 + p.c1) / 64 : p.c0 / 64; // 3x3 slabs (9 taps each)
+    const int nextra = NORM ? (p.ec0 + p.ec1) / 64 : p.ec0 / 64;   // appended 1x1 slabs (centre tap only)
     // This workgroup contracts slabs [cb, NCH) = taps [kt0, KT) of the layer's K: everything, or -- split-K, blockIdx.y = split -- the
     // range whose boundaries are the slab boundaries nearest to the equal-tap cuts (a 3x3 slab weighs nine taps, an appended 1x1 slab one)
     int cb = 0, NCH = nchunks + nextra;
@@ -129,7 +143,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
         if ((abl & 2) && chunk > 0) return;
         const bool extra = chunk >= nchunks;
         const _Float16* base = extra ? e0 + (size_t)(chunk - nchunks) * 64 : a0 + (size_t)chunk * 64;
-        const int ld = extra ? p.elda0 : p.lda0;
+        int ld = extra ? p.elda0 : p.lda0;
+        if constexpr (NORM) {                                  // two sources: the decoder's concatenation is never materialised
+            if (hpix[j] == -2) return;
+            if (!extra && chunk >= n0ch) { base = reinterpret_cast<const _Float16*>(p.a1) + (size_t)(chunk - n0ch) * 64; ld = p.lda1; }
+            if (extra && chunk - nchunks >= ne0ch) { base = reinterpret_cast<const _Float16*>(p.e1) + (size_t)(chunk - nchunks - ne0ch) * 64; ld = p.elda1; }
+        }
         int hcj = hch;
         if constexpr (W <= 16) {                               // halo pixel of this unit: row hp / WP (counted over the tile's image slots), column hp % WP
             const unsigned hp = (unsigned)(j * 64 + (tid >> 3)), hrow = hp / (unsigned)WP, hcol = hp - hrow * (unsigned)WP;
@@ -138,6 +157,52 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
         const _Float16* g = hpix[j] >= 0 ? base + (size_t)hpix[j] * ld + hcj : g_zero_halfs;
         __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + D * WB + hbuf * HB + (j * 512 + wave * 64) * 16), 16, 0, 0);
     };
+    // ---- NORM: the slab's {mu, A, B} rows -> tail of halo buffer hbuf (unit u = tid < NIMG * 48: image slot u / 48, plane (u % 48) / 16) ----
+    auto coef_dma = [&](int chunk, int hbuf) {
+        if constexpr (NORM) {
+            if (wave * 64 < (int)G::COEF_UNITS) {
+                if (tid < (int)G::COEF_UNITS) {
+                    const int sl = tid / 48, rem = tid - sl * 48;
+                    const float* g = p.norm + ((size_t)(img0 + sl) * 3 + (rem >> 4)) * (size_t)(p.c0 + p.c1) + (size_t)chunk * 64 + (rem & 15) * 4;
+                    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + D * WB + hbuf * HB + G::COEF_OFF + wave * 64 * 16), 16, 0, 0);
+                }
+            }
+        }
+    };
+    // ---- NORM: rewrite the unit this thread fetched in round j of a 3x3 slab's halo (buffer hbuf) in place: silu((x - mu) * A + B), fp32
+    // arithmetic, RNE to fp16 -- the expressions of norm_act_kernel (norm_act.hip: xf / to_h4).  Callers guarantee the round has landed. ----
+    auto norm_round = [&](int hbuf, auto jc) {
+        if constexpr (NORM) {
+            constexpr int j = decltype(jc)::value;
+            if (hpix[j] < 0) return;                           // zero page (must stay zero) or no pixel
+            const unsigned hbase = lds_addr2(smem) + D * WB + (unsigned)hbuf * HB;
+            const unsigned ua = hbase + (unsigned)(j * 512 + tid) * 16u;
+            unsigned oct = (unsigned)hch >> 3;                 // channel octet of the unit inside the slab = DMA source offset / 8
+            const unsigned hp = (unsigned)(j * 64 + (tid >> 3));
+            if constexpr (W <= 16) {
+                const unsigned hrow = hp / (unsigned)WP, hcol = hp - hrow * (unsigned)WP;
+                oct = (unsigned)(tid & 7) ^ (((hcol + (W == 8 ? 8u * (hrow & 1u) : 0u)) >> 1) & 7u);
+            }
+            unsigned ca = hbase + G::COEF_OFF + oct * 32u;
+            if constexpr (NIMG > 1) ca += (hp / (unsigned)(HP * WP)) * 768u;
+            f32x4 xr = lds_rd<0>(ua);
+            f32x4 m0 = lds_rd<0>(ca), m1 = lds_rd<16>(ca), g0 = lds_rd<256>(ca), g1 = lds_rd<272>(ca), b0 = lds_rd<512>(ca), b1 = lds_rd<528>(ca);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr), "+v"(m0), "+v"(m1), "+v"(g0), "+v"(g1), "+v"(b0), "+v"(b1));
+            const h8 xh = __builtin_bit_cast(h8, xr);
+            const bool act = p.norm_act == DS_ACT_SILU;
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float mu = e < 4 ? m0[e & 3] : m1[e & 3], ga = e < 4 ? g0[e & 3] : g1[e & 3], be = e < 4 ? b0[e & 3] : b1[e & 3];
+                const float v = (float)xh[e];
+                const float u = (v - mu) * ga + be;
+                t[e] = act ? ds_silu(u) : u;
+            }
+            const f32x4 o = {pack_h2(t[0], t[1]), pack_h2(t[2], t[3]), pack_h2(t[4], t[5]), pack_h2(t[6], t[7])};
+            lds_wr<0>(ua, o);
+        }
+    };
+
     // ---- weight DMA of K tile (tap) kt: rows i * 64 + (tid >> 3), i < NB; the source chunk is pre-swizzled -----------------------
     const _Float16* wsrc = wgt + (size_t)(n0 + (tid >> 3)) * ldbh + (((tid & 7) ^ ((tid >> 4) & 7)) * 8);
     auto w_dma = [&](int kt, int wbuf) {
@@ -221,14 +286,20 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
 
     // ---- prologue: halo of slab 0, the part of slab 1's halo that is due (see the tap), weights of taps 0 and 1 -------------------
     static_for<NDMA>([&](auto jc) { halo_dma(cb, cb & 1, jc); });
+    if (cb < nchunks) coef_dma(cb, cb & 1);
     if (cb + 1 < NCH) {
         if (cb >= nchunks) static_for<NDMA>([&](auto jc) { halo_dma(cb + 1, (cb + 1) & 1, jc); });      // the first slab is a one-tap slab
         else halo_dma(cb + 1, (cb + 1) & 1, IC<0>{});
+        if (cb + 1 < nchunks) coef_dma(cb + 1, (cb + 1) & 1);
     }
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (kt0 + d < KT) w_dma(kt0 + d, d);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (NORM) {                                      // the first slab's halo is normalised here (own units: no barrier needed before)
+        if (cb < nchunks) static_for<NDMA>([&](auto jc) { norm_round(cb & 1, jc); });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     Frag P_, Q_;
     {
@@ -292,6 +363,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
                 if (chunk + 2 < NCH) {
                     if (chunk + 1 >= nchunks) static_for<NDMA>([&](auto jc) { halo_dma(chunk + 2, chunk & 1, jc); });   // next slab has one tap
                     else halo_dma(chunk + 2, chunk & 1, IC<0>{});
+                    if (chunk + 2 < nchunks) coef_dma(chunk + 2, chunk & 1);
                 }
             } else if constexpr (T9 + 1 < NDMA) {
                 if (chunk + 1 < NCH) halo_dma(chunk + 1, (chunk + 1) & 1, IC<T9 + 1>{});
@@ -320,6 +392,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
             }
         }
         DS2_FENCE();
+        if constexpr (NORM && !X && T9 < NDMA) {
+            // round T9 of the NEXT 3x3 slab's halo was issued one tap ago (round 0: at the previous slab's last tap, or in the prologue) and
+            // this tap's DMA wait covered it: normalise it now, in the registers the last K step's fragments have just released
+            if (chunk + 1 < nchunks && chunk + 1 < NCH) norm_round((chunk + 1) & 1, IC<T9>{});
+            DS2_FENCE();
+        }
         ++kt; slot = nslot;
     };
     int chunk = cb;
@@ -371,13 +449,18 @@ int launch_w_nb(KParams p, int n_begin, int ntiles, hipStream_t stream) {
     int smem = (int)f16dma_smem<W, NB>();
     const int epi = 8 * 32 * EPI_LD * (int)sizeof(float);
     if (smem < epi) smem = epi;
-    if (p.splits > 1 || !epi_direct_ok(p, true, NB)) {         // partial tiles leave through the staged epilogue
-        DS_ENSURE_DYN_LDS((&conv3x3_f16dma_kernel<W, NB, false>), 160 * 1024);
-        hipLaunchKernelGGL((conv3x3_f16dma_kernel<W, NB, false>), dim3(grid_1d(p.mtiles, p.ntiles), p.splits), dim3(512), smem, stream, p);
-    } else {
-        DS_ENSURE_DYN_LDS((&conv3x3_f16dma_kernel<W, NB, true>), 160 * 1024);
-        hipLaunchKernelGGL((conv3x3_f16dma_kernel<W, NB, true>), dim3(grid_1d(p.mtiles, p.ntiles), 1), dim3(512), smem, stream, p);
-    }
+    const bool staged = p.splits > 1 || !epi_direct_ok(p, true, NB);          // partial tiles leave through the staged epilogue
+    const dim3 grid(grid_1d(p.mtiles, p.ntiles), staged ? p.splits : 1);
+#define DSD_LAUNCH(DIRECT_, NORM_)                                                                                             \
+    do {                                                                                                                       \
+        DS_ENSURE_DYN_LDS((&conv3x3_f16dma_kernel<W, NB, DIRECT_, NORM_>), 160 * 1024);                                        \
+        hipLaunchKernelGGL((conv3x3_f16dma_kernel<W, NB, DIRECT_, NORM_>), grid, dim3(512), smem, stream, p);                  \
+    } while (0)
+    if (p.norm) {
+        if constexpr (NB < 4) { if (staged) DSD_LAUNCH(false, true); else DSD_LAUNCH(true, true); }        // (max_nb: no 256-column NORM tile)
+        else return DS_E_SHAPE;
+    } else { if (staged) DSD_LAUNCH(false, false); else DSD_LAUNCH(true, false); }
+#undef DSD_LAUNCH
     DS_CHECK_LAUNCH();
     return DS_OK;
 }
@@ -389,8 +472,8 @@ int launch_w(const KParams& p, int nb, int n_begin, int ntiles, hipStream_t stre
         case 2: return launch_w_nb<W, 2>(p, n_begin, ntiles, stream);
         case 3: return launch_w_nb<W, 3>(p, n_begin, ntiles, stream);
         default:
-            if constexpr (f16dma_smem<W, 4>() <= 160u * 1024u) return launch_w_nb<W, 4>(p, n_begin, ntiles, stream);
-            else return DS_E_SHAPE;
+            if constexpr (f16dma_smem<W, 4>() <= 160u * 1024u) { if (!p.norm) return launch_w_nb<W, 4>(p, n_begin, ntiles, stream); }
+            return DS_E_SHAPE;
     }
 }
 
@@ -398,14 +481,18 @@ int launch_w(const KParams& p, int nb, int n_begin, int ntiles, hipStream_t stre
 
 // p.t_nb (ds_conv_args.tune.f16dma_nb), benchmarks / tests: > 0 forces the column-tile width of the main launch (64 * nb columns)
 
-// widest column tile the LDS holds next to two halo buffers
-static int max_nb(int W) { return (W == 16 || W == 32) ? 4 : 3; }
+// widest column tile the LDS holds next to two halo buffers; with the fused input normalisation 192 columns (the 256-column instantiations have
+// no registers left for the normalisation's temporaries: 6 - 137 spilled, tools/kernel_resources.py)
+static int max_nb(const KParams& p) { return (!p.norm && (p.W == 16 || p.W == 32)) ? 4 : 3; }
 
 bool conv3x3_f16dma_applicable(const KParams& p) {
-    if (p.taps != 9 || p.stride > 1 || p.norm != nullptr) return false;
+    if (p.taps != 9 || p.stride > 1) return false;
     if (!(p.W == 8 || p.W == 16 || p.W == 32 || p.W == 64) || p.H != p.W) return false;
     if (p.HW != p.H * p.W || p.M % 256) return false;
-    if (p.c0 <= 0 || p.c0 % 64 || p.c1 != 0 || p.ec0 % 64 || p.ec1 != 0) return false;
+    if (p.c0 <= 0 || p.c0 % 64 || p.ec0 % 64) return false;
+    if (p.norm) {           // fused input normalisation (NORM instantiations): second sources allowed, whole 64-channel slabs each
+        if ((p.norm_act != DS_ACT_NONE && p.norm_act != DS_ACT_SILU) || p.c1 % 64 || p.ec1 % 64 || (p.ec1 && !p.ec0)) return false;
+    } else if (p.c1 != 0 || p.ec1 != 0) return false;
     if (p.N % 64 || !p.vec_ok || p.nrows_b < p.N) return false;
     return true;
 }
@@ -432,9 +519,9 @@ static int tiling(const KParams& p, int nb0, int (*out)[3], int* cost, bool half
 
 int conv3x3_f16dma_plan(const KParams& p, int (*out)[3], bool half = false) {
 #ifdef DS_BUILD_EXPERIMENTS
-    const int cap = half ? conv3x3_f16dmah_max_nb(p.W) : max_nb(p.W);
+    const int cap = half ? conv3x3_f16dmah_max_nb(p.W) : max_nb(p);
 #else
-    const int cap = max_nb(p.W);
+    const int cap = max_nb(p);
 #endif
     int cost;
     if (p.t_nb > 0) return tiling(p, p.t_nb < cap ? p.t_nb : cap, out, &cost, half);
@@ -455,11 +542,11 @@ int conv3x3_f16dma_plan(const KParams& p, int (*out)[3], bool half = false) {
 static int conv3x3_f16dma_splits(const KParams& p, int (*plan)[3], int* n) {
     if (!p.part || !p.vec_part || p.t_splits == 1) return 1;
     int wide[4][3], cost;
-    const int nw = tiling(p, max_nb(p.W), wide, &cost);
+    const int nw = tiling(p, max_nb(p), wide, &cost);
     long long tiles = 0;
     for (int i = 0; i < nw; ++i) tiles += (long long)(p.M / 256) * wide[i][1];
     long long s = p.t_splits > 1 ? p.t_splits : (tiles <= 128 ? 256 / tiles : 1);
-    const long long kt_all = (long long)(p.c0 / 64) * 9 + p.ec0 / 64, mn = (long long)p.M * p.N;
+    const long long kt_all = (long long)((p.c0 + p.c1) / 64) * 9 + (p.ec0 + p.ec1) / 64, mn = (long long)p.M * p.N;
     if (s > 16) s = 16;
     if (s > kt_all / 18) s = kt_all / 18;
     if (s * mn > p.part_cap) s = p.part_cap / mn;

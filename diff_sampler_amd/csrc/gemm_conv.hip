@@ -391,10 +391,15 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     if (a->out_f16 && (!a->in_f16 || (a->cout & 63) || (a->out_ld & 7) || !ds_aligned16(a->out))) return DS_E_ARG;   // fp16 output rows: the fp16-activation kernels only
     if (a->res_f16 && (!a->in_f16 || !a->res || (a->res_ld & 7) || !ds_aligned16(a->res))) return DS_E_ARG;          // fp16 residual rows: the same kernels
     if (a->in_f16) {          // fp16 activations: pure matrix kernels (conv3x3_f16dma.hip / gemm_f16dma.hip); ld in halfs, 16-byte chunks
-        if (a->wgt_f16 != 1 || a->c1 || a->ec1 || a->norm_coefs || a->out_nchw) return DS_E_ARG;
+        if (a->wgt_f16 != 1 || a->out_nchw) return DS_E_ARG;
+        // fused input normalisation on RAW fp16 sources (round 5, conv3x3_f16dma NORM instantiations): 3x3 stride 1 only; with it a second
+        // source per operand is allowed (the concatenation is not materialised); without it the operand is ONE activated fp16 tensor
+        if (a->norm_coefs && (a->taps != 9 || a->stride > 1)) return DS_E_ARG;
+        if (!a->norm_coefs && (a->c1 || a->ec1)) return DS_E_ARG;
         if (a->stride > 1 && (a->stride != 2 || a->taps != 9 || a->ec0 || a->res)) return DS_E_ARG;      // stride 2: the Downsample convolution, csrc/gemm_f16dma.hip (gather)
         if (a->taps == 1 && a->ec0) return DS_E_ARG;
         if ((a->ld0 & 7) || (a->ec0 && ((a->eld0 & 7) || !a->e0 || !ds_aligned16(a->e0)))) return DS_E_ALIGN;
+        if ((a->c1 && (a->ld1 & 7)) || (a->ec1 && ((a->eld1 & 7) || !a->e1 || !ds_aligned16(a->e1)))) return DS_E_ALIGN;
     }
     if ((a->ld0 & 3) || (a->c1 && (a->ld1 & 3))) return DS_E_ALIGN;
     if (!ds_aligned16(a->x0) || (a->c1 && !ds_aligned16(a->x1)) || !ds_aligned16(a->wgt)) return DS_E_ALIGN;
@@ -509,7 +514,7 @@ extern "C" int ds_conv_kernel_id(const ds_conv_args* a) {
     p.stride = a->stride ? a->stride : 1; p.K = a->taps * (a->c0 + a->c1) + a->ec0 + a->ec1; p.norm = a->norm_coefs;
     p.nrows_b = ((a->cout + BN - 1) / BN) * BN;                                     // weights are row-padded, as in ds_conv2d_nhwc
     if (a->wgt_f16 == 1 && a->in_f16 && a->taps == 9 && p.stride == 2) return 2571;
-    if (a->wgt_f16 == 1 && a->in_f16) return a->taps == 1 ? 2567 : (conv3x3_f16dma_use_half(p) ? 2569 : 2566);
+    if (a->wgt_f16 == 1 && a->in_f16) return a->taps == 1 ? 2567 : (conv3x3_f16dma_use_half(p) ? 2569 : (a->norm_coefs ? 2572 : 2566));
     if (a->wgt_f16) return a->wgt_f16 == 2 ? 2563 : (a->taps == 1 ? 2564 : 2562);
     if (p.t_mode == 1) return 0;
     if (p.t_mode == 0 && p.t_variant == 0 && !a->res && !a->cbias && !a->stats_out) {

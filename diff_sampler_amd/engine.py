@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List
 
 import torch
@@ -29,6 +30,10 @@ from .ops import pack_conv_weight, pack_linear_weight, pack_stem_weight
 
 
 from .plan import Builder, Plan as _Plan, ptr as _ptr  # noqa: E402
+
+
+# default of UNetEngine.fuse_norm16 (A/B of round 5, profiles/r5_conv_f16dma_fused_norm_ab.txt)
+FUSE_NORM16_DEFAULT = '0'
 
 
 class UNetEngine:
@@ -46,6 +51,9 @@ class UNetEngine:
         self.device = torch.device(device)
         self.use_fp16 = bool(use_fp16)
         self.split_fp16 = bool(split_fp16) and not self.use_fp16
+        # fp16 mode: GroupNorm apply + SiLU inside the fp16-activation convolution's LDS halo instead of a ds_norm_act pass (plan(): fz0 / fz1;
+        # bit-identical results).  An attribute, not an argument, so that A/B runs flip it per engine: DS_FUSE_NORM16 sets the default.
+        self.fuse_norm16 = os.environ.get('DS_FUSE_NORM16', FUSE_NORM16_DEFAULT) == '1'
         self._w16_cache = {}
         self.conv_mode = 1 if self.use_fp16 else (2 if self.split_fp16 else 0)      # ds_conv_args.wgt_f16 of the eligible 3x3 layers
         self.lib = _lib.load()
@@ -129,7 +137,7 @@ class UNetEngine:
 
     # ------------------------------------------------------------------------------------------ plan
     def plan(self, B: int, emb_rows: int) -> _Plan:
-        key = (B, emb_rows)
+        key = (B, emb_rows, self.fuse_norm16)
         if key in self._plans:
             return self._plans[key]
         spec, dev, w, lib = self.spec, self.device, self.w, self.lib
@@ -287,20 +295,36 @@ class UNetEngine:
                 direct = stream16 and x1 is None and rs == DS_RESAMPLE_NONE and x0.dtype == torch.float16
                 need_raw = (b.skip_conv and not direct) or (stream16 and not b.skip_conv and rs != DS_RESAMPLE_NONE)
                 r16 = r16_buf[:M * cin].view(M, cin) if need_raw else None
+                # Round 5, `fuse_norm16`: where every source of a convolution is a raw fp16 tensor of the layer's own geometry, the GroupNorm
+                # affine + SiLU is applied by the convolution itself to its LDS halo (conv3x3_f16dma NORM: same arithmetic, same bits) and the
+                # ds_norm_act pass -- with it the materialised concatenation and the raw copy for the skip projection -- disappears; the
+                # statistics launch (ds_gn_finalize over the producers' column sums) stays.  Resampling blocks keep the pass for conv0.
+                raw16 = lambda t: t is None or t.dtype == torch.float16
+                fz0 = bool(self.fuse_norm16 and stream16 and rs == DS_RESAMPLE_NONE and raw16(x0) and raw16(x1) and c0 % 64 == 0 and c1 % 64 == 0)
+                fz1 = bool(self.fuse_norm16 and stream16)
                 norm('stats', x0, c0, c0, n, Hin, Hin, nm + '.norm0.stats', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps,
                      gamma=w[f'{nm}.norm0.g'], beta=w[f'{nm}.norm0.b'], coefs=ncoef)
-                norm('apply', x0, c0, c0, n, Hin, Hin, nm + '.norm0', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps, use_stats=False,
-                     act_=DS_ACT_SILU, resample=rs, out=a16, out_ld=cin, out_f16=True, raw_out=r16, raw_ld=cin, coefs=ncoef)
-                conv(a16, cin, cin, n, Ho, Ho, w[f'{nm}.conv0.w'], cout, h16, cout, 9, nm + '.conv0', bias=w[f'{nm}.conv0.b'], stats=True,
-                     w16=w16_0, in_f16=True, out_f16=True, **cb)
+                if fz0:
+                    r16 = None
+                    conv(x0, c0, c0, n, Ho, Ho, w[f'{nm}.conv0.w'], cout, h16, cout, 9, nm + '.conv0', x1=x1, c1=c1, ld1=c1,
+                         bias=w[f'{nm}.conv0.b'], stats=True, w16=w16_0, in_f16=True, out_f16=True, norm_coefs=ncoef, norm_act=DS_ACT_SILU, **cb)
+                else:
+                    norm('apply', x0, c0, c0, n, Hin, Hin, nm + '.norm0', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps, use_stats=False,
+                         act_=DS_ACT_SILU, resample=rs, out=a16, out_ld=cin, out_f16=True, raw_out=r16, raw_ld=cin, coefs=ncoef)
+                    conv(a16, cin, cin, n, Ho, Ho, w[f'{nm}.conv0.w'], cout, h16, cout, 9, nm + '.conv0', bias=w[f'{nm}.conv0.b'], stats=True,
+                         w16=w16_0, in_f16=True, out_f16=True, **cb)
                 ss = dict(scale=aff[:, aoff:], shift=aff[:, aoff + cout:], ss_ld=self.aff_total, ss_rows=Bs) if b.adaptive_scale else {}
                 norm('stats', h16, cout, cout, n, Ho, Ho, nm + '.norm1.stats', groups=G_out, eps=b.eps, gamma=w[f'{nm}.norm1.g'],
                      beta=w[f'{nm}.norm1.b'], coefs=ncoef, **ss)             # from conv0's epilogue sums (fp32), incl. the adaptive scale / shift
-                norm('apply', h16, cout, cout, n, Ho, Ho, nm + '.norm1', groups=G_out, eps=b.eps, use_stats=False, act_=DS_ACT_SILU,
-                     out=b16, out_ld=cout, out_f16=True, in_f16=True, coefs=ncoef)
+                if not fz1:
+                    norm('apply', h16, cout, cout, n, Ho, Ho, nm + '.norm1', groups=G_out, eps=b.eps, use_stats=False, act_=DS_ACT_SILU,
+                         out=b16, out_ld=cout, out_f16=True, in_f16=True, coefs=ncoef)
                 if b.skip_conv:          # 1x1 skip projection fused into conv1 as extra K columns on the raw (resampled) fp16 input
                     c1_w, c1_b = w[f'{nm}.conv1s.w'], w[f'{nm}.conv1s.b']
-                    c1_skip = dict(e0=x0 if direct else r16, ec0=cin)
+                    if fz0 and fz1:      # both raw sources straight from the stream: nothing was copied
+                        c1_skip = dict(e0=x0, ec0=c0, e1=x1, ec1=c1)
+                    else:
+                        c1_skip = dict(e0=x0 if direct else r16, ec0=cin)
                 elif stream16 and rs != DS_RESAMPLE_NONE:
                     c1_w, c1_b = w[f'{nm}.conv1.w'], w[f'{nm}.conv1.b']
                     c1_skip = dict(res=r16, res_ld=cout)          # resampled raw input, already written by the norm0 pass
@@ -313,7 +337,10 @@ class UNetEngine:
                     assert x1 is None and c0 == cout
                     c1_w, c1_b = w[f'{nm}.conv1.w'], w[f'{nm}.conv1.b']
                     c1_skip = dict(res=s0, res_ld=cout)
-                c1_in, c1_norm = b16, dict(in_f16=True)
+                if fz1:
+                    c1_in, c1_norm = h16, dict(in_f16=True, norm_coefs=ncoef, norm_act=DS_ACT_SILU)
+                else:
+                    c1_in, c1_norm = b16, dict(in_f16=True)
             # norm0 + silu (+resample) -> conv0 (+bias, + per-image embedding for the non-adaptive variant)
             elif fuse and rs == DS_RESAMPLE_NONE:
                 norm('stats', x0, c0, c0, n, Hin, Hin, nm + '.norm0.stats', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps,

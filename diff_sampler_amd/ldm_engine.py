@@ -20,6 +20,7 @@ reference runs this U-Net under autocast; fp32 is the stricter contract -- DESIG
 from __future__ import annotations
 
 import math
+import os
 import weakref
 from typing import Dict
 
@@ -43,6 +44,8 @@ class LDMUNetEngine:
         generic fp32 kernel, the round-3 routing) -- A/B knobs of benchmarks, the defaults are what the parity goldens were made with."""
         self.qkv_f16_min_head = int(qkv_f16_min_head)
         self.f16_downsample = bool(f16_downsample)
+        from .engine import FUSE_NORM16_DEFAULT
+        self.fuse_norm16 = os.environ.get('DS_FUSE_NORM16', FUSE_NORM16_DEFAULT) == '1'     # see engine.UNetEngine.fuse_norm16
         self.spec = spec
         self.device = torch.device(device)
         self.use_fp16 = bool(use_fp16)
@@ -127,7 +130,7 @@ class LDMUNetEngine:
     # ------------------------------------------------------------------------------------------ plan
     def plan(self, N: int, emb_rows: int, ctx_len: int) -> Plan:
         """N = images in the U-Net batch (2B under classifier-free guidance); emb_rows = 1 (shared sigma) or N."""
-        key = (N, emb_rows, ctx_len)
+        key = (N, emb_rows, ctx_len, self.fuse_norm16)
         if key in self._plans:
             return self._plans[key]
         spec, w, lib = self.spec, self.w, self.lib
@@ -181,9 +184,21 @@ class LDMUNetEngine:
                 # concatenation as an fp16 tensor (and, for a block with a skip_connection, the raw fp16 copy `raw16` that projection
                 # reads), the convolution is the fp16-activation matrix kernel (csrc/conv3x3_f16dma.hip).  `e16` = (raw fp16 tensor,
                 # channels) of a fused skip_connection; an fp16 `out` (a tensor that only feeds the next normalisation) is stored as such
-                a16 = bd.new16(N * side * side, cin)
                 bd.norm('stats', x0, c0, c0, N, side, side, name + '.gn.stats', x1=x1, c1=c1, ld1=c1, groups=32, eps=eps, gamma=gk,
                         beta=bk, coefs=ncoef)
+                raw_ok = lambda t: t is None or t.dtype == torch.float16
+                if self.fuse_norm16 and raw_ok(x0) and raw_ok(x1) and c0 % 64 == 0 and c1 % 64 == 0 and raw16 is None:
+                    # round 5: the convolution normalises its own LDS halo on the raw fp16 sources (conv3x3_f16dma NORM): no pass, no
+                    # materialised concatenation; a fused skip_connection reads its raw sources in place (e16 may name two)
+                    ex = {}
+                    if e16 is not None:
+                        ex = dict(e0=e16[0], ec0=e16[1])
+                        if len(e16) > 2 and e16[2] is not None:
+                            ex.update(e1=e16[2], ec1=e16[3])
+                    bd.conv(x0, c0, c0, N, side, side, wgt, cout, out, out_ld, 9, name, x1=x1, c1=c1, ld1=c1, bias=bias, stats=True, w16=w16,
+                            in_f16=True, out_f16=(out.dtype == torch.float16), norm_coefs=ncoef, norm_act=DS_ACT_SILU, **ex, **kw)
+                    return
+                a16 = bd.new16(N * side * side, cin)
                 bd.norm('apply', x0, c0, c0, N, side, side, name + '.gn', x1=x1, c1=c1, ld1=c1, groups=32, eps=eps, use_stats=False,
                         act=DS_ACT_SILU, out=a16, out_ld=cin, out_f16=True, raw_out=raw16, raw_ld=cin, coefs=ncoef,
                         in_f16=(x0.dtype == torch.float16))
@@ -217,10 +232,16 @@ class LDMUNetEngine:
             if dma16:
                 h1 = bd.new16(M, cout)                       # in_layers output: only read by the out_layers normalisation
                 direct = x1 is None and x0.dtype == torch.float16          # the input already is one fp16 tensor: no raw copy for the skip_connection
-                r16 = bd.new16(M, cin) if l.skip_conv and not direct else None
+                # fuse_norm16: both raw fp16 sources are read in place by in_layers AND by the fused skip_connection: no raw copy at all
+                both_raw = bool(self.fuse_norm16 and x0.dtype == torch.float16 and (x1 is None or x1.dtype == torch.float16)
+                                and c0 % 64 == 0 and c1 % 64 == 0)
+                r16 = bd.new16(M, cin) if l.skip_conv and not direct and not both_raw else None
                 gn_conv(x0, c0, x1, c1, res, w[f'{p}.n0.g'], w[f'{p}.n0.b'], 1e-5, w[f'{p}.c0.w'], w[f'{p}.c0.b'], cout, h1, cout,
                         p + '.in_layers', w16=w16_0, dma16=True, raw16=r16, cbias=aff[:, ao:], cbias_ld=self.aff_total, cbias_rows=emb_rows)
-                skip = dict(e16=(x0 if direct else r16, cin)) if l.skip_conv else dict(res=x0, res_ld=cout)
+                if l.skip_conv and both_raw and not direct:
+                    skip = dict(e16=(x0, c0, x1, c1))
+                else:
+                    skip = dict(e16=(x0 if direct else r16, cin)) if l.skip_conv else dict(res=x0, res_ld=cout)
                 if not l.skip_conv:
                     assert x1 is None and c0 == cout
                 gn_conv(h1, cout, None, 0, res, w[f'{p}.n1.g'], w[f'{p}.n1.b'], 1e-5, w[f'{p}.c1.w'], w[f'{p}.c1.b'], cout, out, cout,

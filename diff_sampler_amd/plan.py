@@ -258,7 +258,10 @@ class Builder:
             w16, in_f16 = (wgt, 0), True
         elif in_f16:
             # stride 2 (the LDM Downsample on the fp16 stream): the gather form of the fp16-activation GEMM; no extras, no residual
-            assert w16 is not None and taps == 9 and stride in (1, 2) and x1 is None and e1 is None and norm_coefs is None and not out_nchw
+            # (round 5) stride 1 with norm_coefs: RAW fp16 sources, the kernel normalises its LDS halo; second sources x1 / e1 allowed then
+            assert w16 is not None and taps == 9 and stride in (1, 2) and not out_nchw
+            assert norm_coefs is not None or (x1 is None and e1 is None), name
+            assert norm_coefs is None or (stride == 1 and all(t is None or t.dtype == torch.float16 for t in (x0, x1, e0, e1))), name
             assert stride == 1 or (not ec0 and res is None and self.lib.ds_conv_f16dma_stride2_supported(n, h, w, c0, cout)), name
         f16 = in_f16 or w16 is not None and taps == 9 and stride == 1 and self.f16_level(n, h, w, c0, c1, ec0, ec1) >= (2 if norm_coefs is not None else 1)
         shift = 0
@@ -286,7 +289,7 @@ class Builder:
             sb = self.new(-(-(n * h * w) // 64) * 2 * cout)
             a.stats_out = ptr(sb)
             self.stats_of[out.data_ptr()] = (sb, cout)
-        self._autotune(a, (x0, e0 if in_f16 else None))
+        self._autotune(a, (x0, e0 if in_f16 else None, x1 if in_f16 else None, e1 if in_f16 else None, norm_coefs if in_f16 else None))
         self.add(self.lib.ds_conv2d_nhwc, (C.byref(a),), name, keep=(a,))
 
     @staticmethod
@@ -295,7 +298,7 @@ class Builder:
         whether a split-K workspace is offered)."""
         t = a.tune
         return (a.taps, stride, a.n, a.h, a.w, a.c0, a.ec0, a.cout, a.act, a.out_f16, a.res_f16, bool(a.res), bool(a.cbias), bool(a.bias),
-                bool(a.stats_out), t.splits, a.ld0, a.out_ld, bool(a.workspace))
+                bool(a.stats_out), t.splits, a.ld0, a.out_ld, bool(a.workspace), bool(a.norm_coefs), a.c1, a.ec1)
 
     def _autotune(self, a, inputs):
         """Fill a.tune.f16dma_nb / f16dma_nw of an fp16-activation launch with the measured best (module docstring of AUTOTUNE): from the
@@ -327,14 +330,16 @@ class Builder:
         if a.taps == 1:                       # csrc/gemm_f16dma.hip: 128-row tiles hold at most 192 columns; the GEGLU gate pairs even widths
             cands = [(nb, nw) for nw in (4, 8) for nb in ((2, 4) if a.act == _lib.DS_ACT_GEGLU else (1, 2, 3, 4)) if nw == 8 or nb <= 3]
         else:                                 # 3x3 (stride 1: conv3x3_f16dma.hip, 256 columns only on 16- / 32-column images; stride 2: the gather GEMM)
-            cands = [(nb, 8) for nb in (1, 2, 3, 4) if nb < 4 or stride == 2 or a.w in (16, 32)]
+            cands = [(nb, 8) for nb in (1, 2, 3, 4) if nb < 4 or stride == 2 or (a.w in (16, 32) and not a.norm_coefs)]
         cands = [c for c in cands if 64 * c[0] <= -(-a.cout // 64) * 64]
         dev = inputs[0].device
         gen = torch.Generator(device=dev)
         gen.manual_seed(0x5eed)
-        for x in inputs:
+        for x in inputs[:4]:
             if x is not None and x.dtype == torch.float16:
                 x.normal_(generator=gen)
+        if len(inputs) > 4 and inputs[4] is not None:          # fused input normalisation: finite {mu, A, B} planes (the next ds_gn_finalize rewrites them)
+            inputs[4].normal_(generator=gen)
         if dev.index not in _FLUSH:
             _FLUSH[dev.index] = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
         flush = _FLUSH[dev.index]

@@ -153,7 +153,11 @@ typedef struct ds_conv_args {
     /* 1 (with wgt_f16 == 1; taps == 9, or taps == 1 = csrc/gemm_f16dma.hip with the plain-K fp16 weights of the Linear layers): THE INPUT IS fp16 -- x0 (and e0) point to fp16 NHWC tensors [M][ld0] (ld0 / eld0 in halfs,
      * multiples of 8; c0 % 64 == 0, c1 == ec1 == 0), already normalised / activated by ds_norm_act(out_f16) -- the reference's storage
      * type in this mode (networks_edm.py:486 runs the U-Net body on x.to(float16)).  The convolution is then a pure matrix kernel
-     * (csrc/conv3x3_f16dma.hip: both operands staged by LDS-DMA, 256-pixel x 64/128/192/256-channel tiles).  norm_coefs must be NULL.
+     * (csrc/conv3x3_f16dma.hip: both operands staged by LDS-DMA, 256-pixel x 64/128/192/256-channel tiles).
+     * Round 5, taps == 9 and stride 1 only: with norm_coefs != NULL the sources are the RAW fp16 tensors and the kernel applies
+     * in = act((x - mu) * A + B) to the halo in LDS (norm_act NONE / SILU; same arithmetic and rounding as ds_norm_act(out_f16), so
+     * the results equal the two-launch form bit for bit); x1 / e1 (c1, ec1 multiples of 64, ld1 / eld1 in halfs) are then allowed --
+     * the channel concatenation [x0 | x1] is not materialised; the planes are [n][3][c0 + c1].  Without norm_coefs, c1 == ec1 == 0.
      * Bias is fp32; residual / output are fp32 unless res_f16 / out_f16.  Availability: ds_conv_f16dma_supported(); otherwise DS_E_SHAPE. */
     int in_f16;
     /* 1: the OUTPUT is written as fp16 NHWC rows [M][out_ld halfs] (rounded to nearest even from the fp32 epilogue value; the GroupNorm

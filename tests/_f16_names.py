@@ -107,10 +107,10 @@ def f16dma_splits(a):
     M, N = a.n * a.h * a.w, a.cout
     if not a.workspace or a.tune.splits == 1:
         return 1
-    wide, _ = _f16dma_tiling(M, N, 4 if a.w in (16, 32) else 3)
+    wide, _ = _f16dma_tiling(M, N, 4 if (a.w in (16, 32) and not a.norm_coefs) else 3)
     tiles = sum((M // 256) * t for _, t, _ in wide)
     s = a.tune.splits if a.tune.splits > 1 else (256 // tiles if tiles <= 128 else 1)
-    kt_all = (a.c0 // 64) * 9 + a.ec0 // 64
+    kt_all = ((a.c0 + a.c1) // 64) * 9 + (a.ec0 + a.ec1) // 64
     s = min(s, 16, kt_all // 18, a.workspace_floats // (M * N))
     return s if s >= 2 else 1
 
@@ -119,7 +119,7 @@ def f16dma_tile_widths(a):
     """Column-tile widths (in 64-channel units) the launch uses when no width is forced or measured (tune.f16dma_nb == 0): the widest tiling
     for a split layer, else the cost model's (conv3x3_f16dma_plan)."""
     M, N = a.n * a.h * a.w, a.cout
-    cap = 4 if a.w in (16, 32) else 3
+    cap = 4 if (a.w in (16, 32) and not a.norm_coefs) else 3          # max_nb: no 256-column tile with the fused input normalisation
     if a.tune.f16dma_nb > 0:
         return [w for _, _, w in _f16dma_tiling(M, N, min(a.tune.f16dma_nb, cap))[0]]
     if f16dma_splits(a) > 1:

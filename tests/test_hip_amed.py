@@ -130,7 +130,7 @@ def test_init_hook_and_get_amed_prediction_shims_follow_the_reference_helpers(ne
     net = EDMDenoiser(spec, params)
     g = torch.Generator().manual_seed(4)
     B = 3
-    x = torch.randn(B, spec.img_channels, spec.img_resolution, spec.img_resolution, generator=g) * 2.0
+    x = torch.randn(B, spec.in_channels, spec.img_resolution, spec.img_resolution, generator=g) * 2.0
     lab = torch.eye(spec.label_dim)[torch.randint(spec.label_dim, (B,), generator=g)] if spec.label_dim else None
     tap, hook = solvers_amed.init_hook(net, class_labels=lab)
     assert len(tap) == 0

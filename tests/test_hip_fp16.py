@@ -245,3 +245,61 @@ def test_measured_tile_shapes_do_not_change_a_bit(which, monkeypatch):
         plan_mod._TUNE_CACHE.update(saved)
         plan_mod._MEASURED.clear()                                                  # the forced picks are not measurements
         plan_mod._MEASURED.update(saved_m)
+
+
+@pytest.mark.parametrize('which', ['imagenet64', 'sd15'])
+def test_fused_input_normalisation_plan_matches_the_pass_plan(which):
+    """engine.fuse_norm16 (round 5): the fp16 plans with GroupNorm apply + SiLU inside the convolutions' LDS halos against the plans with the
+    ds_norm_act passes, full-size nets (ImageNet-64 ADM at 4 images with labels; SD-1.5 at 2 latents under guidance = 4 U-Net images).  Every
+    fused layer computes the bits of its two-launch form (tests/test_hip_kernels.py); whole-network outputs may still differ in the last fp16
+    roundings where a layer's column tile changes (the fused kernel has no 256-column tile, and the staged epilogue's GroupNorm column sums
+    follow the tile geometry): bounded at 1e-3 of the output scale, a quarter of the mode's own noise.  The fused plan must have dropped at
+    least half of the ds_norm_act launches (what stays: the attention blocks' normalisation, resampling blocks, the fp32 stem) and none of
+    the statistics launches."""
+    from diff_sampler_amd import _lib
+    lib = _lib.load()
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(6)
+    if which == 'imagenet64':
+        from diff_sampler_amd.engine import EDMDenoiser
+        cfg = dict(arch.NAMED_CONFIGS['imagenet64'])
+        spec = arch.edm_precond_spec(**cfg)
+        params = arch.init_params(spec, seed=9)
+        sig = torch.tensor([30.0, 2.5, 0.3, 0.02]).to(dev)
+        x = (torch.randn(4, 3, 64, 64, generator=g)).to(dev) * sig.reshape(-1, 1, 1, 1)
+        lab = torch.eye(spec.label_dim)[torch.randint(spec.label_dim, (4,), generator=g)].to(dev)
+        net = EDMDenoiser(spec, params, use_fp16=True)
+        run = lambda: net(x, sig, class_labels=lab).clone()
+    else:
+        import diff_sampler_amd.ldm_arch as la
+        from diff_sampler_amd.ldm_engine import CFGDenoiser
+        spec = la.ldm_unet_spec(**la.NAMED_LDM_CONFIGS['sd15'])
+        params = la.init_ldm_params(spec, seed=3)
+        x = torch.randn(2, 4, 64, 64, generator=g).to(dev) * 3.0
+        cond, uncond = torch.randn(2, 77, 768, generator=g).to(dev), torch.randn(2, 77, 768, generator=g).to(dev)
+        net = CFGDenoiser(spec, params, dev, guidance_rate=7.5, use_fp16=True)
+        run = lambda: net(x, 3.0, condition=cond, unconditional_condition=uncond).clone()
+
+    def counts():
+        plan = list(net.engine._plans.values())[-1]
+        na = sum(1 for op in plan.ops if op.fn is lib.ds_norm_act)
+        fin = sum(1 for op in plan.ops if op.fn is lib.ds_gn_finalize or op.fn is lib.ds_gn_stats)
+        fused = sum(1 for op in plan.ops if op.fn is lib.ds_conv2d_nhwc and op.keep[0].in_f16 and op.keep[0].norm_coefs)
+        return na, fin, fused
+
+    net.engine.fuse_norm16 = False
+    base = run()
+    torch.cuda.synchronize()
+    na0, fin0, fused0 = counts()
+    net.engine.fuse_norm16 = True
+    out = run()
+    torch.cuda.synchronize()
+    na1, fin1, fused1 = counts()
+    assert torch.isfinite(out).all()
+    assert fused0 == 0 and fused1 >= 30, (fused0, fused1)
+    assert na1 * 2 <= na0 and fin1 == fin0, (na0, na1, fin0, fin1)
+    e = _rel(out, base)
+    REPORT[f'{which}_fused_norm'] = dict(norm_act_launches=[na0, na1], statistics_launches=[fin0, fin1], fused_convolutions=fused1, rel_vs_pass_plan=e)
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    json.dump(REPORT, open(os.path.join(ROOT, 'gpurun_out', 'fp16_parity.json'), 'w'), indent=1)
+    assert e < 1e-3, e

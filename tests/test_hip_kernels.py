@@ -1567,3 +1567,92 @@ def test_fused_attention_reads_fp16_q_k_v(d, heads, sq, skv, mask):
     if mask & 1:
         a.ldq = c + 4
         assert lib.ds_attention_f16(C.byref(a), _lib.stream_ptr()) != 0
+
+
+FUSED_NORM_CASES = [
+    # B, H(=W), c0, c1, cout, ec ('none' | 'same': the skip projection reads the same raw sources), forced nb, silu, forced splits
+    (1, 64, 192, 0, 192, 'none', 0, True, 0),        # ImageNet-64 64x64 layer: three slabs, 192-column tile, seven DMA rounds
+    (1, 64, 64, 64, 128, 'same', 2, True, 0),        # two sources of one slab each + two appended 1x1 slabs from two sources
+    (2, 32, 128, 64, 192, 'same', 3, True, 0),       # decoder concatenation 128 | 64, skip projection on both
+    (1, 32, 64, 0, 64, 'none', 1, False, 0),         # affine only (norm_act NONE), one slab: everything normalised in the prologue
+    (3, 16, 192, 0, 384, 'none', 0, True, 0),        # 16-column images: per-round swizzle
+    (2, 16, 320, 320, 320, 'same', 2, True, 0),      # SD-1.5 decoder shape class 640 -> 320
+    (8, 8, 256, 128, 256, 'same', 2, True, 0),       # four images per tile: per-image coefficient rows, 8-column swizzle
+    (4, 8, 768, 0, 768, 'none', 0, True, 4),         # split-K: every split normalises its own slabs
+    (4, 8, 512, 256, 256, 'same', 1, True, 3),       # split-K across the two sources and the appended slabs
+]
+
+
+@pytest.mark.parametrize('case', FUSED_NORM_CASES)
+def test_conv_f16_activations_fused_input_normalisation_equals_the_two_launch_form(case):
+    """ds_conv2d_nhwc(in_f16, norm_coefs) -- conv3x3_f16dma_kernel<.., NORM>: the RAW fp16 sources go to LDS by DMA and the kernel rewrites
+    its halo in place with silu((x - mu) * A + B) -- against the two-launch form it replaces: ds_norm_act(out_f16, coefs [, raw copy]) writing
+    the activated (and concatenated) fp16 tensor, then the same convolution on that tensor.  Same arithmetic, same rounding, same order of the
+    fp32 sums (tile width and split count forced equal) => EQUAL bits, output and GroupNorm column sums.  Also bounded against an fp64
+    reference on the CPU (1.5e-3 of the output scale: fp16 operands, one ulp of the device exp here and there)."""
+    import ctypes as C
+    from diff_sampler_amd import _lib, ops
+    B, H, c0, c1, cout, ec, nb, silu, splits = case
+    lib = _lib.load()
+    dev = 'cuda'
+    cin, M = c0 + c1, B * H * H
+    g = torch.Generator().manual_seed(sum(case[:5]) + 3)
+    x = torch.randn(M, cin, generator=g).to(torch.float16)
+    planes = torch.stack([0.3 * torch.randn(B, cin, generator=g), 1 + 0.2 * torch.randn(B, cin, generator=g), 0.2 * torch.randn(B, cin, generator=g)], 1).contiguous()
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    we = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5 if ec == 'same' else None
+    bias = torch.randn(cout, generator=g)
+    xd = x.to(dev)
+    x0 = xd[:, :c0].contiguous()
+    x1 = xd[:, c0:].contiguous() if c1 else None
+    pl = planes.to(dev)
+    wp = ops.pack_conv_weight_f16(w.to(dev), we.to(dev) if we is not None else None)
+    biasd = bias.to(dev)
+    ws = torch.zeros(16 * M * cout, device=dev) if splits else None
+    # ---- two-launch form: norm pass (concatenation materialised, raw copy for the skip projection), then the convolution
+    a16 = torch.zeros(M, cin, dtype=torch.float16, device=dev)
+    r16 = torch.zeros(M, cin, dtype=torch.float16, device=dev)
+    na = ops._norm_args(x0, c0, c0, B, H, H, x1=x1, c1=c1, ld1=c1, act=(1 if silu else 0), out=a16, out_ld=cin)
+    na.out, na.coefs, na.in_f16 = C.c_void_p(a16.data_ptr()), C.c_void_p(pl.data_ptr()), 3 if c1 else 1
+    na.out_f16, na.raw_out, na.raw_ld = 1, C.c_void_p(r16.data_ptr()), cin
+    assert lib.ds_norm_act(C.byref(na), _lib.stream_ptr()) == 0
+
+    def run(fused):
+        out = torch.full((M, cout), float('nan'), dtype=torch.float16, device=dev)
+        stats = torch.full((-(-M // 64) * 2 * cout,), float('nan'), device=dev)
+        if fused:
+            a = _lib.ConvArgs(x0.data_ptr(), x1.data_ptr() if c1 else None, c0, c1, c0, c1, B, H, H, 9, wp.data_ptr(), cout, biasd.data_ptr(), None, 0, 1,
+                              None, 0, 0.7071, 0, out.data_ptr(), cout, pl.data_ptr(), 1 if silu else 0,
+                              x0.data_ptr() if we is not None else None, x1.data_ptr() if (we is not None and c1) else None,
+                              c0 if we is not None else 0, c1 if we is not None else 0, c0 if we is not None else 0, c1 if we is not None else 0)
+        else:
+            a = _lib.ConvArgs(a16.data_ptr(), None, cin, 0, cin, 0, B, H, H, 9, wp.data_ptr(), cout, biasd.data_ptr(), None, 0, 1,
+                              None, 0, 0.7071, 0, out.data_ptr(), cout, None, 0,
+                              r16.data_ptr() if we is not None else None, None, cin if we is not None else 0, 0, cin if we is not None else 0, 0)
+        a.wgt_f16, a.in_f16, a.out_f16, a.stats_out = 1, 1, 1, stats.data_ptr()
+        a.tune.f16dma_nb = nb if nb else 3                 # the same column tiles in both forms (the fused kernel has no 256-column tile)
+        if splits:
+            a.workspace, a.workspace_floats, a.tune.splits = ws.data_ptr(), ws.numel(), splits
+        else:
+            a.tune.splits = 1
+        assert lib.ds_conv_kernel_id(C.byref(a)) == (2572 if fused else 2566)
+        rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
+        torch.cuda.synchronize()
+        assert rc == 0, lib.ds_error_string(rc)
+        return out, stats
+
+    o_ref, s_ref = run(False)
+    o_fus, s_fus = run(True)
+    assert torch.isfinite(o_fus.float()).all()
+    assert torch.equal(o_fus, o_ref), float((o_fus.float() - o_ref.float()).abs().max())
+    assert torch.equal(s_fus, s_ref)
+    # fp64 reference of the whole thing
+    xf = x.double().reshape(B, H * H, cin)
+    t = (xf - planes[:, 0].double()[:, None]) * planes[:, 1].double()[:, None] + planes[:, 2].double()[:, None]
+    t = F.silu(t) if silu else t
+    xin = t.to(torch.float16).double().reshape(B, H, H, cin).permute(0, 3, 1, 2)
+    ref = F.conv2d(xin, w.to(torch.float16).double(), padding=1)
+    if we is not None:
+        ref = ref + F.conv2d(x.double().reshape(B, H, H, cin).permute(0, 3, 1, 2), we.to(torch.float16).double())
+    ref = ((ref + bias.double()[None, :, None, None]) * 0.7071).permute(0, 2, 3, 1).reshape(M, cout).float()
+    assert _rel(o_fus.float().cpu(), ref) < 1.5e-3
