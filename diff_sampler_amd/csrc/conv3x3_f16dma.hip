@@ -33,7 +33,7 @@
 // (bias, per-image bias, fp16 / fp32 residual, activation, fp16 / fp32 rows, GroupNorm column sums of the stored values).
 // Fused input normalisation (round 5; NORM instantiations, ds_conv_args.norm_coefs with in_f16): the operand may be the RAW fp16 tensor
 // (the block input / conv0's output as the producing epilogue stored it) instead of the activated copy a ds_norm_act pass writes.  The raw
-// halo still arrives by LDS-DMA; once a DMA round of slab s + 1 has landed (one tap after it was issued) every thread rewrites the 16-byte
+// halo still arrives by LDS-DMA; once a DMA round of slab s + 1 has landed (two taps after it was issued) every thread rewrites the 16-byte
 // unit IT fetched in place: h = silu((x - mu[c]) * A[c] + B[c]) -- the same fp32 expression and the same RNE rounding as norm_act_kernel, so
 // the convolution's output bits equal those of the two-launch form -- while slab s is multiplied.  Out-of-image halo pixels are zero pages
 // and are skipped (they must stay zero AFTER the affine).  The {mu, A, B} rows of the slab's 64 channels (768 B per image of the tile) ride
@@ -392,10 +392,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
             }
         }
         DS2_FENCE();
-        if constexpr (NORM && !X && T9 < NDMA) {
-            // round T9 of the NEXT 3x3 slab's halo was issued one tap ago (round 0: at the previous slab's last tap, or in the prologue) and
-            // this tap's DMA wait covered it: normalise it now, in the registers the last K step's fragments have just released
-            if (chunk + 1 < nchunks && chunk + 1 < NCH) norm_round((chunk + 1) & 1, IC<T9>{});
+        if constexpr (NORM && !X && T9 >= 1 && T9 <= NDMA) {
+            // round T9 - 1 of the NEXT 3x3 slab's halo was issued TWO taps ago (round 0: at the previous slab's last tap, or in the prologue),
+            // so this tap's DMA wait covered it under every ring depth: with D = 4 the wait leaves the youngest 2 NB requests outstanding, and
+            // a round issued only one tap ago sits among them (behind that tap's NB weight rows).  Normalise it now, in the registers the last
+            // K step's fragments have just released; rounds 0 .. NDMA - 1 <= 6 take taps 1 .. 7, the slab's last barrier publishes them.
+            if (chunk + 1 < nchunks && chunk + 1 < NCH) norm_round((chunk + 1) & 1, IC<T9 - 1>{});
             DS2_FENCE();
         }
         ++kt; slot = nslot;

@@ -251,9 +251,9 @@ def test_measured_tile_shapes_do_not_change_a_bit(which, monkeypatch):
 def test_fused_input_normalisation_plan_matches_the_pass_plan(which):
     """engine.fuse_norm16 (round 5): the fp16 plans with GroupNorm apply + SiLU inside the convolutions' LDS halos against the plans with the
     ds_norm_act passes, full-size nets (ImageNet-64 ADM at 4 images with labels; SD-1.5 at 2 latents under guidance = 4 U-Net images).  Every
-    fused layer computes the bits of its two-launch form (tests/test_hip_kernels.py); whole-network outputs may still differ in the last fp16
-    roundings where a layer's column tile changes (the fused kernel has no 256-column tile, and the staged epilogue's GroupNorm column sums
-    follow the tile geometry): bounded at 1e-3 of the output scale, a quarter of the mode's own noise.  The fused plan must have dropped at
+    fused layer computes the bits of its two-launch form (tests/test_hip_kernels.py), so with the tile width and the split-K factor pinned
+    equal in both plans (the fused kernel has no 256-column tile; the split factor follows the widest tiling) the whole-network outputs must
+    be EQUAL bit for bit -- GroupNorm statistics, attention and the guidance combination included.  The fused plan must have dropped at
     least half of the ds_norm_act launches (what stays: the attention blocks' normalisation, resampling blocks, the fp32 stem) and none of
     the statistics launches."""
     from diff_sampler_amd import _lib
@@ -287,11 +287,27 @@ def test_fused_input_normalisation_plan_matches_the_pass_plan(which):
         fused = sum(1 for op in plan.ops if op.fn is lib.ds_conv2d_nhwc and op.keep[0].in_f16 and op.keep[0].norm_coefs)
         return na, fin, fused
 
+    def same_tiles():
+        """Pin what may legitimately differ between the two plans of a layer: the fused kernel has no 256-column tile, and the split-K factor
+        follows the widest tiling -- so cap every fp16 3x3 launch of BOTH plans at 192-column tiles without split-K.  What is left is the
+        same fp32 sum order everywhere: the outputs must then be EQUAL."""
+        plan = list(net.engine._plans.values())[-1]
+        for op in plan.ops:
+            if op.fn is lib.ds_conv2d_nhwc and op.keep[0].in_f16 and op.keep[0].taps == 9 and (op.keep[0].stride or 1) == 1:
+                t = op.keep[0].tune
+                t.f16dma_nb = min(t.f16dma_nb, 3) if t.f16dma_nb else 3
+                t.splits = 1
+        plan.close()                                            # the native copy of the argument structs is rebuilt on the next run
+
     net.engine.fuse_norm16 = False
+    run()
+    same_tiles()
     base = run()
     torch.cuda.synchronize()
     na0, fin0, fused0 = counts()
     net.engine.fuse_norm16 = True
+    run()
+    same_tiles()
     out = run()
     torch.cuda.synchronize()
     na1, fin1, fused1 = counts()
@@ -302,4 +318,4 @@ def test_fused_input_normalisation_plan_matches_the_pass_plan(which):
     REPORT[f'{which}_fused_norm'] = dict(norm_act_launches=[na0, na1], statistics_launches=[fin0, fin1], fused_convolutions=fused1, rel_vs_pass_plan=e)
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     json.dump(REPORT, open(os.path.join(ROOT, 'gpurun_out', 'fp16_parity.json'), 'w'), indent=1)
-    assert e < 1e-3, e
+    assert torch.equal(out, base), e
