@@ -64,7 +64,7 @@ WORKLOAD_NAMES = {'cifar10': 'EDM CIFAR-10 32x32 SongUNet (55.7M params)', 'ffhq
                   'sd15': 'Stable Diffusion v1.5 64x64x4 latent U-Net (859.5M params)'}
 SOLVER_NAMES = {'dpmpp': 'DPM-Solver++(2M) logSNR', 'euler': 'Euler', 'ipndm': 'iPNDM-4', 'heun': 'Heun'}
 LDM_SOLVER_NAME = 'DPM-Solver++(2M) eps-prediction, discrete rho=1, CFG 7.5 (2 U-Net images per latent; new text conditions on every call: the context K / V projections are inside the timed region)'
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r4_bench_pmc_hbm.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r5_bench_pmc_hbm.json')
 PMC_NOTE = {}
 KERNEL_NAMES = {0: 'igemm_f32_kernel<0> (generic gather conv / 1x1 / linear)', 128: 'conv3x3_halo_kernel<2> (128-pixel tiles)',
                 1284: 'conv3x3_halo_kernel<2, WN=4, NT=1> (128-pixel tiles on 8 waves of 64 x 32)',

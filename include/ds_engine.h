@@ -48,7 +48,8 @@ extern "C" {
 #define DS_RESAMPLE_UP 2    /* nearest neighbour x2      (networks_edm.py:75 with resample_filter [1,1]) */
 
 DS_API int ds_version(void);      /* 2 since round 4: ds_conv_args.tune / ds_update_args.variant appended (struct sizes changed), ds_fid_moments added, the
-                               * process-global ds_debug_* setters removed.  A host must check it before passing argument structs. */
+                               * process-global ds_debug_* setters removed.  A host must check it before passing argument structs.  Round 5 kept every
+                               * struct layout (still 2): ds_build_experiments() is new, ds_conv_args.norm_coefs is now also accepted with in_f16. */
 DS_API const char* ds_error_string(int code);
 DS_API int ds_build_experiments(void);   /* 1: the library was built with DS_BUILD_EXPERIMENTS=1 and also holds the kernel variants kept as A/B records
                                           * (conv3x3_f16dmah, conv3x3_halo2 modes 0 / 1: reachable through ds_conv_args.tune only, never chosen by

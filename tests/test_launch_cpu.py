@@ -150,14 +150,16 @@ def test_pmc_traffic_is_tied_to_the_kernel_source_it_was_measured_on(tmp_path, m
     f.write_text(json.dumps({'kernels': kern}))                               # a summary without provenance (round 3's) is not trusted
     assert bench.pmc_traffic(2565) is None
     # kernel CLASSES of the fp16 engines (other_configs): all instantiations of the class, averaged over their launches
-    kern16 = {'void igemm::(anonymous namespace)::conv3x3_f16dma_kernel<64, 3, true>(igemm::KParams)': row(1000.0, 400.0, 30),
-              'void igemm::(anonymous namespace)::conv3x3_f16dma_kernel<8, 2, false>(igemm::KParams)': row(100.0, 40.0, 10),
+    kern16 = {'void igemm::(anonymous namespace)::conv3x3_f16dma_kernel<64, 3, true, false>(igemm::KParams)': row(1000.0, 400.0, 30),
+              'void igemm::(anonymous namespace)::conv3x3_f16dma_kernel<8, 2, false, false>(igemm::KParams)': row(100.0, 40.0, 10),
+              'void igemm::(anonymous namespace)::conv3x3_f16dma_kernel<32, 3, true, true>(igemm::KParams)': row(7.0, 3.0, 5),      # NORM instantiation: class 2572
               'norm_act_kernel(ds_norm_args, int, int, int)': row(50.0, 50.0, 7)}
     f16 = tmp_path / 'pmc16.json'
     monkeypatch.setitem(bench.PMC_FILES, ('imagenet64', 'fp16'), str(f16))
     f16.write_text(json.dumps({'meta': {'session': 'gpurun_out/y', 'kernel_source_sha256': build.source_hashes()}, 'kernels': kern16}))
     byts, src = bench.pmc_traffic(2566, ('imagenet64', 'fp16'))
     assert byts == round(1024 * (2 * (1000.0 * 30 + 100.0 * 10) + (400.0 * 30 + 40.0 * 10)) / 40) and src['instantiations'] == 2
+    assert bench.pmc_traffic(2572, ('imagenet64', 'fp16'))[0] == round(1024 * 17.0)
     assert bench.pmc_traffic('norm_act', ('imagenet64', 'fp16'))[0] == round(1024 * 150.0)
     assert bench.pmc_traffic(2567, ('imagenet64', 'fp16')) is None            # no row of that class in the pass
     # the hash is of the CODE: comments and whitespace do not count, a changed token does
