@@ -208,13 +208,48 @@ def test_bench_defaults_are_the_workloads_the_kept_lines_are_quoted_on():
         line = [x for x in open(os.path.join(ROOT, 'profiles', name)).read().splitlines() if x.startswith('{')][-1]
         assert f'batch {b}/GPU' in json.loads(line)['config']['workload'], name
     # round 4: ONE default run carries the headline and, under the same clock, the other configurations (`other_configs`) + `latency`
-    line = json.loads([x for x in open(os.path.join(ROOT, 'profiles', 'r4_bench_line.json')).read().splitlines() if x.startswith('{')][-1])
+    line = json.loads([x for x in open(os.path.join(ROOT, 'profiles', 'r5_bench_line.json')).read().splitlines() if x.startswith('{')][-1])
     assert 'batch 256/GPU' in line['config']['workload'] and line['dtype'] == 'fp32'
     got = [(o['config']['workload'], o['dtype']) for o in line['other_configs']]
     for (cfg, dt, b), (wl, odt) in zip(bench.OTHER_CONFIGS, got):
         assert f'batch {b}/GPU' in wl and odt == dt and bench.WORKLOAD_NAMES[cfg].split(' (')[0] in wl, (cfg, wl)
     assert all('error' not in o and o['roofline']['frac'] > 0 and 0 < o['application']['frac'] < 1 for o in line['other_configs'])
     assert set(line['latency']) == {'cifar10_fp32_B8_nfe10_ms', 'sd15_fp16_B1_nfe10_ms'}
+    # round 5: every line's dominant kernel carries its HBM traffic (PMC, with provenance), the fp16 lines an HBM-bound entry for the norm pass
+    assert line['roofline']['traffic'] > 0 and line['roofline']['traffic_source']['file'] == 'profiles/r5_bench_pmc_hbm.json'
+    for o in line['other_configs']:
+        assert o['roofline']['traffic'] > 0 and o['roofline']['traffic_source']['file'].startswith('profiles/r5_pmc_hbm_'), o['config']
+        if o['dtype'] == 'fp16':
+            n = o['roofline_norm_act']
+            assert n['bound'] == 'hbm' and 0.2 < n['frac'] < 1 and n['traffic'] > 0.9 * n['algorithmic_bytes_per_launch'], n
+
+
+def test_committed_tile_table_matches_the_kernel_sources_and_covers_the_benchmarked_plans():
+    """profiles/tile_table.json (plan.Builder._autotune): measured on THESE kernel sources (else it would be ignored and plan builds would fall
+    back to on-box timing races), and it holds every eligible fp16-activation launch of the two benchmarked fp16 plans -- built here on the
+    CPU, where nothing is measured -- so that `bench.py` builds them without a single measurement launch."""
+    sys.path.insert(0, ROOT)
+    import diff_sampler_amd.arch as arch
+    import diff_sampler_amd.ldm_arch as la
+    from diff_sampler_amd import _lib, plan as plan_mod
+    from diff_sampler_amd.engine import UNetEngine
+    from diff_sampler_amd.ldm_engine import LDMUNetEngine
+    entries = plan_mod.load_tile_table(force=True)
+    assert plan_mod._TABLE['why'] is None, plan_mod._TABLE['why']
+    assert len(entries) >= 300
+    lib = _lib.load()
+    spec = arch.edm_precond_spec(**dict(arch.NAMED_CONFIGS['imagenet64']))
+    plans = [UNetEngine(spec, arch.init_params(spec, seed=0), device='cpu', use_fp16=True).plan(64, 64)]
+    lspec = la.ldm_unet_spec(**dict(la.NAMED_LDM_CONFIGS['sd15']))
+    plans.append(LDMUNetEngine(lspec, la.init_ldm_params(lspec, seed=0), device='cpu', use_fp16=True).plan(32, 1, 77))
+    missing = n = 0
+    for P in plans:
+        for op in P.ops:
+            if op.fn is lib.ds_conv2d_nhwc and op.keep[0].in_f16 and plan_mod._tile_neutral(op.keep[0]):
+                a = op.keep[0]
+                n += 1
+                missing += str(plan_mod.Builder._tune_key(a, a.stride or 1)) not in entries
+    assert n > 150 and missing == 0, (n, missing)
 
 
 def test_sample_cli_under_two_gloo_ranks_writes_every_seed_exactly_once(tmp_path):
