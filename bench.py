@@ -701,6 +701,14 @@ def main(argv=None):
                           frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, launches_per_step=ul, avg_launch_ms=round(ums / ul, 4),
                           algorithmic_bytes_per_step=byts,
                           note='latency-bound at this batch (3 MB per operand, one workgroup per image); roofline_update_large_batch has the same kernel at 16 384 images per launch')
+        elif ldm is None and args.solver != 'dpmpp' and 'solver_update_kernel' not in rec:
+            # the linear solvers' update runs INSIDE the network head (ds_conv_args.update, csrc/conv3x3_thin.hip): there is no update launch
+            # to time -- its bytes (x, history in; x', history entry out) move in the head's epilogue while F is still in a register
+            passes = {'euler': 3, 'ipndm': 7, 'heun': 3.5}[args.solver]
+            roof_u = dict(bound='hbm', kernel='conv3x3_thin_kernel<., UPD> epilogue (the solver update rides in the network head: no launch of its own)',
+                          fused=True, achieved=None, peak=PEAK_HBM_GBS, unit='GB/s', frac=None, traffic=None, launches_per_step=0,
+                          algorithmic_bytes_per_step=int((passes - 1) * per * B * args.nfe),
+                          note='F is never re-read; see roofline_update_large_batch for the stand-alone kernel where it is bandwidth-bound')
         elif 'solver_update_kernel' in rec and ldm is None:
             ums, ul, _ = rec['solver_update_kernel']
             passes = {'dpmpp': 7, 'euler': 3, 'ipndm': 7, 'heun': 3.5}[args.solver]

@@ -74,7 +74,8 @@ class ConvArgs(C.Structure):
                 ('norm_coefs', vp), ('norm_act', C.c_int),
                 ('e0', vp), ('e1', vp), ('ec0', C.c_int), ('ec1', C.c_int), ('eld0', C.c_int), ('eld1', C.c_int),
                 ('stride', C.c_int), ('workspace', vp), ('workspace_floats', C.c_longlong),
-                ('out_nchw', C.c_int), ('stats_out', vp), ('wgt_f16', C.c_int), ('wgt_shift', C.c_int), ('in_f16', C.c_int), ('out_f16', C.c_int), ('res_f16', C.c_int), ('tune', ConvTune)]
+                ('out_nchw', C.c_int), ('stats_out', vp), ('wgt_f16', C.c_int), ('wgt_shift', C.c_int), ('in_f16', C.c_int), ('out_f16', C.c_int), ('res_f16', C.c_int), ('tune', ConvTune),
+                ('update', vp)]          # const ds_update_args*: the solver update fused into the network head (ABI 3)
 
 
 class GemmArgs(C.Structure):
@@ -227,8 +228,8 @@ def load():
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.ds_version() != 2:
-        raise DsError(f'{LIB_PATH} reports ABI version {lib.ds_version()}, this binding is written for 2: rebuild it (python diff_sampler_amd/build.py)')
+    if lib.ds_version() != 3:
+        raise DsError(f'{LIB_PATH} reports ABI version {lib.ds_version()}, this binding is written for 3: rebuild it (python diff_sampler_amd/build.py)')
     _lib = lib
     return lib
 

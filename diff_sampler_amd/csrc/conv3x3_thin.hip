@@ -12,6 +12,11 @@
 // + SiLU, four 16-byte weight vectors from LDS ([tap][step][channel of the quad][j][4 outputs]: 128 contiguous bytes per instruction and
 // pixel group, the eight groups read the same addresses), 16 FMAs.  The eight channel-quad lanes of a pixel are summed at the end (two
 // quad_perm adds + one row_half_mirror add) and lane j = 0 stores: channel-planar (NCHW, ds_conv_args.out_nchw) or rows.
+// Round 5, UPD instantiations (ds_conv_args.update): the SOLVER UPDATE runs in this epilogue -- north_star's "fused back-to-back with the
+// solver's scaled-AXPY / multistep linear-combination update" taken literally.  The lane that holds a pixel's <= 4 outputs F applies
+// ds_upd_element (csrc/ds_common.h: the arithmetic of ds_solver_update, one definition for both forms => equal bits) per channel: EDM
+// preconditioning D = c_skip x + c_out F, d = (x - D) / t, x' = cx xb + cm m + sum ch[k] hist[k], and stores x' and the history entry m next
+// to F.  No update launch, no re-read of F; the per-sample coefficient rows of the AMED solvers work unchanged.
 // Arithmetic: exact fp32 products, fp32 accumulation (order: channel-quad lane, then 32-channel steps, then taps) -- the same class as the fp32
 // MFMA kernels it replaces; tests compare it with them (ds_conv_tune.mode = 8 switches it off).
 #include "igemm_common.h"
@@ -26,8 +31,8 @@ __device__ __forceinline__ float thin_dpp_add(float v) {
 
 // NORM: 0 = plain input, 1 = fused {mu, A, B} normalisation, 2 = normalisation + SiLU (compile time: a runtime branch per tap inside the
 // loop split it into nine scheduling regions and the allocator spilled 144 registers)
-template <int NORM>
-__global__ void __launch_bounds__(256, 4) conv3x3_thin_kernel(const KParams p) {
+template <int NORM, bool UPD>
+__global__ void __launch_bounds__(256, 4) conv3x3_thin_kernel(const KParams p, const ds_update_args u) {
     extern __shared__ __attribute__((aligned(16))) float smem_thin[];
     f32x4* wl = reinterpret_cast<f32x4*>(smem_thin);              // [9][S][4][8] vectors of 4 outputs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -106,12 +111,28 @@ __global__ void __launch_bounds__(256, 4) conv3x3_thin_kernel(const KParams p) {
             acc[n] = r;
         }
         if (j == 0) {
+            DsUpdCoefs k{};
+            float cskip = 0.f, cout_ = 0.f;
+            if constexpr (UPD) {
+                k = ds_upd_load_coefs(u, img);
+                cskip = ds_c_skip(k.sig, u.sigma_data); cout_ = ds_c_out(k.sig, u.sigma_data);
+            }
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 if (n < p.N) {
                     const float o = (acc[n] + bias[n]) * scale;
                     if (p.out_planar) p.out[((size_t)img * p.N + n) * p.HW + pim] = o;
                     else p.out[(size_t)m * p.ldo + n] = o;
+                    if constexpr (UPD) {                       // the solver update on this element: NCHW operands at the element's own offset
+                        const size_t off = ((size_t)img * p.N + n) * p.HW + pim;
+                        const float x = u.xe[off];
+                        const float xb = u.xb != u.xe ? u.xb[off] : x;
+                        float mm, xo;
+                        ds_upd_element(k, cskip, cout_, true, u.store_d != 0, x, xb, o, u.hist[0] != nullptr, u.hist[0] ? u.hist[0][off] : 0.f,
+                                       u.hist[1] != nullptr, u.hist[1] ? u.hist[1][off] : 0.f, u.hist[2] != nullptr, u.hist[2] ? u.hist[2][off] : 0.f, mm, xo);
+                        if (u.m_out) u.m_out[off] = mm;
+                        if (u.x_out) u.x_out[off] = xo;
+                    }
                 }
             }
         }
@@ -131,19 +152,29 @@ bool conv3x3_thin_applicable(const KParams& p) {
     return true;
 }
 
+// the fused update is on when the call carries a struct with at least one output (ds_conv_args.update)
+static bool thin_update_on(const KParams& p) { return p.upd && (p.upd->x_out || p.upd->m_out); }
+
 int launch_conv3x3_thin(KParams& p, hipStream_t stream) {
     const int smem = 9 * p.c0 * 16;
     const unsigned blocks = (unsigned)((p.M + 255) / 256);
-    if (p.norm && p.norm_act == DS_ACT_SILU) {
-        DS_ENSURE_DYN_LDS((&conv3x3_thin_kernel<2>), 160 * 1024);
-        hipLaunchKernelGGL((conv3x3_thin_kernel<2>), dim3(blocks), dim3(256), smem, stream, p);
-    } else if (p.norm) {
-        DS_ENSURE_DYN_LDS((&conv3x3_thin_kernel<1>), 160 * 1024);
-        hipLaunchKernelGGL((conv3x3_thin_kernel<1>), dim3(blocks), dim3(256), smem, stream, p);
-    } else {
-        DS_ENSURE_DYN_LDS((&conv3x3_thin_kernel<0>), 160 * 1024);
-        hipLaunchKernelGGL((conv3x3_thin_kernel<0>), dim3(blocks), dim3(256), smem, stream, p);
+    const bool upd = thin_update_on(p);
+    ds_update_args u{};
+    if (upd) {
+        u = *p.upd;                                                // read at call time (include/ds_engine.h)
+        if (!p.out_planar || !u.xe || !u.xb || !u.raw || u.afs || u.f_ld != 0) return DS_E_ARG;
+        if (u.c != p.N || (long long)u.n * u.h * u.w != (long long)p.M || u.h * u.w != p.HW) return DS_E_ARG;
+        if (u.coefs && u.coef_rows != 1 && u.coef_rows != u.n) return DS_E_ARG;
     }
+#define DST_LAUNCH(NORM_, UPD_)                                                                                    \
+    do {                                                                                                           \
+        DS_ENSURE_DYN_LDS((&conv3x3_thin_kernel<NORM_, UPD_>), 160 * 1024);                                        \
+        hipLaunchKernelGGL((conv3x3_thin_kernel<NORM_, UPD_>), dim3(blocks), dim3(256), smem, stream, p, u);       \
+    } while (0)
+    if (p.norm && p.norm_act == DS_ACT_SILU) { if (upd) DST_LAUNCH(2, true); else DST_LAUNCH(2, false); }
+    else if (p.norm) { if (upd) DST_LAUNCH(1, true); else DST_LAUNCH(1, false); }
+    else { if (upd) DST_LAUNCH(0, true); else DST_LAUNCH(0, false); }
+#undef DST_LAUNCH
     DS_CHECK_LAUNCH();
     return DS_OK;
 }

@@ -42,3 +42,34 @@ __device__ __forceinline__ float ds_silu(float v) { return v * __builtin_amdgcn_
 __device__ __forceinline__ float ds_c_skip(float s, float sd) { return (sd * sd) / (s * s + sd * sd); }
 __device__ __forceinline__ float ds_c_out(float s, float sd) { return s * sd / sqrtf(s * s + sd * sd); }
 __device__ __forceinline__ float ds_c_in(float s, float sd) { return 1.0f / sqrtf(sd * sd + s * s); }
+
+// ---- The solver update's per-element arithmetic (ds_solver_update, include/ds_engine.h), shared by the update kernels (solver.hip) and by the
+// network head that applies it in its epilogue (conv3x3_thin.hip, ds_conv_args.update): ONE definition with explicit fused multiply-adds,
+// so that the fused and the two-launch form produce equal bits by construction (no compiler contraction choice is involved).
+//     D = raw ? c_skip * x + c_out * F : F;  d = (x - D) / t;  m = store_d ? d : D;  x' = cx * xb + cm * m + sum_k ch[k] * hist[k]
+struct DsUpdCoefs { float cx, cm, ch0, ch1, ch2, t, sig, pad; };
+
+__device__ __forceinline__ DsUpdCoefs ds_upd_load_coefs(const ds_update_args& a, int img) {
+    DsUpdCoefs c;
+    if (a.coefs) {
+        const float* r = a.coefs + (size_t)(a.coef_rows == 1 ? 0 : img) * 8;
+        c.cx = r[0]; c.cm = r[1]; c.ch0 = r[2]; c.ch1 = r[3]; c.ch2 = r[4]; c.t = r[5]; c.sig = r[6]; c.pad = 0.f;
+    } else {
+        c.cx = a.hcoefs[0]; c.cm = a.hcoefs[1]; c.ch0 = a.hcoefs[2]; c.ch1 = a.hcoefs[3]; c.ch2 = a.hcoefs[4];
+        c.t = a.hcoefs[5]; c.sig = a.hcoefs[6]; c.pad = 0.f;
+    }
+    return c;
+}
+
+// one element; h0 / h1 / h2 are read only where has0 / has1 / has2 (the history pointers) say so
+__device__ __forceinline__ void ds_upd_element(const DsUpdCoefs& k, float cskip, float cout_, bool raw, bool store_d, float x, float xb, float f,
+                                               bool has0, float h0, bool has1, float h1, bool has2, float h2, float& m, float& xo) {
+    const float D = raw ? __builtin_fmaf(cskip, x, cout_ * f) : f;             // networks_edm.py:495
+    const float d = (x - D) / k.t;                                             // solvers.py:80
+    m = store_d ? d : D;
+    float acc = __builtin_fmaf(k.cx, xb, k.cm * m);
+    if (has0) acc = __builtin_fmaf(k.ch0, h0, acc);
+    if (has1) acc = __builtin_fmaf(k.ch1, h1, acc);
+    if (has2) acc = __builtin_fmaf(k.ch2, h2, acc);
+    xo = acc;
+}

@@ -448,6 +448,7 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
         p.part = a->workspace; p.part_cap = a->workspace_floats; p.vec_part = (p.N & 3) ? 0 : 1;
     }
     if (a->wgt_f16) {
+        if (a->update && (a->update->x_out || a->update->m_out)) return DS_E_ARG;      // the fused solver update exists in the fp32 head kernel only
         // fp16 operands (1) or split fp16 hi/lo operands (2): second-generation halo kernel only, every 128-column tile (the ragged
         // last one included)
         if (a->wgt_f16 == 1 && a->taps == 1 && stride == 1) {
@@ -491,7 +492,10 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     }
     const bool generic = p.t_mode == 1;                    // tune.mode 1: the generic gather kernel (A/B runs, cross-checks)
     // network heads (cout <= 4): VALU kernel instead of a 64- / 128-column matrix tile (tune.mode != 0 keeps the matrix kernels: 8 = just that)
+    p.upd = a->update;
+    const bool want_update = a->update && (a->update->x_out || a->update->m_out);
     if (p.t_mode == 0 && p.t_variant == 0 && conv3x3_thin_applicable(p)) return launch_conv3x3_thin(p, (hipStream_t)stream);
+    if (want_update) return DS_E_ARG;                      // the fused solver update exists in the head kernel only: fail loudly, never skip it
     if (!generic && stride == 1 && conv3x3_halo_supported(p)) return launch_conv3x3_halo(p, (hipStream_t)stream);
     if (p.norm) return DS_E_SHAPE;           // fused input normalisation exists only in the halo kernel
     if (!generic && p.t_mode != 6 && gemm_dma8_applicable(p)) return launch_gemm_dma8(p, (hipStream_t)stream);     // mode 6: no 8-wave DMA kernel

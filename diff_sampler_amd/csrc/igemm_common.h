@@ -48,6 +48,8 @@ struct KParams {
     // per-call kernel selection overrides (ds_conv_args.tune, all 0 = the library's own choice; host side only).  There is no process-wide
     // selection state: two threads / streams may run layers with different overrides at the same time.
     int t_mode, t_variant, t_splits, t_nb, t_nw, t_ablate;
+    // the solver update fused into the network head (ds_conv_args.update; host pointer, read by launch_conv3x3_thin only)
+    const ds_update_args* upd;
 };
 
 // Fused epilogue of one wave's 64x64 accumulator tile (2x2 MFMA 32x32 tiles).

@@ -6,19 +6,8 @@
 
 namespace {
 
-struct Coefs { float cx, cm, ch0, ch1, ch2, t, sig, pad; };
-
-__device__ __forceinline__ Coefs load_coefs(const ds_update_args& a, int img) {
-    Coefs c;
-    if (a.coefs) {
-        const float* r = a.coefs + (size_t)(a.coef_rows == 1 ? 0 : img) * 8;
-        c.cx = r[0]; c.cm = r[1]; c.ch0 = r[2]; c.ch1 = r[3]; c.ch2 = r[4]; c.t = r[5]; c.sig = r[6]; c.pad = 0.f;
-    } else {
-        c.cx = a.hcoefs[0]; c.cm = a.hcoefs[1]; c.ch0 = a.hcoefs[2]; c.ch1 = a.hcoefs[3]; c.ch2 = a.hcoefs[4];
-        c.t = a.hcoefs[5]; c.sig = a.hcoefs[6]; c.pad = 0.f;
-    }
-    return c;
-}
+typedef DsUpdCoefs Coefs;
+__device__ __forceinline__ Coefs load_coefs(const ds_update_args& a, int img) { return ds_upd_load_coefs(a, img); }
 
 // One thread = 4 consecutive pixels of one image, all channels.  Every NCHW plane access is a float4 (16 B/lane,
 // 1 KiB per wave instruction); the raw NHWC network output (3 or 4 channels, row = f_ld floats) is read as whole rows.
@@ -85,20 +74,19 @@ __global__ void __launch_bounds__(256) solver_update_kernel(const ds_update_args
             float m[VEC], xo[VEC];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                float D, d;
                 if (a.afs) {
-                    d = xe[j] / afs_div;                          // solvers.py:77
-                    D = xe[j] - k.t * d;                          // solvers.py:680
-                } else {
-                    D = a.raw ? cskip * xe[j] + cout_ * f[j] : f[j];   // networks_edm.py:495
-                    d = (xe[j] - D) / k.t;                        // solvers.py:80
+                    const float d = xe[j] / afs_div;              // solvers.py:77
+                    const float D = xe[j] - k.t * d;              // solvers.py:680
+                    m[j] = a.store_d ? d : D;
+                    float acc = k.cx * xb[j] + k.cm * m[j];
+                    if (a.hist[0]) acc += k.ch0 * h0[j];
+                    if (a.hist[1]) acc += k.ch1 * h1[j];
+                    if (a.hist[2]) acc += k.ch2 * h2[j];
+                    xo[j] = acc;
+                } else {                                          // the arithmetic shared with the head-fused form (ds_common.h)
+                    ds_upd_element(k, cskip, cout_, a.raw != 0, a.store_d != 0, xe[j], xb[j], f[j], a.hist[0] != nullptr, h0[j], a.hist[1] != nullptr, h1[j],
+                                   a.hist[2] != nullptr, h2[j], m[j], xo[j]);
                 }
-                m[j] = a.store_d ? d : D;
-                float acc = k.cx * xb[j] + k.cm * m[j];
-                if (a.hist[0]) acc += k.ch0 * h0[j];
-                if (a.hist[1]) acc += k.ch1 * h1[j];
-                if (a.hist[2]) acc += k.ch2 * h2[j];
-                xo[j] = acc;
             }
             if (VEC == 4) {
                 if (a.m_out) { f32x4 v = {m[0], m[1], m[2], m[3]}; *reinterpret_cast<f32x4*>(a.m_out + off) = v; }
@@ -151,21 +139,22 @@ __global__ void __launch_bounds__(256) solver_update_fast_kernel(const ds_update
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float x = xe[ch][j];
-                float D, d;
                 if (a.afs) {
-                    d = x / afs_div;
-                    D = x - k.t * d;
-                } else {
+                    const float d = x / afs_div;
+                    const float D = x - k.t * d;
+                    m[j] = a.store_d ? d : D;
+                    float acc = k.cx * (has_xb ? xb[ch][j] : x) + k.cm * m[j];
+                    if (a.hist[0]) acc += k.ch0 * h0[ch][j];
+                    if (a.hist[1]) acc += k.ch1 * h1[ch][j];
+                    if (a.hist[2]) acc += k.ch2 * h2[ch][j];
+                    xo[j] = acc;
+                } else {                                          // the arithmetic shared with the head-fused form (ds_common.h)
                     const float f = rows ? fr[j][ch] : fv[ch][j];
-                    D = a.raw ? cskip * x + cout_ * f : f;
-                    d = (x - D) / k.t;
+                    float mm, xx;
+                    ds_upd_element(k, cskip, cout_, a.raw != 0, a.store_d != 0, x, has_xb ? xb[ch][j] : x, f, a.hist[0] != nullptr, a.hist[0] ? h0[ch][j] : 0.f,
+                                   a.hist[1] != nullptr, a.hist[1] ? h1[ch][j] : 0.f, a.hist[2] != nullptr, a.hist[2] ? h2[ch][j] : 0.f, mm, xx);
+                    m[j] = mm; xo[j] = xx;
                 }
-                m[j] = a.store_d ? d : D;
-                float acc = k.cx * (has_xb ? xb[ch][j] : x) + k.cm * m[j];
-                if (a.hist[0]) acc += k.ch0 * h0[ch][j];
-                if (a.hist[1]) acc += k.ch1 * h1[ch][j];
-                if (a.hist[2]) acc += k.ch2 * h2[ch][j];
-                xo[j] = acc;
             }
             if (a.m_out) __builtin_nontemporal_store(m, reinterpret_cast<f32x4*>(a.m_out + off));
             if (a.x_out) __builtin_nontemporal_store(xo, reinterpret_cast<f32x4*>(a.x_out + off));
@@ -650,7 +639,7 @@ extern "C" int ds_build_experiments(void) {
     return 0;
 #endif
 }
-extern "C" int ds_version(void) { return 2; }      // 2: ds_conv_args.tune, ds_update_args.variant (struct layouts changed), ds_fid_moments; no ds_debug_* entry points
+extern "C" int ds_version(void) { return 3; }      // 2: ds_conv_args.tune, ds_update_args.variant (struct layouts changed), ds_fid_moments; no ds_debug_* entry points
 
 extern "C" const char* ds_error_string(int code) {
     switch (code) {

@@ -444,6 +444,15 @@ class UNetEngine:
             norm('apply', xo, co, co, B, R, R, 'out.norm', groups=arch.num_groups(co), eps=spec.out_eps, gamma=w['out.g'],
                  beta=w['out.b'], act_=DS_ACT_SILU, out=act, out_ld=co)
             conv(act, co, co, B, R, R, w['outc.w'], spec.out_channels, bufs['out'], 4, 9, 'out.conv', bias=w['outc.b'], out_nchw=1)
+        # ---- the solver update fused into the head (round 5, ds_conv_args.update): the head launch carries a pointer to ONE persistent
+        # ds_update_args of this plan; EDMDenoiser.raw(update=...) fills it before a run and clears its outputs afterwards (x_out == m_out ==
+        # NULL = plain head).  Possible where the head runs on conv3x3_thin_kernel with a channel-planar output (ds_conv_kernel_id 2570).
+        head = P.ops[-1].keep[0]
+        P.head_update = _lib.UpdateArgs()
+        P.head_fusable = bool(P.ops[-1].fn is lib.ds_conv2d_nhwc and head.out_nchw and not head.wgt_f16
+                              and lib.ds_conv_kernel_id(C.byref(head)) == 2570)
+        if P.head_fusable:
+            head.update = C.cast(C.pointer(P.head_update), C.c_void_p)
         from .plan import release_tuning_scratch
         release_tuning_scratch()            # the tile measurement's 512 MiB flush buffer does not outlive the plan build
         self._plans[key] = P
@@ -532,12 +541,30 @@ class EDMDenoiser:
                 _lib.check(lib.ds_copy_rows(_ptr(cl), self.label_dim, _ptr(lb), lb.shape[1], B, self.label_dim, st), 'copy labels')
         return plan, emb_rows
 
-    def raw(self, x, sigma, class_labels=None):
+    def raw(self, x, sigma, class_labels=None, update=None):
         """F(c_in x; c_noise), the raw network output, as an NCHW [B, C, H, W] tensor.  Engine-owned, overwritten by the
-        next evaluation at the same batch size."""
+        next evaluation at the same batch size.
+        update: a filled ``_lib.UpdateArgs`` (raw = 1, f ignored): the network head applies that solver update in its epilogue -- no update
+        launch (``head_update_ok(B, ...)`` says whether this plan's head can; csrc/conv3x3_thin.hip)."""
         plan, _ = self._prepare(x, sigma, class_labels)
-        plan.run(_lib.stream_ptr())
+        if update is None:
+            plan.run(_lib.stream_ptr())
+            return plan.bufs['out'], plan
+        if not plan.head_fusable:
+            raise _lib.DsError('this plan\'s head does not run on the kernel that can fuse the solver update')
+        hu = plan.head_update
+        C.memmove(C.byref(hu), C.byref(update), C.sizeof(hu))
+        try:
+            plan.run(_lib.stream_ptr())
+        finally:
+            hu.x_out, hu.m_out = None, None                      # the next plain evaluation must not update anything
         return plan.bufs['out'], plan
+
+    def head_update_ok(self, B, sigma, class_labels=None):
+        """True when an evaluation at this batch / sigma form can carry a fused solver update (solvers._Run asks before it defers)."""
+        host_scalar = isinstance(sigma, (int, float))
+        emb_rows = (B if self.label_dim else 1) if host_scalar else (B if (torch.as_tensor(sigma).numel() > 1 or self.label_dim) else 1)
+        return bool(self.engine.plan(B, emb_rows).head_fusable)
 
     def __call__(self, x, sigma, class_labels=None, force_fp32=False, **kwargs):
         from . import ops

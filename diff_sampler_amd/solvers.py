@@ -16,6 +16,7 @@ Contract kept from the reference: signatures and defaults
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -33,6 +34,13 @@ def get_denoised(net, x, t, class_labels=None, condition=None, unconditional_con
     if hasattr(net, 'guidance_type'):
         return net(x, t, condition=condition, unconditional_condition=unconditional_condition)
     return net(x, t, class_labels=class_labels)
+
+
+# The solver update of the linear solvers runs in the network head's epilogue (engine.EDMDenoiser.raw(update=...), csrc/conv3x3_thin.hip)
+# instead of in a launch of its own: north_star's "fused back-to-back" taken literally.  Same arithmetic definition for both forms
+# (csrc/ds_common.h), so the trajectories are equal bit for bit (tests/test_hip_samplers.py).  DS_FUSE_HEAD=0 keeps the two-launch form.
+FUSE_HEAD = os.environ.get('DS_FUSE_HEAD', '1') != '0'
+FUSED_UPDATES = [0]        # process-wide count of updates that ran inside a network head (tests, bench.py)
 
 
 class _Run:
@@ -59,6 +67,19 @@ class _Run:
             self.inters.append(self.x.clone())
         self._f = None
         self._raw = False
+        self._plan = None
+        # head-fused update: evaluate() only NOTES the evaluation; the update() that follows runs the network with the update attached
+        self.fuse_head = bool(self.fused and FUSE_HEAD and hasattr(net, 'head_update_ok'))
+        self._pending = None
+        self.fused_updates = 0              # how many updates ran inside the head (tests, bench.py)
+
+    def _flush(self):
+        """Run a noted evaluation on its own (someone needs F, or the update that follows cannot ride in the head)."""
+        if self._pending is not None:
+            x, sigma = self._pending
+            self._pending = None
+            self._f, self._plan = self.net.raw(x, sigma, self.cl)
+            self._raw = True
 
     def new(self):
         return torch.empty_like(self.latents)
@@ -67,6 +88,11 @@ class _Run:
     def evaluate(self, x, sigma: float):
         if self.fused:
             # sigma: Python float (uniform) or a device tensor [B] (per-sample, AMED second stage)
+            self._flush()
+            if self.fuse_head and self.net.head_update_ok(self.B, sigma, self.cl):
+                self._pending = (x, sigma)                       # deferred: see update()
+                self._f, self._raw = None, True
+                return
             self._f, self._plan = self.net.raw(x, sigma, self.cl)
             self._raw = True
         else:
@@ -94,6 +120,20 @@ class _Run:
         hc[0], hc[1], hc[5], hc[6] = cx, cm, t, sigma
         for i, c in enumerate(ch):
             hc[2 + i] = c
+        if self._pending is not None:
+            px, ps = self._pending
+            if f is None and raw is None and not afs and xe is px and (x_out is not None or m_out is not None):
+                # the update rides in the head of the evaluation it consumes: one plan run, no update launch
+                a = ops.make_update_args(xe, xb, None, self.B, self.C, self.H, self.W, x_out, raw=True, f_ld=0, hist=list(hist), hcoefs=hc,
+                                         afs=False, sigma_data=self.sigma_data, m_out=m_out, store_d=store_d, coefs=coefs,
+                                         coef_rows=(self.B if coefs is not None else 1))
+                self._pending = None
+                self._f, self._plan = self.net.raw(px, ps, self.cl, update=a)
+                self._raw = True
+                self.fused_updates += 1
+                FUSED_UPDATES[0] += 1
+                return
+            self._flush()
         f = self._f if f is None else f
         raw = self._raw if raw is None else raw
         a = ops.make_update_args(xe, xb, None if afs else f, self.B, self.C, self.H, self.W, x_out, raw=(raw and not afs),
@@ -103,6 +143,7 @@ class _Run:
 
     def dpmpp_x0_step(self, xe, xb, t, sigma, cx, cm, x_out, m_out, hist=(), ch=(), afs=False):
         """D -> dynamic threshold -> multistep combination of one data-prediction step in ONE launch (ds_dpmpp_x0_step)."""
+        self._flush()                       # needs F in memory: the per-sample quantile sits between D and the combination
         hc = [0.0] * 8
         hc[0], hc[1], hc[5], hc[6] = cx, cm, t, sigma
         for i, c in enumerate(ch):

@@ -139,6 +139,7 @@ def _amed_loop(mode, net, latents, class_labels, condition, unconditional_condit
         raise NotImplementedError('the training branches of solvers_amed are out of scope of the HIP engine (SURVEY.md section 2, row 7)')
     t_steps = get_schedule(num_steps, sigma_min, sigma_max, device=latents.device, schedule_type=schedule_type, schedule_rho=schedule_rho, net=net)
     run = _Run(net, latents, class_labels, condition, unconditional_condition, t_steps, return_inters, False)
+    run.fuse_head = False               # the bottleneck is read between an evaluation and its update: evaluations run on their own
     if not run.fused:
         raise RuntimeError('AMED samplers need the bottleneck tap of engine.EDMDenoiser (the reference hooks net.model.enc[...])')
     predictor = _as_predictor(predictor, latents.device)

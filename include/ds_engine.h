@@ -47,7 +47,7 @@ extern "C" {
 #define DS_RESAMPLE_DOWN 1  /* 2x2 box filter, stride 2  (networks_edm.py:77 with resample_filter [1,1]) */
 #define DS_RESAMPLE_UP 2    /* nearest neighbour x2      (networks_edm.py:75 with resample_filter [1,1]) */
 
-DS_API int ds_version(void);      /* 2 since round 4: ds_conv_args.tune / ds_update_args.variant appended (struct sizes changed), ds_fid_moments added, the
+DS_API int ds_version(void);      /* 3 since round 5: ds_conv_args.update appended (the head-fused solver update).  2 since round 4: ds_conv_args.tune / ds_update_args.variant appended (struct sizes changed), ds_fid_moments added, the
                                * process-global ds_debug_* setters removed.  A host must check it before passing argument structs.  Round 5 kept every
                                * struct layout (still 2): ds_build_experiments() is new, ds_conv_args.norm_coefs is now also accepted with in_f16. */
 DS_API const char* ds_error_string(int code);
@@ -68,6 +68,8 @@ DS_API int ds_build_experiments(void);   /* 1: the library was built with DS_BUI
  * Constraints: c0 % 32 == 0, c1 % 32 == 0, all leading dimensions % 4 == 0, pointers 16-byte aligned,
  * W has ceil(cout/128)*128 rows (zero padded).
  */
+struct ds_update_args;            /* defined below ("Solver side"); ds_conv_args.update points to one */
+
 typedef struct ds_conv_tune {
     /* 1 = generic gather kernel instead of the LDS-halo / LDS-DMA kernels (both exact fp32: cross-check), 128 / 256 = forced M tile of
      * the halo kernel, 2 = halo kernel with register-staged weights, 4 = no 64-column tail tiles, 6 = no 8-wave DMA kernel for 1x1 /
@@ -172,6 +174,16 @@ typedef struct ds_conv_args {
      * engines pass).  They travel with the call (and with a ds_plan entry): the library keeps NO process-wide selection state, so two
      * threads / streams can run layers under different overrides at the same time (tests/test_hip_kernels.py: two-thread test). */
     ds_conv_tune tune;
+    /* Round 5 (ABI version 3): the solver update FUSED into the network head.  Non-NULL with a non-NULL x_out or m_out inside: the layer must
+     * be a network head that runs on conv3x3_thin_kernel (taps == 9, cout <= 4, out_nchw; ds_conv_kernel_id() == 2570) -- else DS_E_ARG --
+     * and its epilogue then applies ds_solver_update's arithmetic to every output element while it still holds it in a register:
+     * F = this layer's output (raw network output: update->raw must be 1, f_ld 0, afs 0; update->f is ignored), xe / xb / hist / coefs /
+     * hcoefs / sigma_data / store_d / m_out / x_out / n, c, h, w as in ds_update_args (n, c, h, w must equal this layer's n, cout, h, w).
+     * `out` still receives F.  One definition of the arithmetic serves both forms (csrc/ds_common.h: ds_upd_element), so the results equal
+     * those of ds_conv2d_nhwc followed by ds_solver_update bit for bit.  The struct is READ AT CALL TIME: a ds_plan entry keeps the
+     * pointer, so a host re-fills the same struct before each run (x_out == m_out == NULL = no fusion for this run).
+     * Replaces the separate update launch of the linear solvers (solvers.py:76-81, :156-168, :245-258, :344-352, :574-585). */
+    const struct ds_update_args* update;
 } ds_conv_args;
 
 DS_API int ds_conv2d_nhwc(const ds_conv_args* a, void* stream);

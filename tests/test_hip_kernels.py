@@ -1656,3 +1656,81 @@ def test_conv_f16_activations_fused_input_normalisation_equals_the_two_launch_fo
         ref = ref + F.conv2d(x.double().reshape(B, H, H, cin).permute(0, 3, 1, 2), we.to(torch.float16).double())
     ref = ((ref + bias.double()[None, :, None, None]) * 0.7071).permute(0, 2, 3, 1).reshape(M, cout).float()
     assert _rel(o_fus.float().cpu(), ref) < 1.5e-3
+
+
+@pytest.mark.parametrize('case', [
+    # B, H, C_in, cout, fused norm + SiLU, history tensors, per-sample coefficient rows, separate base point, store_d
+    (3, 16, 64, 3, True, 0, False, False, True),          # Euler-like on a SongUNet head
+    (2, 32, 128, 3, True, 3, False, False, True),         # iPNDM order 4
+    (4, 16, 96, 3, False, 1, True, True, True),           # per-sample rows (AMED form), xb != xe (second stage of a two-stage solver), plain input
+    (1, 64, 192, 3, False, 2, False, False, False),       # m = D (denoised), 64x64
+])
+def test_network_head_with_fused_solver_update_equals_conv_then_update(case):
+    """ds_conv2d_nhwc(update = &ds_update_args) on a network head (conv3x3_thin_kernel<., UPD>): F, x' and the history entry m must equal, bit
+    for bit, what the same head followed by ds_solver_update(raw = 1, f = F planar) writes.  Through the C ABI; also: the struct is read at call
+    time (NULL outputs = plain head), and a layer that is not a head refuses the update."""
+    import ctypes as C
+    from diff_sampler_amd import _lib, ops
+    B, H, cin, cout, norm, nh, rows, sep_xb, store_d = case
+    lib = _lib.load()
+    dev = 'cuda'
+    M = B * H * H
+    g = torch.Generator().manual_seed(sum(case[:4]) + 17)
+    a_in = torch.randn(M, cin, generator=g).to(dev)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    wp = ops.pack_conv_weight(w.to(dev))
+    bias = torch.randn(cout, generator=g).to(dev)
+    planes = torch.stack([0.3 * torch.randn(B, cin, generator=g), 1 + 0.2 * torch.randn(B, cin, generator=g), 0.2 * torch.randn(B, cin, generator=g)], 1).contiguous().to(dev)
+    xe = (torch.randn(B, cout, H, H, generator=g) * 3).to(dev)
+    xb = (torch.randn(B, cout, H, H, generator=g) * 3).to(dev) if sep_xb else xe
+    hist = [torch.randn(B, cout, H, H, generator=g).to(dev) for _ in range(nh)]
+    hc = [1.0, -0.37, 0.21, -0.11, 0.05, 1.7, 1.7, 0.0]
+    coefs = None
+    if rows:
+        coefs = torch.tensor(hc).repeat(B, 1)
+        coefs[:, 1] += 0.01 * torch.arange(B)
+        coefs[:, 5] += 0.1 * torch.arange(B)
+        coefs[:, 6] = coefs[:, 5]
+        coefs = coefs.contiguous().to(dev)
+
+    def head(update):
+        F_ = torch.full((B, cout, H, H), float('nan'), device=dev)
+        a = _lib.ConvArgs(a_in.data_ptr(), None, cin, 0, cin, 0, B, H, H, 9, wp.data_ptr(), cout, bias.data_ptr(), None, 0, 1, None, 0, 1.0, 0,
+                          F_.data_ptr(), 4, planes.data_ptr() if norm else None, 1 if norm else 0)
+        a.out_nchw = 1
+        if update is not None:
+            a.update = C.cast(C.pointer(update), C.c_void_p)
+        assert lib.ds_conv_kernel_id(C.byref(a)) == 2570
+        rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
+        torch.cuda.synchronize()
+        return rc, F_
+
+    def upd_args(f, x_out, m_out):
+        return ops.make_update_args(xe, xb, f, B, cout, H, H, x_out, raw=True, f_ld=0, hist=hist, hcoefs=hc, sigma_data=0.5, m_out=m_out,
+                                    store_d=store_d, coefs=coefs, coef_rows=(B if rows else 1))
+    # two launches
+    rc, F0 = head(None)
+    assert rc == 0
+    x0, m0 = torch.full_like(xe, float('nan')), torch.full_like(xe, float('nan'))
+    ops.solver_update(upd_args(F0, x0, m0))
+    torch.cuda.synchronize()
+    # one launch
+    x1, m1 = torch.full_like(xe, float('nan')), torch.full_like(xe, float('nan'))
+    u = upd_args(None, x1, m1)
+    rc, F1 = head(u)
+    assert rc == 0, lib.ds_error_string(rc)
+    assert torch.equal(F1, F0) and torch.isfinite(x1).all()
+    assert torch.equal(x1, x0), float((x1 - x0).abs().max())
+    assert torch.equal(m1, m0), float((m1 - m0).abs().max())
+    # read at call time: the same struct with its outputs cleared is a plain head
+    u.x_out, u.m_out = None, None
+    x1.fill_(7.0)
+    rc, F2 = head(u)
+    assert rc == 0 and torch.equal(F2, F0) and bool((x1 == 7.0).all())
+    # a layer that cannot fuse refuses loudly (64 output channels: a matrix kernel)
+    wide = torch.zeros(M, 64, device=dev)
+    wp64 = ops.pack_conv_weight((torch.randn(64, cin, 3, 3, generator=g) / 30).to(dev))
+    a = _lib.ConvArgs(a_in.data_ptr(), None, cin, 0, cin, 0, B, H, H, 9, wp64.data_ptr(), 64, None, None, 0, 1, None, 0, 1.0, 0, wide.data_ptr(), 64)
+    u2 = upd_args(None, x1, m1)
+    a.update = C.cast(C.pointer(u2), C.c_void_p)
+    assert lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr()) == -1          # DS_E_ARG

@@ -238,3 +238,49 @@ def test_dpmpp_x0_step_register_kernel_ties(dev):
     a = ops.make_update_args(x, x, x, 3, 3, 32, 32, None, raw=False, f_ld=0, hist=[], hcoefs=[0, 1, 0, 0, 0, 1, 1, 0], m_out=mo, store_d=False)
     ops.dpmpp_x0_step(a)
     assert torch.equal(mo.cpu(), solvers_ref.threshold(x.cpu()))
+
+
+@pytest.mark.parametrize('netname', ['tiny_song', 'tiny_song_cond'])
+def test_head_fused_update_trajectories_equal_the_two_launch_form(netname, dev, monkeypatch):
+    """Round 5: the solver update of the linear solvers runs in the network head's epilogue (ds_conv_args.update, csrc/conv3x3_thin.hip)
+    instead of in a ds_solver_update launch.  Both forms share one definition of the arithmetic (csrc/ds_common.h: ds_upd_element), so every
+    sampler's whole trajectory -- and its eps record -- must be EQUAL bit for bit with `solvers.FUSE_HEAD` on and off; the fused runs must
+    really have fused (solvers.FUSED_UPDATES counts), the DPM-Solver++ data-prediction form must not (its per-sample quantile sits between D
+    and the combination)."""
+    from diff_sampler_amd import solvers, solver_utils
+    z = np.load(os.path.join(G, f'sampler_{netname}.npz'))
+    net = _hip_net(netname, int(z['seed']))
+    latents = torch.from_numpy(z['latents']).to(dev)
+    lab = torch.from_numpy(z['labels']).to(dev) if z['labels'].size else None
+    checked = fused_somewhere = 0
+    for tag, fn, kind, rho, n, extra in cases.SAMPLER_CASES:
+        if f'{tag}_inters' not in z.files:
+            continue
+        extra = dict(extra)
+        ts = torch.from_numpy(z[f'{tag}_t']).to(dev)
+        if fn == 'deis_sampler':
+            extra['coeff_list'] = solver_utils.get_deis_coeff_list(ts, extra['max_order'], deis_mode=extra.pop('deis_mode'))
+        want_eps = fn != 'unipc_sampler'
+        res = {}
+        for mode in (True, False):
+            monkeypatch.setattr(solvers, 'FUSE_HEAD', mode)
+            before = solvers.FUSED_UPDATES[0]
+            r = getattr(solvers, fn)(net, latents, class_labels=lab, num_steps=n, t_steps=ts, return_inters=True, return_eps=want_eps, **dict(extra))
+            torch.cuda.synchronize()
+            res[mode] = (r if want_eps else (r, None)), solvers.FUSED_UPDATES[0] - before
+        (tr1, e1), n1 = res[True]
+        (tr0, e0), n0 = res[False]
+        assert n0 == 0, (tag, n0)
+        assert torch.equal(tr1, tr0), (netname, tag, float((tr1 - tr0).abs().max()))
+        if want_eps:
+            assert torch.equal(e1, e0), (netname, tag)
+        x0_form = fn == 'dpm_pp_sampler' and extra.get('predict_x0', True)
+        if x0_form or fn == 'unipc_sampler':
+            pass                                            # (UniPC's updates are its own kernels; DPM-Solver++ x0 form: ds_dpmpp_x0_step)
+        else:
+            assert n1 >= len(ts) - 2, (tag, n1, len(ts))    # every network evaluation of a linear solver carried its update
+            fused_somewhere += 1
+        # and the fused trajectory is still the reference's
+        assert _rel(tr1.cpu(), torch.from_numpy(z[f'{tag}_inters'])) < TOL_X, (netname, tag)
+        checked += 1
+    assert checked >= 6 and fused_somewhere >= 4, (checked, fused_somewhere)
