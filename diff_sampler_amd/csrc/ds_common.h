@@ -38,10 +38,25 @@ static inline bool ds_aligned16(const void* p) { return (reinterpret_cast<uintpt
 // the activation sits in the convolution's halo loader and epilogue, where every VALU instruction is exposed.
 __device__ __forceinline__ float ds_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
-// EDM preconditioning coefficients (diff-solvers-main/models/networks_edm.py:488-491), fp32, same operation order.
-__device__ __forceinline__ float ds_c_skip(float s, float sd) { return (sd * sd) / (s * s + sd * sd); }
-__device__ __forceinline__ float ds_c_out(float s, float sd) { return s * sd / sqrtf(s * s + sd * sd); }
-__device__ __forceinline__ float ds_c_in(float s, float sd) { return 1.0f / sqrtf(sd * sd + s * s); }
+// EDM preconditioning coefficients (diff-solvers-main/models/networks_edm.py:488-491), fp32, the reference's operation order EXACTLY: every
+// product and sum rounded on its own (contraction off inside these bodies).  Round 5: with the compiler free to contract `s * s + sd * sd`
+// either way, two kernels inlining the same source line disagreed in the last bit of c_skip / c_out at small sigma -- invisible at every
+// tolerance, but the head-fused solver update (conv3x3_thin.hip) and the stand-alone update kernel (solver.hip) must produce EQUAL bits.
+__device__ __forceinline__ float ds_c_skip(float s, float sd) {
+#pragma clang fp contract(off)
+    const float s2 = s * s, d2 = sd * sd;
+    return d2 / (s2 + d2);
+}
+__device__ __forceinline__ float ds_c_out(float s, float sd) {
+#pragma clang fp contract(off)
+    const float s2 = s * s, d2 = sd * sd, num = s * sd;
+    return num / sqrtf(s2 + d2);
+}
+__device__ __forceinline__ float ds_c_in(float s, float sd) {
+#pragma clang fp contract(off)
+    const float s2 = s * s, d2 = sd * sd;
+    return 1.0f / sqrtf(d2 + s2);
+}
 
 // ---- The solver update's per-element arithmetic (ds_solver_update, include/ds_engine.h), shared by the update kernels (solver.hip) and by the
 // network head that applies it in its epilogue (conv3x3_thin.hip, ds_conv_args.update): ONE definition with explicit fused multiply-adds,
@@ -64,6 +79,7 @@ __device__ __forceinline__ DsUpdCoefs ds_upd_load_coefs(const ds_update_args& a,
 // one element; h0 / h1 / h2 are read only where has0 / has1 / has2 (the history pointers) say so
 __device__ __forceinline__ void ds_upd_element(const DsUpdCoefs& k, float cskip, float cout_, bool raw, bool store_d, float x, float xb, float f,
                                                bool has0, float h0, bool has1, float h1, bool has2, float h2, float& m, float& xo) {
+#pragma clang fp contract(off)
     const float D = raw ? __builtin_fmaf(cskip, x, cout_ * f) : f;             // networks_edm.py:495
     const float d = (x - D) / k.t;                                             // solvers.py:80
     m = store_d ? d : D;
