@@ -1,3 +1,7 @@
+"""Diagnostic of the head-fused solver update (round 5): for a few samplers on the tiny SongUNet, is each form deterministic run to run, and
+where along the trajectory do the fused and the two-launch form differ?  (It found the last-bit disagreement of c_skip / c_out at small sigma
+between two kernels that inlined the same source line under different contraction choices -- docs/HISTORY.md G.7.)
+    python tools/diag_fuse_head.py        # on a GPU box"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, '/root/repo')
