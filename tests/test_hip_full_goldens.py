@@ -12,7 +12,7 @@
 Tolerances (fp32 path): 2e-4 per evaluation, 5e-4 per EDM trajectory, 1e-3 for the 5-step SD trajectory.
 Trajectories are bounded PER STEP, each step against its own golden scale (tests/_parity.py: a trajectory runs from scale ~300 at sigma_max
 to an image of scale ~3, so one normalisation over the whole trajectory would leave the final image unconstrained), and the final image
-explicitly.  What every test observed goes to gpurun_out/r4_parity.json (kept copy: profiles/r4_parity.json)."""
+explicitly.  What every test observed goes to gpurun_out/r5_parity.json (kept copy: profiles/r5_parity.json; round 4: profiles/r4_parity.json)."""
 import ctypes as C
 import os
 import sys
