@@ -32,8 +32,21 @@ from .ops import pack_conv_weight, pack_linear_weight, pack_stem_weight
 from .plan import Builder, Plan as _Plan, ptr as _ptr  # noqa: E402
 
 
-# default of UNetEngine.fuse_norm16 (A/B of round 5, profiles/r5_conv_f16dma_fused_norm_ab.txt)
-FUSE_NORM16_DEFAULT = '0'
+# default of UNetEngine.fuse_norm16: '0' never, '1' every eligible layer, 'auto' the layer classes where the per-layer A/B of round 5 found the
+# fusion faster than pass + convolution (profiles/r5_conv_f16dma_fused_norm_per_layer.txt): 64x64 images and one column tile (cout <= 192).
+# Whole-net A/B of '1' against '0': profiles/r5_conv_f16dma_fused_norm_ab.txt (ImageNet-64 +0.4 %, SD-1.5 -6.8 %).
+FUSE_NORM16_DEFAULT = 'auto'
+
+
+def fuse_norm16_value(text):
+    """'0' / '1' / 'auto' (DS_FUSE_NORM16, or the engines' attribute) -> False / True / 'auto'."""
+    return {'0': False, '1': True}.get(str(text), 'auto')
+
+
+def fuse_norm16_here(mode, side, cout):
+    """Does the 3x3 convolution of this geometry normalise its own LDS halo (conv3x3_f16dma NORM) under `mode`?"""
+    return mode is True or (mode == 'auto' and side == 64 and cout <= 192)
+
 
 
 class UNetEngine:
@@ -53,7 +66,7 @@ class UNetEngine:
         self.split_fp16 = bool(split_fp16) and not self.use_fp16
         # fp16 mode: GroupNorm apply + SiLU inside the fp16-activation convolution's LDS halo instead of a ds_norm_act pass (plan(): fz0 / fz1;
         # bit-identical results).  An attribute, not an argument, so that A/B runs flip it per engine: DS_FUSE_NORM16 sets the default.
-        self.fuse_norm16 = os.environ.get('DS_FUSE_NORM16', FUSE_NORM16_DEFAULT) == '1'
+        self.fuse_norm16 = fuse_norm16_value(os.environ.get('DS_FUSE_NORM16', FUSE_NORM16_DEFAULT))
         self._w16_cache = {}
         self.conv_mode = 1 if self.use_fp16 else (2 if self.split_fp16 else 0)      # ds_conv_args.wgt_f16 of the eligible 3x3 layers
         self.lib = _lib.load()
@@ -300,8 +313,9 @@ class UNetEngine:
                 # ds_norm_act pass -- with it the materialised concatenation and the raw copy for the skip projection -- disappears; the
                 # statistics launch (ds_gn_finalize over the producers' column sums) stays.  Resampling blocks keep the pass for conv0.
                 raw16 = lambda t: t is None or t.dtype == torch.float16
-                fz0 = bool(self.fuse_norm16 and stream16 and rs == DS_RESAMPLE_NONE and raw16(x0) and raw16(x1) and c0 % 64 == 0 and c1 % 64 == 0)
-                fz1 = bool(self.fuse_norm16 and stream16)
+                fz_here = fuse_norm16_here(self.fuse_norm16, Ho, cout)
+                fz0 = bool(fz_here and stream16 and rs == DS_RESAMPLE_NONE and raw16(x0) and raw16(x1) and c0 % 64 == 0 and c1 % 64 == 0)
+                fz1 = bool(fz_here and stream16)
                 norm('stats', x0, c0, c0, n, Hin, Hin, nm + '.norm0.stats', x1=x1, c1=c1, ld1=c1, groups=G_in, eps=b.eps,
                      gamma=w[f'{nm}.norm0.g'], beta=w[f'{nm}.norm0.b'], coefs=ncoef)
                 if fz0:

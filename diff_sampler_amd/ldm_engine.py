@@ -30,6 +30,7 @@ from . import _lib, ldm_arch, ops
 from ._lib import DS_ACT_GEGLU, DS_ACT_SILU, DS_RESAMPLE_UP
 from .ops import pack_conv_weight, pack_linear_weight, pack_stem_weight
 from .plan import Builder, Plan, ptr
+from .engine import fuse_norm16_here
 
 
 class LDMUNetEngine:
@@ -44,8 +45,8 @@ class LDMUNetEngine:
         generic fp32 kernel, the round-3 routing) -- A/B knobs of benchmarks, the defaults are what the parity goldens were made with."""
         self.qkv_f16_min_head = int(qkv_f16_min_head)
         self.f16_downsample = bool(f16_downsample)
-        from .engine import FUSE_NORM16_DEFAULT
-        self.fuse_norm16 = os.environ.get('DS_FUSE_NORM16', FUSE_NORM16_DEFAULT) == '1'     # see engine.UNetEngine.fuse_norm16
+        from .engine import FUSE_NORM16_DEFAULT, fuse_norm16_value
+        self.fuse_norm16 = fuse_norm16_value(os.environ.get('DS_FUSE_NORM16', FUSE_NORM16_DEFAULT))     # see engine.UNetEngine.fuse_norm16 ('auto': SD-1.5 has no such layer class)
         self.spec = spec
         self.device = torch.device(device)
         self.use_fp16 = bool(use_fp16)
@@ -187,7 +188,7 @@ class LDMUNetEngine:
                 bd.norm('stats', x0, c0, c0, N, side, side, name + '.gn.stats', x1=x1, c1=c1, ld1=c1, groups=32, eps=eps, gamma=gk,
                         beta=bk, coefs=ncoef)
                 raw_ok = lambda t: t is None or t.dtype == torch.float16
-                if self.fuse_norm16 and raw_ok(x0) and raw_ok(x1) and c0 % 64 == 0 and c1 % 64 == 0 and raw16 is None:
+                if fuse_norm16_here(self.fuse_norm16, side, cout) and raw_ok(x0) and raw_ok(x1) and c0 % 64 == 0 and c1 % 64 == 0 and raw16 is None:
                     # round 5: the convolution normalises its own LDS halo on the raw fp16 sources (conv3x3_f16dma NORM): no pass, no
                     # materialised concatenation; a fused skip_connection reads its raw sources in place (e16 may name two)
                     ex = {}
@@ -233,7 +234,7 @@ class LDMUNetEngine:
                 h1 = bd.new16(M, cout)                       # in_layers output: only read by the out_layers normalisation
                 direct = x1 is None and x0.dtype == torch.float16          # the input already is one fp16 tensor: no raw copy for the skip_connection
                 # fuse_norm16: both raw fp16 sources are read in place by in_layers AND by the fused skip_connection: no raw copy at all
-                both_raw = bool(self.fuse_norm16 and x0.dtype == torch.float16 and (x1 is None or x1.dtype == torch.float16)
+                both_raw = bool(fuse_norm16_here(self.fuse_norm16, res, cout) and x0.dtype == torch.float16 and (x1 is None or x1.dtype == torch.float16)
                                 and c0 % 64 == 0 and c1 % 64 == 0)
                 r16 = bd.new16(M, cin) if l.skip_conv and not direct and not both_raw else None
                 gn_conv(x0, c0, x1, c1, res, w[f'{p}.n0.g'], w[f'{p}.n0.b'], 1e-5, w[f'{p}.c0.w'], w[f'{p}.c0.b'], cout, h1, cout,

@@ -127,7 +127,10 @@ def _dtype_lint(P, lib):
     for op in P.ops:
         if op.fn is lib.ds_conv2d_nhwc:
             a = op.keep[0]
-            check(a.x0, a.in_f16, op.name + '.x0'); check(a.x1, False, op.name + '.x1'); check(a.e0, a.in_f16 and a.ec0, op.name + '.e0')
+            # second sources exist on fp16-activation launches only with the fused input normalisation (round 5): fp16 like the first
+            assert not (a.in_f16 and (a.c1 or a.ec1)) or a.norm_coefs, op.name
+            check(a.x0, a.in_f16, op.name + '.x0'); check(a.x1, a.in_f16 and a.c1, op.name + '.x1'); check(a.e0, a.in_f16 and a.ec0, op.name + '.e0')
+            check(a.e1, a.in_f16 and a.ec1, op.name + '.e1')
             check(a.res, a.res_f16, op.name + '.res'); check(a.out, a.out_f16, op.name + '.out')
             assert not (a.res_f16 or a.out_f16) or a.in_f16, op.name
         elif op.fn in (lib.ds_norm_act, lib.ds_gn_stats):
