@@ -296,7 +296,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
     for (int d = 0; d < D; ++d)
         if (kt0 + d < KT) w_dma(kt0 + d, d);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (NORM) {                                      // the first slab's halo is normalised here (own units: no barrier needed before)
+    if constexpr (NORM) {
+        // the first slab's halo is normalised here.  A thread rewrites only the unit it fetched itself -- covered by its own vmcnt(0) -- but the
+        // COEFFICIENT rows were fetched by wave 0 alone: every other wave needs wave 0's wait + a barrier before it reads them.  (Without this
+        // barrier the kernel passed every test and whole-network comparison for a day and then produced four wrong images in one first run at
+        // 64 images per call: tools/diag_fuse_norm.py, docs/HISTORY.md G.5.  In the steady state the taps' own barriers separate the two.)
+        __builtin_amdgcn_s_barrier();
         if (cb < nchunks) static_for<NDMA>([&](auto jc) { norm_round(cb & 1, jc); });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
