@@ -257,3 +257,33 @@ def test_planner_tile_measurement_is_off_on_the_cpu_and_for_launches_whose_bits_
             assert not ok                              # proj_out: column sums through the staged epilogue
         if not a.stats_out:
             assert ok
+
+
+def test_fuse_norm16_auto_fuses_exactly_the_measured_layer_class():
+    """engine.fuse_norm16 (round 5): 'auto' -- the default -- moves GroupNorm apply + SiLU into the fp16 convolution's LDS halo on the layer
+    class where the per-layer A/B found it faster (profiles/r5_conv_f16dma_fused_norm_per_layer.txt: 64x64 images, one column tile), nowhere
+    else; True / False fuse every eligible layer / none.  Host logic: the plans are built on the CPU."""
+    import ctypes as C
+    import diff_sampler_amd.ldm_arch as la
+    from diff_sampler_amd import engine
+    from diff_sampler_amd.ldm_engine import LDMUNetEngine
+    lib = _lib.load()
+    assert engine.fuse_norm16_value('0') is False and engine.fuse_norm16_value('1') is True and engine.fuse_norm16_value('auto') == 'auto'
+    assert engine.fuse_norm16_here('auto', 64, 192) and not engine.fuse_norm16_here('auto', 64, 384) and not engine.fuse_norm16_here('auto', 32, 192)
+    assert engine.fuse_norm16_here(True, 8, 768) and not engine.fuse_norm16_here(False, 64, 192)
+
+    def fused(P):
+        return [op.keep[0] for op in P.ops if op.fn is lib.ds_conv2d_nhwc and op.keep[0].in_f16 and op.keep[0].norm_coefs]
+
+    spec, eng = _engine('imagenet64', use_fp16=True)
+    assert eng.fuse_norm16 == 'auto'                       # the default (DS_FUSE_NORM16 unset)
+    f = fused(eng.plan(64, 64))
+    assert len(f) == 12 and all(a.h == 64 and a.cout == 192 and a.taps == 9 and lib.ds_conv_kernel_id(C.byref(a)) == 2572 for a in f)
+    assert sum(1 for a in f if a.c1) == 3 and sum(1 for a in f if a.ec1) == 3        # the decoder's concatenations are read in place, skip projection too
+    eng.fuse_norm16 = False
+    assert fused(eng.plan(64, 64)) == []
+    eng.fuse_norm16 = True
+    assert len(fused(eng.plan(64, 64))) == 64
+    lspec = la.ldm_unet_spec(**dict(la.NAMED_LDM_CONFIGS['sd15']))
+    leng = LDMUNetEngine(lspec, la.init_ldm_params(lspec, seed=0), device='cpu', use_fp16=True)
+    assert leng.fuse_norm16 == 'auto' and fused(leng.plan(32, 1, 77)) == []          # SD-1.5 has no layer of that class (its 64x64 layers have 320 channels)
