@@ -32,6 +32,8 @@ Parts
             ipndm_sampler max_order=4 on the 11-point GITS-form schedule literal (t_steps), NFE=10, B=1: the whole trajectory
   full5b    BASELINE config 5 at full size for TWO latents (round 5): the reference's dpm_pp_sampler (eps form, discrete rho=1, num_steps=6,
             CFG 7.5) on latents / conditions the GPU tests scatter over the BENCHMARK batch of 16 latents (bench.py --config sd15 --batch 16)
+  ldmw16    the full-size SD-1.5 evaluation of `ldm` with every U-Net weight rounded through fp16 (what a public fp16 .ckpt holds): the
+            expectation of the checkpoint loader test (round 6)
   full4     BASELINE config 4 at full size through the reference sampler: FFHQ-64 SongUNet (61.8M params) + AMED_predictor
             (num_steps=4, afs=True, time_uniform rho=1, scale_dir=0.01, scale_time=0; amed-solver-main/launch.sh:21-24), 5 NFE, B=2
 """
@@ -478,7 +480,26 @@ def part_fullsolv():
     np.savez_compressed(os.path.join(OUT, 'sampler_cifar10_solvers_nfe10_b4.npz'), **d)
 
 
-PARTS = dict(full5b=part_full5b, gitsldm=part_gitsldm, fullffhq=part_fullffhq, fullgits=part_fullgits, fullsolv=part_fullsolv, full3=part_full3, full4=part_full4, net=part_net, sched=part_sched, samplers=part_samplers, amed=part_amed, gits=part_gits, ldm=part_ldm, full=part_full)
+def part_ldmw16():
+    """The SD-checkpoint loader's expectation (round 6): public SD-1.x ``.ckpt`` files hold fp16 tensors under ``model.diffusion_model.`` and the
+    loader widens them (``sample.py:create_model``: ``v.float()``).  The REAL reference CFGPrecond + UNetModel at full SD-1.5 size with every weight
+    rounded through fp16, on the inputs of ``ldm_sd15.npz``: what an fp32 evaluation of such a checkpoint must return."""
+    sys.path.insert(0, os.path.join(REF, 'diff-solvers-main'))
+    net, unet, kw, spec = _ref_cfg_net('sd15', 23)
+    with torch.no_grad():
+        for p in unet.parameters():
+            p.copy_(p.half().float())
+    z = np.load(os.path.join(OUT, 'ldm_sd15.npz'))
+    x, sig = torch.from_numpy(z['x']), torch.from_numpy(z['sigma'])
+    cond, uncond = torch.from_numpy(z['cond']), torch.from_numpy(z['uncond'])
+    with torch.no_grad():
+        out = net(x, sig, condition=cond, unconditional_condition=uncond).numpy()
+    rel = float(np.abs(out - z['out_vec']).max() / np.abs(z['out_vec']).max())
+    np.savez_compressed(os.path.join(OUT, 'ldm_sd15_w16.npz'), seed=23, out_vec=out, rel_to_fp32_weights=rel)
+    print('ldm sd15 with fp16-rounded weights: rel distance from the fp32-weight golden', rel, flush=True)
+
+
+PARTS = dict(ldmw16=part_ldmw16, full5b=part_full5b, gitsldm=part_gitsldm, fullffhq=part_fullffhq, fullgits=part_fullgits, fullsolv=part_fullsolv, full3=part_full3, full4=part_full4, net=part_net, sched=part_sched, samplers=part_samplers, amed=part_amed, gits=part_gits, ldm=part_ldm, full=part_full)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
