@@ -26,10 +26,10 @@ Prints ONE JSON line on rank 0 with the driver's contract fields plus
                    (roofline_update_large_batch_other_solver: the Adams-Bashforth family's ds_solver_update, iPNDM order 4)
   kernels          time share of every kernel class in the instrumented step
   launch_modes     the same sampler call eager vs replayed from one captured hipGraph, at B=8 and at the benchmark batch
-  throughput_by_batch  (cifar10) the same call at 1024 images per call next to the benchmark batch (informational)
+  throughput_by_batch  (cifar10) the same call over SURVEY 8d's batch sweep {64, 256, 1024, 4096} (informational; 2 timed calls, 1 at 4096)
   other_configs    (N = 1, default run) the other benchmarked configurations / arithmetic modes, each timed in THIS process under the
                    driver's clock: ImageNet-64 fp16 B=64 iPNDM-4, SD-1.5 fp16 B=16, FFHQ-64 fp32 B=128, CIFAR-10 fp16x3 B=256 -- value,
-                   ms_per_step (2 timed calls after 1 warm-up), the dominant kernel's own roofline and the whole-application fraction of
+                   value_min / value_max, ms_per_step (MEDIAN of 5 individually timed calls after 2 warm-ups), the dominant kernel's own roofline and the whole-application fraction of
                    the matrix peak of the datatype used (SURVEY 8d FLOPs per evaluation x evaluations / time / peak)
   latency          small-batch sampler calls (BASELINE config 1 is B = 8): CIFAR-10 B=8 NFE=10 and SD-1.5 fp16 B=1 NFE=10, ms per call
   cpu_baseline     the oracle (CPU restatement of the reference, ``oracle/``; the real reference when /root/reference is
@@ -106,7 +106,9 @@ def parse(argv=None):
     ap.add_argument('--cpu-calls', type=int, default=2)
     ap.add_argument('--cpu-threads', default='sweep', help="'sweep' (8,16,32; best reported) or a thread count")
     ap.add_argument('--no-launch-modes', action='store_true', help='skip the eager-vs-hipGraph comparison')
-    ap.add_argument('--no-batch-sweep', action='store_true', help='skip the extra throughput measurement at 1024 images per call')
+    ap.add_argument('--no-batch-sweep', action='store_true', help='skip the throughput_by_batch sweep (SURVEY 8d config 2: 64 / 256 / 1024 / 4096 images per call)')
+    ap.add_argument('--sweep-batches', type=lambda t: [int(v) for v in t.split(',') if v], default=[64, 1024, 4096],
+                    help='batches of throughput_by_batch next to --batch (comma separated)')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the other_configs / latency measurements of the default run')
     ap.add_argument('--stub', action='store_true', help=argparse.SUPPRESS)   # launcher self-test: gloo ranks on CPU, no kernels
     args = ap.parse_args(argv)
@@ -538,8 +540,9 @@ def application_fraction(config, dtype, images_per_sec, nfe):
                 gflop_per_image=round(GFLOP_PER_EVAL[config] * nfe, 1))
 
 
-def measure_config(config, dtype, batch, nfe, dev, calls=2, latency_batch=None):
-    """One of `other_configs`: build the net, 1 warm-up + `calls` timed sampler calls, one instrumented call for the kernel shares."""
+def measure_config(config, dtype, batch, nfe, dev, calls=5, warmup=2, latency_batch=None):
+    """One of `other_configs`: build the net, `warmup` untimed + `calls` individually timed sampler calls (value = the MEDIAN call; min / max
+    next to it: box-to-box and call-to-call spread on the fp16 lines is a few per cent), one instrumented call for the kernel shares."""
     from diff_sampler_amd import solvers
     t_build = time.perf_counter()
     factory, is_ldm = build_net(config, dtype, dev)
@@ -555,33 +558,41 @@ def measure_config(config, dtype, batch, nfe, dev, calls=2, latency_batch=None):
                for _ in range(2)] if is_ldm else None
         return lat, ldm
 
-    def timed(lat, ldm, n):
-        sampler_call(solvers, solver, net, lat, nfe, ldm)
+    def timed(lat, ldm, n, w=1):
+        """Seconds of each of n sampler calls (each bracketed by a device synchronisation) after w untimed ones."""
+        for _ in range(w):
+            sampler_call(solvers, solver, net, lat, nfe, ldm)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        dts = []
         for _ in range(n):
+            t0 = time.perf_counter()
             out = sampler_call(solvers, solver, net, lat, nfe, ldm)
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            dts.append(time.perf_counter() - t0)
         assert torch.isfinite(out).all()
-        return (time.perf_counter() - t0) / n
+        return sorted(dts)
 
     lat, ldm = inputs(batch)
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
-    dt = timed(lat, ldm, calls)
+    dts = timed(lat, ldm, calls, warmup)
+    dt = dts[len(dts) // 2]                                   # median call
     rec = instrumented_pass(net, solvers, solver, lat, nfe, ldm)
     kernels, roof, dom_id, _ = kernel_report(rec)
     attach_traffic(roof, dom_id, (config, dtype))
     roof_norm = norm_act_roofline(rec, (config, dtype)) if dtype == 'fp16' else None
     top = dict(list(kernels.items())[:5])
     res = dict(config=dict(workload='%s, %s NFE=%d, batch %d/GPU' % (WORKLOAD_NAMES.get(config, config), LDM_SOLVER_NAME if is_ldm else SOLVER_NAMES[solver], nfe, batch)),
-               dtype=dtype, value=round(batch / dt, 2), unit='images/sec', ms_per_step=round(dt * 1e3, 2), steps=calls, warmup=1,
+               dtype=dtype, value=round(batch / dt, 2), value_min=round(batch / dts[-1], 2), value_max=round(batch / dts[0], 2),
+               value_stat=f'median of {calls} individually timed sampler calls after {warmup} warm-up calls', unit='images/sec',
+               ms_per_step=round(dt * 1e3, 2), steps=calls, warmup=warmup,
                roofline=roof, roofline_norm_act=roof_norm, application=application_fraction(config, dtype, batch / dt, nfe), kernels_top5=top,
                setup_s=round(t_build, 1))
     lat_ms = None
     if latency_batch is not None:
         l2, ldm2 = inputs(latency_batch)
-        lat_ms = round(timed(l2, ldm2, 3) * 1e3, 2)
+        d2 = timed(l2, ldm2, 5, 1)
+        lat_ms = round(d2[len(d2) // 2] * 1e3, 2)
     del net
     torch.cuda.empty_cache()
     return res, lat_ms
@@ -679,6 +690,12 @@ def main(argv=None):
         assert torch.isfinite(out).all()
 
     roof = roof_u = kernels = roof_norm = None
+    if rank == 0 and stub:
+        # launcher self-test: no kernels ran, but the N > 1 line must carry rank 0's roofline object like a real line does (a SCALE record is
+        # then self-contained): the SAME report path over a synthetic one-kernel record, marked as such
+        kernels, roof, dom_id, _ = kernel_report({('conv', 2565): [1.0, 1, 1.0e9]})
+        attach_traffic(roof, dom_id, (args.config, args.dtype))
+        roof['stub'] = True
     if rank == 0 and not stub:
         rec = instrumented_pass(net, solvers, args.solver, latents, args.nfe, ldm)
         kernels, roof, dom_id, total_ms = kernel_report(rec)
@@ -725,20 +742,35 @@ def main(argv=None):
         if not args.no_launch_modes and world == 1:
             modes = launch_modes(args, solvers, net_factory, spec, dev)
         if not args.no_batch_sweep and world == 1 and args.config == 'cifar10' and not args.graph:
-            # the same sampler call at a larger batch (SURVEY 8d sweeps B for this config): per-launch fixed costs are amortised over more
-            # rounds of tiles.  Informational; `value` stays the batch named in config.workload.
-            by_batch = {str(B): round(B * args.steps / dt_local, 2)}
-            for b2 in (1024,):
+            # the same sampler call over SURVEY 8d's batch sweep of this configuration {64, 256, 1024, 4096}: per-launch fixed costs are
+            # amortised over more rounds of tiles.  Informational; `value` stays the batch named in config.workload.  Two timed calls after
+            # one warm-up call (4 096 images: one network evaluation as warm-up and ONE timed call -- a call takes ~13 s there); the plans
+            # of a swept batch (4 096 images: ~180 GB of workspaces) are released before the next one is built.
+            by_batch = {str(B): dict(value=round(B * args.steps / dt_local, 2), steps=args.steps, warmup=args.warmup)}
+            for b2 in args.sweep_batches:
                 if b2 == B:
                     continue
-                lat2 = torch.randn(b2, spec.in_channels, spec.img_resolution, spec.img_resolution, device=dev)
-                sampler_call(solvers, args.solver, net, lat2, args.nfe); sync()
-                t1 = time.perf_counter()
-                for _ in range(2):
-                    sampler_call(solvers, args.solver, net, lat2, args.nfe)
-                sync()
-                by_batch[str(b2)] = round(2 * b2 / (time.perf_counter() - t1), 2)
-                del lat2
+                try:
+                    lat2 = torch.randn(b2, spec.in_channels, spec.img_resolution, spec.img_resolution, device=dev)
+                    n2 = 1 if b2 > 2048 else 2
+                    if b2 > 2048:
+                        net(lat2, 1.0); sync()                      # plan build + one evaluation
+                    else:
+                        sampler_call(solvers, args.solver, net, lat2, args.nfe); sync()
+                    t1 = time.perf_counter()
+                    for _ in range(n2):
+                        o2 = sampler_call(solvers, args.solver, net, lat2, args.nfe)
+                    sync()
+                    by_batch[str(b2)] = dict(value=round(n2 * b2 / (time.perf_counter() - t1), 2), steps=n2, warmup='1 call' if b2 <= 2048 else '1 network evaluation',
+                                             finite=bool(torch.isfinite(o2).all()))
+                    del lat2, o2
+                except Exception as e:                              # (e.g. out of device memory on a smaller part): the headline line survives
+                    by_batch[str(b2)] = dict(error=f'{type(e).__name__}: {str(e)[:200]}')
+                net._last = None
+                for k_ in [k_ for k_ in net.engine._plans if k_[0] == b2]:
+                    del net.engine._plans[k_]
+                torch.cuda.empty_cache()
+            by_batch = dict(sorted(by_batch.items(), key=lambda kv: int(kv[0])))
     others = latency = None
     if (rank == 0 and world == 1 and not stub and not args.no_other_configs and not args.graph
             and (args.config, args.dtype, B, args.solver, args.nfe) == ('cifar10', 'fp32', 256, 'dpmpp', 10)):

@@ -243,3 +243,21 @@ def check(code, what=''):
 def stream_ptr():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_HIP = [None]
+
+
+def capture_id():
+    """Id of the stream capture the current stream is recording into (hipStreamGetCaptureInfo), or 0 when it is not capturing.  Scopes
+    per-capture caches (ldm_engine: the context K / V projections recorded once per hipGraph) to ONE capture: a later capture -- by anyone,
+    on the same static tensors -- never matches an earlier capture's key."""
+    if _HIP[0] is None:
+        _HIP[0] = C.CDLL('libamdhip64.so')
+        _HIP[0].hipStreamGetCaptureInfo.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_ulonglong)]
+        _HIP[0].hipStreamGetCaptureInfo.restype = C.c_int
+    status, cid = C.c_int(0), C.c_ulonglong(0)
+    rc = _HIP[0].hipStreamGetCaptureInfo(stream_ptr(), C.byref(status), C.byref(cid))
+    if rc != 0 or status.value != 1:          # hipStreamCaptureStatusActive == 1
+        return 0
+    return int(cid.value) or 1

@@ -76,39 +76,97 @@ def source_hashes():
     return {os.path.basename(s): source_sha256(os.path.basename(s)) for s in sources()}
 
 
-def build_lib(force=False, verbose=True):
-    if not force and not needs_build():
-        return LIB
+# Test-only VARIANT builds of the same sources (round 6): DS_RACE_STRESS libraries whose LDS-producing waves are delayed ~2 us
+# (csrc/ds_common.h: DS_RACE_SKEW) -- two complementary wave masks.  They live next to libdsamd.so as libdsamd_<tag>.so (objects in
+# csrc/build_<tag>/), are loaded only through DS_LIB_PATH (tests/test_hip_race_stress.py) and are never what the engines run.
+# 'stress_g5' = stress_a with the round-5 race RE-INTRODUCED (conv3x3_f16dma.hip without its prologue barrier, docs/HISTORY.md G.5): the
+# test suite asserts that the kernel tests FAIL against it -- the detector detects.  It recompiles that one translation unit and links the
+# other objects of stress_a.
+VARIANTS = {'stress_a': ['-DDS_RACE_STRESS=0x21'], 'stress_b': ['-DDS_RACE_STRESS=0xDE'],
+            'stress_g5': ['-DDS_RACE_STRESS=0x21', '-DDS_TEST_DROP_G5_BARRIER=1']}
+VARIANT_BASE = {'stress_g5': ('stress_a', ('conv3x3_f16dma.hip',))}        # tag -> (variant whose objects it shares, the translation units it compiles itself)
+
+
+def variant_lib(tag):
+    return os.path.join(CSRC, f'libdsamd_{tag}.so') if tag else LIB
+
+
+def _variant_paths(tag):
+    """(library, object directory, stamp file, extra flags) of a build: tag '' = the product library."""
+    if not tag:
+        return LIB, CSRC, STAMP, []
+    odir = os.path.join(CSRC, f'build_{tag}')
+    return variant_lib(tag), odir, os.path.join(odir, '.build_flags'), list(VARIANTS[tag])
+
+
+def _stamp_ok(stamp, text):
+    try:
+        with open(stamp) as fh:
+            return fh.read() == text
+    except OSError:
+        return False
+
+
+def variant_needs_build(tag):
+    lib, odir, stamp, extra = _variant_paths(tag)
+    if not os.path.exists(lib) or not _stamp_ok(stamp, _flags_stamp() + ' ' + ' '.join(extra)):
+        return True
+    t = os.path.getmtime(lib)
+    return any(os.path.getmtime(d) > t for d in sources() + headers())
+
+
+def build_libs(tags=('',), force=False, verbose=True):
+    """Compile every translation unit of every requested build in ONE pool (one hipcc per (build, translation unit); the two convolution
+    files dominate: ~2-3 min each), then link each library."""
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    todo = [t for t in tags if force or (needs_build() if not t else variant_needs_build(t))]
+    for t in list(todo):                                        # a variant that shares objects needs its base built in the same pass
+        b = VARIANT_BASE.get(t, (None,))[0]
+        if b is not None and b not in todo:
+            todo.insert(todo.index(t), b)
+    if not todo:
+        return [variant_lib(t) for t in tags]
     if not os.path.exists(hipcc):
         raise RuntimeError('hipcc not found: libdsamd.so cannot be built on this machine')
     from concurrent.futures import ThreadPoolExecutor
 
     newest_header = max([os.path.getmtime(h) for h in headers()] or [0.0])
-    if not _stamp_matches():
-        force = True                                            # objects compiled under other flags (visibility, experiments) are stale
+    jobs, links = [], []
+    for tag in todo:
+        lib, odir, stamp, extra = _variant_paths(tag)
+        os.makedirs(odir, exist_ok=True)
+        text = _flags_stamp() + ((' ' + ' '.join(extra)) if tag else '')
+        stale = force or not _stamp_ok(stamp, text)             # objects compiled under other flags (visibility, experiments) are stale
+        objs = []
+        base, own = VARIANT_BASE.get(tag, (None, ()))
+        for src in sources():
+            if base is not None and os.path.basename(src) not in own:
+                objs.append(os.path.join(_variant_paths(base)[1], os.path.basename(src)[:-4] + '.o'))       # compiled by the base variant's jobs
+                continue
+            obj = os.path.join(odir, os.path.basename(src)[:-4] + '.o')
+            objs.append(obj)
+            if stale or not os.path.exists(obj) or os.path.getmtime(obj) <= max(os.path.getmtime(src), newest_header):
+                jobs.append((os.path.getsize(src), [hipcc, f'--offload-arch={ARCH}'] + BASE_FLAGS + EXTRA_FLAGS + extra + ['-c', src, '-o', obj]))
+        links.append((lib, objs, stamp, text))
 
-    def compile_one(src):
-        obj = src[:-4] + '.o'
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
-            return obj                                          # this translation unit is up to date
-        cmd = [hipcc, f'--offload-arch={ARCH}'] + BASE_FLAGS + EXTRA_FLAGS + ['-c', src, '-o', obj]
+    def run(cmd):
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
-        return obj
 
-    # one hipcc per translation unit, in parallel (the two convolution files dominate: ~2-3 min each)
-    with ThreadPoolExecutor(max_workers=max(1, min(len(sources()), os.cpu_count() or 1))) as pool:
-        objs = list(pool.map(compile_one, sources()))
-    cmd = [hipcc, f'--offload-arch={ARCH}', '-shared', '-fPIC', '-fvisibility=hidden', '-o', LIB] + objs
-    if verbose:
-        print(' '.join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    with open(STAMP, 'w') as fh:
-        fh.write(_flags_stamp())
-    return LIB
+    jobs.sort(key=lambda j: -j[0])                              # the long compilations first
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs) or 1, os.cpu_count() or 1))) as pool:
+        list(pool.map(run, [j[1] for j in jobs]))
+    for lib, objs, stamp, text in links:
+        run([hipcc, f'--offload-arch={ARCH}', '-shared', '-fPIC', '-fvisibility=hidden', '-o', lib] + objs)
+        with open(stamp, 'w') as fh:
+            fh.write(text)
+    return [variant_lib(t) for t in tags]
+
+
+def build_lib(force=False, verbose=True):
+    return build_libs(('',), force=force, verbose=verbose)[0]
 
 
 if __name__ == '__main__':
-    build_lib(force='--force' in sys.argv)
+    build_libs(('',) + (tuple(VARIANTS) if '--variants' in sys.argv else ()), force='--force' in sys.argv)

@@ -81,6 +81,7 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(const ds_attn_args a) {
         }
     };
     auto sstore = [&]() {
+        DS_RACE_SKEW(tid >> 6);
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             const int idx = tid + 256 * j;

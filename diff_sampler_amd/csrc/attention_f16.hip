@@ -162,6 +162,7 @@ __global__ void __launch_bounds__(512, DS_ATTN_WAVES(D)) flash_attn_f16_kernel(c
     };
     auto sstore = [&](int buf) {
         unsigned char* base = smem_b + buf * TILE_B;
+        DS_RACE_SKEW(wave);
 #pragma unroll
         for (int j = 0; j < NLK; ++j) {
             const int idx = tid + 512 * j;

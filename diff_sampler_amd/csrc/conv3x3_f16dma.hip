@@ -155,6 +155,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
             hcj = (int)(((unsigned)(tid & 7) ^ (((hcol + (W == 8 ? 8u * (hrow & 1u) : 0u)) >> 1) & 7u)) * 8u);
         }
         const _Float16* g = hpix[j] >= 0 ? base + (size_t)hpix[j] * ld + hcj : g_zero_halfs;
+        DS_RACE_SKEW(wave);
         __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + D * WB + hbuf * HB + (j * 512 + wave * 64) * 16), 16, 0, 0);
     };
     // ---- NORM: the slab's {mu, A, B} rows -> tail of halo buffer hbuf (unit u = tid < NIMG * 48: image slot u / 48, plane (u % 48) / 16) ----
@@ -164,6 +165,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
                 if (tid < (int)G::COEF_UNITS) {
                     const int sl = tid / 48, rem = tid - sl * 48;
                     const float* g = p.norm + ((size_t)(img0 + sl) * 3 + (rem >> 4)) * (size_t)(p.c0 + p.c1) + (size_t)chunk * 64 + (rem & 15) * 4;
+                    DS_RACE_SKEW(wave);
                     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + D * WB + hbuf * HB + G::COEF_OFF + wave * 64 * 16), 16, 0, 0);
                 }
             }
@@ -199,6 +201,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
                 t[e] = act ? ds_silu(u) : u;
             }
             const f32x4 o = {pack_h2(t[0], t[1]), pack_h2(t[2], t[3]), pack_h2(t[4], t[5]), pack_h2(t[6], t[7])};
+            DS_RACE_SKEW(wave);
             lds_wr<0>(ua, o);
         }
     };
@@ -207,6 +210,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
     const _Float16* wsrc = wgt + (size_t)(n0 + (tid >> 3)) * ldbh + (((tid & 7) ^ ((tid >> 4) & 7)) * 8);
     auto w_dma = [&](int kt, int wbuf) {
         if ((abl & 1) && kt >= D) return;
+        DS_RACE_SKEW(wave);
 #pragma unroll
         for (int i = 0; i < NB; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (size_t)i * 64 * ldbh + (size_t)kt * 64),
@@ -215,6 +219,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
     auto w_dma_row = [&](int kt, int wbuf, auto ic) {            // one 64-row block of it (issued between MFMAs, see the tap)
         constexpr int i = decltype(ic)::value;
         if ((abl & 1) && kt >= D) return;
+        if (i == 0) DS_RACE_SKEW(wave);
         __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (size_t)i * 64 * ldbh + (size_t)kt * 64),
                                          (lptr_t)(lds + wbuf * WB + (i * 64 + wave * 8) * 128), 16, 0, 0);
     };
@@ -301,7 +306,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
         // COEFFICIENT rows were fetched by wave 0 alone: every other wave needs wave 0's wait + a barrier before it reads them.  (Without this
         // barrier the kernel passed every test and whole-network comparison for a day and then produced four wrong images in one first run at
         // 64 images per call: tools/diag_fuse_norm.py, docs/HISTORY.md G.5.  In the steady state the taps' own barriers separate the two.)
+#ifndef DS_TEST_DROP_G5_BARRIER                                // tests only (build.py 'stress_g5'): the race re-introduced, to prove that the stress build catches it
         __builtin_amdgcn_s_barrier();
+#endif
         if (cb < nchunks) static_for<NDMA>([&](auto jc) { norm_round(cb & 1, jc); });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }

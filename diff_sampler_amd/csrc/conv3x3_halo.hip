@@ -217,6 +217,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WN == 4 ? 2 : WN) conv3x3_halo_k
     float* Cs = Ah + p.NP * LDSK;                   // [nimg][3][Ctot]
     auto coef_stage = [&]() {
         const int per = 3 * Ctot;
+        DS_RACE_SKEW(wave);
         for (int i = tid * 4; i < p.nimg * per; i += T * 4) {
             const int s = i / per;
             f32x4 v = {0.f, 1.f, 0.f, 0.f};
@@ -227,6 +228,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WN == 4 ? 2 : WN) conv3x3_halo_k
     auto halo_store = [&](int chunk) {
         const bool do_norm = norm_on && chunk < nchunks && !(VAR & VAR_NO_NORM);
         const int cq = chunk * BK + ld_col;
+        DS_RACE_SKEW(wave);
 #pragma unroll
         for (int j = 0; j < NS_MAX; ++j) {
             if (j < ns) {
@@ -253,11 +255,13 @@ __global__ void __launch_bounds__(64 * WM * WN, WN == 4 ? 2 : WN) conv3x3_halo_k
     auto b_addr = [&](int kt, int i) -> const float* { return b_ok[i] ? p.b + b_off[i] + kt * BK : zero; };
     auto b_store = [&](int buf) {
         float* bs = Bs + buf * BNT * LDSK + ld_row * LDSK + ld_col;
+        DS_RACE_SKEW(wave);
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) *reinterpret_cast<f32x4*>(bs + (T / 8) * i * LDSK) = rb[i];
     };
     // LDS-DMA of weight tile kt into buffer buf: one 1-KiB wave instruction covers 8 rows x 128 B
     auto b_dma = [&](int kt, int buf) {
+        DS_RACE_SKEW(wave);
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) {
             float* dst = Bs + buf * BNT * 32 + (wave * 8 + (T / 8) * i) * 32;      // wave-uniform base
@@ -273,6 +277,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WN == 4 ? 2 : WN) conv3x3_halo_k
     const unsigned b_voff = (unsigned)((ld_row * p.ldb + (((tid & 7) ^ ((ld_row >> 1) & 7)) * 4)) * (int)sizeof(float));
     auto b_dma_lean = [&](int kt, int buf) {
         const char* tap = reinterpret_cast<const char*>(p.b + (size_t)n0 * p.ldb + (size_t)kt * BK);
+        DS_RACE_SKEW(wave_u);
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) {
             float* dst = Bs + buf * BNT * 32 + (wave_u * 8 + (T / 8) * i) * 32;

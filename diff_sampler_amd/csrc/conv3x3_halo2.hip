@@ -106,6 +106,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo2_kernel(const KParams p) 
     for (int i = 0; i < 2; ++i)
         bsrc[i] = p.b + (size_t)(n0 + ld_row + 64 * i) * p.ldb + (((tid & 7) ^ ((ld_row >> 1) & 7)) * 4);
     auto b_dma = [&](int kt, int buf) {
+        DS_RACE_SKEW(wave);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             float* dst = smem + buf * 4096 + (wave * 8 + 64 * i) * 32;
@@ -177,6 +178,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo2_kernel(const KParams p) 
     };
     auto store_slot = [&](auto jc, unsigned st_addr) {
         constexpr int j = decltype(jc)::value;
+        DS_RACE_SKEW(wave);
         if (j < NS - 1 || last_slot_valid) {
             if constexpr (SPLIT) {
                 const f32x2 hi = {cvt[0], cvt[1]}, lo = {cvt[2], cvt[3]};

@@ -32,6 +32,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
         }                                                                                                                       \
     } while (0)
 
+// ---- Race-stress build (tests only; round 6).  -DDS_RACE_STRESS=<wave mask> (build.py: build_variant('stress_a' / 'stress_b')) makes the waves of
+// the mask sleep ~2 us (s_sleep 75 = 4 800 cycles: several L2 -> LDS round trips) at every point where a wave PRODUCES shared LDS contents --
+// right before it issues an LDS-DMA (global_load_lds) or a staging ds_write that other waves consume.  A slept wave's data lands late and its
+// own later reads come late, while the other waves run ahead to their next reads AND their next overwrites: an ordering that rests on timing
+// instead of on `s_waitcnt` + `s_barrier` (docs/HISTORY.md G.5: coefficient rows fetched by wave 0, read by waves 1 - 7 with no barrier) then
+// fails on every run instead of once per cold box.  Two complementary masks are built: 0x21 (waves 0 and 5 late: the single-wave producers
+// are late -> read-before-landed) and 0xDE (every other wave late: the producers are early -> overwritten-before-read).  Results of a
+// correct kernel do not depend on the mask; tests/test_hip_race_stress.py runs the kernel / fp16 suites against both libraries.
+#ifdef DS_RACE_STRESS
+#define DS_RACE_SKEW(wave_)                                                                          \
+    do {                                                                                             \
+        if (((unsigned)(DS_RACE_STRESS) >> ((unsigned)(wave_) & 31u)) & 1u) __builtin_amdgcn_s_sleep(75); \
+    } while (0)
+#else
+#define DS_RACE_SKEW(wave_) do { } while (0)
+#endif
+
 static inline bool ds_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // SiLU with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division sequence (~10 VALU instructions):

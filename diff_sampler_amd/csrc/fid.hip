@@ -71,6 +71,7 @@ __global__ void __launch_bounds__(256) fid_moments_kernel(const void* __restrict
     request(0);
     for (int r0 = 0; r0 < rows; r0 += FR) {
         __syncthreads();                                        // the previous chunk's reads are done
+        DS_RACE_SKEW(tid >> 6);
 #pragma unroll
         for (int o = 0; o < 2; ++o)
 #pragma unroll

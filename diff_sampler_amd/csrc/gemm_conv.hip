@@ -104,6 +104,7 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(const KParams p) {
     };
     auto b_addr = [&](int kt, int i) -> const float* { return b_ok[i] ? b_base + b_off[i] + kt * BK : zero; };
     auto store_tiles = [&](int buf) {
+        DS_RACE_SKEW(wave);
         float* as = As + buf * BM * LDSK + ld_row * LDSK + ld_col;
         float* bs = Bs + buf * BN * LDSK + ld_row * LDSK + ld_col;
 #pragma unroll

@@ -55,6 +55,7 @@ __global__ void __launch_bounds__(512, 2) gemm_dma8_kernel(const KParams p) {
         const int ld_ = first_ ? p.lda0 : p.lda1;                                                                           \
         float* As_ = smem + (buf_) * STAGE8;                                                                                \
         float* Bs_ = As_ + TM8 * 32;                                                                                        \
+        DS_RACE_SKEW(wave);                                                                                                 \
         DS_DMA8_A(0); DS_DMA8_A(1); DS_DMA8_A(2); DS_DMA8_A(3); DS_DMA8_B(0); DS_DMA8_B(1);                                 \
     } while (0)
 

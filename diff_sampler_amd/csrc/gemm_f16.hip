@@ -48,6 +48,7 @@ __global__ void __launch_bounds__(512, 2) gemm_f16_kernel(const KParams p) {
     for (int i = 0; i < 2; ++i)
         bsrc[i] = p.b + (size_t)(n0 + ld_row + 64 * i) * p.ldb + (((tid & 7) ^ ((ld_row >> 1) & 7)) * 4);
     auto b_dma = [&](int kt, int buf) {
+        DS_RACE_SKEW(wave);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             float* dst = smem + buf * 4096 + (wave * 8 + 64 * i) * 32;
@@ -79,6 +80,7 @@ __global__ void __launch_bounds__(512, 2) gemm_f16_kernel(const KParams p) {
         f32x4 cvt;
         cvt[0] = pack_h2(lo[0], lo[1]); cvt[1] = pack_h2(lo[2], lo[3]);
         cvt[2] = pack_h2(hi[0], hi[1]); cvt[3] = pack_h2(hi[2], hi[3]);
+        if (j == 0) DS_RACE_SKEW(wave);
         lds_wr<j * 9216>(st_addr, cvt);
     };
 

@@ -82,6 +82,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_f16dma_kernel(const KParams p
             const int ty = tap / 3;
             toff = ty * p.IW + (tap - ty * 3);
         }
+        DS_RACE_SKEW(wave);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const _Float16* g;

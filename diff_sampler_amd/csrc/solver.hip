@@ -632,14 +632,17 @@ extern "C" int ds_copy_rows(const float* src, int src_ld, float* dst, int dst_ld
     return DS_OK;
 }
 
-extern "C" int ds_build_experiments(void) {
+extern "C" int ds_build_experiments(void) {          // bit 0: DS_BUILD_EXPERIMENTS (A/B-record kernels present); bit 1: DS_RACE_STRESS (tests-only delayed build)
+    int flags = 0;
 #ifdef DS_BUILD_EXPERIMENTS
-    return 1;
-#else
-    return 0;
+    flags |= 1;
 #endif
+#ifdef DS_RACE_STRESS
+    flags |= 2;
+#endif
+    return flags;
 }
-extern "C" int ds_version(void) { return 3; }      // 2: ds_conv_args.tune, ds_update_args.variant (struct layouts changed), ds_fid_moments; no ds_debug_* entry points
+extern "C" int ds_version(void) { return 3; }      // ABI 3: ds_conv_args.update appended (head-fused solver update), ds_build_experiments(); ABI 2: ds_conv_args.tune / ds_update_args.variant, ds_fid_moments
 
 extern "C" const char* ds_error_string(int code) {
     switch (code) {

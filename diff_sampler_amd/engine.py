@@ -461,10 +461,10 @@ class UNetEngine:
         # ---- the solver update fused into the head (round 5, ds_conv_args.update): the head launch carries a pointer to ONE persistent
         # ds_update_args of this plan; EDMDenoiser.raw(update=...) fills it before a run and clears its outputs afterwards (x_out == m_out ==
         # NULL = plain head).  Possible where the head runs on conv3x3_thin_kernel with a channel-planar output (ds_conv_kernel_id 2570).
-        head = P.ops[-1].keep[0]
+        last = P.ops[-1]
+        head = last.keep[0] if (last.fn is lib.ds_conv2d_nhwc and last.keep) else None         # the last launch IS the head convolution
         P.head_update = _lib.UpdateArgs()
-        P.head_fusable = bool(P.ops[-1].fn is lib.ds_conv2d_nhwc and head.out_nchw and not head.wgt_f16
-                              and lib.ds_conv_kernel_id(C.byref(head)) == 2570)
+        P.head_fusable = bool(head is not None and head.out_nchw and not head.wgt_f16 and lib.ds_conv_kernel_id(C.byref(head)) == 2570)
         if P.head_fusable:
             head.update = C.cast(C.pointer(P.head_update), C.c_void_p)
         from .plan import release_tuning_scratch
@@ -559,7 +559,10 @@ class EDMDenoiser:
         """F(c_in x; c_noise), the raw network output, as an NCHW [B, C, H, W] tensor.  Engine-owned, overwritten by the
         next evaluation at the same batch size.
         update: a filled ``_lib.UpdateArgs`` (raw = 1, f ignored): the network head applies that solver update in its epilogue -- no update
-        launch (``head_update_ok(B, ...)`` says whether this plan's head can; csrc/conv3x3_thin.hip)."""
+        launch (``head_update_ok(B, ...)`` says whether this plan's head can; csrc/conv3x3_thin.hip).
+        A plan is SINGLE-STREAM state: its workspaces, its input buffers and the one ``head_update`` struct the head launch points at are
+        written here and read by the launches that follow, so two threads / streams must not evaluate the same (denoiser, batch) plan
+        concurrently -- build one denoiser per stream (the reference's module has the same contract: one process, one stream per rank)."""
         plan, _ = self._prepare(x, sigma, class_labels)
         if update is None:
             plan.run(_lib.stream_ptr())

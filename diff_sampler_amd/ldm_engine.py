@@ -203,6 +203,10 @@ class LDMUNetEngine:
                 bd.norm('apply', x0, c0, c0, N, side, side, name + '.gn', x1=x1, c1=c1, ld1=c1, groups=32, eps=eps, use_stats=False,
                         act=DS_ACT_SILU, out=a16, out_ld=cin, out_f16=True, raw_out=raw16, raw_ld=cin, coefs=ncoef,
                         in_f16=(x0.dtype == torch.float16))
+                # the pass form takes ONE raw source for a fused skip_connection (the materialised copy `raw16`, or the single fp16 input): a
+                # two-source e16 belongs to the fused branch above only -- res_layer evaluates the same predicate; if the two ever disagreed the
+                # second source would be dropped silently
+                assert e16 is None or len(e16) == 2 or e16[2] is None, (name, 'two raw skip sources need the fused normalisation')
                 ex = dict(e0=e16[0], ec0=e16[1]) if e16 is not None else {}
                 bd.conv(a16, cin, cin, N, side, side, wgt, cout, out, out_ld, 9, name, bias=bias, stats=True, w16=w16, in_f16=True,
                         out_f16=(out.dtype == torch.float16), **ex, **kw)
@@ -513,9 +517,13 @@ class CFGDenoiser(CFGSchedule):
             # on the same condition tensors skip them -- a replay then pays them once per graph, not once per denoiser evaluation.  The key
             # is scoped to the capture: invalidate_context_cache() (graph.GraphedSampler calls it right after capturing and after every
             # replay) clears it, and an eager call never matches it.
-            cap_key = ('capture',) + tuple((t.data_ptr(), tuple(t.shape), t._version) for t in parts)
+            # (round 6) ... and it carries the id of THIS capture (hipStreamGetCaptureInfo): a capture made by someone else's
+            # torch.cuda.graph, one aborted by an exception, or two captures in a row on the same static tensors never match each other
+            cap_key = ('capture', _lib.capture_id()) + tuple((t.data_ptr(), tuple(t.shape), t._version) for t in parts)
             same = self.cache_context and getattr(plan, 'ctx_capture_key', None) == cap_key
             plan.ctx_capture_key = cap_key
+        else:
+            plan.ctx_capture_key = None          # an eager evaluation ends every capture scope
         if not same:
             for i, c_ in enumerate(parts):
                 c_ = c_.to(device=self.device, dtype=torch.float32)

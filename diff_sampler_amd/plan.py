@@ -40,13 +40,16 @@ _TUNE_CACHE: Dict[tuple, tuple] = {}     # (device, layer signature) -> (nb, nw,
 _MEASURED: Dict[str, list] = {}          # table keys measured in THIS process (misses of the persisted table): save_tile_table() writes them
 _FLUSH: Dict[int, torch.Tensor] = {}     # device index -> the 512 MiB scratch written before every timed launch; freed by release_tuning_scratch()
 
-# ---- The measured table is PERSISTED (round 5): profiles/tile_table.json, keyed by layer signature and tied to the hash of the two kernel
+# ---- The measured table is PERSISTED (round 5; package data since round 6: diff_sampler_amd/data/tile_table.json travels with an installed or
+# relocated package), keyed by layer signature and tied to the hash of the two kernel
 # translation units it was measured on.  A plan build looks a shape up there first and measures only on a miss, so (a) two runs of the
 # same tree choose identical tiles -- routing is reproducible, where an on-box timing race was not --, (b) building the benchmarked
 # plans costs no measurement launches (bench.py's setup_s), and (c) the profiler sees no tuning launches.  The table is regenerated on
 # a GPU box by `python tools/make_tile_table.py` (it builds the benchmarked plans with the table ignored and writes what it measured);
-# a table whose kernel hashes differ from the current sources is ignored -- stale measurements never steer a new kernel.
-TILE_TABLE_FILE = os.environ.get('DS_TILE_TABLE', os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles', 'tile_table.json'))
+# a table whose kernel hashes differ from the current sources, or that was measured on another device (architecture name + CU count), is
+# ignored -- stale or foreign measurements never steer a kernel -- and the miss is reported ONCE (RuntimeWarning): routing then falls back to
+# on-box measurement (+5 ... 9 s per network on first use, tiles no longer reproducible run to run).  DS_TILE_TABLE=<path> | off overrides.
+TILE_TABLE_FILE = os.environ.get('DS_TILE_TABLE', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'tile_table.json'))
 TILE_TABLE_KERNELS = ('conv3x3_f16dma.hip', 'gemm_f16dma.hip')
 _TABLE = {'loaded': False, 'entries': {}, 'why': None}
 
@@ -56,9 +59,17 @@ def _table_hashes():
     return {tu: build.source_sha256(tu) for tu in TILE_TABLE_KERNELS}
 
 
+def _device_tag():
+    """'gfx950:sramecc+:xnack-/256' of the current GPU, or None without one (CPU-side tests read the table without a device check)."""
+    if not torch.cuda.is_available():
+        return None
+    pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+    return f'{pr.gcnArchName}/{pr.multi_processor_count}'
+
+
 def load_tile_table(path=None, force=False):
-    """Entries {key string: [nb, nw, {"nb,nw": ms}]} of the persisted table, or {} (with _TABLE['why']) when it is absent / stale / switched
-    off by DS_TILE_TABLE=off."""
+    """Entries {key string: [nb, nw, {"nb,nw": ms}]} of the persisted table, or {} (with _TABLE['why']) when it is absent / stale / measured on
+    another device / switched off by DS_TILE_TABLE=off."""
     if _TABLE['loaded'] and not force and path is None:
         return _TABLE['entries']
     _TABLE.update(loaded=True, entries={}, why=None)
@@ -71,12 +82,19 @@ def load_tile_table(path=None, force=False):
         with open(f) as fh:
             z = json.load(fh)
         then, now = z['meta']['kernel_source_sha256'], _table_hashes()
+        here, there = _device_tag(), z['meta'].get('device')
         if any(then.get(tu) != now[tu] for tu in TILE_TABLE_KERNELS):
             _TABLE['why'] = f'{os.path.basename(f)} was measured on other kernel sources: ignored'
+        elif here is not None and there is not None and '/' in str(there) and there != here:
+            _TABLE['why'] = f'{os.path.basename(f)} was measured on {there}, this device is {here}: ignored'
         else:
             _TABLE['entries'] = dict(z['entries'])
     except (OSError, KeyError, ValueError) as e:
         _TABLE['why'] = f'no usable tile table ({type(e).__name__}: {e})'
+    if _TABLE['why'] and torch.cuda.is_available():
+        import warnings
+        warnings.warn(f'diff_sampler_amd: {_TABLE["why"]} -- fp16 tile shapes will be measured on this box (slower first plan build, routing not '
+                      f'reproducible run to run); regenerate with tools/make_tile_table.py', RuntimeWarning, stacklevel=2)
     return _TABLE['entries']
 
 
@@ -86,7 +104,7 @@ def save_tile_table(path, session=''):
     entries = dict(load_tile_table())
     entries.update(_MEASURED)
     meta = dict(kernel_source_sha256=_table_hashes(), session=session,
-                device=(torch.cuda.get_device_properties(0).gcnArchName if torch.cuda.is_available() else None),
+                device=_device_tag(),
                 note='keys: Builder._tune_key; values: [nb, nw, {"nb,nw": ms per launch, cold operands}]; (0, 0) = the library\'s own choice')
     with open(path, 'w') as fh:
         json.dump(dict(meta=meta, entries=entries), fh, indent=0, sort_keys=True)
@@ -306,7 +324,7 @@ class Builder:
         t = a.tune
         if not (AUTOTUNE and self.autotune and a.in_f16) or not inputs[0].is_cuda or not _tile_neutral(a):
             return
-        if t.mode or t.variant or t.f16dma_nb or t.f16dma_nw or t.ablate or torch.cuda.is_current_stream_capturing():
+        if t.mode or t.variant or t.f16dma_nb or t.f16dma_nw or t.ablate:
             return
         stride = a.stride if a.stride else 1
         key = self._tune_key(a, stride)
@@ -314,8 +332,10 @@ class Builder:
         hit = _TUNE_CACHE.get(dkey)
         if hit is None:
             row = load_tile_table().get(str(key))
-            if row is not None:
+            if row is not None:          # a table hit needs no launches: fine inside a stream capture too
                 hit = (int(row[0]), int(row[1]), {tuple(int(v) for v in k.split(',')): ms for k, ms in row[2].items()})
+            elif torch.cuda.is_current_stream_capturing():
+                return                   # nothing is measured during a capture: the library's own choice
             else:
                 hit = self._measure_tiles(a, inputs, stride)
                 _MEASURED[str(key)] = [hit[0], hit[1], {'%d,%d' % k: round(ms, 5) for k, ms in hit[2].items()}]

@@ -47,14 +47,16 @@ extern "C" {
 #define DS_RESAMPLE_DOWN 1  /* 2x2 box filter, stride 2  (networks_edm.py:77 with resample_filter [1,1]) */
 #define DS_RESAMPLE_UP 2    /* nearest neighbour x2      (networks_edm.py:75 with resample_filter [1,1]) */
 
-DS_API int ds_version(void);      /* 3 since round 5: ds_conv_args.update appended (the head-fused solver update).  2 since round 4: ds_conv_args.tune / ds_update_args.variant appended (struct sizes changed), ds_fid_moments added, the
-                               * process-global ds_debug_* setters removed.  A host must check it before passing argument structs.  Round 5 kept every
-                               * struct layout (still 2): ds_build_experiments() is new, ds_conv_args.norm_coefs is now also accepted with in_f16. */
+DS_API int ds_version(void);      /* ABI version; a host must check it before passing argument structs.  3 (round 5): ds_conv_args.update appended (the head-fused
+                               * solver update; struct size changed), ds_build_experiments() added, ds_conv_args.norm_coefs also accepted with in_f16.
+                               * 2 (round 4): ds_conv_args.tune / ds_update_args.variant appended (struct sizes changed), ds_fid_moments added, the
+                               * process-global ds_debug_* setters removed. */
 DS_API const char* ds_error_string(int code);
-DS_API int ds_build_experiments(void);   /* 1: the library was built with DS_BUILD_EXPERIMENTS=1 and also holds the kernel variants kept as A/B records
-                                          * (conv3x3_f16dmah, conv3x3_halo2 modes 0 / 1: reachable through ds_conv_args.tune only, never chosen by
-                                          * default); 0: the product kernels only -- ds_conv_f16_supported() answers 0 and tune.f16dma_nw = 4 / tune.variant
-                                          * = 3 are ignored for 3x3 layers */
+DS_API int ds_build_experiments(void);   /* build flags.  Bit 0: built with DS_BUILD_EXPERIMENTS=1 -- the library also holds the kernel variants kept as A/B records
+                                          * (conv3x3_f16dmah, conv3x3_halo2 modes 0 / 1: reachable through ds_conv_args.tune only, never chosen by default);
+                                          * clear: the product kernels only -- ds_conv_f16_supported() answers 0 and tune.f16dma_nw = 4 / tune.variant = 3 are
+                                          * ignored for 3x3 layers.  Bit 1 (round 6): a DS_RACE_STRESS build -- tests only: the same kernels with ~2 us delays in the
+                                          * waves that produce shared LDS contents (csrc/ds_common.h); never shipped as libdsamd.so. */
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution / linear layer on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32; exact fp32).

@@ -5,14 +5,14 @@ over the WHOLE trajectory leaves the final image unconstrained (0.16 absolute on
 normalises every step by that step's own golden maximum; the tests bound every step and, explicitly, the final image.
 
 Every GPU parity test records what it measured through `record`; the file lands in gpurun_out/ (merged back by gpurun) and the kept copy is
-profiles/r5_parity.json."""
+profiles/r6_parity.json (round 5: r5_parity.json)."""
 import json
 import os
 
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LOG = os.path.join(ROOT, 'gpurun_out', 'r5_parity.json')
+LOG = os.path.join(ROOT, 'gpurun_out', 'r6_parity.json')
 
 
 def rel(a, b):
@@ -32,7 +32,7 @@ def step_scales(gold):
 
 
 def record(key, **values):
-    """Merge {key: values} into gpurun_out/r5_parity.json (best effort: a read-only tree must not fail a parity test)."""
+    """Merge {key: values} into gpurun_out/r6_parity.json (best effort: a read-only tree must not fail a parity test)."""
     try:
         os.makedirs(os.path.dirname(LOG), exist_ok=True)
         data = {}

@@ -221,7 +221,7 @@ def test_measured_tile_shapes_do_not_change_a_bit(which, monkeypatch):
     torch.cuda.synchronize()
     assert torch.isfinite(base).all() and all(t == (0, 0) for t in tiles(base_net))
     monkeypatch.setattr(plan_mod, 'AUTOTUNE', True)
-    monkeypatch.setattr(plan_mod, 'load_tile_table', lambda *a, **k: {})        # the persisted table (profiles/tile_table.json) must not pre-empt the forced choice
+    monkeypatch.setattr(plan_mod, 'load_tile_table', lambda *a, **k: {})        # the persisted table (diff_sampler_amd/data/tile_table.json) must not pre-empt the forced choice
     saved, saved_m = dict(plan_mod._TUNE_CACHE), dict(plan_mod._MEASURED)
     try:
         for kind in ('narrow', 'wide'):

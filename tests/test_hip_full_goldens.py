@@ -12,7 +12,7 @@
 Tolerances (fp32 path): 2e-4 per evaluation, 5e-4 per EDM trajectory, 1e-3 for the 5-step SD trajectory.
 Trajectories are bounded PER STEP, each step against its own golden scale (tests/_parity.py: a trajectory runs from scale ~300 at sigma_max
 to an image of scale ~3, so one normalisation over the whole trajectory would leave the final image unconstrained), and the final image
-explicitly.  What every test observed goes to gpurun_out/r5_parity.json (kept copy: profiles/r5_parity.json; round 4: profiles/r4_parity.json)."""
+explicitly.  What every test observed goes to gpurun_out/r6_parity.json (kept copy: profiles/r6_parity.json; round 5: profiles/r5_parity.json; round 4: profiles/r4_parity.json)."""
 import ctypes as C
 import os
 import sys
@@ -82,6 +82,37 @@ def test_headline_sampler_at_the_benchmark_batch_b256_matches_reference(dev):
     torch.cuda.synchronize()
     assert torch.isfinite(out).all()
     assert _rel(out.cpu()[slots], torch.from_numpy(z['out'])) < 5e-4
+
+
+def test_headline_sampler_at_the_largest_swept_batch_b4096_matches_reference(dev):
+    """SURVEY 8d config 2 sweeps B over {64, 256, 1024, 4096}; `bench.py`'s `throughput_by_batch` times all four.  4 096 images per call is
+    where 32-bit offsets would first overflow (a 32x32 x 256-channel fp32 tensor of that batch is 4.3 GB) and where a 32x32 layer runs 64
+    rounds of 256-tile waves: the 64 golden samples of the real reference's run, one per 64-image stride (slot 64 i + i: every residue mod
+    64), must come out as in the reference; all other slots carry different latents.  ~180 GB of plan workspaces: skipped (loudly) only if
+    the device does not have them free."""
+    from diff_sampler_amd import solvers
+    from diff_sampler_amd.engine import EDMDenoiser
+    torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info()
+    if free < 215e9:
+        pytest.skip(f'needs ~200 GB of free device memory for the 4 096-image plan, {free / 1e9:.0f} GB free of {total / 1e9:.0f}')
+    z = np.load(os.path.join(G, 'sampler_cifar10_dpmpp2m_nfe10_b64.npz'))
+    net = EDMDenoiser.from_config('cifar10', seed=int(z['seed']))
+    gold = torch.randn(64, 3, 32, 32, generator=torch.Generator().manual_seed(int(z['latent_seed'])))
+    latents = torch.randn(4096, 3, 32, 32, generator=torch.Generator().manual_seed(77))
+    slots = torch.arange(64) * 64 + torch.arange(64)
+    latents[slots] = gold
+    out = solvers.dpm_pp_sampler(net, latents.to(dev), num_steps=11, sigma_min=0.002, sigma_max=80., schedule_type='logsnr', schedule_rho=7,
+                                 max_order=2, predict_x0=True, lower_order_final=True)
+    torch.cuda.synchronize()
+    got = out[slots.to(dev)].cpu()
+    fin = bool(torch.isfinite(out).all())
+    del out, net
+    torch.cuda.empty_cache()
+    assert fin
+    e = _rel(got, torch.from_numpy(z['out']))
+    record('headline_b4096', final_image_rel=e)
+    assert e < 5e-4, e
 
 
 @pytest.mark.parametrize('name', ['ffhq', 'imagenet64'])

@@ -105,6 +105,18 @@ def test_bench_gpus8_self_launch_runs_eight_ranks():
     assert mg['fid_moment_allreduce']['sigma_32MiB_ms'] > 0 and mg['fid_moment_allreduce']['sigma_busbw_GBs'] > 0
     assert line['config']['images_per_step'] == 8 * 256
     assert line['other_configs'] is None and line['latency'] is None          # side measurements belong to the N = 1 default run only
+    _assert_roofline_object(line)
+
+
+def _assert_roofline_object(line):
+    """The N > 1 line carries rank 0's `roofline` object (a SCALE record is self-contained): under --stub through the same report path
+    over a synthetic record, with every contract key present."""
+    roof = line['roofline']
+    assert isinstance(roof, dict) and roof.get('stub') is True
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel'):
+        assert k in roof, k
+    assert roof['bound'] == 'mfma' and roof['unit'] == 'TFLOP/s' and abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3
+    assert line['cpu_baseline'] is None                                       # rank 0 at N = 1 only
 
 
 @pytest.mark.parametrize('config,batch', [('imagenet64', 64), ('sd15', 16)])
@@ -126,6 +138,7 @@ def test_bench_gpus8_fp16_configs_3_and_5(config, batch):
     assert abs(mg['barrier_skew_ms_per_step'] - (mg['per_rank_ms_per_step_max'] - mg['per_rank_ms_per_step_min'])) < 1e-2
     # whole-job value = all ranks' images over the slowest rank's (barrier-bracketed) time: never above 8 x the slowest rank's own rate
     assert line['value'] <= 8 * mg['per_rank_value_min'] * 1.01
+    _assert_roofline_object(line)
 
 
 def test_pmc_traffic_is_tied_to_the_kernel_source_it_was_measured_on(tmp_path, monkeypatch):
@@ -225,7 +238,7 @@ def test_bench_defaults_are_the_workloads_the_kept_lines_are_quoted_on():
 
 
 def test_committed_tile_table_matches_the_kernel_sources_and_covers_the_benchmarked_plans():
-    """profiles/tile_table.json (plan.Builder._autotune): measured on THESE kernel sources (else it would be ignored and plan builds would fall
+    """diff_sampler_amd/data/tile_table.json (package data; plan.Builder._autotune): measured on THESE kernel sources (else it would be ignored and plan builds would fall
     back to on-box timing races), and it holds every eligible fp16-activation launch of the two benchmarked fp16 plans -- built here on the
     CPU, where nothing is measured -- so that `bench.py` builds them without a single measurement launch."""
     sys.path.insert(0, ROOT)

@@ -1,11 +1,11 @@
 #!/usr/bin/env python
-"""Regenerate profiles/tile_table.json -- the persisted tile-shape table of the fp16-activation kernels (diff_sampler_amd/plan.py, AUTOTUNE).
+"""Regenerate diff_sampler_amd/data/tile_table.json -- the persisted tile-shape table of the fp16-activation kernels (diff_sampler_amd/plan.py, AUTOTUNE).
 
     python tools/make_tile_table.py [out.json]          # on a GPU box; default out = gpurun_out/tile_table.json
 
 Builds the plans of every benchmarked / tested fp16 configuration at its batch with the persisted table IGNORED (DS_TILE_TABLE=off), so every
 eligible layer shape is measured in this process (cold operands, the library's own choice timed first and last, a candidate must win by 3 %),
-and writes what was measured together with the hashes of the two kernel translation units.  Copy the file to profiles/tile_table.json and
+and writes what was measured together with the hashes of the two kernel translation units.  Copy the file to diff_sampler_amd/data/tile_table.json and
 commit it: plan builds then look shapes up instead of racing timers, so two runs of one tree choose identical tiles."""
 import os
 import sys
