@@ -196,6 +196,8 @@ def instrumented_pass(net, solvers, solver, latents, nfe, ldm=None):
             px = a.n * a.h * a.w
             byts = px * (a.c0 * (2 if a.in_f16 & 1 else 4) + a.c1 * (2 if a.in_f16 & 2 else 4))
             byts += px * k * (a.c0 + a.c1) * ((2 if a.out_f16 else 4) + (2 if a.raw_out else 0))
+            if a.stats0:          # the pass computes its own statistics: + the producers' column sums, once per image (algorithmic; every workgroup of an image re-reads them)
+                byts += (px // 64) * 2 * (a.c0 + a.c1) * 4
             return 'norm_act_kernel', float(byts)
         return 'other', 0.0
 
@@ -289,7 +291,7 @@ KERNEL_TU = {0: 'gemm_conv.hip', 128: 'conv3x3_halo.hip', 1284: 'conv3x3_halo.hi
 # kernel CLASSES of the fp16 engines cover several template instantiations (tile shapes): their PMC rows are matched by pattern and averaged
 # over all launches of the class, exactly as the HIP-event average of the class is taken
 PMC_PATTERNS = {2566: r'conv3x3_f16dma_kernel<\d+, \d+, (?:true|false), false>', 2572: r'conv3x3_f16dma_kernel<\d+, \d+, (?:true|false), true>', 2567: r'gemm_f16dma_kernel<\d+, \d+, (?:true|false), false>', 2571: r'gemm_f16dma_kernel<\d+, \d+, (?:true|false), true>',
-                2563: r'conv3x3_halo2_kernel<\d+, 2>', 2564: r'gemm_f16_kernel', 'norm_act': r'^norm_act_kernel\('}
+                2563: r'conv3x3_halo2_kernel<\d+, 2>', 2564: r'gemm_f16_kernel', 'norm_act': r'norm_act(?:16)?_kernel'}
 # one PMC summary per benchmarked workload (tools/gpu_session.sh pmc:<bench.py args>): (config, dtype) -> file under profiles/
 PMC_FILES = {('cifar10', 'fp32'): PMC_FILE,
              ('imagenet64', 'fp16'): os.path.join(ROOT, 'profiles', 'r5_pmc_hbm_imagenet64_fp16.json'),

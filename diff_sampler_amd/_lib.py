@@ -91,7 +91,8 @@ class NormArgs(C.Structure):
                 ('n', C.c_int), ('h', C.c_int), ('w', C.c_int), ('groups', C.c_int), ('eps', C.c_float),
                 ('mean', vp), ('rstd', vp), ('gamma', vp), ('beta', vp), ('scale', vp), ('shift', vp),
                 ('ss_ld', C.c_int), ('ss_rows', C.c_int), ('act', C.c_int), ('resample', C.c_int), ('out', vp),
-                ('out_ld', C.c_int), ('coefs', vp), ('partial', vp), ('counters', vp), ('out_f16', C.c_int), ('raw_out', vp), ('raw_ld', C.c_int), ('in_f16', C.c_int)]
+                ('out_ld', C.c_int), ('coefs', vp), ('partial', vp), ('counters', vp), ('out_f16', C.c_int), ('raw_out', vp), ('raw_ld', C.c_int), ('in_f16', C.c_int),
+                ('stats0', vp), ('stats1', vp), ('tune_variant', C.c_int)]          # ABI 4: the pass that computes its own GroupNorm statistics
 
 
 class AttnArgs(C.Structure):
@@ -228,8 +229,8 @@ def load():
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.ds_version() != 3:
-        raise DsError(f'{LIB_PATH} reports ABI version {lib.ds_version()}, this binding is written for 3: rebuild it (python diff_sampler_amd/build.py)')
+    if lib.ds_version() != 4:
+        raise DsError(f'{LIB_PATH} reports ABI version {lib.ds_version()}, this binding is written for 4: rebuild it (python diff_sampler_amd/build.py)')
     _lib = lib
     return lib
 

@@ -41,9 +41,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // are late -> read-before-landed) and 0xDE (every other wave late: the producers are early -> overwritten-before-read).  Results of a
 // correct kernel do not depend on the mask; tests/test_hip_race_stress.py runs the kernel / fp16 suites against both libraries.
 #ifdef DS_RACE_STRESS
-#define DS_RACE_SKEW(wave_)                                                                          \
-    do {                                                                                             \
-        if (((unsigned)(DS_RACE_STRESS) >> ((unsigned)(wave_) & 31u)) & 1u) __builtin_amdgcn_s_sleep(75); \
+// The wave index goes through v_readfirstlane: the test is then a SCALAR branch around the s_sleep.  On the per-lane value the compiler only
+// masks EXEC (s_and_saveexec) and lets the scalar s_sleep run in every wave -- a uniform delay, no skew (session r9a: the library with the
+// round-5 race re-introduced passed its tests until this was fixed).
+#define DS_RACE_SKEW(wave_)                                                                                                    \
+    do {                                                                                                                       \
+        if (((unsigned)(DS_RACE_STRESS) >> ((unsigned)__builtin_amdgcn_readfirstlane((int)(wave_)) & 31u)) & 1u) __builtin_amdgcn_s_sleep(75); \
     } while (0)
 #else
 #define DS_RACE_SKEW(wave_) do { } while (0)

@@ -5,6 +5,16 @@
 
 namespace {
 
+// ONE definition of the normalisation's per-channel coefficients and of its per-element arithmetic (explicit fused multiply-adds: no compiler
+// contraction choice), shared by the statistics kernels that write the {mu, A, B} planes, the pass kernels that apply them and the pass
+// that computes them itself (norm_act16_kernel<FIN>): the paths must agree bit for bit.
+//     A = rstd * gamma * (1 + scale),  B = beta * (1 + scale) + shift,  y = act((x - mu) * A + B)
+__device__ __forceinline__ void gn_coefs(float r, float gm, float bt, float sc1, float sh, float& A, float& B) {
+    A = r * gm * sc1;
+    B = __builtin_fmaf(bt, sc1, sh);
+}
+__device__ __forceinline__ float gn_affine(float x, float mu, float A, float B) { return __builtin_fmaf(x - mu, A, B); }
+
 // --------------------------------------------------------------------------------------------------------------
 // GroupNorm statistics.  One block per image; thread t owns channel quad (t % CQ) and walks pixels t / CQ, t / CQ + PL, ...
 // Sums are kept in fp64 (one pass, no cancellation problem in E[x^2] - E[x]^2), reduced through LDS atomics per group.
@@ -93,7 +103,9 @@ __device__ __forceinline__ void gn_finalize(const ds_norm_args& a, double* s_sum
                 sc1 = a.scale[row * a.ss_ld + c] + 1.f;
                 sh = a.shift[row * a.ss_ld + c];
             }
-            cp[c] = m; cp[C + c] = r * gm * sc1; cp[2 * C + c] = bt * sc1 + sh;
+            float A_, B_;
+            gn_coefs(r, gm, bt, sc1, sh, A_, B_);
+            cp[c] = m; cp[C + c] = A_; cp[2 * C + c] = B_;
         }
     }
 }
@@ -149,7 +161,8 @@ __global__ void __launch_bounds__(1024) norm_act_kernel(const ds_norm_args a, in
             sc1 = a.scale[row * a.ss_ld + c + j] + 1.f;
             sh = a.shift[row * a.ss_ld + c + j];
         }
-        mu[j] = m; A[j] = r * gm * sc1; Bc[j] = bt * sc1 + sh;
+        mu[j] = m;
+        gn_coefs(r, gm, bt, sc1, sh, A[j], Bc[j]);
     }
     const bool identity = !planes && !a.mean && !a.gamma && !a.scale;
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -158,7 +171,7 @@ __global__ void __launch_bounds__(1024) norm_act_kernel(const ds_norm_args a, in
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float t = identity ? v[j] : (v[j] - mu[j]) * A[j] + Bc[j];
+            float t = identity ? v[j] : gn_affine(v[j], mu[j], A[j], Bc[j]);
             o[j] = (a.act == DS_ACT_SILU) ? ds_silu(t) : t;
         }
         return o;
@@ -220,6 +233,127 @@ __global__ void __launch_bounds__(1024) norm_act_kernel(const ds_norm_args a, in
         }
         st4(p, o, raw);
     }
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// The fp16-mode pass at 16 bytes per lane (round 6): y = silu((x - mu[c]) * A[c] + B[c]) on fp16 rows -> fp16 rows, both sources of a
+// concatenation, optional raw copy, no resampling.  norm_act_kernel moves 8 bytes per lane and access (four channels: the fp32 geometry
+// applied to halfs) and ran at 0.45 of the 8 TB/s on the ImageNet-64 mix (profiles/r5_*): here a thread owns a channel OCTET (one
+// global_load_dwordx4 / global_store_dwordx4 per pixel), four pixels in flight, the same arithmetic through gn_affine / ds_silu / RNE.
+// FIN: the pass computes the GroupNorm statistics ITSELF from the per-(64-row block, channel) sums the producing convolutions left behind
+// (what ds_gn_finalize does in a launch of its own, ~6 us each, 950 per ImageNet-64 sampler call): channel sums in fp64 over the image's row
+// blocks in order, group sums in channel order, mean / rstd and the coefficients by gn_coefs -- every workgroup of an image repeats that for
+// the whole image, so the launcher takes this form only where the sums are small next to the tensor (images of at most 32 x 32 pixels) and
+// gives an image few, fat workgroups.
+typedef unsigned n16_u4 __attribute__((ext_vector_type(4)));
+typedef _Float16 n16_h8 __attribute__((ext_vector_type(8)));
+
+template <bool FIN>
+__global__ void __launch_bounds__(512) norm_act16_kernel(const ds_norm_args a, int CO, int PL, int chunk) {
+    extern __shared__ __attribute__((aligned(16))) double fin_lds[];          // FIN: [2][C] channel sums, then [2][64] floats mean / rstd
+    const int tid = threadIdx.x, n = blockIdx.y;
+    const int C = a.c0 + a.c1, HW = a.h * a.w;
+    float* g_mean = reinterpret_cast<float*>(fin_lds + 2 * C);
+    float* g_rstd = g_mean + 64;
+    if constexpr (FIN) {
+        double* ch_s = fin_lds;
+        double* ch_q = fin_lds + C;
+        const int nrb = HW >> 6;
+        for (int c = tid; c < C; c += blockDim.x) {
+            const bool first = c < a.c0;
+            const float* sp = first ? a.stats0 : a.stats1;
+            const int cs = first ? a.c0 : a.c1, cc = first ? c : c - a.c0;
+            const float* base = sp + ((size_t)n * nrb * 2) * cs + cc;
+            double s = 0.0, q = 0.0;
+            for (int rb = 0; rb < nrb; ++rb) { s += (double)base[(size_t)rb * 2 * cs]; q += (double)base[((size_t)rb * 2 + 1) * cs]; }
+            ch_s[c] = s; ch_q[c] = q;
+        }
+        __syncthreads();
+        if (tid < a.groups) {
+            const int cpg = C / a.groups;
+            double s = 0.0, q = 0.0;
+            for (int k = 0; k < cpg; ++k) { s += ch_s[tid * cpg + k]; q += ch_q[tid * cpg + k]; }
+            const double cnt = (double)cpg * (double)HW;
+            const double mean = s / cnt;
+            double var = q / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            g_mean[tid] = (float)mean;
+            g_rstd[tid] = (float)(1.0 / sqrt(var + (double)a.eps));
+        }
+        __syncthreads();
+    }
+    const int co = tid % CO, pl = tid / CO;
+    if (pl >= PL) return;
+    const int c = co * 8;
+    const bool first = c < a.c0;
+    const _Float16* src = reinterpret_cast<const _Float16*>(first ? a.x0 : a.x1) + (size_t)n * HW * (first ? a.ld0 : a.ld1) + (first ? c : c - a.c0);
+    const int ld = first ? a.ld0 : a.ld1;
+    float mu[8], A[8], Bc[8];
+    if constexpr (FIN) {
+        const int cpg = C / a.groups;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int g = (c + j) / cpg;
+            const float gm = a.gamma ? a.gamma[c + j] : 1.f;
+            const float bt = a.beta ? a.beta[c + j] : 0.f;
+            float sc1 = 1.f, sh = 0.f;
+            if (a.scale) {
+                const size_t row = (a.ss_rows == 1) ? 0 : (size_t)n;
+                sc1 = a.scale[row * a.ss_ld + c + j] + 1.f;
+                sh = a.shift[row * a.ss_ld + c + j];
+            }
+            mu[j] = g_mean[g];
+            gn_coefs(g_rstd[g], gm, bt, sc1, sh, A[j], Bc[j]);
+        }
+    } else {
+        const float* cp = a.coefs + (size_t)n * 3 * C + c;
+        const f32x4 m0 = *reinterpret_cast<const f32x4*>(cp), m1 = *reinterpret_cast<const f32x4*>(cp + 4);
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(cp + C), a1 = *reinterpret_cast<const f32x4*>(cp + C + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(cp + 2 * C), b1 = *reinterpret_cast<const f32x4*>(cp + 2 * C + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { mu[j] = m0[j]; mu[4 + j] = m1[j]; A[j] = a0[j]; A[4 + j] = a1[j]; Bc[j] = b0[j]; Bc[4 + j] = b1[j]; }
+    }
+    const bool silu = a.act == DS_ACT_SILU;
+    auto xf = [&](const n16_u4 raw) -> n16_u4 {
+        const n16_h8 x = __builtin_bit_cast(n16_h8, raw);
+        n16_h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t = gn_affine((float)x[j], mu[j], A[j], Bc[j]);
+            o[j] = (_Float16)(silu ? ds_silu(t) : t);                       // RNE, like .to(float16)
+        }
+        return __builtin_bit_cast(n16_u4, o);
+    };
+    _Float16* dst = reinterpret_cast<_Float16*>(a.out) + (size_t)n * HW * a.out_ld + c;
+    _Float16* raw16 = a.raw_out ? reinterpret_cast<_Float16*>(a.raw_out) + (size_t)n * HW * a.raw_ld + c : nullptr;
+    const int p_begin = blockIdx.x * chunk, p_end = min(p_begin + chunk, HW);
+    int p = p_begin + pl;
+    for (; p + 3 * PL < p_end; p += 4 * PL) {
+        n16_u4 r[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] = __builtin_nontemporal_load(reinterpret_cast<const n16_u4*>(src + (size_t)(p + q * PL) * ld));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<n16_u4*>(dst + (size_t)(p + q * PL) * a.out_ld) = xf(r[q]);
+            if (raw16) *reinterpret_cast<n16_u4*>(raw16 + (size_t)(p + q * PL) * a.raw_ld) = r[q];
+        }
+    }
+    for (; p < p_end; p += PL) {
+        const n16_u4 r = __builtin_nontemporal_load(reinterpret_cast<const n16_u4*>(src + (size_t)p * ld));
+        *reinterpret_cast<n16_u4*>(dst + (size_t)p * a.out_ld) = xf(r);
+        if (raw16) *reinterpret_cast<n16_u4*>(raw16 + (size_t)p * a.raw_ld) = r;
+    }
+}
+
+// Which ds_norm_act calls take norm_act16_kernel: fp16 rows in (every source present) and out, no resampling, whole channel octets.
+static bool norm16_ok(const ds_norm_args* a) {
+    if (!a->out_f16 || a->resample != DS_RESAMPLE_NONE) return false;
+    if (!(a->in_f16 & 1) || (a->c1 && !(a->in_f16 & 2))) return false;
+    const int C = a->c0 + a->c1;
+    if ((C & 7) || (a->c0 & 7) || (a->ld0 & 7) || (a->c1 && (a->ld1 & 7)) || (a->out_ld & 7) || C > 4096) return false;
+    if (!ds_aligned16(a->x0) || (a->c1 && !ds_aligned16(a->x1)) || !ds_aligned16(a->out)) return false;
+    if (a->raw_out && ((a->raw_ld & 7) || !ds_aligned16(a->raw_out))) return false;
+    return a->coefs != nullptr || a->stats0 != nullptr;
 }
 
 // --------------------------------------------------------------------------------------------------------------
@@ -439,7 +573,9 @@ __global__ void __launch_bounds__(256) gn_from_partials_kernel(const ds_gn_final
                 sc1 = f.scale[row * f.ss_ld + c] + 1.f;
                 sh = f.shift[row * f.ss_ld + c];
             }
-            cp[c] = m; cp[C + c] = r * gm * sc1; cp[2 * C + c] = bt * sc1 + sh;
+            float A_, B_;
+            gn_coefs(r, gm, bt, sc1, sh, A_, B_);
+            cp[c] = m; cp[C + c] = A_; cp[2 * C + c] = B_;
         }
     }
 }
@@ -500,6 +636,39 @@ extern "C" int ds_norm_act(const ds_norm_args* a, void* stream) {
     const int OH = (a->resample == DS_RESAMPLE_DOWN) ? a->h / 2 : (a->resample == DS_RESAMPLE_UP ? a->h * 2 : a->h);
     const int OW = (a->resample == DS_RESAMPLE_DOWN) ? a->w / 2 : (a->resample == DS_RESAMPLE_UP ? a->w * 2 : a->w);
     if (a->coefs && a->out_f16 && !ds_aligned16(a->coefs)) return DS_E_ALIGN;
+    if (a->stats0) {
+        // the pass computes its own statistics from the producers' column sums (norm_act16_kernel<FIN>): no ds_gn_finalize launch in front of it
+        if (!norm16_ok(a) || a->coefs || (a->c1 && !a->stats1) || a->groups <= 0 || a->groups > 64 || (a->c0 + a->c1) % a->groups) return DS_E_SHAPE;
+        if ((a->h * a->w) & 63 || (a->h * a->w) > 1024) return DS_E_SHAPE;
+        if ((a->scale == nullptr) != (a->shift == nullptr)) return DS_E_ARG;
+    }
+    if (norm16_ok(a) && !(a->tune_variant & 1)) {
+        const bool fin = a->stats0 != nullptr;
+        const int C = a->c0 + a->c1, CO = C / 8, HW = a->h * a->w;
+        const int T = CO <= 256 ? 256 : 512;
+        int PL16 = T / CO;
+        if (PL16 > HW) PL16 = HW;
+        // workgroups per image.  Plain: >= 16 pixels per thread on the large tensors, 4 on the small ones (see below).  FIN: every workgroup re-reads
+        // the image's column sums (HW / 64 x 2 x C floats): at most as many workgroups as keep that below a quarter of a workgroup's own rows
+        const long long elems = (long long)a->n * HW * C;
+        const int ppt = elems < (16ll << 20) ? 4 : 16;
+        int chunks = (HW + ppt * PL16 - 1) / (ppt * PL16);
+        if (fin) {
+            const long long sums = (long long)(HW / 64) * 2 * C * 4, rows = (long long)HW * C * 2;
+            int cap = (int)(rows / (4 * sums));
+            if (cap < 1) cap = 1;
+            if (chunks > cap) chunks = cap;
+        }
+        if (chunks < 1) chunks = 1;
+        int chunk = (HW + chunks - 1) / chunks;
+        chunk = ((chunk + PL16 - 1) / PL16) * PL16;
+        chunks = (HW + chunk - 1) / chunk;
+        const size_t lds = fin ? (size_t)2 * C * sizeof(double) + 128 * sizeof(float) : 0;
+        if (fin) hipLaunchKernelGGL((norm_act16_kernel<true>), dim3(chunks, a->n), dim3(T), lds, (hipStream_t)stream, *a, CO, PL16, chunk);
+        else hipLaunchKernelGGL((norm_act16_kernel<false>), dim3(chunks, a->n), dim3(T), 0, (hipStream_t)stream, *a, CO, PL16, chunk);
+        DS_CHECK_LAUNCH();
+        return DS_OK;
+    }
     if (a->out_f16) {
         // the fp16-mode pass streams whole tensors (it runs twice per block): 256-thread workgroups, and few enough of them that a thread
         // walks >= 16 pixels with four loads in flight -- the 1024-thread / 2048-workgroup geometry below left ~6 pixels per thread behind

@@ -642,7 +642,7 @@ extern "C" int ds_build_experiments(void) {          // bit 0: DS_BUILD_EXPERIME
 #endif
     return flags;
 }
-extern "C" int ds_version(void) { return 3; }      // ABI 3: ds_conv_args.update appended (head-fused solver update), ds_build_experiments(); ABI 2: ds_conv_args.tune / ds_update_args.variant, ds_fid_moments
+extern "C" int ds_version(void) { return 4; }      // ABI 4: ds_norm_args.stats0 / stats1 / tune_variant appended; ABI 3: ds_conv_args.update appended (head-fused solver update), ds_build_experiments(); ABI 2: ds_conv_args.tune / ds_update_args.variant, ds_fid_moments
 
 extern "C" const char* ds_error_string(int code) {
     switch (code) {

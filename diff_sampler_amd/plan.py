@@ -36,6 +36,7 @@ SPLITK_WORKSPACE_FLOATS = 64 << 20      # 256 MiB per plan
 # is measured during a stream capture.  Measured gain on whole sampler calls (session r7a, alternating in one process): SD-1.5 fp16
 # +1.5 %, ImageNet-64 fp16 +0.6 %.
 AUTOTUNE = os.environ.get('DS_AUTOTUNE', '1') != '0'
+FOLD_FINALIZE = os.environ.get('DS_FOLD_GN_FINALIZE', '1') != '0'       # Builder._fold_finalize
 _TUNE_CACHE: Dict[tuple, tuple] = {}     # (device, layer signature) -> (nb, nw, {candidate: ms}): the table's entries + what this process measured
 _MEASURED: Dict[str, list] = {}          # table keys measured in THIS process (misses of the persisted table): save_tile_table() writes them
 _FLUSH: Dict[int, torch.Tensor] = {}     # device index -> the 512 MiB scratch written before every timed launch; freed by release_tuning_scratch()
@@ -434,6 +435,7 @@ class Builder:
         if out_f16:
             assert kind == 'apply' and out.dtype == torch.float16 and (raw_out is None or raw_out.dtype == torch.float16)
             a.out_f16, a.raw_out, a.raw_ld = 1, ptr(raw_out), raw_ld
+            self._fold_finalize(a, coefs)
         if kind == 'stats' and n < 256:
             if self.gn_partial is None or self.gn_counters.numel() < n:
                 self.gn_partial = torch.empty(n * _lib.DS_GN_MAX_CHUNKS * 128, dtype=torch.float64, device=self.dev)
@@ -441,6 +443,32 @@ class Builder:
                 self.P.keep += [self.gn_partial, self.gn_counters]
             a.partial, a.counters = ptr(self.gn_partial), ptr(self.gn_counters)
         self.add(self.lib.ds_gn_stats if kind == 'stats' else self.lib.ds_norm_act, (C.byref(a),), name, keep=(a,))
+
+    def _fold_finalize(self, a, coefs):
+        """Round 6: an fp16 pass whose {mu, A, B} planes come from the ds_gn_finalize launch right in front of it computes the statistics itself
+        (ds_norm_args.stats0 / stats1, csrc/norm_act.hip norm_act16_kernel<FIN>) -- the finalize launch (~6 us each; 950 per ImageNet-64 sampler
+        call in round 5) is dropped from the plan.  Only where every workgroup can afford to re-read the image's column sums: images of at most
+        32 x 32 pixels, on the 16-byte form of the pass (the host-side mirror of norm16_ok + the FIN checks of ds_norm_act).  The planes are not
+        written then: nothing else may read them (the engines' passes are their only readers).  Same arithmetic, same coefficient expressions
+        (gn_coefs): the plans agree bit for bit (tests/test_hip_fp16.py).  DS_FOLD_GN_FINALIZE=0 keeps the two-launch form (A/B runs)."""
+        if not FOLD_FINALIZE or coefs is None or not self.P.ops:
+            return
+        prev = self.P.ops[-1]
+        if prev.fn is not self.lib.ds_gn_finalize:
+            return
+        f = prev.keep[0]
+        C_ = a.c0 + a.c1
+        hw = a.h * a.w
+        if f.coefs != coefs.data_ptr() or (f.c0, f.c1, f.n, f.hw) != (a.c0, a.c1, a.n, hw):
+            return
+        all16 = (a.in_f16 & 1) and (not a.c1 or (a.in_f16 & 2))
+        if not (all16 and a.resample == DS_RESAMPLE_NONE and hw % 64 == 0 and hw <= 1024 and C_ % 8 == 0 and a.c0 % 8 == 0 and C_ <= 4096
+                and a.ld0 % 8 == 0 and (not a.c1 or a.ld1 % 8 == 0) and a.out_ld % 8 == 0 and (not a.raw_out or a.raw_ld % 8 == 0)):
+            return
+        self.P.ops.pop()
+        a.stats0, a.stats1, a.coefs = f.stats0, f.stats1, None
+        a.groups, a.eps = f.groups, f.eps
+        a.gamma, a.beta, a.scale, a.shift, a.ss_ld, a.ss_rows = f.gamma, f.beta, f.scale, f.shift, f.ss_ld, f.ss_rows
 
     def gemm(self, a_, lda, b_, ldb, c_, ldc, m, n, k, name, batch=1, heads=1, a_bs=0, a_hs=0, b_bs=0, b_hs=0, c_bs=0, c_hs=0,
              alpha=1.0, rowbias=None, colbias=None):

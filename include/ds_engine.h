@@ -47,7 +47,8 @@ extern "C" {
 #define DS_RESAMPLE_DOWN 1  /* 2x2 box filter, stride 2  (networks_edm.py:77 with resample_filter [1,1]) */
 #define DS_RESAMPLE_UP 2    /* nearest neighbour x2      (networks_edm.py:75 with resample_filter [1,1]) */
 
-DS_API int ds_version(void);      /* ABI version; a host must check it before passing argument structs.  3 (round 5): ds_conv_args.update appended (the head-fused
+DS_API int ds_version(void);      /* ABI version; a host must check it before passing argument structs.  4 (round 6): ds_norm_args.stats0 / stats1 / tune_variant
+                               * appended (the pass that computes its own GroupNorm statistics; struct size changed).  3 (round 5): ds_conv_args.update appended (the head-fused
                                * solver update; struct size changed), ds_build_experiments() added, ds_conv_args.norm_coefs also accepted with in_f16.
                                * 2 (round 4): ds_conv_args.tune / ds_update_args.variant appended (struct sizes changed), ds_fid_moments added, the
                                * process-global ds_debug_* setters removed. */
@@ -293,6 +294,15 @@ typedef struct ds_norm_args {
     /* ds_norm_act / ds_gn_stats.  in_f16 bit 0: x0 is an fp16 tensor [rows][ld0 halfs]; bit 1: x1 is (ld1 in halfs) -- tensors written
      * with ds_conv_args.out_f16 (conv0 outputs, the fp16 residual stream).  Values are widened to fp32 before any arithmetic. */
     int in_f16;
+    /* ds_norm_act only, ABI 4 (round 6).  stats0 (and stats1 for a second source) non-NULL: the per-(64-row block, channel) sums {sum, sum of
+     * squares} [ceil(n h w / 64)][2][c] the producing convolutions left behind (ds_conv_args.stats_out) -- the pass then computes the GroupNorm
+     * statistics of every image ITSELF (what ds_gn_finalize does in a launch of its own) and applies them: `coefs` must be NULL, gamma / beta /
+     * scale / shift / groups / eps are read as ds_gn_finalize reads them, mean / rstd are not written.  Only for the 16-byte fp16 form of the
+     * pass (fp16 rows in and out, no resampling, channel counts multiples of 8) on images of 64 ... 1 024 pixels (h * w % 64 == 0);
+     * anything else returns DS_E_SHAPE.  tune_variant bit 0 (benchmarks / tests): keep the 8-byte kernel of rounds 3 - 5 where the 16-byte one
+     * would be taken. */
+    const float* stats0; const float* stats1;
+    int tune_variant;
 } ds_norm_args;
 
 #define DS_GN_MAX_CHUNKS 32

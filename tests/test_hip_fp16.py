@@ -283,7 +283,8 @@ def test_fused_input_normalisation_plan_matches_the_pass_plan(which):
     def counts():
         plan = list(net.engine._plans.values())[-1]
         na = sum(1 for op in plan.ops if op.fn is lib.ds_norm_act)
-        fin = sum(1 for op in plan.ops if op.fn is lib.ds_gn_finalize or op.fn is lib.ds_gn_stats)
+        # statistics: a launch of their own (ds_gn_finalize / ds_gn_stats) or, round 6, computed by the pass itself (ds_norm_args.stats0)
+        fin = sum(1 for op in plan.ops if op.fn is lib.ds_gn_finalize or op.fn is lib.ds_gn_stats or (op.fn is lib.ds_norm_act and op.keep[0].stats0))
         fused = sum(1 for op in plan.ops if op.fn is lib.ds_conv2d_nhwc and op.keep[0].in_f16 and op.keep[0].norm_coefs)
         return na, fin, fused
 

@@ -1352,6 +1352,100 @@ def test_norm_passes_read_fp16_sources_like_their_fp32_copies(resample):
     assert lib.ds_gn_stats(C.byref(bad), _lib.stream_ptr()) != 0
 
 
+NORM16_CASES = [
+    # B, H, c0, c1, silu, raw copy, adaptive scale / shift (ADM), rows of scale / shift
+    (8, 8, 768, 0, True, False, True, 8),            # ImageNet-64 8x8 stage: one row block per image, adaptive scale / shift per image
+    (4, 16, 576, 0, True, False, True, 4),           # 16x16: four row blocks
+    (3, 32, 384, 0, True, False, False, 1),          # 32x32: sixteen row blocks (the largest image the pass finalises itself)
+    (2, 16, 320, 320, True, True, False, 1),         # SD-1.5 decoder concatenation 320 | 320 with the raw copy for the skip projection
+    (2, 8, 1280, 1280, True, True, False, 1),        # 2 560 channels: 320 octets -> 512-thread workgroups
+    (5, 16, 192, 64, False, False, False, 1),        # affine only, ragged octet count (32 octets, 8 pixel lanes)
+    (2, 64, 192, 0, True, False, False, 1),          # 64x64: 16-byte kernel, but the statistics stay a launch of their own (not folded)
+]
+
+
+@pytest.mark.parametrize('case', NORM16_CASES)
+def test_norm_pass_16_byte_kernel_and_folded_finalize_equal_the_two_launch_form(case):
+    """Round 6 (csrc/norm_act.hip): norm_act16_kernel -- the fp16 pass at 16 bytes per lane -- against norm_act_kernel (8 bytes per lane,
+    ds_norm_args.tune_variant = 1) on the same {mu, A, B} planes, and norm_act16_kernel<FIN> -- the pass that computes the GroupNorm
+    statistics itself from the producers' per-(64-row block, channel) sums (ds_norm_args.stats0 / stats1) -- against ds_gn_finalize + pass:
+    EQUAL bits, output rows and raw copy, incl. the ADM adaptive scale / shift; plus an fp64 reference of the whole normalisation."""
+    import ctypes as C
+    from diff_sampler_amd import _lib, ops
+    B, H, c0, c1, silu, raw, adaptive, ss_rows = case
+    lib = _lib.load()
+    dev = 'cuda'
+    Ct, HW, M = c0 + c1, H * H, B * H * H
+    g = torch.Generator().manual_seed(sum(case[:4]))
+    x = (torch.randn(M, Ct, generator=g) * 1.5 + 0.3).to(torch.float16).to(dev)
+    x0 = x[:, :c0].contiguous()
+    x1 = x[:, c0:].contiguous() if c1 else None
+    gm, bt = (1 + 0.1 * torch.randn(Ct, generator=g)).to(dev), (0.1 * torch.randn(Ct, generator=g)).to(dev)
+    sc = (0.2 * torch.randn(ss_rows, Ct, generator=g)).to(dev) if adaptive else None
+    sh = (0.2 * torch.randn(ss_rows, Ct, generator=g)).to(dev) if adaptive else None
+    # the producers' column sums: per 64-row block and channel {sum, sum of squares} of the stored (fp16) values, fp32 -- what a convolution's
+    # epilogue leaves behind (ds_conv_args.stats_out), one tensor per source
+    def colsums(t, c):
+        v = t.float().reshape(M // 64, 64, c)
+        return torch.stack([v.sum(1), (v * v).sum(1)], 1).contiguous()          # [M / 64][2][c]
+    s0 = colsums(x0, c0)
+    s1 = colsums(x1, c1) if c1 else None
+    mean, rstd = torch.empty(B * 32, device=dev), torch.empty(B * 32, device=dev)
+    planes = torch.empty(B, 3, Ct, device=dev)
+    f = _lib.GnFinalizeArgs(s0.data_ptr(), s1.data_ptr() if c1 else None, c0, c1, B, HW, 32, 1e-5, gm.data_ptr(), bt.data_ptr(),
+                            sc.data_ptr() if adaptive else None, sh.data_ptr() if adaptive else None, Ct, ss_rows, mean.data_ptr(), rstd.data_ptr(),
+                            planes.data_ptr())
+    assert lib.ds_gn_finalize(C.byref(f), _lib.stream_ptr()) == 0
+
+    def run(variant, fin):
+        out = torch.full((M, Ct), float('nan'), dtype=torch.float16, device=dev)
+        rw = torch.full((M, Ct), float('nan'), dtype=torch.float16, device=dev) if raw else None
+        a = ops._norm_args(x0, c0, c0, B, H, H, x1=x1, c1=c1, ld1=c1, groups=32, eps=1e-5, act=(1 if silu else 0), out=out, out_ld=Ct)
+        a.in_f16, a.out_f16 = (3 if c1 else 1), 1
+        if raw:
+            a.raw_out, a.raw_ld = C.c_void_p(rw.data_ptr()), Ct
+        a.tune_variant = variant
+        if fin:
+            a.stats0, a.stats1 = C.c_void_p(s0.data_ptr()), (C.c_void_p(s1.data_ptr()) if c1 else None)
+            a.gamma, a.beta = C.c_void_p(gm.data_ptr()), C.c_void_p(bt.data_ptr())
+            if adaptive:
+                a.scale, a.shift, a.ss_ld, a.ss_rows = C.c_void_p(sc.data_ptr()), C.c_void_p(sh.data_ptr()), Ct, ss_rows
+        else:
+            a.coefs = C.c_void_p(planes.data_ptr())
+        rc = lib.ds_norm_act(C.byref(a), _lib.stream_ptr())
+        torch.cuda.synchronize()
+        return rc, out, rw
+
+    rc8, o8, r8 = run(1, False)
+    rc16, o16, r16 = run(0, False)
+    assert rc8 == 0 and rc16 == 0
+    assert torch.isfinite(o16.float()).all() and torch.equal(o16, o8)
+    if raw:
+        assert torch.equal(r16, r8) and torch.equal(r16, x)
+    rcf, of, rf = run(0, True)
+    if HW <= 1024:
+        assert rcf == 0, lib.ds_error_string(rcf)
+        assert torch.equal(of, o8)
+        if raw:
+            assert torch.equal(rf, x)
+    else:
+        assert rcf != 0                                     # images above 32 x 32: the statistics stay a launch of their own
+    # fp64 reference: group statistics of the stored values, affine, SiLU, RNE to fp16
+    xd = x.double().cpu().reshape(B, HW, 32, Ct // 32)
+    mu_ = xd.mean((1, 3), keepdim=True)
+    var = (xd * xd).mean((1, 3), keepdim=True) - mu_ * mu_
+    y = ((xd - mu_) / torch.sqrt(var + 1e-5)).reshape(B, HW, Ct)
+    if adaptive:
+        scd, shd = sc.double().cpu(), sh.double().cpu()
+        scd = scd.expand(B, Ct) if ss_rows == 1 else scd
+        shd = shd.expand(B, Ct) if ss_rows == 1 else shd
+        y = y * (gm.double().cpu()[None, None] * (1 + scd[:, None])) + (bt.double().cpu()[None, None] * (1 + scd[:, None]) + shd[:, None])
+    else:
+        y = y * gm.double().cpu()[None, None] + bt.double().cpu()[None, None]
+    y = F.silu(y) if silu else y
+    assert _rel(o16.float().cpu().reshape(B, HW, Ct), y.float()) < 1.5e-3
+
+
 def test_layernorm_rows_on_fp16_rows():
     """ds_layernorm_rows_f16io (fp16 in, fp16 out: LayerNorm of a tensor of the fp16 residual stream) == ds_layernorm_rows_f16 on the widened
     rows, for every lanes-per-row variant of the kernel (320 / 640 / 1280 columns) and a ragged row count."""
