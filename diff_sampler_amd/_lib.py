@@ -61,6 +61,9 @@ def current_tuning():
 _ENV_TUNE = {k: int(os.environ[e]) for k, e in (('variant', 'DS_CONV_VARIANT'), ('mode', 'DS_CONV'), ('ablate', 'DS_CONV_ABLATE')) if os.environ.get(e)}
 
 
+_ENV_ATTN_VARIANT = int(os.environ.get('DS_ATTN_VARIANT', '0') or 0)
+
+
 class ConvArgs(C.Structure):
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
@@ -96,10 +99,15 @@ class NormArgs(C.Structure):
 
 
 class AttnArgs(C.Structure):
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        if _ENV_ATTN_VARIANT and 'variant' not in k and len(a) < 21:
+            self.variant = _ENV_ATTN_VARIANT          # DS_ATTN_VARIANT=1 / 2 (A/B runs of whole programs): ds_attn_args.variant of every call built here
+
     _fields_ = [('q', vp), ('k', vp), ('v', vp), ('out', vp), ('ldq', C.c_int), ('ldk', C.c_int), ('ldv', C.c_int),
                 ('ldo', C.c_int), ('q_bs', C.c_longlong), ('k_bs', C.c_longlong), ('v_bs', C.c_longlong),
                 ('o_bs', C.c_longlong), ('batch', C.c_int), ('heads', C.c_int), ('sq', C.c_int), ('skv', C.c_int),
-                ('d', C.c_int), ('scale', C.c_float), ('out_f16', C.c_int), ('in_f16', C.c_int)]
+                ('d', C.c_int), ('scale', C.c_float), ('out_f16', C.c_int), ('in_f16', C.c_int), ('variant', C.c_int)]      # variant: ABI 4
 
 
 class GnFinalizeArgs(C.Structure):

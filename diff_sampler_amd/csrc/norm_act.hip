@@ -253,20 +253,52 @@ __global__ void __launch_bounds__(512) norm_act16_kernel(const ds_norm_args a, i
     extern __shared__ __attribute__((aligned(16))) double fin_lds[];          // FIN: [2][C] channel sums, then [2][64] floats mean / rstd
     const int tid = threadIdx.x, n = blockIdx.y;
     const int C = a.c0 + a.c1, HW = a.h * a.w;
-    float* g_mean = reinterpret_cast<float*>(fin_lds + 2 * C);
-    float* g_rstd = g_mean + 64;
+    const int co = tid % CO, pl = tid / CO;
+    const bool live = pl < PL;
+    const int c = co * 8;
+    const bool first = c < a.c0;
+    const _Float16* src = reinterpret_cast<const _Float16*>(first ? a.x0 : a.x1) + (size_t)n * HW * (first ? a.ld0 : a.ld1) + (first ? c : c - a.c0);
+    const int ld = first ? a.ld0 : a.ld1;
+    const int p_begin = blockIdx.x * chunk, p_end = min(p_begin + chunk, HW);
+    int p = p_begin + pl;
+    // FIN: everything that does not depend on the statistics is requested BEFORE they are reduced -- the thread's first four pixels and its
+    // channels' gamma / beta / scale / shift -- so that the reduction's memory round trip is the only one in front of the first store
+    n16_u4 r[4];
+    bool have = false;
+    f32x4 gmv[2], btv[2], scv[2], shv[2];
     if constexpr (FIN) {
+        if (live) {
+            if (p + 3 * PL < p_end) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) r[q] = __builtin_nontemporal_load(reinterpret_cast<const n16_u4*>(src + (size_t)(p + q * PL) * ld));
+                have = true;
+            }
+            const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                gmv[h] = a.gamma ? *reinterpret_cast<const f32x4*>(a.gamma + c + 4 * h) : one;
+                btv[h] = a.beta ? *reinterpret_cast<const f32x4*>(a.beta + c + 4 * h) : zero;
+                scv[h] = zero; shv[h] = zero;
+                if (a.scale) {
+                    const size_t row = (a.ss_rows == 1) ? 0 : (size_t)n;
+                    scv[h] = *reinterpret_cast<const f32x4*>(a.scale + row * a.ss_ld + c + 4 * h);
+                    shv[h] = *reinterpret_cast<const f32x4*>(a.shift + row * a.ss_ld + c + 4 * h);
+                }
+            }
+        }
+        float* g_mean = reinterpret_cast<float*>(fin_lds + 2 * C);
+        float* g_rstd = g_mean + 64;
         double* ch_s = fin_lds;
         double* ch_q = fin_lds + C;
         const int nrb = HW >> 6;
-        for (int c = tid; c < C; c += blockDim.x) {
-            const bool first = c < a.c0;
-            const float* sp = first ? a.stats0 : a.stats1;
-            const int cs = first ? a.c0 : a.c1, cc = first ? c : c - a.c0;
+        for (int cc_ = tid; cc_ < C; cc_ += blockDim.x) {
+            const bool f0 = cc_ < a.c0;
+            const float* sp = f0 ? a.stats0 : a.stats1;
+            const int cs = f0 ? a.c0 : a.c1, cc = f0 ? cc_ : cc_ - a.c0;
             const float* base = sp + ((size_t)n * nrb * 2) * cs + cc;
             double s = 0.0, q = 0.0;
             for (int rb = 0; rb < nrb; ++rb) { s += (double)base[(size_t)rb * 2 * cs]; q += (double)base[((size_t)rb * 2 + 1) * cs]; }
-            ch_s[c] = s; ch_q[c] = q;
+            ch_s[cc_] = s; ch_q[cc_] = q;
         }
         __syncthreads();
         if (tid < a.groups) {
@@ -282,28 +314,17 @@ __global__ void __launch_bounds__(512) norm_act16_kernel(const ds_norm_args a, i
         }
         __syncthreads();
     }
-    const int co = tid % CO, pl = tid / CO;
-    if (pl >= PL) return;
-    const int c = co * 8;
-    const bool first = c < a.c0;
-    const _Float16* src = reinterpret_cast<const _Float16*>(first ? a.x0 : a.x1) + (size_t)n * HW * (first ? a.ld0 : a.ld1) + (first ? c : c - a.c0);
-    const int ld = first ? a.ld0 : a.ld1;
+    if (!live) return;
     float mu[8], A[8], Bc[8];
     if constexpr (FIN) {
+        const float* g_mean = reinterpret_cast<const float*>(fin_lds + 2 * C);
+        const float* g_rstd = g_mean + 64;
         const int cpg = C / a.groups;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int g = (c + j) / cpg;
-            const float gm = a.gamma ? a.gamma[c + j] : 1.f;
-            const float bt = a.beta ? a.beta[c + j] : 0.f;
-            float sc1 = 1.f, sh = 0.f;
-            if (a.scale) {
-                const size_t row = (a.ss_rows == 1) ? 0 : (size_t)n;
-                sc1 = a.scale[row * a.ss_ld + c + j] + 1.f;
-                sh = a.shift[row * a.ss_ld + c + j];
-            }
             mu[j] = g_mean[g];
-            gn_coefs(g_rstd[g], gm, bt, sc1, sh, A[j], Bc[j]);
+            gn_coefs(g_rstd[g], gmv[j >> 2][j & 3], btv[j >> 2][j & 3], a.scale ? scv[j >> 2][j & 3] + 1.f : 1.f, a.scale ? shv[j >> 2][j & 3] : 0.f, A[j], Bc[j]);
         }
     } else {
         const float* cp = a.coefs + (size_t)n * 3 * C + c;
@@ -326,12 +347,12 @@ __global__ void __launch_bounds__(512) norm_act16_kernel(const ds_norm_args a, i
     };
     _Float16* dst = reinterpret_cast<_Float16*>(a.out) + (size_t)n * HW * a.out_ld + c;
     _Float16* raw16 = a.raw_out ? reinterpret_cast<_Float16*>(a.raw_out) + (size_t)n * HW * a.raw_ld + c : nullptr;
-    const int p_begin = blockIdx.x * chunk, p_end = min(p_begin + chunk, HW);
-    int p = p_begin + pl;
     for (; p + 3 * PL < p_end; p += 4 * PL) {
-        n16_u4 r[4];
+        if (!have) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) r[q] = __builtin_nontemporal_load(reinterpret_cast<const n16_u4*>(src + (size_t)(p + q * PL) * ld));
+            for (int q = 0; q < 4; ++q) r[q] = __builtin_nontemporal_load(reinterpret_cast<const n16_u4*>(src + (size_t)(p + q * PL) * ld));
+        }
+        have = false;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             *reinterpret_cast<n16_u4*>(dst + (size_t)(p + q * PL) * a.out_ld) = xf(r[q]);
@@ -339,9 +360,9 @@ __global__ void __launch_bounds__(512) norm_act16_kernel(const ds_norm_args a, i
         }
     }
     for (; p < p_end; p += PL) {
-        const n16_u4 r = __builtin_nontemporal_load(reinterpret_cast<const n16_u4*>(src + (size_t)p * ld));
-        *reinterpret_cast<n16_u4*>(dst + (size_t)p * a.out_ld) = xf(r);
-        if (raw16) *reinterpret_cast<n16_u4*>(raw16 + (size_t)p * a.raw_ld) = r;
+        const n16_u4 r1 = __builtin_nontemporal_load(reinterpret_cast<const n16_u4*>(src + (size_t)p * ld));
+        *reinterpret_cast<n16_u4*>(dst + (size_t)p * a.out_ld) = xf(r1);
+        if (raw16) *reinterpret_cast<n16_u4*>(raw16 + (size_t)p * a.raw_ld) = r1;
     }
 }
 
@@ -655,7 +676,8 @@ extern "C" int ds_norm_act(const ds_norm_args* a, void* stream) {
         int chunks = (HW + ppt * PL16 - 1) / (ppt * PL16);
         if (fin) {
             const long long sums = (long long)(HW / 64) * 2 * C * 4, rows = (long long)HW * C * 2;
-            int cap = (int)(rows / (4 * sums));
+            const int div = (a->tune_variant & 2) ? 1 : ((a->tune_variant & 4) ? 0 : 4);          // (benchmarks: tune_variant bits 1 / 2 relax the cap)
+            int cap = div ? (int)(rows / (div * sums)) : chunks;
             if (cap < 1) cap = 1;
             if (chunks > cap) chunks = cap;
         }

@@ -47,7 +47,7 @@ extern "C" {
 #define DS_RESAMPLE_DOWN 1  /* 2x2 box filter, stride 2  (networks_edm.py:77 with resample_filter [1,1]) */
 #define DS_RESAMPLE_UP 2    /* nearest neighbour x2      (networks_edm.py:75 with resample_filter [1,1]) */
 
-DS_API int ds_version(void);      /* ABI version; a host must check it before passing argument structs.  4 (round 6): ds_norm_args.stats0 / stats1 / tune_variant
+DS_API int ds_version(void);      /* ABI version; a host must check it before passing argument structs.  4 (round 6): ds_norm_args.stats0 / stats1 / tune_variant and ds_attn_args.variant
                                * appended (the pass that computes its own GroupNorm statistics; struct size changed).  3 (round 5): ds_conv_args.update appended (the head-fused
                                * solver update; struct size changed), ds_build_experiments() added, ds_conv_args.norm_coefs also accepted with in_f16.
                                * 2 (round 4): ds_conv_args.tune / ds_update_args.variant appended (struct sizes changed), ds_fid_moments added, the
@@ -342,6 +342,9 @@ typedef struct ds_attn_args {
     int in_f16;      /* ds_attention_f16 only: bit 0: q is an fp16 tensor (ldq / q_bs in halfs, multiples of 8), bit 1: k and v are (ldk, k_bs
                         multiples of 8; ldv, v_bs of 4) -- the fp16 tensors the reference's qkv projection emits in its fp16 mode
                         (networks_edm.py:171-173; attention.py:168-176 under autocast); `scale` then multiplies the fp32 scores */
+    int variant;     /* ABI 4.  ds_attention_f16 only (ds_attention ignores it): 0 = the library's choice; 1 = the kernel with one 32-query block per wave
+                        (rounds 2 - 5); 2 = two query blocks per wave, software-pipelined (round 6; head sizes <= 64, else DS_E_SHAPE) -- for benchmarks
+                        and tests: results do not depend on it */
 } ds_attn_args;
 
 DS_API int ds_attention(const ds_attn_args* a, void* stream);

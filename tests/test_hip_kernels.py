@@ -1663,6 +1663,45 @@ def test_fused_attention_reads_fp16_q_k_v(d, heads, sq, skv, mask):
         assert lib.ds_attention_f16(C.byref(a), _lib.stream_ptr()) != 0
 
 
+@pytest.mark.parametrize('d,heads,sq,skv,mask,out16', [(40, 8, 1024, 1024, 3, 1), (40, 4, 4096, 4096, 3, 1), (64, 6, 1024, 1024, 3, 1), (64, 9, 256, 256, 3, 0),
+                                                        (40, 8, 300, 77, 1, 0), (32, 3, 130, 130, 2, 0), (64, 2, 64, 200, 0, 1), (40, 2, 257, 515, 3, 1)])
+def test_fused_attention_two_query_blocks_per_wave_equals_the_one_block_kernel(d, heads, sq, skv, mask, out16):
+    """flash_attn_f16x2_kernel (round 6: a wave owns two 32-query blocks, skewed by half a phase; csrc/attention_f16.hip) against
+    flash_attn_f16_kernel (one block per wave) through ds_attn_args.variant = 2 / 1: the same MFMA operands in the same order and the same
+    softmax expressions per query => EQUAL bits, fp16 or fp32 operand tensors, fp16 or fp32 output rows, ragged query / key counts
+    (partial last query block, partial last key tile, a workgroup whose later waves have no queries); the default picks it from 256 queries
+    on; head sizes above 64 refuse variant 2."""
+    import ctypes as C
+    from diff_sampler_amd import _lib
+    lib = _lib.load()
+    dev = 'cuda'
+    B, c = 2, heads * d
+    g = torch.Generator().manual_seed(d + sq + skv)
+    q = torch.randn(B * sq, c, generator=g).to(torch.float16)
+    kv = torch.randn(B * skv, 2 * c, generator=g).to(torch.float16)
+    qd = q.to(dev) if mask & 1 else q.float().to(dev)
+    kvd = kv.to(dev) if mask & 2 else kv.float().to(dev)
+    outs = []
+    for variant in (1, 2, 0):
+        out = torch.full((B * sq, c), float('nan'), device=dev, dtype=(torch.float16 if out16 else torch.float32))
+        a = _lib.AttnArgs(qd.data_ptr(), kvd.data_ptr(), kvd[:, c:].data_ptr(), out.data_ptr(), c, 2 * c, 2 * c, c, sq * c, skv * 2 * c, skv * 2 * c,
+                          sq * c, B, heads, sq, skv, d, d ** -0.5)
+        a.in_f16, a.out_f16, a.variant = mask, out16, variant
+        rc = lib.ds_attention_f16(C.byref(a), _lib.stream_ptr())
+        torch.cuda.synchronize()
+        assert rc == 0, (variant, lib.ds_error_string(rc))
+        outs.append(out)
+    assert torch.isfinite(outs[1].float()).all()
+    assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0])
+    qq = q.double().reshape(B, sq, heads, d).permute(0, 2, 1, 3)
+    kk = kv[:, :c].double().reshape(B, skv, heads, d).permute(0, 2, 1, 3)
+    vv = kv[:, c:].double().reshape(B, skv, heads, d).permute(0, 2, 1, 3)
+    ref = (torch.softmax(qq @ kk.transpose(-1, -2) * d ** -0.5, -1) @ vv).permute(0, 2, 1, 3).reshape(B * sq, c).float()
+    assert _rel(outs[1].float().cpu(), ref) < 1.5e-3
+    a.variant, a.d = 2, 80
+    assert lib.ds_attention_f16(C.byref(a), _lib.stream_ptr()) != 0
+
+
 FUSED_NORM_CASES = [
     # B, H(=W), c0, c1, cout, ec ('none' | 'same': the skip projection reads the same raw sources), forced nb, silu, forced splits
     (1, 64, 192, 0, 192, 'none', 0, True, 0),        # ImageNet-64 64x64 layer: three slabs, 192-column tile, seven DMA rounds

@@ -18,6 +18,7 @@ ap.add_argument('--images', type=int, default=16)
 ap.add_argument('--iters', type=int, default=5)
 ap.add_argument('--only', type=int, nargs='*', help='shape indices')
 ap.add_argument('--f16-only', action='store_true')
+ap.add_argument('--variant', type=int, default=0, help='ds_attn_args.variant with --f16-rows: 1 = one query block per wave, 2 = two (round 6)')
 ap.add_argument('--f16-rows', action='store_true', help='q / k / v given as fp16 tensors (ds_attn_args.in_f16) instead of fp32 rows rounded while staged')
 args = ap.parse_args()
 B = args.images
@@ -35,7 +36,7 @@ for si, (heads, d, sq, skv) in enumerate(SHAPES):
         lib = _lib.load()
         q16, kv16, out16 = q.half(), kv.half(), out.half()
         a = _lib.AttnArgs(q16.data_ptr(), kv16.data_ptr(), kv16[:, :, c:].data_ptr(), out16.data_ptr(), c, 2 * c, 2 * c, c, sq * c, skv * 2 * c,
-                          skv * 2 * c, sq * c, B, heads, sq, skv, d, d ** -0.5, 1, 3)
+                          skv * 2 * c, sq * c, B, heads, sq, skv, d, d ** -0.5, 1, 3, args.variant)
         run16 = lambda: _lib.check(lib.ds_attention_f16(C.byref(a), _lib.stream_ptr()))
         for _ in range(2):
             run16()
