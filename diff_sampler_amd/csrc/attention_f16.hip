@@ -231,7 +231,10 @@ __global__ void __launch_bounds__(512, DS_ATTN_WAVES(D)) flash_attn_f16_kernel(c
                     st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kv, qf[ks], st[kb], 0, 0, 0);
                 }
             }
-            if (t == ntiles - 1) {
+            if (t == ntiles - 1 && (a.skv & (KT - 1))) {
+                // a REAL (wave-uniform) branch: without the asm statement the compiler if-converts this block into 32 v_cndmask per tile -- a
+                // fifth of the loop's VALU instructions, on every tile, for a mask that can only matter on a ragged LAST tile (round 6)
+                asm volatile("; ragged last key tile" ::: "memory");
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -490,7 +493,8 @@ __global__ void __launch_bounds__(256, 2) flash_attn_f16x2_kernel(const ds_attn_
         // softmax of one block on its scores: running maximum / rescale, un-normalised weights -> the fp16 operand registers of P V
         auto softmax = [&](auto xc) {
             constexpr int x = decltype(xc)::value;
-            if (t == ntiles - 1) {
+            if (t == ntiles - 1 && (a.skv & (KT - 1))) {
+                asm volatile("; ragged last key tile" ::: "memory");        // a real branch, not 32 v_cndmask per tile (see flash_attn_f16_kernel)
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll

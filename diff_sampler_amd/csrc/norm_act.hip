@@ -296,8 +296,18 @@ __global__ void __launch_bounds__(512) norm_act16_kernel(const ds_norm_args a, i
             const float* sp = f0 ? a.stats0 : a.stats1;
             const int cs = f0 ? a.c0 : a.c1, cc = f0 ? cc_ : cc_ - a.c0;
             const float* base = sp + ((size_t)n * nrb * 2) * cs + cc;
+            // up to 16 row blocks (images of at most 32 x 32 pixels): ALL loads first -- a loop of load / add pairs costs one memory round trip
+            // per row block (~1 us each) --, then the additions in row-block order
+            float vs[16], vq[16];
+#pragma unroll
+            for (int rb = 0; rb < 16; ++rb) {
+                const int rc = rb < nrb ? rb : nrb - 1;
+                vs[rb] = base[(size_t)rc * 2 * cs]; vq[rb] = base[((size_t)rc * 2 + 1) * cs];
+            }
             double s = 0.0, q = 0.0;
-            for (int rb = 0; rb < nrb; ++rb) { s += (double)base[(size_t)rb * 2 * cs]; q += (double)base[((size_t)rb * 2 + 1) * cs]; }
+#pragma unroll
+            for (int rb = 0; rb < 16; ++rb)
+                if (rb < nrb) { s += (double)vs[rb]; q += (double)vq[rb]; }
             ch_s[cc_] = s; ch_q[cc_] = q;
         }
         __syncthreads();
