@@ -334,8 +334,8 @@ __global__ void __launch_bounds__(512, DS_ATTN_WAVES(D)) flash_attn_f16_kernel(c
 // Workgroup = 4 waves x 64 queries = 256 queries (the same query blocks per workgroup and the same K / V staging per query as the one-block
 // kernel's 8 x 32), ~50 KB of LDS and < 256 VGPRs: two workgroups per CU, i.e. the two waves of a SIMD belong to DIFFERENT workgroups and are
 // out of phase.  Same arithmetic per query as the one-block kernel (the same MFMA operands in the same order, the same softmax
-// expressions): results are bit-identical to it -- tests/test_hip_kernels.py compares the two.  Head sizes 32 / 40 / 64 (registers);
-// taken for sq >= 256 (ds_attn_args.variant: 1 forces the one-block kernel, 2 this one).
+// expressions): results are bit-identical to it -- tests/test_hip_kernels.py compares the two.  Head sizes 32 / 40 / 64 (registers).
+// MEASURED SLOWER (use_x2 below): never the library's choice, reachable through ds_attn_args.variant = 2 only.
 template <int D, int INF16>
 __global__ void __launch_bounds__(256, 2) flash_attn_f16x2_kernel(const ds_attn_args a, const int qblocks, const int pairs) {
     static_assert(D <= 64, "two query blocks per wave: head sizes up to 64");
@@ -636,11 +636,11 @@ int launch_t(const ds_attn_args* a, hipStream_t stream) {
     return DS_OK;
 }
 
-// two query blocks per wave where the head size allows it and a workgroup's four waves all have queries (ds_attn_args.variant 1 / 2 force)
-static bool use_x2(const ds_attn_args* a) {
-    if (a->d > 64 || a->variant == 1) return false;
-    return a->variant == 2 || a->sq >= 256;
-}
+// Two query blocks per wave: ONLY on request (ds_attn_args.variant = 2).  Measured slower than the one-block kernel on every shape of the two
+// fp16 lines (profiles/r6_attn_f16_two_blocks_ab.txt: d = 40, S = 4 096, 32 latents 1.35 -> 1.44 ms; d = 64, S = 1 024 0.078 -> 0.085 ms; SD-1.5
+// fp16 78.3 -> 76.9 images/s): at 210 - 242 VGPRs it runs two waves per SIMD against four, and what the in-wave skew hides is less than what the
+// two extra waves hid.  Kept, bit-identical and tested, as the record of that experiment (docs/HISTORY.md H.3).
+static bool use_x2(const ds_attn_args* a) { return a->d <= 64 && a->variant == 2; }
 
 template <int D>
 int launch(const ds_attn_args* a, hipStream_t stream) {

@@ -244,7 +244,8 @@ __global__ void __launch_bounds__(1024) norm_act_kernel(const ds_norm_args a, in
 // (what ds_gn_finalize does in a launch of its own, ~6 us each, 950 per ImageNet-64 sampler call): channel sums in fp64 over the image's row
 // blocks in order, group sums in channel order, mean / rstd and the coefficients by gn_coefs -- every workgroup of an image repeats that for
 // the whole image, so the launcher takes this form only where the sums are small next to the tensor (images of at most 32 x 32 pixels) and
-// gives an image few, fat workgroups.
+// caps the workgroups per image.  MEASURED (profiles/r6_norm_pass_ab.txt): the launch it saves (~6 us) is about what every workgroup's own
+// reduction costs -- +-1 us per layer either way, a wash on both fp16 lines -- so the engines keep ds_gn_finalize (plan.FOLD_FINALIZE off).
 typedef unsigned n16_u4 __attribute__((ext_vector_type(4)));
 typedef _Float16 n16_h8 __attribute__((ext_vector_type(8)));
 
@@ -680,13 +681,13 @@ extern "C" int ds_norm_act(const ds_norm_args* a, void* stream) {
         int PL16 = T / CO;
         if (PL16 > HW) PL16 = HW;
         // workgroups per image.  Plain: >= 16 pixels per thread on the large tensors, 4 on the small ones (see below).  FIN: every workgroup re-reads
-        // the image's column sums (HW / 64 x 2 x C floats): at most as many workgroups as keep that below a quarter of a workgroup's own rows
+        // the image's column sums (HW / 64 x 2 x C floats): at most as many workgroups as keep that below a workgroup's own rows
         const long long elems = (long long)a->n * HW * C;
         const int ppt = elems < (16ll << 20) ? 4 : 16;
         int chunks = (HW + ppt * PL16 - 1) / (ppt * PL16);
         if (fin) {
             const long long sums = (long long)(HW / 64) * 2 * C * 4, rows = (long long)HW * C * 2;
-            const int div = (a->tune_variant & 2) ? 1 : ((a->tune_variant & 4) ? 0 : 4);          // (benchmarks: tune_variant bits 1 / 2 relax the cap)
+            const int div = (a->tune_variant & 2) ? 4 : ((a->tune_variant & 4) ? 0 : 1);          // (benchmarks: tune_variant bits 1 / 2 change the cap; 1x measured best)
             int cap = div ? (int)(rows / (div * sums)) : chunks;
             if (cap < 1) cap = 1;
             if (chunks > cap) chunks = cap;

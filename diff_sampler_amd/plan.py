@@ -36,7 +36,7 @@ SPLITK_WORKSPACE_FLOATS = 64 << 20      # 256 MiB per plan
 # is measured during a stream capture.  Measured gain on whole sampler calls (session r7a, alternating in one process): SD-1.5 fp16
 # +1.5 %, ImageNet-64 fp16 +0.6 %.
 AUTOTUNE = os.environ.get('DS_AUTOTUNE', '1') != '0'
-FOLD_FINALIZE = os.environ.get('DS_FOLD_GN_FINALIZE', '1') != '0'       # Builder._fold_finalize
+FOLD_FINALIZE = os.environ.get('DS_FOLD_GN_FINALIZE', '0') == '1'       # Builder._fold_finalize: OFF by default (measured a wash, see there)
 _TUNE_CACHE: Dict[tuple, tuple] = {}     # (device, layer signature) -> (nb, nw, {candidate: ms}): the table's entries + what this process measured
 _MEASURED: Dict[str, list] = {}          # table keys measured in THIS process (misses of the persisted table): save_tile_table() writes them
 _FLUSH: Dict[int, torch.Tensor] = {}     # device index -> the 512 MiB scratch written before every timed launch; freed by release_tuning_scratch()
@@ -450,7 +450,10 @@ class Builder:
         call in round 5) is dropped from the plan.  Only where every workgroup can afford to re-read the image's column sums: images of at most
         32 x 32 pixels, on the 16-byte form of the pass (the host-side mirror of norm16_ok + the FIN checks of ds_norm_act).  The planes are not
         written then: nothing else may read them (the engines' passes are their only readers).  Same arithmetic, same coefficient expressions
-        (gn_coefs): the plans agree bit for bit (tests/test_hip_fp16.py).  DS_FOLD_GN_FINALIZE=0 keeps the two-launch form (A/B runs)."""
+        (gn_coefs): the plans agree bit for bit (tests/test_hip_fp16.py, tools/ab_norm.py).
+        OFF by default (DS_FOLD_GN_FINALIZE=1 / plan.FOLD_FINALIZE switch it on): built as VERDICT r5 item 3 asked and MEASURED a wash -- the
+        launch saved is paid back by every workgroup's own reduction of the column sums: ImageNet-64 fp16 322.3 (two launches) vs 320.1 images/s
+        (folded), SD-1.5 fp16 78.1 vs 77.3 (session r9d, alternating; profiles/r6_norm_pass_ab.txt)."""
         if not FOLD_FINALIZE or coefs is None or not self.P.ops:
             return
         prev = self.P.ops[-1]

@@ -299,8 +299,10 @@ typedef struct ds_norm_args {
      * statistics of every image ITSELF (what ds_gn_finalize does in a launch of its own) and applies them: `coefs` must be NULL, gamma / beta /
      * scale / shift / groups / eps are read as ds_gn_finalize reads them, mean / rstd are not written.  Only for the 16-byte fp16 form of the
      * pass (fp16 rows in and out, no resampling, channel counts multiples of 8) on images of 64 ... 1 024 pixels (h * w % 64 == 0);
-     * anything else returns DS_E_SHAPE.  tune_variant bit 0 (benchmarks / tests): keep the 8-byte kernel of rounds 3 - 5 where the 16-byte one
-     * would be taken. */
+     * anything else returns DS_E_SHAPE.  (The engines do NOT use this form by default: measured, it saves the ~6 us launch and pays about as
+     * much in every workgroup's own reduction -- profiles/r6_norm_pass_ab.txt; plan.FOLD_FINALIZE / DS_FOLD_GN_FINALIZE=1 switches it on.)
+     * tune_variant (benchmarks / tests): bit 0 keeps the 8-byte kernel of rounds 3 - 5 where the 16-byte one would be taken; bits 1 / 2 change how
+     * many workgroups share an image in the self-finalising form (0: column sums <= rows / 1 per workgroup; bit 1: <= rows / 4; bit 2: no cap). */
     const float* stats0; const float* stats1;
     int tune_variant;
 } ds_norm_args;
@@ -342,9 +344,10 @@ typedef struct ds_attn_args {
     int in_f16;      /* ds_attention_f16 only: bit 0: q is an fp16 tensor (ldq / q_bs in halfs, multiples of 8), bit 1: k and v are (ldk, k_bs
                         multiples of 8; ldv, v_bs of 4) -- the fp16 tensors the reference's qkv projection emits in its fp16 mode
                         (networks_edm.py:171-173; attention.py:168-176 under autocast); `scale` then multiplies the fp32 scores */
-    int variant;     /* ABI 4.  ds_attention_f16 only (ds_attention ignores it): 0 = the library's choice; 1 = the kernel with one 32-query block per wave
-                        (rounds 2 - 5); 2 = two query blocks per wave, software-pipelined (round 6; head sizes <= 64, else DS_E_SHAPE) -- for benchmarks
-                        and tests: results do not depend on it */
+    int variant;     /* ABI 4.  ds_attention_f16 only (ds_attention ignores it): 0 = the library's choice (the kernel with one 32-query block per wave,
+                        rounds 2 - 6); 1 = the same, explicitly; 2 = two query blocks per wave, skewed by half a phase (round 6 experiment, measured
+                        5 - 8 % slower and therefore never chosen; head sizes <= 64, else DS_E_SHAPE) -- for benchmarks and tests: results do not
+                        depend on it */
 } ds_attn_args;
 
 DS_API int ds_attention(const ds_attn_args* a, void* stream);

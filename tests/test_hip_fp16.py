@@ -320,3 +320,44 @@ def test_fused_input_normalisation_plan_matches_the_pass_plan(which):
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     json.dump(REPORT, open(os.path.join(ROOT, 'gpurun_out', 'fp16_parity.json'), 'w'), indent=1)
     assert torch.equal(out, base), e
+
+
+@pytest.mark.parametrize('which', ['imagenet64', 'sd15'])
+def test_folded_gn_finalize_plan_matches_the_two_launch_plan(which, monkeypatch):
+    """plan.FOLD_FINALIZE (round 6, OFF by default: measured a wash, profiles/r6_norm_pass_ab.txt): the fp16 passes on images of at most
+    32 x 32 pixels compute their GroupNorm statistics themselves (ds_norm_args.stats0 / stats1, norm_act16_kernel<FIN>) and the
+    ds_gn_finalize launches in front of them leave the plan -- same coefficient expressions, same arithmetic: whole-network outputs EQUAL
+    bit for bit (ImageNet-64 ADM at 4 images with labels and adaptive scale / shift; SD-1.5 at 2 latents under guidance)."""
+    from diff_sampler_amd import _lib, plan as plan_mod
+    lib = _lib.load()
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(8)
+    if which == 'imagenet64':
+        from diff_sampler_amd.engine import EDMDenoiser
+        spec = arch.edm_precond_spec(**dict(arch.NAMED_CONFIGS['imagenet64']))
+        params = arch.init_params(spec, seed=9)
+        sig = torch.tensor([30.0, 2.5, 0.3, 0.02]).to(dev)
+        x = (torch.randn(4, 3, 64, 64, generator=g)).to(dev) * sig.reshape(-1, 1, 1, 1)
+        lab = torch.eye(spec.label_dim)[torch.randint(spec.label_dim, (4,), generator=g)].to(dev)
+        make = lambda: EDMDenoiser(spec, params, use_fp16=True)
+        run = lambda net: net(x, sig, class_labels=lab).clone()
+    else:
+        import diff_sampler_amd.ldm_arch as la
+        from diff_sampler_amd.ldm_engine import CFGDenoiser
+        spec = la.ldm_unet_spec(**la.NAMED_LDM_CONFIGS['sd15'])
+        params = la.init_ldm_params(spec, seed=3)
+        x = torch.randn(2, 4, 64, 64, generator=g).to(dev) * 3.0
+        cond, uncond = torch.randn(2, 77, 768, generator=g).to(dev), torch.randn(2, 77, 768, generator=g).to(dev)
+        make = lambda: CFGDenoiser(spec, params, dev, guidance_rate=7.5, use_fp16=True)
+        run = lambda net: net(x, 3.0, condition=cond, unconditional_condition=uncond).clone()
+    outs, counts = [], []
+    for fold in (False, True):
+        monkeypatch.setattr(plan_mod, 'FOLD_FINALIZE', fold)
+        net = make()
+        outs.append(run(net))
+        torch.cuda.synchronize()
+        P = list(net.engine._plans.values())[-1]
+        counts.append((sum(1 for op in P.ops if op.fn is lib.ds_gn_finalize), sum(1 for op in P.ops if op.fn is lib.ds_norm_act and op.keep[0].stats0)))
+    (fin0, folded0), (fin1, folded1) = counts
+    assert folded0 == 0 and folded1 >= 20 and fin1 == fin0 - folded1, counts
+    assert torch.isfinite(outs[1]).all() and torch.equal(outs[1], outs[0]), float((outs[1] - outs[0]).abs().max())

@@ -1669,8 +1669,9 @@ def test_fused_attention_two_query_blocks_per_wave_equals_the_one_block_kernel(d
     """flash_attn_f16x2_kernel (round 6: a wave owns two 32-query blocks, skewed by half a phase; csrc/attention_f16.hip) against
     flash_attn_f16_kernel (one block per wave) through ds_attn_args.variant = 2 / 1: the same MFMA operands in the same order and the same
     softmax expressions per query => EQUAL bits, fp16 or fp32 operand tensors, fp16 or fp32 output rows, ragged query / key counts
-    (partial last query block, partial last key tile, a workgroup whose later waves have no queries); the default picks it from 256 queries
-    on; head sizes above 64 refuse variant 2."""
+    (partial last query block, partial last key tile, a workgroup whose later waves have no queries).  The library's own choice (variant 0)
+    is the one-block kernel: the two-block form measured 5 - 8 % slower (profiles/r6_attn_f16_two_blocks_ab.txt) and is kept as that record;
+    head sizes above 64 refuse variant 2."""
     import ctypes as C
     from diff_sampler_amd import _lib
     lib = _lib.load()

@@ -4,7 +4,8 @@
 
     r5      the round-5 form: 8-byte pass (ds_norm_args.tune_variant = 1), statistics always a launch of their own (plan.FOLD_FINALIZE off)
     16B     the 16-byte pass (norm_act16_kernel), statistics a launch of their own
-    16B+F   the default: 16-byte pass that computes the statistics itself on images of at most 32 x 32 pixels (no ds_gn_finalize there)
+    16B+F   plan.FOLD_FINALIZE on: the 16-byte pass computes the statistics itself on images of at most 32 x 32 pixels (no ds_gn_finalize there)
+    (the engines' default is 16B)
 
 Prints the launches of each plan (passes, statistics launches), max |variant - r5| (expected 0: same arithmetic) and images/s per round."""
 import argparse
@@ -60,7 +61,7 @@ for config in args.config:
         folded = sum(1 for op in P.ops if op.fn is lib.ds_norm_act and op.keep[0].stats0)
         print(f'{config} {name:6s}: {len(P.ops)} launches per evaluation: {na} passes ({folded} with their own statistics), {nf} ds_gn_finalize', flush=True)
         nets.append((name, net, out))
-    plan_mod.FOLD_FINALIZE = True
+    plan_mod.FOLD_FINALIZE = False
     for name, _, out in nets[1:]:
         print(f'{config}: max |{name} - r5| = {float((out - nets[0][2]).abs().max()):.3e}', flush=True)
     for rnd in range(args.rounds):

@@ -71,7 +71,7 @@ for B, res, c0, c1, raw in SHAPES:
         return a
 
     a8, a16, af = args_for(1, False), args_for(0, False), args_for(0, True)
-    af1, afn = args_for(2, True), args_for(4, True)           # workgroup cap of the self-finalising pass relaxed: sums <= rows / no cap
+    af1, afn = args_for(2, True), args_for(4, True)           # other workgroup caps of the self-finalising pass: sums <= rows / 4, no cap
 
     def two(a):
         def go():
@@ -87,5 +87,5 @@ for B, res, c0, c1, raw in SHAPES:
     best = min(t16, tf, tf1, tfn) if tf is not None else t16
     sums['8B'] += t8; sums['16B'] += t16; sums['best'] += best
     print(f'{B:3d} x {res:2d}x{res:2d} x {c0:4d}+{c1:<4d} raw={raw}  {byts / 1e6:7.1f} MB   8B {t8:7.1f} us {byts / t8 / 1e3:6.0f} GB/s   16B {t16:7.1f} us {byts / t16 / 1e3:6.0f} GB/s   '
-          + (f'16B+F {tf:7.1f} us {byts / tf / 1e3:6.0f} GB/s  (cap 1x: {tf1:6.1f} us, no cap: {tfn:6.1f} us)' if tf is not None else '16B+F     --'), flush=True)
+          + (f'16B+F {tf:7.1f} us {byts / tf / 1e3:6.0f} GB/s  (cap 4x: {tf1:6.1f} us, no cap: {tfn:6.1f} us)' if tf is not None else '16B+F     --'), flush=True)
 print(f'# sum over the shapes: 8B {sums["8B"]:.0f} us, 16B {sums["16B"]:.0f} us, best of 16B / 16B+F {sums["best"]:.0f} us')
