@@ -64,7 +64,7 @@ WORKLOAD_NAMES = {'cifar10': 'EDM CIFAR-10 32x32 SongUNet (55.7M params)', 'ffhq
                   'sd15': 'Stable Diffusion v1.5 64x64x4 latent U-Net (859.5M params)'}
 SOLVER_NAMES = {'dpmpp': 'DPM-Solver++(2M) logSNR', 'euler': 'Euler', 'ipndm': 'iPNDM-4', 'heun': 'Heun'}
 LDM_SOLVER_NAME = 'DPM-Solver++(2M) eps-prediction, discrete rho=1, CFG 7.5 (2 U-Net images per latent; new text conditions on every call: the context K / V projections are inside the timed region)'
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r5_bench_pmc_hbm.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r6_bench_pmc_hbm.json')
 PMC_NOTE = {}
 KERNEL_NAMES = {0: 'igemm_f32_kernel<0> (generic gather conv / 1x1 / linear)', 128: 'conv3x3_halo_kernel<2> (128-pixel tiles)',
                 1284: 'conv3x3_halo_kernel<2, WN=4, NT=1> (128-pixel tiles on 8 waves of 64 x 32)',
@@ -201,8 +201,12 @@ def instrumented_pass(net, solvers, solver, latents, nfe, ldm=None):
             return 'norm_act_kernel', float(byts)
         return 'other', 0.0
 
+    # Every launch of the call is bracketed by its own event pair and NOTHING synchronises until the sampler call has been enqueued to its end:
+    # the stream stays busy, so an event pair measures its kernel, not the host's time to enqueue it on an idle stream (until round 6 the update
+    # launches were read back one by one -- each then started on an idle GPU and its "duration" was 12 - 40 us of host latency around a 10-us kernel)
+    pending = []
+
     def timed_plan_run(self, stream):
-        evs = []
         for op in self.ops:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -210,17 +214,13 @@ def instrumented_pass(net, solvers, solver, latents, nfe, ldm=None):
             e1.record()
             if rc:
                 _lib.check(rc, op.name)
-            evs.append((op, e0, e1))
-        torch.cuda.synchronize()
-        for op, e0, e1 in evs:
-            kind, fl = classify(op)
-            add(kind, e0.elapsed_time(e1), fl)
+            pending.append((classify(op), e0, e1))
 
     def timed_call(kind, fn):
         def w(*a, **k):
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(); r = fn(*a, **k); e1.record(); torch.cuda.synchronize()
-            add(kind, e0.elapsed_time(e1))
+            e0.record(); r = fn(*a, **k); e1.record()
+            pending.append(((kind, 0.0), e0, e1))
             return r
         return w
 
@@ -235,6 +235,8 @@ def instrumented_pass(net, solvers, solver, latents, nfe, ldm=None):
     try:
         sampler_call(solvers, solver, net, latents, nfe, ldm)
         torch.cuda.synchronize()
+        for (kind, fl), e0, e1 in pending:
+            add(kind, e0.elapsed_time(e1), fl)
     finally:
         engine._Plan.run = plan_run
         ops.solver_update = upd
@@ -294,10 +296,10 @@ PMC_PATTERNS = {2566: r'conv3x3_f16dma_kernel<\d+, \d+, (?:true|false), false>',
                 2563: r'conv3x3_halo2_kernel<\d+, 2>', 2564: r'gemm_f16_kernel', 'norm_act': r'norm_act(?:16)?_kernel'}
 # one PMC summary per benchmarked workload (tools/gpu_session.sh pmc:<bench.py args>): (config, dtype) -> file under profiles/
 PMC_FILES = {('cifar10', 'fp32'): PMC_FILE,
-             ('imagenet64', 'fp16'): os.path.join(ROOT, 'profiles', 'r5_pmc_hbm_imagenet64_fp16.json'),
-             ('sd15', 'fp16'): os.path.join(ROOT, 'profiles', 'r5_pmc_hbm_sd15_fp16.json'),
-             ('ffhq', 'fp32'): os.path.join(ROOT, 'profiles', 'r5_pmc_hbm_ffhq_fp32.json'),
-             ('cifar10', 'fp16x3'): os.path.join(ROOT, 'profiles', 'r5_pmc_hbm_cifar10_fp16x3.json')}
+             ('imagenet64', 'fp16'): os.path.join(ROOT, 'profiles', 'r6_pmc_hbm_imagenet64_fp16.json'),
+             ('sd15', 'fp16'): os.path.join(ROOT, 'profiles', 'r6_pmc_hbm_sd15_fp16.json'),
+             ('ffhq', 'fp32'): os.path.join(ROOT, 'profiles', 'r6_pmc_hbm_ffhq_fp32.json'),
+             ('cifar10', 'fp16x3'): os.path.join(ROOT, 'profiles', 'r6_pmc_hbm_cifar10_fp16x3.json')}
 
 
 def pmc_traffic(kid, workload=('cifar10', 'fp32')):
