@@ -240,7 +240,9 @@ __global__ void __launch_bounds__(1024) norm_act_kernel(const ds_norm_args a, in
 // concatenation, optional raw copy, no resampling.  norm_act_kernel moves 8 bytes per lane and access (four channels: the fp32 geometry
 // applied to halfs) and ran at 0.45 of the 8 TB/s on the ImageNet-64 mix (profiles/r5_*): here a thread owns a channel OCTET (one
 // global_load_dwordx4 / global_store_dwordx4 per pixel), four pixels in flight, the same arithmetic through gn_affine / ds_silu / RNE.
-// FIN: the pass computes the GroupNorm statistics ITSELF from the per-(64-row block, channel) sums the producing convolutions left behind
+// MODE 2: mean / rstd per (image, group) + gamma / beta [+ adaptive scale / shift] instead of planes (the attention blocks' norm2, the
+// SpatialTransformer's GroupNorm): the coefficients are formed in the prologue exactly as norm_act_kernel forms them.
+// MODE 1 (FIN): the pass computes the GroupNorm statistics ITSELF from the per-(64-row block, channel) sums the producing convolutions left behind
 // (what ds_gn_finalize does in a launch of its own, ~6 us each, 950 per ImageNet-64 sampler call): channel sums in fp64 over the image's row
 // blocks in order, group sums in channel order, mean / rstd and the coefficients by gn_coefs -- every workgroup of an image repeats that for
 // the whole image, so the launcher takes this form only where the sums are small next to the tensor (images of at most 32 x 32 pixels) and
@@ -249,8 +251,9 @@ __global__ void __launch_bounds__(1024) norm_act_kernel(const ds_norm_args a, in
 typedef unsigned n16_u4 __attribute__((ext_vector_type(4)));
 typedef _Float16 n16_h8 __attribute__((ext_vector_type(8)));
 
-template <bool FIN>
+template <int MODE>          // 0: {mu, A, B} planes (a.coefs); 1: FIN -- the producers' column sums (a.stats0 / stats1); 2: a.mean / a.rstd + gamma / beta [/ scale / shift]
 __global__ void __launch_bounds__(512) norm_act16_kernel(const ds_norm_args a, int CO, int PL, int chunk) {
+    constexpr bool FIN = MODE == 1;
     extern __shared__ __attribute__((aligned(16))) double fin_lds[];          // FIN: [2][C] channel sums, then [2][64] floats mean / rstd
     const int tid = threadIdx.x, n = blockIdx.y;
     const int C = a.c0 + a.c1, HW = a.h * a.w;
@@ -267,7 +270,7 @@ __global__ void __launch_bounds__(512) norm_act16_kernel(const ds_norm_args a, i
     n16_u4 r[4];
     bool have = false;
     f32x4 gmv[2], btv[2], scv[2], shv[2];
-    if constexpr (FIN) {
+    if constexpr (MODE != 0) {
         if (live) {
             if (p + 3 * PL < p_end) {
 #pragma unroll
@@ -287,6 +290,8 @@ __global__ void __launch_bounds__(512) norm_act16_kernel(const ds_norm_args a, i
                 }
             }
         }
+    }
+    if constexpr (FIN) {
         float* g_mean = reinterpret_cast<float*>(fin_lds + 2 * C);
         float* g_rstd = g_mean + 64;
         double* ch_s = fin_lds;
@@ -337,6 +342,16 @@ __global__ void __launch_bounds__(512) norm_act16_kernel(const ds_norm_args a, i
             mu[j] = g_mean[g];
             gn_coefs(g_rstd[g], gmv[j >> 2][j & 3], btv[j >> 2][j & 3], a.scale ? scv[j >> 2][j & 3] + 1.f : 1.f, a.scale ? shv[j >> 2][j & 3] : 0.f, A[j], Bc[j]);
         }
+    } else if constexpr (MODE == 2) {
+        // statistics from ds_gn_stats / ds_gn_finalize as mean / rstd per (image, group): the attention blocks' norm2, the transformer's GroupNorm
+        const int cpg = a.mean ? C / a.groups : 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float m_ = 0.f, r_ = 1.f;
+            if (a.mean) { const int g = (c + j) / cpg; m_ = a.mean[(size_t)n * a.groups + g]; r_ = a.rstd[(size_t)n * a.groups + g]; }
+            mu[j] = m_;
+            gn_coefs(r_, gmv[j >> 2][j & 3], btv[j >> 2][j & 3], a.scale ? scv[j >> 2][j & 3] + 1.f : 1.f, a.scale ? shv[j >> 2][j & 3] : 0.f, A[j], Bc[j]);
+        }
     } else {
         const float* cp = a.coefs + (size_t)n * 3 * C + c;
         const f32x4 m0 = *reinterpret_cast<const f32x4*>(cp), m1 = *reinterpret_cast<const f32x4*>(cp + 4);
@@ -385,7 +400,9 @@ static bool norm16_ok(const ds_norm_args* a) {
     if ((C & 7) || (a->c0 & 7) || (a->ld0 & 7) || (a->c1 && (a->ld1 & 7)) || (a->out_ld & 7) || C > 4096) return false;
     if (!ds_aligned16(a->x0) || (a->c1 && !ds_aligned16(a->x1)) || !ds_aligned16(a->out)) return false;
     if (a->raw_out && ((a->raw_ld & 7) || !ds_aligned16(a->raw_out))) return false;
-    return a->coefs != nullptr || a->stats0 != nullptr;
+    if (a->coefs != nullptr || a->stats0 != nullptr) return true;
+    // mean / rstd form: statistics present and an affine map to apply (the identity / raw-resampler uses of ds_norm_act keep the generic kernel)
+    return a->mean != nullptr && a->groups > 0 && (a->c0 + a->c1) % a->groups == 0;
 }
 
 // --------------------------------------------------------------------------------------------------------------
@@ -697,8 +714,9 @@ extern "C" int ds_norm_act(const ds_norm_args* a, void* stream) {
         chunk = ((chunk + PL16 - 1) / PL16) * PL16;
         chunks = (HW + chunk - 1) / chunk;
         const size_t lds = fin ? (size_t)2 * C * sizeof(double) + 128 * sizeof(float) : 0;
-        if (fin) hipLaunchKernelGGL((norm_act16_kernel<true>), dim3(chunks, a->n), dim3(T), lds, (hipStream_t)stream, *a, CO, PL16, chunk);
-        else hipLaunchKernelGGL((norm_act16_kernel<false>), dim3(chunks, a->n), dim3(T), 0, (hipStream_t)stream, *a, CO, PL16, chunk);
+        if (fin) hipLaunchKernelGGL((norm_act16_kernel<1>), dim3(chunks, a->n), dim3(T), lds, (hipStream_t)stream, *a, CO, PL16, chunk);
+        else if (a->coefs) hipLaunchKernelGGL((norm_act16_kernel<0>), dim3(chunks, a->n), dim3(T), 0, (hipStream_t)stream, *a, CO, PL16, chunk);
+        else hipLaunchKernelGGL((norm_act16_kernel<2>), dim3(chunks, a->n), dim3(T), 0, (hipStream_t)stream, *a, CO, PL16, chunk);
         DS_CHECK_LAUNCH();
         return DS_OK;
     }

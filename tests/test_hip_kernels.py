@@ -1422,6 +1422,18 @@ def test_norm_pass_16_byte_kernel_and_folded_finalize_equal_the_two_launch_form(
     assert torch.isfinite(o16.float()).all() and torch.equal(o16, o8)
     if raw:
         assert torch.equal(r16, r8) and torch.equal(r16, x)
+    # the mean / rstd form (no planes: the attention blocks' norm2, the SpatialTransformer's GroupNorm): coefficients formed in the prologue
+    def run_mr(variant):
+        out = torch.full((M, Ct), float('nan'), dtype=torch.float16, device=dev)
+        a = ops._norm_args(x0, c0, c0, B, H, H, x1=x1, c1=c1, ld1=c1, groups=32, eps=1e-5, mean=mean, rstd=rstd, gamma=gm, beta=bt,
+                           scale=sc, shift=sh, ss_ld=Ct, ss_rows=ss_rows, act=(1 if silu else 0), out=out, out_ld=Ct)
+        a.in_f16, a.out_f16, a.tune_variant = (3 if c1 else 1), 1, variant
+        rc = lib.ds_norm_act(C.byref(a), _lib.stream_ptr())
+        torch.cuda.synchronize()
+        assert rc == 0
+        return out
+    m8, m16 = run_mr(1), run_mr(0)
+    assert torch.equal(m16, m8) and torch.equal(m16, o8)            # ... and they are the planes' coefficients (gn_coefs in all three places)
     rcf, of, rf = run(0, True)
     if HW <= 1024:
         assert rcf == 0, lib.ds_error_string(rcf)
