@@ -251,19 +251,25 @@ __global__ void __launch_bounds__(1024) norm_act_kernel(const ds_norm_args a, in
 typedef unsigned n16_u4 __attribute__((ext_vector_type(4)));
 typedef _Float16 n16_h8 __attribute__((ext_vector_type(8)));
 
-template <int MODE>          // 0: {mu, A, B} planes (a.coefs); 1: FIN -- the producers' column sums (a.stats0 / stats1); 2: a.mean / a.rstd + gamma / beta [/ scale / shift]
+// MODE 0: {mu, A, B} planes (a.coefs); 1: FIN -- the producers' column sums (a.stats0 / stats1); 2: a.mean / a.rstd + gamma / beta [/ scale / shift].
+// RS: the pass resamples by 2 (a.resample; its own instantiation: the box filter's registers would cost the plain pass two waves per SIMD).
+template <int MODE, bool RS>
 __global__ void __launch_bounds__(512) norm_act16_kernel(const ds_norm_args a, int CO, int PL, int chunk) {
     constexpr bool FIN = MODE == 1;
+    static_assert(!(FIN && RS), "the self-finalising pass does not resample");
     extern __shared__ __attribute__((aligned(16))) double fin_lds[];          // FIN: [2][C] channel sums, then [2][64] floats mean / rstd
     const int tid = threadIdx.x, n = blockIdx.y;
-    const int C = a.c0 + a.c1, HW = a.h * a.w;
+    const int C = a.c0 + a.c1, HW = a.h * a.w;                     // HW: INPUT pixels per image (statistics, source rows)
+    const int rs = RS ? a.resample : DS_RESAMPLE_NONE, W = a.w;
+    const int OW = rs == DS_RESAMPLE_DOWN ? a.w / 2 : (rs == DS_RESAMPLE_UP ? a.w * 2 : a.w);
+    const int OHW = rs == DS_RESAMPLE_DOWN ? HW / 4 : (rs == DS_RESAMPLE_UP ? HW * 4 : HW);      // output pixels per image: the loop below walks these
     const int co = tid % CO, pl = tid / CO;
     const bool live = pl < PL;
     const int c = co * 8;
     const bool first = c < a.c0;
     const _Float16* src = reinterpret_cast<const _Float16*>(first ? a.x0 : a.x1) + (size_t)n * HW * (first ? a.ld0 : a.ld1) + (first ? c : c - a.c0);
     const int ld = first ? a.ld0 : a.ld1;
-    const int p_begin = blockIdx.x * chunk, p_end = min(p_begin + chunk, HW);
+    const int p_begin = blockIdx.x * chunk, p_end = min(p_begin + chunk, OHW);
     int p = p_begin + pl;
     // FIN: everything that does not depend on the statistics is requested BEFORE they are reduced -- the thread's first four pixels and its
     // channels' gamma / beta / scale / shift -- so that the reduction's memory round trip is the only one in front of the first store
@@ -272,7 +278,7 @@ __global__ void __launch_bounds__(512) norm_act16_kernel(const ds_norm_args a, i
     f32x4 gmv[2], btv[2], scv[2], shv[2];
     if constexpr (MODE != 0) {
         if (live) {
-            if (p + 3 * PL < p_end) {
+            if (rs == DS_RESAMPLE_NONE && p + 3 * PL < p_end) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) r[q] = __builtin_nontemporal_load(reinterpret_cast<const n16_u4*>(src + (size_t)(p + q * PL) * ld));
                 have = true;
@@ -371,12 +377,63 @@ __global__ void __launch_bounds__(512) norm_act16_kernel(const ds_norm_args a, i
         }
         return __builtin_bit_cast(n16_u4, o);
     };
-    _Float16* dst = reinterpret_cast<_Float16*>(a.out) + (size_t)n * HW * a.out_ld + c;
-    _Float16* raw16 = a.raw_out ? reinterpret_cast<_Float16*>(a.raw_out) + (size_t)n * HW * a.raw_ld + c : nullptr;
+    _Float16* dst = reinterpret_cast<_Float16*>(a.out) + (size_t)n * OHW * a.out_ld + c;
+    _Float16* raw16 = a.raw_out ? reinterpret_cast<_Float16*>(a.raw_out) + (size_t)n * OHW * a.raw_ld + c : nullptr;
+    if constexpr (RS) if (rs == DS_RESAMPLE_DOWN) {
+        // 2x2 box filter, stride 2 (networks_edm.py:77 with resample_filter [1, 1]): the four ACTIVATED pixels are averaged in fp32 and rounded once,
+        // the raw copy is the same filter on the widened input -- norm_act_kernel's expressions; two output pixels = eight loads in flight
+        auto xf32 = [&](const n16_u4 raw, float (&o)[8], float (&w)[8]) {
+            const n16_h8 x = __builtin_bit_cast(n16_h8, raw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                w[j] = (float)x[j];
+                const float t = gn_affine(w[j], mu[j], A[j], Bc[j]);
+                o[j] = silu ? ds_silu(t) : t;
+            }
+        };
+        auto down = [&](const n16_u4 (&q4)[4], int po) {
+            float v[4][8], w[4][8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xf32(q4[k], v[k], w[k]);
+            n16_h8 o, rw;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                o[j] = (_Float16)(((v[0][j] + v[1][j]) + (v[2][j] + v[3][j])) * 0.25f);
+                rw[j] = (_Float16)(((w[0][j] + w[1][j]) + (w[2][j] + w[3][j])) * 0.25f);
+            }
+            *reinterpret_cast<n16_u4*>(dst + (size_t)po * a.out_ld) = __builtin_bit_cast(n16_u4, o);
+            if (raw16) *reinterpret_cast<n16_u4*>(raw16 + (size_t)po * a.raw_ld) = __builtin_bit_cast(n16_u4, rw);
+        };
+        auto load4 = [&](int po, n16_u4 (&q4)[4]) {
+            const int oh = po / OW, ow = po - oh * OW;
+            const _Float16* s0 = src + (size_t)((2 * oh) * W + 2 * ow) * ld;
+            q4[0] = __builtin_nontemporal_load(reinterpret_cast<const n16_u4*>(s0));
+            q4[1] = __builtin_nontemporal_load(reinterpret_cast<const n16_u4*>(s0 + ld));
+            q4[2] = __builtin_nontemporal_load(reinterpret_cast<const n16_u4*>(s0 + (size_t)W * ld));
+            q4[3] = __builtin_nontemporal_load(reinterpret_cast<const n16_u4*>(s0 + (size_t)(W + 1) * ld));
+        };
+        for (; p + PL < p_end; p += 2 * PL) {
+            n16_u4 qa[4], qb[4];
+            load4(p, qa); load4(p + PL, qb);
+            down(qa, p); down(qb, p + PL);
+        }
+        for (; p < p_end; p += PL) {
+            n16_u4 qa[4];
+            load4(p, qa);
+            down(qa, p);
+        }
+        return;
+    }
+    // no resampling, or nearest-neighbour x2 (networks_edm.py:75): output pixel (oh, ow) reads input pixel (oh / 2, ow / 2)
+    auto sidx = [&](int po) -> size_t {
+        if (rs == DS_RESAMPLE_NONE) return (size_t)po;
+        const int oh = po / OW, ow = po - oh * OW;
+        return (size_t)((oh >> 1) * W + (ow >> 1));
+    };
     for (; p + 3 * PL < p_end; p += 4 * PL) {
         if (!have) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) r[q] = __builtin_nontemporal_load(reinterpret_cast<const n16_u4*>(src + (size_t)(p + q * PL) * ld));
+            for (int q = 0; q < 4; ++q) r[q] = __builtin_nontemporal_load(reinterpret_cast<const n16_u4*>(src + sidx(p + q * PL) * ld));
         }
         have = false;
 #pragma unroll
@@ -386,15 +443,16 @@ __global__ void __launch_bounds__(512) norm_act16_kernel(const ds_norm_args a, i
         }
     }
     for (; p < p_end; p += PL) {
-        const n16_u4 r1 = __builtin_nontemporal_load(reinterpret_cast<const n16_u4*>(src + (size_t)p * ld));
+        const n16_u4 r1 = __builtin_nontemporal_load(reinterpret_cast<const n16_u4*>(src + sidx(p) * ld));
         *reinterpret_cast<n16_u4*>(dst + (size_t)p * a.out_ld) = xf(r1);
         if (raw16) *reinterpret_cast<n16_u4*>(raw16 + (size_t)p * a.raw_ld) = r1;
     }
 }
 
-// Which ds_norm_act calls take norm_act16_kernel: fp16 rows in (every source present) and out, no resampling, whole channel octets.
+// Which ds_norm_act calls take norm_act16_kernel: fp16 rows in (every source present) and out, whole channel octets; 2x resampling included
+// (not in the self-finalising form).
 static bool norm16_ok(const ds_norm_args* a) {
-    if (!a->out_f16 || a->resample != DS_RESAMPLE_NONE) return false;
+    if (!a->out_f16 || (a->resample != DS_RESAMPLE_NONE && a->stats0 != nullptr)) return false;
     if (!(a->in_f16 & 1) || (a->c1 && !(a->in_f16 & 2))) return false;
     const int C = a->c0 + a->c1;
     if ((C & 7) || (a->c0 & 7) || (a->ld0 & 7) || (a->c1 && (a->ld1 & 7)) || (a->out_ld & 7) || C > 4096) return false;
@@ -693,7 +751,7 @@ extern "C" int ds_norm_act(const ds_norm_args* a, void* stream) {
     }
     if (norm16_ok(a) && !(a->tune_variant & 1)) {
         const bool fin = a->stats0 != nullptr;
-        const int C = a->c0 + a->c1, CO = C / 8, HW = a->h * a->w;
+        const int C = a->c0 + a->c1, CO = C / 8, HW = OH * OW;          // the OUTPUT pixels of an image are what the workgroups share out
         const int T = CO <= 256 ? 256 : 512;
         int PL16 = T / CO;
         if (PL16 > HW) PL16 = HW;
@@ -714,9 +772,12 @@ extern "C" int ds_norm_act(const ds_norm_args* a, void* stream) {
         chunk = ((chunk + PL16 - 1) / PL16) * PL16;
         chunks = (HW + chunk - 1) / chunk;
         const size_t lds = fin ? (size_t)2 * C * sizeof(double) + 128 * sizeof(float) : 0;
-        if (fin) hipLaunchKernelGGL((norm_act16_kernel<1>), dim3(chunks, a->n), dim3(T), lds, (hipStream_t)stream, *a, CO, PL16, chunk);
-        else if (a->coefs) hipLaunchKernelGGL((norm_act16_kernel<0>), dim3(chunks, a->n), dim3(T), 0, (hipStream_t)stream, *a, CO, PL16, chunk);
-        else hipLaunchKernelGGL((norm_act16_kernel<2>), dim3(chunks, a->n), dim3(T), 0, (hipStream_t)stream, *a, CO, PL16, chunk);
+        const bool rsm = a->resample != DS_RESAMPLE_NONE;
+#define DS_N16(MODE_, RS_, LDS_) hipLaunchKernelGGL((norm_act16_kernel<MODE_, RS_>), dim3(chunks, a->n), dim3(T), LDS_, (hipStream_t)stream, *a, CO, PL16, chunk)
+        if (fin) DS_N16(1, false, lds);
+        else if (a->coefs) { if (rsm) DS_N16(0, true, 0); else DS_N16(0, false, 0); }
+        else { if (rsm) DS_N16(2, true, 0); else DS_N16(2, false, 0); }
+#undef DS_N16
         DS_CHECK_LAUNCH();
         return DS_OK;
     }

@@ -1458,6 +1458,54 @@ def test_norm_pass_16_byte_kernel_and_folded_finalize_equal_the_two_launch_form(
     assert _rel(o16.float().cpu().reshape(B, HW, Ct), y.float()) < 1.5e-3
 
 
+@pytest.mark.parametrize('resample,B,H,c0,c1,raw,planes', [(1, 4, 32, 192, 0, True, True), (2, 3, 16, 384, 0, True, True), (1, 2, 64, 192, 0, True, True),
+                                                          (2, 2, 8, 768, 0, False, False), (1, 2, 16, 320, 0, True, False), (2, 2, 16, 128, 64, True, True)])
+def test_norm_pass_16_byte_kernel_resamples_like_the_8_byte_kernel(resample, B, H, c0, c1, raw, planes):
+    """norm_act16_kernel<., RS>: the 2x2 box filter down (four activated pixels averaged in fp32, rounded once; the raw copy filtered the same
+    way) and nearest-neighbour x2 up of the resampling blocks (networks_edm.py:74-77) at 16 bytes per lane, against norm_act_kernel
+    (tune_variant = 1): EQUAL bits, output and raw copy, planes or mean / rstd coefficients, one or two sources."""
+    import ctypes as C
+    from diff_sampler_amd import _lib, ops
+    lib = _lib.load()
+    dev = 'cuda'
+    Ct, M = c0 + c1, B * H * H
+    OH = H // 2 if resample == 1 else H * 2
+    g = torch.Generator().manual_seed(resample * 100 + H + Ct)
+    x = (torch.randn(M, Ct, generator=g) * 1.5 + 0.3).to(torch.float16).to(dev)
+    x0 = x[:, :c0].contiguous()
+    x1 = x[:, c0:].contiguous() if c1 else None
+    gm, bt = (1 + 0.1 * torch.randn(Ct, generator=g)).to(dev), (0.1 * torch.randn(Ct, generator=g)).to(dev)
+    mean, rstd = (0.2 * torch.randn(B * 32, generator=g)).to(dev), (1 + 0.2 * torch.rand(B * 32, generator=g)).to(dev)
+    pl = torch.stack([0.3 * torch.randn(B, Ct, generator=g), 1 + 0.2 * torch.randn(B, Ct, generator=g), 0.2 * torch.randn(B, Ct, generator=g)], 1).contiguous().to(dev)
+    outs = []
+    for variant in (1, 0):
+        out = torch.full((B * OH * OH, Ct), float('nan'), dtype=torch.float16, device=dev)
+        rw = torch.full((B * OH * OH, Ct), float('nan'), dtype=torch.float16, device=dev) if raw else None
+        if planes:
+            a = ops._norm_args(x0, c0, c0, B, H, H, x1=x1, c1=c1, ld1=c1, groups=32, eps=1e-5, act=1, resample=resample, out=out, out_ld=Ct)
+            a.coefs = C.c_void_p(pl.data_ptr())
+        else:
+            a = ops._norm_args(x0, c0, c0, B, H, H, x1=x1, c1=c1, ld1=c1, groups=32, eps=1e-5, mean=mean, rstd=rstd, gamma=gm, beta=bt, act=1,
+                               resample=resample, out=out, out_ld=Ct)
+        a.in_f16, a.out_f16, a.tune_variant = (3 if c1 else 1), 1, variant
+        if raw:
+            a.raw_out, a.raw_ld = C.c_void_p(rw.data_ptr()), Ct
+        assert lib.ds_norm_act(C.byref(a), _lib.stream_ptr()) == 0
+        torch.cuda.synchronize()
+        outs.append((out, rw))
+    assert torch.isfinite(outs[1][0].float()).all()
+    assert torch.equal(outs[1][0], outs[0][0])
+    if raw:
+        assert torch.equal(outs[1][1], outs[0][1])
+        xr = x.float().reshape(B, H, H, Ct)
+        want = xr.reshape(B, H // 2, 2, H // 2, 2, Ct).permute(0, 1, 3, 2, 4, 5) if resample == 1 else None
+        if resample == 2:
+            assert torch.equal(outs[1][1].reshape(B, OH, OH, Ct), xr.repeat_interleave(2, 1).repeat_interleave(2, 2).to(torch.float16))
+        else:
+            ref = ((want[..., 0, 0, :] + want[..., 0, 1, :]) + (want[..., 1, 0, :] + want[..., 1, 1, :])) * 0.25
+            assert torch.equal(outs[1][1].reshape(B, OH, OH, Ct), ref.to(torch.float16))
+
+
 def test_layernorm_rows_on_fp16_rows():
     """ds_layernorm_rows_f16io (fp16 in, fp16 out: LayerNorm of a tensor of the fp16 residual stream) == ds_layernorm_rows_f16 on the widened
     rows, for every lanes-per-row variant of the kernel (320 / 640 / 1280 columns) and a ragged row count."""
