@@ -83,7 +83,8 @@ def source_hashes():
 # test suite asserts that the kernel tests FAIL against it -- the detector detects.  It recompiles that one translation unit and links the
 # other objects of stress_a.
 VARIANTS = {'stress_a': ['-DDS_RACE_STRESS=0x21'], 'stress_b': ['-DDS_RACE_STRESS=0xDE'],
-            'stress_g5': ['-DDS_RACE_STRESS=0x21', '-DDS_TEST_DROP_G5_BARRIER=1']}
+            'stress_g5': ['-DDS_RACE_STRESS=0x21', '-DDS_TEST_DROP_G5_BARRIER=1'],
+            'timeline': ['-DDS_TIMELINE=1']}        # diagnostics (tools/timeline_gemm.py): phase stamps per workgroup, never what the engines run
 VARIANT_BASE = {'stress_g5': ('stress_a', ('conv3x3_f16dma.hip',))}        # tag -> (variant whose objects it shares, the translation units it compiles itself)
 
 

@@ -52,6 +52,37 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define DS_RACE_SKEW(wave_) do { } while (0)
 #endif
 
+// ---- Timeline build (diagnostics only; round 6).  -DDS_TIMELINE=1 (build.py variant 'timeline', loaded through DS_LIB_PATH by tools/timeline_gemm.py):
+// a launch whose ds_conv_args.tune.ablate has bit 15 set and which was given a workspace writes, per workgroup and wave, s_memtime stamps of its
+// phases (slots 0 .. 6) and {HW_ID, XCC_ID} (slot 7) into the workspace as u64[tile][8 waves][8 slots].  The product library does not
+// contain a single instruction of it.
+#ifdef DS_TIMELINE
+__device__ __forceinline__ void ds_timeline_mark(float* buf, int abl, int slot, int tile) {
+    if (!(abl & 0x8000) || !buf) return;
+    if ((threadIdx.x & 63) == 0) {
+        unsigned long long* b = reinterpret_cast<unsigned long long*>(buf) + ((size_t)tile * 8 + (threadIdx.x >> 6)) * 8;
+        b[slot] = __builtin_amdgcn_s_memtime();
+        if (slot == 0) b[7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+    }
+}
+#define DS_TL(buf_, abl_, slot_, tile_) ds_timeline_mark((buf_), (abl_), (slot_), (tile_))
+#else
+#define DS_TL(buf_, abl_, slot_, tile_) do { } while (0)
+#endif
+
+// CUs of the current device (persistent grids); cached per device id.
+static inline int ds_cu_count() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int n = cached[dev & 63].load(std::memory_order_relaxed);
+    if (n <= 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev & 63].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
 static inline bool ds_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // SiLU with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division sequence (~10 VALU instructions):

@@ -457,6 +457,9 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
             if (a->wgt_shift) return DS_E_ARG;
             p.ldb = p.K / 2;
             p.part = nullptr; p.part_cap = 0; p.splits = 1;
+#ifdef DS_TIMELINE
+            if ((p.t_ablate & 0x8000) && a->workspace) p.part = a->workspace;         // diagnostics build only: phase stamps (ds_common.h)
+#endif
             if (a->in_f16) {            // fp16 activations: both operands by LDS-DMA
                 p.out_f16 = a->out_f16 ? 1 : 0; p.res_f16 = a->res_f16 ? 1 : 0;
                 if (!gemm_f16dma_applicable(p)) return DS_E_SHAPE;

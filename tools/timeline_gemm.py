@@ -1,0 +1,87 @@
+#!/usr/bin/env python
+"""Phase timeline of one launch of the fp16-activation GEMM (gemm_f16dma_kernel), from s_memtime stamps written by the 'timeline' build of the
+library (csrc/ds_common.h: DS_TIMELINE; `python -c "from diff_sampler_amd import build; build.build_libs(('timeline',))"`): per workgroup
+  0 entry   1 first operands landed (prologue done)   2 main loop done   3 epilogue issued   4 stores acknowledged
+plus {HW_ID, XCC_ID}.  Prints the duration of each phase (median / p10 / p90 over workgroups), the launch's span, how many workgroups were in
+each phase at sample instants, and -- for CUs that ran two workgroups at once -- the offset between the partners' phases.
+
+    DS_LIB_PATH=diff_sampler_amd/csrc/libdsamd_timeline.so python tools/timeline_gemm.py --m 131072 --k 320 --n 960 [--geglu] [--res] [--nw 4] [--nb 3]"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diff_sampler_amd import _lib, ops  # noqa: E402
+from diff_sampler_amd._lib import ConvArgs  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--m', type=int, default=131072)
+ap.add_argument('--k', type=int, default=320)
+ap.add_argument('--n', type=int, default=960)
+ap.add_argument('--geglu', action='store_true')
+ap.add_argument('--res', action='store_true')
+ap.add_argument('--nw', type=int, default=0)
+ap.add_argument('--nb', type=int, default=0)
+ap.add_argument('--ablate', type=int, default=0)
+ap.add_argument('--cold', action='store_true', help='flush L2 / MALL before the stamped launch')
+args = ap.parse_args()
+lib = _lib.load()
+dev = 'cuda'
+M, K, N = args.m, args.k, args.n
+x16 = torch.randn(M, K, device=dev).to(torch.float16)
+w = torch.randn(N, K, 1, 1, device=dev) / K ** 0.5
+wp = ops.pack_linear_weight_f16(ops.pack_conv_weight(w))
+bias = torch.randn(N, device=dev)
+n_out = N // 2 if args.geglu else N
+out16 = torch.zeros(M, n_out, device=dev, dtype=torch.float16)
+res16 = torch.randn(M, N, device=dev).to(torch.float16) if args.res and not args.geglu else None
+ws = torch.zeros(32 << 20, device=dev)                                    # u64[workgroup][8][8]
+a = ConvArgs(x16.data_ptr(), None, K, 0, K, 0, M, 1, 1, 1, wp.data_ptr(), N, bias.data_ptr(), None, 0, 1, res16.data_ptr() if res16 is not None else None,
+             N, 1.0, 2 if args.geglu else 0, out16.data_ptr(), n_out)
+a.wgt_f16, a.in_f16, a.out_f16, a.res_f16 = 1, 1, 1, 1 if res16 is not None else 0
+a.tune.f16dma_nb, a.tune.f16dma_nw = args.nb, args.nw
+a.workspace, a.workspace_floats = ws.data_ptr(), ws.numel()
+st = _lib.stream_ptr()
+fn = lib.ds_conv2d_nhwc
+a.tune.ablate = args.ablate
+for _ in range(3):
+    assert fn(C.byref(a), st) == 0
+torch.cuda.synchronize()
+if args.cold:
+    flush = torch.empty(768 << 20, dtype=torch.uint8, device=dev)
+    flush.fill_(1)
+    torch.cuda.synchronize()
+a.tune.ablate = args.ablate | 0x8000
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+assert fn(C.byref(a), st) == 0
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1)
+raw = ws.cpu().numpy().view(np.uint64).reshape(-1, 8, 8)
+used = np.nonzero(raw[:, 0, 1])[0]
+if len(used) == 0:
+    sys.exit('no stamps: is DS_LIB_PATH the timeline build?')
+T = raw[used][:, 0, :].astype(np.int64)                                   # wave 0 of every TILE: slots 0 entry (first tile of a workgroup) / previous
+#                                                                           epilogue issued (later tiles), 1 operands landed, 2 main loop done, 3 epilogue issued
+hw = raw[used][:, 0, 7]
+hwid, xcc = (hw & 0xffffffff).astype(np.int64), (hw >> 32).astype(np.int64) & 0xf
+cu = (xcc << 16) | (((hwid >> 13) & 7) << 8) | (((hwid >> 12) & 1) << 7) | ((hwid >> 8) & 0xf)          # (xcc, se, sh, cu)
+# s_memtime is not one clock across the chip: only differences inside a workgroup are used.  Tick length: a persistent workgroup is busy for the
+# whole launch, so the largest per-CU sum of tile times (divided by the workgroups resident on a CU) ~ the launch's duration by events.
+whole = T[:, 3] - T[:, 0]
+per_cu = np.array([whole[cu == c].sum() for c in np.unique(cu)])
+wg_per_cu = 2 if (args.nw == 4 or (args.nw == 0 and K <= 2560 and N <= 1280)) else 1
+tick_us = ms * 1e3 / (np.median(per_cu) / wg_per_cu)
+print(f'# M={M} K={K} N={N}{" geglu" if args.geglu else ""}{" res" if res16 is not None else ""}: {len(used)} tiles on {len(per_cu)} CUs, launch {ms*1e3:.1f} us by events, '
+      f'~{1 / tick_us:.0f} ticks per us (assuming {wg_per_cu} resident workgroup(s) per CU busy for the whole launch)')
+names = ['entry / previous epilogue -> operands landed', 'main loop', 'epilogue (arithmetic + store issue)', 'whole tile']
+d = [T[:, 1] - T[:, 0], T[:, 2] - T[:, 1], T[:, 3] - T[:, 2], whole]
+for nm, v in zip(names, d):
+    print(f'{nm:48s} median {np.median(v):8.0f} ticks = {np.median(v) * tick_us:6.2f} us   p10 {np.percentile(v, 10):8.0f}   p90 {np.percentile(v, 90):8.0f}   '
+          f'sum per CU {v.sum() / len(per_cu) * tick_us:8.1f} us')
+print(f'# tiles by XCC: {np.bincount(xcc, minlength=8).tolist()}')
