@@ -70,19 +70,6 @@ __device__ __forceinline__ void ds_timeline_mark(float* buf, int abl, int slot, 
 #define DS_TL(buf_, abl_, slot_, tile_) do { } while (0)
 #endif
 
-// CUs of the current device (persistent grids); cached per device id.
-static inline int ds_cu_count() {
-    static std::atomic<int> cached[64];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    int n = cached[dev & 63].load(std::memory_order_relaxed);
-    if (n <= 0) {
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cached[dev & 63].store(n, std::memory_order_relaxed);
-    }
-    return n;
-}
-
 static inline bool ds_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // SiLU with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division sequence (~10 VALU instructions):

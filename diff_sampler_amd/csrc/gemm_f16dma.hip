@@ -28,21 +28,6 @@ __device__ __attribute__((aligned(128))) _Float16 g_zero_halfs_g[64];
 template <int NB, int NW>
 constexpr unsigned gemm16_smem() { return 2u * (NW * 4096u + NB * 8192u); }
 
-// PERSISTENT (round 6, session r10): the grid is one workgroup per CU slot (256 eight-wave or 512 four-wave workgroups) and every workgroup walks
-// tiles b = blockIdx.x, b + gridDim.x, ... of the launch's 1-D tile order (gridDim.x is a multiple of 8: a workgroup stays on the XCD whose L2
-// holds its tiles' operands, exactly as the one-tile-per-workgroup launch placed them).  Why -- tools/timeline_gemm.py (s_memtime stamps of the
-// phases, profiles/r6_gemm_timeline.txt): on the short-K projections of SD-1.5 a tile's life was  slot turnover (a workgroup ends -> the next one
-// enters: 0.9 us for 256 threads / 80 KB of LDS, 2.8 us for 512 threads / 128 KB)  +  prologue (first operands from HBM: 1.4 - 3.2 us)  +  main loop
-// (5 K tiles: 7 - 8 us)  +  epilogue (3.8 - 4.1 us): a quarter of it is spent before the first MFMA.  Here the NEXT tile's first two K tiles are
-// requested as soon as the main loop's last barrier has released the stage buffers -- they land under the epilogue (which stores straight from
-// the accumulators and touches no LDS) -- and there is no turnover.  The staged epilogue (fp32 rows) uses the stage buffers, so that
-// instantiation requests the next tile after its epilogue (behind a barrier): it saves the turnover only.
-// Which instantiations walk several tiles: those that store from the accumulators.  The staged-epilogue instantiations (fp32 rows: a handful of
-// layers per network) hold their 250 - 256 registers through the LDS transposes and spill 62 - 137 more with the tile loop around them
-// (tools/kernel_resources.py), and so does the 256-column gather tile: they keep one tile per workgroup.
-template <int NB, bool DIRECT, bool GATHER>
-constexpr bool gemm16_persistent() { return DIRECT && !(GATHER && NB == 4); }
-
 template <int NB, int NW, bool DIRECT, bool GATHER = false>
 __global__ void __launch_bounds__(NW * 64, 2) gemm_f16dma_kernel(const KParams p) {
     constexpr unsigned AB = NW * 4096u, WB = NB * 8192u;       // bytes of one A / W stage
@@ -53,43 +38,41 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_f16dma_kernel(const KParams p
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
+    int mt, nt;
+    if (!decode_tile(blockIdx.x, p.mtiles, p.ntiles, mt, nt, 0)) return;
+    const int m0 = mt * BM, n0 = p.n_begin + nt * (NB * 64);
     const _Float16* a0 = reinterpret_cast<const _Float16*>(p.a0);
     const _Float16* wgt = reinterpret_cast<const _Float16*>(p.b);
     const size_t ldbh = (size_t)p.ldb * 2;
     const int KT = p.K / 64;
-    const int ntotal = p.ntotal;                               // tiles of the launch's 1-D order (incl. the padding of its last group of 8); set by launch_nb
 
     // DMA: thread tid owns 16-B unit j * NT + tid of round j: row j * (NT / 8) + (tid >> 3), LDS chunk slot tid & 7 = source chunk ^ ((row >> 1) & 7)
     const int sw = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;
     const _Float16* asrc[4];
     int pixb[4];                         // GATHER: input pixel index of tap (0, 0) of the row's output pixel (may lie outside the image)
     unsigned vmask[4];                   // GATHER: bit t = tap t of this row reads inside the image (0 for rows >= M)
-    const _Float16* wsrc;
-    // operand addresses of tile (m0, n0)
-    auto setup = [&](int m0, int n0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = m0 + j * (NT / 8) + (tid >> 3);
-            if constexpr (GATHER) {
-                asrc[j] = nullptr; pixb[j] = 0; vmask[j] = 0u;
-                if (row < p.M) {
-                    const int img = row / p.HW, rem = row - img * p.HW;
-                    const int oy = rem / p.W, ox = rem - oy * p.W;
-                    const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;
-                    pixb[j] = (img * p.IH + iy0) * p.IW + ix0;
-                    unsigned m = 0u;
+    for (int j = 0; j < 4; ++j) {
+        const int row = m0 + j * (NT / 8) + (tid >> 3);
+        if constexpr (GATHER) {
+            asrc[j] = nullptr; pixb[j] = 0; vmask[j] = 0u;
+            if (row < p.M) {
+                const int img = row / p.HW, rem = row - img * p.HW;
+                const int oy = rem / p.W, ox = rem - oy * p.W;
+                const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;
+                pixb[j] = (img * p.IH + iy0) * p.IW + ix0;
+                unsigned m = 0u;
 #pragma unroll
-                    for (int t = 0; t < 9; ++t)
-                        if ((unsigned)(iy0 + t / 3) < (unsigned)p.IH && (unsigned)(ix0 + t % 3) < (unsigned)p.IW) m |= 1u << t;
-                    vmask[j] = m;
-                }
-            } else {
-                asrc[j] = row < p.M ? a0 + (size_t)row * p.lda0 + sw : nullptr;
+                for (int t = 0; t < 9; ++t)
+                    if ((unsigned)(iy0 + t / 3) < (unsigned)p.IH && (unsigned)(ix0 + t % 3) < (unsigned)p.IW) m |= 1u << t;
+                vmask[j] = m;
             }
+        } else {
+            asrc[j] = row < p.M ? a0 + (size_t)row * p.lda0 + sw : nullptr;
         }
-        wsrc = wgt + (size_t)(n0 + (tid >> 3)) * ldbh + sw;
-    };
-    const int abl = p.coef_lds;          // timing ablations (ds_conv_args.tune.ablate; results are WRONG when bits 0 / 2 are set): bit 0 = no DMA after
+    }
+    const _Float16* wsrc = wgt + (size_t)(n0 + (tid >> 3)) * ldbh + sw;
+    const int abl = p.coef_lds & 0x7fff; // timing ablations (ds_conv_args.tune.ablate; results are WRONG when bits 0 / 2 are set): bit 0 = no DMA after
                                          // the prologue, bit 2 = no epilogue
     auto dma = [&](int kt, int buf) {
         if ((abl & 1) && kt > 1) return;
@@ -114,12 +97,6 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_f16dma_kernel(const KParams p
             __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (size_t)i * (NT / 8) * ldbh + (size_t)kt * 64),
                                              (lptr_t)(lds + 2 * AB + buf * WB + (i * (NT / 8) + wave * 8) * 128), 16, 0, 0);
     };
-    // next valid tile at or after b (the 1-D order pads the last group of eight row tiles)
-    auto next_tile = [&](int b, int& mt, int& nt) -> int {
-        for (; b < ntotal; b += (int)gridDim.x)
-            if (decode_tile(b, p.mtiles, p.ntiles, mt, nt, 0)) return b;
-        return -1;
-    };
 
     const unsigned lds0 = lds_addr2(smem);
     const unsigned gsel = (unsigned)(lane >> 5);
@@ -131,6 +108,14 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_f16dma_kernel(const KParams p
     }
     const unsigned brow = (unsigned)(wc * (NB * 32) + (lane & 31));
     const unsigned bbase = lds0 + 2 * AB + brow * 128u + 16u * (((brow >> 1) & 7u) ^ gsel);
+
+    f32x16 accA[2][2], accB[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accA[i][j][r] = 0.f; accB[i][j][r] = 0.f; }
 
     struct Frag { f32x4 a0, a1, b0, b1, b2, b3; };
     auto frag_read = [&](Frag& f, unsigned va0, unsigned va1, unsigned vb) {
@@ -149,106 +134,69 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_f16dma_kernel(const KParams p
         if constexpr (NB == 4)
             asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f.a0), "+v"(f.a1), "+v"(f.b0), "+v"(f.b1), "+v"(f.b2), "+v"(f.b3) : "n"(N));
     };
+    // SWAPPED product (round 4): the weight fragment is the MFMA's first operand, so an accumulator block holds lane = row (pixel), registers =
+    // columns (channels) -- what epilogue_direct (igemm_common.h) stores without an LDS transpose
+#define DSG16_MM(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, b_), __builtin_bit_cast(h8, a_), acc_, 0, 0, 0)
+    auto mfma_group = [&](Frag& f) {
+        DSG16_MM(accA[0][0], f.a0, f.b0); DSG16_MM(accA[1][0], f.a1, f.b0);
+        if constexpr (NB > 1) { DSG16_MM(accA[0][1], f.a0, f.b1); DSG16_MM(accA[1][1], f.a1, f.b1); }
+        if constexpr (NB > 2) { DSG16_MM(accB[0][0], f.a0, f.b2); DSG16_MM(accB[1][0], f.a1, f.b2); }
+        if constexpr (NB > 3) { DSG16_MM(accB[0][1], f.a0, f.b3); DSG16_MM(accB[1][1], f.a1, f.b3); }
+    };
     constexpr int NR = 2 + NB;
 
-    int mt, nt;
-    int b = next_tile((int)blockIdx.x, mt, nt);
-    if (b < 0) return;
-    setup(mt * BM, p.n_begin + nt * (NB * 64));
-    DS_TL(p.part, p.coef_lds, 0, b);
+    DS_TL(p.part, p.coef_lds, 0, blockIdx.x);                  // (phase stamps: the 'timeline' diagnostics build only, csrc/ds_common.h)
     dma(0, 0);
     if (KT > 1) dma(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    DS_TL(p.part, p.coef_lds, 1, blockIdx.x);
+    Frag P, Q;
+    frag_read(P, abase[0], abase[1], bbase);
+    for (int kt = 0; kt < KT; ++kt) {
+        const unsigned ao = (unsigned)(kt & 1) * AB, wo = (unsigned)(kt & 1) * WB;
+        const unsigned a_0 = abase[0] + ao, a_1 = abase[1] + ao, vb = bbase + wo;
+        frag_read(Q, a_0 ^ 32u, a_1 ^ 32u, vb ^ 32u);
+        frag_wait(P, IC<NR>{});
+        DS2_FENCE(); mfma_group(P); DS2_FENCE();
+        frag_read(P, a_0 ^ 64u, a_1 ^ 64u, vb ^ 64u);
+        frag_wait(Q, IC<NR>{});
+        DS2_FENCE(); mfma_group(Q); DS2_FENCE();
+        frag_read(Q, a_0 ^ 96u, a_1 ^ 96u, vb ^ 96u);
+        frag_wait(P, IC<NR>{});
+        DS2_FENCE(); mfma_group(P); DS2_FENCE();
+        frag_wait(Q, IC<0>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // own DMAs of K tile kt + 1 landed
+        __builtin_amdgcn_s_barrier();                        // stage kt & 1 is free, K tile kt + 1 is in LDS
+        DS2_FENCE();
+        if (kt + 1 < KT) {
+            const unsigned no = (unsigned)((kt + 1) & 1);
+            frag_read(P, abase[0] + no * AB, abase[1] + no * AB, bbase + no * WB);
+        }
+        DS2_FENCE(); mfma_group(Q); DS2_FENCE();
+        if (kt + 2 < KT) dma(kt + 2, kt & 1);                // in the shadow of the last K step's MFMAs
+        DS2_FENCE();
+    }
+#undef DSG16_MM
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    DS_TL(p.part, p.coef_lds, 2, blockIdx.x);
 
-    while (true) {
-        // (mt, nt) pass through an empty asm at every tile boundary: the operand addresses are then RECOMPUTED here instead of being kept in ~12
-        // VGPRs across the epilogue, where the 128 accumulator registers of the 256-column tile leave no room for them (34 - 161 spilled otherwise)
-        asm volatile("" : "+s"(mt), "+s"(nt));
-        const int m0 = mt * BM, n0 = p.n_begin + nt * (NB * 64);
-        setup(m0, n0);
-        f32x16 accA[2][2], accB[2][2];
+    if (abl & 4) {                       // no epilogue: every accumulator block (and so every MFMA) is kept alive
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { accA[i][j][r] = 0.f; accB[i][j][r] = 0.f; }
-        // SWAPPED product (round 4): the weight fragment is the MFMA's first operand, so an accumulator block holds lane = row (pixel), registers =
-        // columns (channels) -- what epilogue_direct (igemm_common.h) stores without an LDS transpose
-#define DSG16_MM(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, b_), __builtin_bit_cast(h8, a_), acc_, 0, 0, 0)
-        auto mfma_group = [&](Frag& f) {
-            DSG16_MM(accA[0][0], f.a0, f.b0); DSG16_MM(accA[1][0], f.a1, f.b0);
-            if constexpr (NB > 1) { DSG16_MM(accA[0][1], f.a0, f.b1); DSG16_MM(accA[1][1], f.a1, f.b1); }
-            if constexpr (NB > 2) { DSG16_MM(accB[0][0], f.a0, f.b2); DSG16_MM(accB[1][0], f.a1, f.b2); }
-            if constexpr (NB > 3) { DSG16_MM(accB[0][1], f.a0, f.b3); DSG16_MM(accB[1][1], f.a1, f.b3); }
-        };
-
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        DS_TL(p.part, p.coef_lds, 1, b);
-        Frag P, Q;
-        frag_read(P, abase[0], abase[1], bbase);
-        for (int kt = 0; kt < KT; ++kt) {
-            const unsigned ao = (unsigned)(kt & 1) * AB, wo = (unsigned)(kt & 1) * WB;
-            const unsigned a_0 = abase[0] + ao, a_1 = abase[1] + ao, vb = bbase + wo;
-            frag_read(Q, a_0 ^ 32u, a_1 ^ 32u, vb ^ 32u);
-            frag_wait(P, IC<NR>{});
-            DS2_FENCE(); mfma_group(P); DS2_FENCE();
-            frag_read(P, a_0 ^ 64u, a_1 ^ 64u, vb ^ 64u);
-            frag_wait(Q, IC<NR>{});
-            DS2_FENCE(); mfma_group(Q); DS2_FENCE();
-            frag_read(Q, a_0 ^ 96u, a_1 ^ 96u, vb ^ 96u);
-            frag_wait(P, IC<NR>{});
-            DS2_FENCE(); mfma_group(P); DS2_FENCE();
-            frag_wait(Q, IC<0>{});
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // own DMAs of K tile kt + 1 landed
-            __builtin_amdgcn_s_barrier();                        // stage kt & 1 is free, K tile kt + 1 is in LDS
-            DS2_FENCE();
-            if (kt + 1 < KT) {
-                const unsigned no = (unsigned)((kt + 1) & 1);
-                frag_read(P, abase[0] + no * AB, abase[1] + no * AB, bbase + no * WB);
-            }
-            DS2_FENCE(); mfma_group(Q); DS2_FENCE();
-            if (kt + 2 < KT) dma(kt + 2, kt & 1);                // in the shadow of the last K step's MFMAs
-            DS2_FENCE();
-        }
-#undef DSG16_MM
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        DS_TL(p.part, p.coef_lds, 2, b);
-
-        // the last barrier of the K loop has released both stages (every wave's fragment reads were complete before it): the next tile's first
-        // two K tiles go out now and land under the epilogue
-        const int bcur = b;
-        int mtn = 0, ntn = 0;
-        if constexpr (gemm16_persistent<NB, DIRECT, GATHER>()) b = next_tile(b + (int)gridDim.x, mtn, ntn);
-        else b = -1;
-        if (DIRECT && b >= 0) {
-            setup(mtn * BM, p.n_begin + ntn * (NB * 64));
-            dma(0, 0);
-            if (KT > 1) dma(1, 1);
-        }
-
-        if (abl & 4) {                   // no epilogue: every accumulator block (and so every MFMA) is kept alive
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) { asm volatile("" :: "v"(accA[i][j])); asm volatile("" :: "v"(accB[i][j])); }
-        } else {
-            float* stage = smem + wave * 32 * EPI_LD;
-            const int wn0 = n0 + wc * (NB * 32);
-            if constexpr (DIRECT) epilogue_direct<false, NB, GATHER>(p, accA, accB, lane, m0 + wr * 64, wn0);      // GATHER layers carry GroupNorm column sums
-            else epilogue_pipe<0, false, (NB == 1 ? 32 : 64), (NB == 3 ? 32 : (NB == 4 ? 64 : 0)), true>(p, accA, accB, stage, lane, m0 + wr * 64, wn0, p.out);
-        }
-        DS_TL(p.part, p.coef_lds, 3, bcur);
-        if (b < 0) break;
-        if constexpr (!DIRECT) {
-            __syncthreads();             // the staged epilogue's transposes live in the stage buffers: every wave is done with them
-            setup(mtn * BM, p.n_begin + ntn * (NB * 64));
-            dma(0, 0);
-            if (KT > 1) dma(1, 1);
-        }
-        mt = mtn; nt = ntn;
-        DS_TL(p.part, p.coef_lds, 0, b);
+            for (int j = 0; j < 2; ++j) { asm volatile("" :: "v"(accA[i][j])); asm volatile("" :: "v"(accB[i][j])); }
+        return;
     }
+    float* stage = smem + wave * 32 * EPI_LD;
+    const int wn0 = n0 + wc * (NB * 32);
+    if constexpr (DIRECT) epilogue_direct<false, NB, GATHER>(p, accA, accB, lane, m0 + wr * 64, wn0);      // GATHER layers carry GroupNorm column sums
+    else epilogue_pipe<0, false, (NB == 1 ? 32 : 64), (NB == 3 ? 32 : (NB == 4 ? 64 : 0)), true>(p, accA, accB, stage, lane, m0 + wr * 64, wn0, p.out);
+#ifdef DS_TIMELINE
+    DS_TL(p.part, p.coef_lds, 3, blockIdx.x);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DS_TL(p.part, p.coef_lds, 4, blockIdx.x);
+#endif
 }
 
 template <int NB, int NW, bool GATHER = false>
@@ -261,23 +209,12 @@ int launch_nb(KParams p, int n_begin, int ntiles, hipStream_t stream) {
     int smem = (int)gemm16_smem<NB, NW>();
     const int epi = NW * 32 * EPI_LD * (int)sizeof(float);
     if (smem < epi) smem = epi;
-    // persistent grid: one workgroup per CU slot (launch_bounds: two waves per SIMD -> one eight-wave or two four-wave workgroups per CU, LDS permitting),
-    // rounded down to a multiple of 8 so that `b += gridDim.x` keeps a workgroup's tiles on its XCD; ds_conv_args.tune.ablate bit 13 = one tile per
-    // workgroup (the round-5 launch; A/B runs), bit 14 = a grid of eight workgroups (tests)
-    const unsigned total = grid_1d(p.mtiles, p.ntiles);
-    unsigned slots = (unsigned)ds_cu_count() * (NW == 4 && 2 * smem <= 160 * 1024 ? 2u : 1u);
-    slots -= slots % 8u;
-    if (p.t_ablate & 16384) slots = 8u;                        // tests: eight workgroups walk the whole launch (tests/test_hip_kernels.py)
-    const bool direct = epi_direct_ok(p, GATHER, NB);
-    const bool persist = direct ? gemm16_persistent<NB, true, GATHER>() : gemm16_persistent<NB, false, GATHER>();
-    unsigned grid = (p.t_ablate & 8192) || !persist || total < slots || slots == 0 ? total : slots;
-    p.ntotal = (int)total;
-    if (direct) {
+    if (epi_direct_ok(p, GATHER, NB)) {
         DS_ENSURE_DYN_LDS((&gemm_f16dma_kernel<NB, NW, true, GATHER>), 160 * 1024);
-        hipLaunchKernelGGL((gemm_f16dma_kernel<NB, NW, true, GATHER>), dim3(grid, 1), dim3(NW * 64), smem, stream, p);
+        hipLaunchKernelGGL((gemm_f16dma_kernel<NB, NW, true, GATHER>), dim3(grid_1d(p.mtiles, p.ntiles), 1), dim3(NW * 64), smem, stream, p);
     } else {
         DS_ENSURE_DYN_LDS((&gemm_f16dma_kernel<NB, NW, false, GATHER>), 160 * 1024);
-        hipLaunchKernelGGL((gemm_f16dma_kernel<NB, NW, false, GATHER>), dim3(grid, 1), dim3(NW * 64), smem, stream, p);
+        hipLaunchKernelGGL((gemm_f16dma_kernel<NB, NW, false, GATHER>), dim3(grid_1d(p.mtiles, p.ntiles), 1), dim3(NW * 64), smem, stream, p);
     }
     DS_CHECK_LAUNCH();
     return DS_OK;

@@ -20,7 +20,6 @@ struct KParams {
     const float* b; int ldb; long long b_bs, b_hs; int nrows_b;   // rows of B that may be read
     int M, N, K;
     int mtiles, ntiles;
-    int ntotal;                                                    // persistent kernels: tiles of the launch's 1-D order (grid_1d), walked gridDim.x apart
     int n_begin;                   // first output column of this launch (halo kernel: the 64-column tail launch)
     // halo kernel geometry: a 128-pixel M tile = nimg image slots x TH rows x W columns
     int TH, nimg, HP, WP, NP;      // HP = TH + 2, WP = W + 2, NP = nimg * HP * WP halo pixels

@@ -1583,67 +1583,6 @@ def test_f16_activation_kernels_with_fp16_residual_and_output_rows(kind, nw):
     assert lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr()) != 0
 
 
-PERSISTENT_GEMM_CASES = [
-    # rows, k, cout, forced nb, wave count, epilogue
-    (5000, 320, 960, 0, 4, 'plain'),                         # ragged rows: 40 row tiles x 5 column tiles on 8 workgroups
-    (4096, 640, 640, 0, 8, 'res'),
-    (4096, 320, 2560, 4, 8, 'geglu'),                        # the SD-1.5 GEGLU projection's tile shape
-    (3000, 320, 2560, 2, 4, 'geglu'),
-    (2048, 64, 64, 1, 4, 'res'),                             # one K tile: the prefetch is the whole operand
-    (4096, 1280, 320, 0, 4, 'res'),
-]
-
-
-@pytest.mark.parametrize('case', PERSISTENT_GEMM_CASES)
-def test_gemm_f16_persistent_tile_walk_equals_one_tile_per_workgroup(case):
-    """Round 6: gemm_f16dma_kernel is persistent -- a workgroup walks tiles blockIdx.x, + gridDim.x, ... and requests the next tile's first
-    operands before its epilogue (csrc/gemm_f16dma.hip).  The full-size networks walk 2 - 20 tiles per workgroup; here a grid of EIGHT
-    workgroups (ds_conv_tune.ablate bit 14) walks the whole launch, against one tile per workgroup (bit 13): equal bits, and the usual
-    distance to the CPU reference (fp16 operands, fp64 sums).  Three repeats: a missing wait between a tile's stores / fragment reads and
-    the next tile's LDS-DMA would not fail the same way twice."""
-    import ctypes as C
-    from diff_sampler_amd import _lib, ops
-    rows, k, cout, nb, nw, mode = case
-    lib = _lib.load()
-    dev = 'cuda'
-    g = torch.Generator().manual_seed(rows + k + cout + nb)
-    x = torch.randn(rows, k, generator=g).to(torch.float16)
-    wt = torch.randn(cout, k, generator=g) / k ** 0.5
-    bias = torch.randn(cout, generator=g)
-    res16 = torch.randn(rows, cout, generator=g).to(torch.float16)
-    y = x.double() @ wt.to(torch.float16).double().t() + bias.double()
-    geglu = mode == 'geglu'
-    if geglu:
-        inner = cout // 2
-        val = torch.arange(inner).reshape(-1, 32)
-        perm = torch.stack([val, val + inner], 1).reshape(-1)
-        wp = ops.pack_linear_weight_f16(ops.pack_linear_weight(wt[perm].to(dev)))
-        bp = bias[perm].contiguous()
-        ref = (y[:, :inner] * F.gelu(y[:, inner:])).float()
-        ocols = inner
-    else:
-        wp = ops.pack_linear_weight_f16(ops.pack_linear_weight(wt.to(dev)))
-        bp = bias
-        ref = ((y + res16.double()) * 0.7071).float() if mode == 'res' else y.float()
-        ocols = cout
-    xd, bd_, rd = x.to(dev), bp.to(dev), res16.to(dev)
-    outs = []
-    for ablate in (8192, 16384, 16384, 16384, 0):
-        out = torch.full((rows, ocols), float('nan'), dtype=torch.float16, device=dev)
-        a = _lib.ConvArgs(xd.data_ptr(), None, k, 0, k, 0, rows, 1, 1, 1, wp.data_ptr(), cout, bd_.data_ptr(), None, 0, 1,
-                          rd.data_ptr() if mode == 'res' else None, cout, 0.7071 if mode == 'res' else 1.0, 2 if geglu else 0, out.data_ptr(), ocols)
-        a.wgt_f16, a.in_f16, a.out_f16, a.res_f16 = 1, 1, 1, int(mode == 'res')
-        a.tune.f16dma_nb, a.tune.f16dma_nw, a.tune.ablate = nb, nw, ablate
-        rc = lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr())
-        torch.cuda.synchronize()
-        assert rc == 0, lib.ds_error_string(rc)
-        outs.append(out.cpu())
-    assert torch.isfinite(outs[0].float()).all()
-    assert _rel(outs[0].float(), ref.to(torch.float16).float()) < 1.5e-3
-    for o in outs[1:]:
-        assert torch.equal(o, outs[0])
-
-
 DIRECT_EPILOGUE_CASES = [
     # kind, wave count (GEMM), shape, forced nb, epilogue
     ('gemm', 4, (1000, 320, 320), 0, 'bias'),                # ragged rows

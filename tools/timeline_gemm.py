@@ -66,22 +66,32 @@ raw = ws.cpu().numpy().view(np.uint64).reshape(-1, 8, 8)
 used = np.nonzero(raw[:, 0, 1])[0]
 if len(used) == 0:
     sys.exit('no stamps: is DS_LIB_PATH the timeline build?')
-T = raw[used][:, 0, :].astype(np.int64)                                   # wave 0 of every TILE: slots 0 entry (first tile of a workgroup) / previous
-#                                                                           epilogue issued (later tiles), 1 operands landed, 2 main loop done, 3 epilogue issued
+T = raw[used][:, 0, :].astype(np.int64)                                   # wave 0 of every workgroup (= tile)
 hw = raw[used][:, 0, 7]
 hwid, xcc = (hw & 0xffffffff).astype(np.int64), (hw >> 32).astype(np.int64) & 0xf
 cu = (xcc << 16) | (((hwid >> 13) & 7) << 8) | (((hwid >> 12) & 1) << 7) | ((hwid >> 8) & 0xf)          # (xcc, se, sh, cu)
-# s_memtime is not one clock across the chip: only differences inside a workgroup are used.  Tick length: a persistent workgroup is busy for the
-# whole launch, so the largest per-CU sum of tile times (divided by the workgroups resident on a CU) ~ the launch's duration by events.
-whole = T[:, 3] - T[:, 0]
-per_cu = np.array([whole[cu == c].sum() for c in np.unique(cu)])
-wg_per_cu = 2 if (args.nw == 4 or (args.nw == 0 and K <= 2560 and N <= 1280)) else 1
-tick_us = ms * 1e3 / (np.median(per_cu) / wg_per_cu)
-print(f'# M={M} K={K} N={N}{" geglu" if args.geglu else ""}{" res" if res16 is not None else ""}: {len(used)} tiles on {len(per_cu)} CUs, launch {ms*1e3:.1f} us by events, '
-      f'~{1 / tick_us:.0f} ticks per us (assuming {wg_per_cu} resident workgroup(s) per CU busy for the whole launch)')
-names = ['entry / previous epilogue -> operands landed', 'main loop', 'epilogue (arithmetic + store issue)', 'whole tile']
-d = [T[:, 1] - T[:, 0], T[:, 2] - T[:, 1], T[:, 3] - T[:, 2], whole]
+# s_memtime counts shader cycles and is NOT one clock across the chip: only differences on one CU are used
+print(f'# M={M} K={K} N={N}{" geglu" if args.geglu else ""}{" res" if res16 is not None else ""}: {len(used)} workgroups on {len(np.unique(cu))} CUs, '
+      f'launch {ms*1e3:.1f} us by events; durations in shader cycles (s_memtime)')
+names = ['prologue (entry -> first operands landed)', 'main loop', 'epilogue (arithmetic + store issue)', 'store drain (vmcnt 0)', 'whole workgroup']
+d = [T[:, 1] - T[:, 0], T[:, 2] - T[:, 1], T[:, 3] - T[:, 2], T[:, 4] - T[:, 3], T[:, 4] - T[:, 0]]
 for nm, v in zip(names, d):
-    print(f'{nm:48s} median {np.median(v):8.0f} ticks = {np.median(v) * tick_us:6.2f} us   p10 {np.percentile(v, 10):8.0f}   p90 {np.percentile(v, 90):8.0f}   '
-          f'sum per CU {v.sum() / len(per_cu) * tick_us:8.1f} us')
-print(f'# tiles by XCC: {np.bincount(xcc, minlength=8).tolist()}')
+    print(f'{nm:45s} median {np.median(v):8.0f}   p10 {np.percentile(v, 10):8.0f}   p90 {np.percentile(v, 90):8.0f}   sum per CU {v.sum() / len(np.unique(cu)):10.0f}')
+gaps, partner = [], []
+for c in np.unique(cu):
+    idx = np.nonzero(cu == c)[0]
+    order = idx[np.argsort(T[idx, 0])]
+    ends = []
+    for i in order:
+        s_, e_ = T[i, 0], T[i, 4]
+        live = [x for x in ends if x[1] > s_]
+        if live:                                                          # a partner is resident: where is it in its own timeline?
+            partner.append(int(np.searchsorted(T[live[-1][0], :5], s_, side='right')) - 1)
+        prev = [x[1] for x in ends if x[1] <= s_]
+        if prev:
+            gaps.append(s_ - max(prev))
+        ends.append((i, e_))
+if gaps:
+    print(f'slot turnover (a workgroup ends -> the next one on that CU enters): median {np.median(gaps):.0f} cycles   p90 {np.percentile(gaps, 90):.0f}')
+if partner:
+    print('when a workgroup enters, its resident partner is in [prologue, main, epilogue, drain, done]:', np.bincount(np.array(partner), minlength=5).tolist())
