@@ -290,6 +290,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
     const unsigned halo0 = lds0 + D * WB;
 
     // ---- prologue: halo of slab 0, the part of slab 1's halo that is due (see the tap), weights of taps 0 and 1 -------------------
+    DS_TL(p.splits > 1 ? nullptr : p.part, abl, 0, blockIdx.x);        // (phase stamps: the 'timeline' diagnostics build only, csrc/ds_common.h)
     static_for<NDMA>([&](auto jc) { halo_dma(cb, cb & 1, jc); });
     if (cb < nchunks) coef_dma(cb, cb & 1);
     if (cb + 1 < NCH) {
@@ -313,6 +314,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
+    DS_TL(p.splits > 1 ? nullptr : p.part, abl, 1, blockIdx.x);
     Frag P_, Q_;
     {
         const unsigned ctr = cb < nchunks ? 0u : 4u;           // first tap: (0, 0) of a 3x3 slab, or the centre tap of a 1x1 slab
@@ -424,6 +426,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
     for (; chunk < NCH; ++chunk) tap(IC<9>{}, chunk);
 #undef DSD_MM
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (no fragment read is pending after the last tap; cheap insurance)
+    DS_TL(p.splits > 1 ? nullptr : p.part, abl, 2, blockIdx.x);
 
     if (abl & 4) {                                             // no epilogue: every accumulator block (and so every MFMA) is kept alive
 #pragma unroll
@@ -448,6 +451,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
     // kernel on the vector path (vec_ok, cout a multiple of the tile width)
     if constexpr (DIRECT) epilogue_direct<false, NB, true>(p, accA, accB, lane, m0 + wr * 64, wn0);
     else epilogue_pipe<0, true, (NB == 1 ? 32 : 64), (NB == 3 ? 32 : (NB == 4 ? 64 : 0)), true>(p, accA, accB, stage, lane, m0 + wr * 64, wn0, p.out);
+#ifdef DS_TIMELINE
+    DS_TL(p.part, abl, 3, blockIdx.x);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DS_TL(p.part, abl, 4, blockIdx.x);
+#endif
 }
 
 // p.t_ablate (ds_conv_args.tune.ablate), benchmarks only: bit 0 = no weight DMA after the prologue, 1 = no halo DMA after slab 0,

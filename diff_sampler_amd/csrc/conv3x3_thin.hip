@@ -46,7 +46,10 @@ __global__ void __launch_bounds__(256, 4) conv3x3_thin_kernel(const KParams p, c
         wl[i] = f32x4{b[0], b[(size_t)p.ldb], b[2 * (size_t)p.ldb], b[3 * (size_t)p.ldb]};
     }
     __syncthreads();
-    const int mb = blockIdx.x * 256 + wave * 64;                  // this wave's 64 pixels: one image (HW % 64 == 0)
+    // a wave takes R rounds of eight pixels, R = 8 unless the layer is small (round 6: launch_conv3x3_thin, p.mtiles): its pixels lie in one image
+    // (HW % 64 == 0).  The arithmetic of a pixel does not depend on R.
+    const int R = p.mtiles;
+    const int mb = blockIdx.x * (32 * R) + wave * (8 * R);
     if (mb >= p.M) return;
     const int img = mb / p.HW;
     const int g = lane >> 3, j = lane & 7;
@@ -58,7 +61,7 @@ __global__ void __launch_bounds__(256, 4) conv3x3_thin_kernel(const KParams p, c
         for (int n = 0; n < 4; ++n) bias[n] = n < p.N ? p.colbias[n] : 0.f;
     }
 #pragma unroll 1
-    for (int round = 0; round < 8; ++round) {
+    for (int round = 0; round < R; ++round) {
         const int m = mb + round * 8 + g;
         const int pim = m - img * p.HW;
         const int y = pim / p.W, x = pim - y * p.W;
@@ -157,7 +160,12 @@ static bool thin_update_on(const KParams& p) { return p.upd && (p.upd->x_out || 
 
 int launch_conv3x3_thin(KParams& p, hipStream_t stream) {
     const int smem = 9 * p.c0 * 16;
-    const unsigned blocks = (unsigned)((p.M + 255) / 256);
+    // pixels per workgroup: 256 (four waves x eight rounds of eight), fewer rounds while the launch would leave CUs without a workgroup -- at 8
+    // images a 32x32 head was 32 workgroups of 140 us each (round 6, tools/time_plan_ops.py: 146 us of a 6.2 ms evaluation; 280 us at 256 images)
+    int rounds = 8;
+    while (rounds > 1 && (p.M + 32 * rounds - 1) / (32 * rounds) < 512) rounds >>= 1;
+    p.mtiles = rounds;
+    const unsigned blocks = (unsigned)((p.M + 32 * rounds - 1) / (32 * rounds));
     const bool upd = thin_update_on(p);
     ds_update_args u{};
     if (upd) {

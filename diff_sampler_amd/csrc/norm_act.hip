@@ -646,6 +646,19 @@ __global__ void __launch_bounds__(256) gn_from_partials_kernel(const ds_gn_final
     const int nrb = f.hw >> 6;
     const int cb0 = g0 * cpg, cb1 = g1 * cpg;
     const int cl = tid & 63, rl = tid >> 6;
+    // The affine operands of this thread's FIRST channel are requested before the sums (round 6): the kernel is two dependent memory round trips
+    // long (partial sums, then gamma / beta / scale / shift) and nothing else; the second one now overlaps the first.  Same values, same arithmetic.
+    const int c_first = cb0 + tid;
+    float pf_gm = 1.f, pf_bt = 0.f, pf_sc = 0.f, pf_sh = 0.f;
+    if (f.coefs && c_first < cb1) {
+        if (f.gamma) pf_gm = f.gamma[c_first];
+        if (f.beta) pf_bt = f.beta[c_first];
+        if (f.scale) {
+            const size_t row = (f.ss_rows == 1) ? 0 : (size_t)n;
+            pf_sc = f.scale[row * f.ss_ld + c_first];
+            pf_sh = f.shift[row * f.ss_ld + c_first];
+        }
+    }
     for (int c = cb0 + cl; c < cb1; c += 64) {
         const bool first = c < f.c0;
         const float* sp = first ? f.stats0 : f.stats1;
@@ -672,13 +685,18 @@ __global__ void __launch_bounds__(256) gn_from_partials_kernel(const ds_gn_final
         for (int c = cb0 + tid; c < cb1; c += blockDim.x) {
             const int g = c / cpg - g0;
             const float m = (float)s_sum[g], r = (float)s_sq[g];
-            const float gm = f.gamma ? f.gamma[c] : 1.f;
-            const float bt = f.beta ? f.beta[c] : 0.f;
-            float sc1 = 1.f, sh = 0.f;
-            if (f.scale) {
-                const size_t row = (f.ss_rows == 1) ? 0 : (size_t)n;
-                sc1 = f.scale[row * f.ss_ld + c] + 1.f;
-                sh = f.shift[row * f.ss_ld + c];
+            float gm, bt, sc1 = 1.f, sh = 0.f;
+            if (c == c_first) {
+                gm = pf_gm; bt = pf_bt;
+                if (f.scale) { sc1 = pf_sc + 1.f; sh = pf_sh; }
+            } else {
+                gm = f.gamma ? f.gamma[c] : 1.f;
+                bt = f.beta ? f.beta[c] : 0.f;
+                if (f.scale) {
+                    const size_t row = (f.ss_rows == 1) ? 0 : (size_t)n;
+                    sc1 = f.scale[row * f.ss_ld + c] + 1.f;
+                    sh = f.shift[row * f.ss_ld + c];
+                }
             }
             float A_, B_;
             gn_coefs(r, gm, bt, sc1, sh, A_, B_);

@@ -28,23 +28,46 @@ ap.add_argument('--nw', type=int, default=0)
 ap.add_argument('--nb', type=int, default=0)
 ap.add_argument('--ablate', type=int, default=0)
 ap.add_argument('--cold', action='store_true', help='flush L2 / MALL before the stamped launch')
+ap.add_argument('--conv', type=int, nargs=4, metavar=('IMAGES', 'SIDE', 'CIN', 'COUT'), help='a 3x3 convolution on fp16 rows (conv3x3_f16dma_kernel) instead of the GEMM')
+ap.add_argument('--stats', action='store_true', help='--conv: GroupNorm column sums in the epilogue')
+ap.add_argument('--silu', action='store_true')
 args = ap.parse_args()
 lib = _lib.load()
 dev = 'cuda'
-M, K, N = args.m, args.k, args.n
-x16 = torch.randn(M, K, device=dev).to(torch.float16)
-w = torch.randn(N, K, 1, 1, device=dev) / K ** 0.5
-wp = ops.pack_linear_weight_f16(ops.pack_conv_weight(w))
-bias = torch.randn(N, device=dev)
-n_out = N // 2 if args.geglu else N
-out16 = torch.zeros(M, n_out, device=dev, dtype=torch.float16)
-res16 = torch.randn(M, N, device=dev).to(torch.float16) if args.res and not args.geglu else None
-ws = torch.zeros(32 << 20, device=dev)                                    # u64[workgroup][8][8]
-a = ConvArgs(x16.data_ptr(), None, K, 0, K, 0, M, 1, 1, 1, wp.data_ptr(), N, bias.data_ptr(), None, 0, 1, res16.data_ptr() if res16 is not None else None,
-             N, 1.0, 2 if args.geglu else 0, out16.data_ptr(), n_out)
-a.wgt_f16, a.in_f16, a.out_f16, a.res_f16 = 1, 1, 1, 1 if res16 is not None else 0
-a.tune.f16dma_nb, a.tune.f16dma_nw = args.nb, args.nw
-a.workspace, a.workspace_floats = ws.data_ptr(), ws.numel()
+if args.conv:
+    nimg, side, cin, cout = args.conv
+    M, K, N = nimg * side * side, 9 * cin, cout
+    x16 = torch.randn(M, cin, device=dev).to(torch.float16)
+    wp = ops.pack_conv_weight_f16(torch.randn(cout, cin, 3, 3, device=dev) / (9 * cin) ** 0.5)
+    bias = torch.randn(cout, device=dev)
+    out16 = torch.zeros(M, cout, device=dev, dtype=torch.float16)
+    res16 = torch.randn(M, cout, device=dev).to(torch.float16) if args.res else None
+    stats = torch.zeros((M // 64) * 2 * cout, device=dev) if args.stats else None
+    ws = torch.zeros(32 << 20, device=dev)
+    a = ConvArgs(x16.data_ptr(), None, cin, 0, cin, 0, nimg, side, side, 9, wp.data_ptr(), cout, bias.data_ptr(), None, 0, 1,
+                 res16.data_ptr() if res16 is not None else None, cout, 0.70710678 if res16 is not None else 1.0, 1 if args.silu else 0, out16.data_ptr(), cout)
+    a.wgt_f16, a.in_f16, a.out_f16, a.res_f16 = 1, 1, 1, 1 if res16 is not None else 0
+    if stats is not None:
+        a.stats_out = stats.data_ptr()
+    a.tune.f16dma_nb = args.nb
+    a.tune.splits = 1
+    a.workspace, a.workspace_floats = ws.data_ptr(), ws.numel()
+    n_out = cout
+else:
+    M, K, N = args.m, args.k, args.n
+    x16 = torch.randn(M, K, device=dev).to(torch.float16)
+    w = torch.randn(N, K, 1, 1, device=dev) / K ** 0.5
+    wp = ops.pack_linear_weight_f16(ops.pack_conv_weight(w))
+    bias = torch.randn(N, device=dev)
+    n_out = N // 2 if args.geglu else N
+    out16 = torch.zeros(M, n_out, device=dev, dtype=torch.float16)
+    res16 = torch.randn(M, N, device=dev).to(torch.float16) if args.res and not args.geglu else None
+    ws = torch.zeros(32 << 20, device=dev)                                    # u64[workgroup][8][8]
+    a = ConvArgs(x16.data_ptr(), None, K, 0, K, 0, M, 1, 1, 1, wp.data_ptr(), N, bias.data_ptr(), None, 0, 1, res16.data_ptr() if res16 is not None else None,
+                 N, 1.0, 2 if args.geglu else 0, out16.data_ptr(), n_out)
+    a.wgt_f16, a.in_f16, a.out_f16, a.res_f16 = 1, 1, 1, 1 if res16 is not None else 0
+    a.tune.f16dma_nb, a.tune.f16dma_nw = args.nb, args.nw
+    a.workspace, a.workspace_floats = ws.data_ptr(), ws.numel()
 st = _lib.stream_ptr()
 fn = lib.ds_conv2d_nhwc
 a.tune.ablate = args.ablate
@@ -71,7 +94,7 @@ hw = raw[used][:, 0, 7]
 hwid, xcc = (hw & 0xffffffff).astype(np.int64), (hw >> 32).astype(np.int64) & 0xf
 cu = (xcc << 16) | (((hwid >> 13) & 7) << 8) | (((hwid >> 12) & 1) << 7) | ((hwid >> 8) & 0xf)          # (xcc, se, sh, cu)
 # s_memtime counts shader cycles and is NOT one clock across the chip: only differences on one CU are used
-print(f'# M={M} K={K} N={N}{" geglu" if args.geglu else ""}{" res" if res16 is not None else ""}: {len(used)} workgroups on {len(np.unique(cu))} CUs, '
+print(f'# {"conv3x3 " + "x".join(map(str, args.conv)) + " " if args.conv else ""}M={M} K={K} N={N}{" geglu" if args.geglu else ""}{" res" if res16 is not None else ""}: {len(used)} workgroups on {len(np.unique(cu))} CUs, '
       f'launch {ms*1e3:.1f} us by events; durations in shader cycles (s_memtime)')
 names = ['prologue (entry -> first operands landed)', 'main loop', 'epilogue (arithmetic + store issue)', 'store drain (vmcnt 0)', 'whole workgroup']
 d = [T[:, 1] - T[:, 0], T[:, 2] - T[:, 1], T[:, 3] - T[:, 2], T[:, 4] - T[:, 3], T[:, 4] - T[:, 0]]
