@@ -85,6 +85,7 @@ def source_hashes():
 VARIANTS = {'stress_a': ['-DDS_RACE_STRESS=0x21'], 'stress_b': ['-DDS_RACE_STRESS=0xDE'],
             'stress_g5': ['-DDS_RACE_STRESS=0x21', '-DDS_TEST_DROP_G5_BARRIER=1'],
             'timeline': ['-DDS_TIMELINE=1']}        # diagnostics (tools/timeline_gemm.py): phase stamps per workgroup, never what the engines run
+TEST_VARIANTS = ('stress_a', 'stress_b', 'stress_g5')      # what __graft_entry__.build() compiles next to the product ('timeline' is built on demand by its tool)
 VARIANT_BASE = {'stress_g5': ('stress_a', ('conv3x3_f16dma.hip',))}        # tag -> (variant whose objects it shares, the translation units it compiles itself)
 
 

@@ -323,6 +323,10 @@ THIN_CASES = [
     (3, 8, 8, 64, 1, 1, False, False),           # one output, 8x8 images (a wave = one image), no bias
     (2, 16, 32, 96, 2, 2, True, False),          # non-square
     (5, 16, 16, 32, 4, 0, True, True),           # one 32-channel step, five images (M = 1 280: the last workgroup is ragged)
+    # rounds per wave (round 6: small launches take fewer than eight, launch_conv3x3_thin): the cases above all run one round
+    (130, 32, 32, 32, 3, 2, True, True),         # M = 133 120: eight rounds, 520 workgroups
+    (40, 32, 32, 32, 4, 0, False, True),         # M = 40 960: two rounds
+    (70, 32, 32, 32, 3, 1, True, False),         # M = 71 680: four rounds
 ]
 
 
