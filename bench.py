@@ -79,13 +79,14 @@ KERNEL_NAMES = {0: 'igemm_f32_kernel<0> (generic gather conv / 1x1 / linear)', 1
                 2569: 'conv3x3_f16dmah_kernel (fp16 activations, 32-channel half slabs, four waves on 128-pixel x 64..256-channel tiles, two workgroups per CU)',
                 2567: 'gemm_f16dma_kernel (1x1 / Linear on fp16 activations, both operands by LDS-DMA, 256 x 64..256 tiles, v_mfma_f32_32x32x16_f16)',
                 2570: 'conv3x3_thin_kernel (network head: 3x3 with <= 4 output channels, VALU, fused GroupNorm + SiLU)',
-                2571: 'gemm_f16dma_kernel<GATHER> (3x3 stride-2 Downsample on fp16 activations: gathered A tile, both operands by LDS-DMA)'}
+                2571: 'gemm_f16dma_kernel<GATHER> (3x3 stride-2 Downsample on fp16 activations: gathered A tile, both operands by LDS-DMA)',
+                2573: 'gemv_rows_kernel (Linear on <= 4 rows: the embedding path, a wave per output column)'}
 # roofline peaks by kernel: the split mode issues three fp16 MFMAs per algorithmic multiply-add, so its ceiling in ALGORITHMIC FLOPs is a third
 KERNEL_PEAK = {2562: PEAK_FP16_MFMA_TFLOPS, 2563: PEAK_FP16_MFMA_TFLOPS / 3, 2564: PEAK_FP16_MFMA_TFLOPS, 2566: PEAK_FP16_MFMA_TFLOPS, 2572: PEAK_FP16_MFMA_TFLOPS, 2567: PEAK_FP16_MFMA_TFLOPS, 2569: PEAK_FP16_MFMA_TFLOPS,
                2571: PEAK_FP16_MFMA_TFLOPS}
 PMC_KEYS = {0: 'void igemm::igemm_f32_kernel<0>(igemm::KParams)', 1284: 'void igemm::conv3x3_halo_kernel<2, true, 4, 0, 1>(igemm::KParams)', 128: 'void igemm::conv3x3_halo_kernel<2, true, 2, 0, 2>(igemm::KParams)',
             256: 'void igemm::conv3x3_halo_kernel<4, true, 2, 0, 2>(igemm::KParams)', 2561: 'igemm::gemm_dma8_kernel(igemm::KParams)',
-            2562: None, 2563: None, 2564: None, 2566: None, 2572: None, 2567: None, 2568: None, 2569: None, 2570: None, 2571: None, 2565: 'void igemm::conv3x3_halo_kernel<4, true, 2, 160, 4>(igemm::KParams)'}
+            2562: None, 2563: None, 2564: None, 2566: None, 2572: None, 2567: None, 2568: None, 2569: None, 2570: None, 2571: None, 2573: None, 2565: 'void igemm::conv3x3_halo_kernel<4, true, 2, 160, 4>(igemm::KParams)'}
 
 
 def parse(argv=None):
@@ -289,7 +290,7 @@ def update_roofline_large_batch(dev, batch=16384, kind='ipndm'):
 
 KERNEL_TU = {0: 'gemm_conv.hip', 128: 'conv3x3_halo.hip', 1284: 'conv3x3_halo.hip', 256: 'conv3x3_halo.hip', 2565: 'conv3x3_halo.hip',
              2568: 'conv3x3_halo.hip', 2561: 'gemm_dma8.hip', 2570: 'conv3x3_thin.hip', 2563: 'conv3x3_halo2.hip', 2564: 'gemm_f16.hip',
-             2566: 'conv3x3_f16dma.hip', 2572: 'conv3x3_f16dma.hip', 2567: 'gemm_f16dma.hip', 2571: 'gemm_f16dma.hip', 'norm_act': 'norm_act.hip'}
+             2566: 'conv3x3_f16dma.hip', 2572: 'conv3x3_f16dma.hip', 2567: 'gemm_f16dma.hip', 2571: 'gemm_f16dma.hip', 2573: 'gemm_conv.hip', 'norm_act': 'norm_act.hip'}
 # kernel CLASSES of the fp16 engines cover several template instantiations (tile shapes): their PMC rows are matched by pattern and averaged
 # over all launches of the class, exactly as the HIP-event average of the class is taken
 PMC_PATTERNS = {2566: r'conv3x3_f16dma_kernel<\d+, \d+, (?:true|false), false>', 2572: r'conv3x3_f16dma_kernel<\d+, \d+, (?:true|false), true>', 2567: r'gemm_f16dma_kernel<\d+, \d+, (?:true|false), false>', 2571: r'gemm_f16dma_kernel<\d+, \d+, (?:true|false), true>',

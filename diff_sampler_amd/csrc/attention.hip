@@ -17,7 +17,14 @@
 
 namespace {
 
-template <int D>
+// DSPLIT (round 6; head sizes that are multiples of 128): the block is 32 queries and its four waves split the CHANNELS, not the queries --
+// wave w contracts channels [w D/4, (w + 1) D/4) of Q K^T, the four partial S^T blocks are summed through LDS in wave order (every wave ends up
+// with the same bits), every wave runs the softmax of the same 32 queries, and wave w accumulates and stores rows [w D/4, (w + 1) D/4) of O^T.
+// A quarter of the MFMAs per wave on four times the waves: for launches that leave most SIMDs without a wave -- the single 256-wide head of the
+// SongUNet nets at 8 images was 16 blocks = 64 waves, each 131 000 cycles of dependent fp32 MFMAs (92 us per launch, tools/time_plan_ops.py);
+// the launcher takes it while the query-split grid has fewer than 1 024 waves.  The scores are summed in a different order (four 64-channel
+// partial sums): results agree with the query-split kernel to fp32 rounding, not bit for bit -- ds_attn_args.variant 1 / 2 force either one.
+template <int D, bool DSPLIT = false>
 __global__ void __launch_bounds__(256) flash_attn_kernel(const ds_attn_args a) {
     // A head size that leaves 8 channels beyond the last full 32-row block of O^T (d = 40: SD-1.5's 64x64 stage) would spend
     // a whole MFMA block (16 MFMAs per key tile) on 8 useful rows; those VREM channels are accumulated by the vector ALU
@@ -28,7 +35,10 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(const ds_attn_args a) {
     constexpr int VLD = DB * 32 + 8;         // rows 4 apart land 32 banks apart (and room for the VREM channels)
     constexpr int NQ4 = D / 8;
     constexpr int D4 = D / 4;
-    constexpr bool PREFETCH = D <= 96;       // larger heads: the O^T / Q registers leave no room for a staged tile
+    static_assert(!DSPLIT || (D % 128 == 0), "channel split: four waves x a multiple of 32 channels");
+    constexpr int DBW = DSPLIT ? DB / 4 : DB;               // 32-row blocks of O^T per wave
+    constexpr int NQW = DSPLIT ? NQ4 / 4 : NQ4;             // Q fragments (8 channels each) per wave
+    constexpr bool PREFETCH = D <= 96 || DSPLIT;            // larger heads: the O^T / Q registers leave no room for a staged tile (the channel split has)
     // 32-key blocks per K/V tile: 64-key tiles halve the barriers and the per-tile softmax bookkeeping (max / rescale) where
     // the registers still allow two waves per SIMD (d = 64: 7.07 -> 6.85 ms on ImageNet-64; d = 40 with 64-key tiles needs
     // 288 registers, drops to one wave per SIMD and loses 13 %)
@@ -39,27 +49,29 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(const ds_attn_args a) {
     float* Ks = smem;
     float* Vs = smem + KT * KLD;
     float* Es = smem + KT * KLD + KT * VLD + 32;   // epilogue transposition patches, 32 x 33 floats per wave
+    float* Rs = Es + 4 * 32 * 33;                  // DSPLIT: the four waves' partial S^T blocks, [wave][register][lane]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hb = lane >> 5, l31 = lane & 31;
     const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = DSPLIT ? blockIdx.x * 32 : blockIdx.x * 128 + wave * 32;
+    const int d0 = DSPLIT ? wave * (D / 4) : 0;    // this wave's channels: the contraction range of Q K^T and the rows of O^T
     const bool active = q0 < a.sq;
     const float* qp = a.q + (size_t)b * a.q_bs + h * D;
     const float* kp = a.k + (size_t)b * a.k_bs + h * D;
     const float* vp = a.v + (size_t)b * a.v_bs + h * D;
 
     const float sc = a.scale * 1.4426950408889634f;
-    f32x4 qf[NQ4];
+    f32x4 qf[NQW];
     {
         const int qrow = min(q0 + l31, a.sq - 1);
-        const float* qr = qp + (size_t)qrow * a.ldq + 4 * hb;
+        const float* qr = qp + (size_t)qrow * a.ldq + 4 * hb + d0;
 #pragma unroll
-        for (int ks = 0; ks < NQ4; ++ks) qf[ks] = *reinterpret_cast<const f32x4*>(qr + 8 * ks) * sc;
+        for (int ks = 0; ks < NQW; ++ks) qf[ks] = *reinterpret_cast<const f32x4*>(qr + 8 * ks) * sc;
     }
-    f32x16 ot[DB];
+    f32x16 ot[DBW];
 #pragma unroll
-    for (int i = 0; i < DB; ++i)
+    for (int i = 0; i < DBW; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
     float m = -1e30f, l = 0.f;
@@ -95,7 +107,7 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(const ds_attn_args a) {
 
     const int ntiles = (a.skv + KT - 1) / KT;
     if (PREFETCH) gload(0);
-    const float* kfrag = Ks + l31 * KLD + 4 * hb;
+    const float* kfrag = Ks + l31 * KLD + 4 * hb + d0;
     for (int t = 0; t < ntiles; ++t) {
         if (!PREFETCH) gload(t);
         __syncthreads();                     // every wave is done with the previous tile
@@ -110,11 +122,23 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(const ds_attn_args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < NQ4; ++ks) {
+            for (int ks = 0; ks < NQW; ++ks) {
                 const f32x4 kv = *reinterpret_cast<const f32x4*>(kfrag + kb * 32 * KLD + 8 * ks);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) st[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[r], qf[ks][r], st[kb], 0, 0, 0);
             }
+        }
+        if constexpr (DSPLIT) {
+            // S^T = the four waves' partial blocks, summed in wave order by every wave (same lane, same register: same layout).  The buffer is
+            // rewritten in the next tile only behind that tile's barriers, which every wave reaches after these reads.
+            static_assert(!DSPLIT || KB == 1, "channel split: 32-key tiles");
+            DS_RACE_SKEW(wave);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Rs[(wave * 16 + r) * 64 + lane] = st[0][r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                st[0][r] = ((Rs[(0 * 16 + r) * 64 + lane] + Rs[(1 * 16 + r) * 64 + lane]) + Rs[(2 * 16 + r) * 64 + lane]) + Rs[(3 * 16 + r) * 64 + lane];
         }
         if (t == ntiles - 1) {
 #pragma unroll
@@ -139,7 +163,7 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(const ds_attn_args a) {
             for (int r = 0; r < 16; ++r) { st[kb][r] = __builtin_amdgcn_exp2f(st[kb][r] - mn); rs += st[kb][r]; }
         l = l * alpha + rs;
 #pragma unroll
-        for (int i = 0; i < DB; ++i) ot[i] *= alpha;
+        for (int i = 0; i < DBW; ++i) ot[i] *= alpha;
         if (VREM) {
 #pragma unroll
             for (int j = 0; j < VREM; ++j) oe[j] *= alpha;
@@ -156,10 +180,10 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(const ds_attn_args a) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < DB; ++i) {
+        for (int i = 0; i < DBW; ++i) {
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
-                const float* vcol = Vs + (kb * 32 + 4 * hb) * VLD + i * 32 + l31;
+                const float* vcol = Vs + (kb * 32 + 4 * hb) * VLD + d0 + i * 32 + l31;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float vv = vcol[((r & 3) + 8 * (r >> 2)) * VLD];
@@ -174,7 +198,7 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(const ds_attn_args a) {
     float* patch = Es + wave * (32 * 33);
     float* op = a.out + (size_t)b * a.o_bs + h * D;
 #pragma unroll
-    for (int i = 0; i < DB; ++i) {
+    for (int i = 0; i < DBW; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) patch[l31 * 33 + (r & 3) + 8 * (r >> 2) + 4 * hb] = ot[i][r] * inv;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -186,8 +210,8 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(const ds_attn_args a) {
             f32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = patch[q * 33 + c4 + j];
-            if (q0 + q < a.sq && i * 32 + c4 < D)
-                *reinterpret_cast<f32x4*>(op + (size_t)(q0 + q) * a.ldo + i * 32 + c4) = o;
+            if (q0 + q < a.sq && d0 + i * 32 + c4 < D)
+                *reinterpret_cast<f32x4*>(op + (size_t)(q0 + q) * a.ldo + d0 + i * 32 + c4) = o;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -212,6 +236,19 @@ int launch(const ds_attn_args* a, hipStream_t stream) {
     constexpr int DB = (D > 32 && (D % 32) == 8) ? D / 32 : (D + 31) / 32;
     constexpr int KT = (D <= 64 && !(D > 32 && (D % 32) == 8)) ? 64 : 32;
     constexpr int bytes = (KT * (D + 4) + KT * (DB * 32 + 8) + 32 + 4 * 32 * 33) * (int)sizeof(float);
+    if constexpr (D % 128 == 0) {
+        // the channel-split block (32 queries, four waves x D / 4 channels) while the query-split grid has fewer than 1 024 waves (one per SIMD);
+        // ds_attn_args.variant: 1 = query split, 2 = channel split (tests, A/B runs)
+        const long long waves = (long long)((a->sq + 127) / 128) * a->heads * a->batch * 4;
+        if (a->variant == 2 || (a->variant != 1 && waves < 1024)) {
+            constexpr int bytes_d = bytes + 4 * 16 * 64 * (int)sizeof(float);
+            DS_ENSURE_DYN_LDS((&flash_attn_kernel<D, true>), bytes_d);
+            dim3 grid((a->sq + 31) / 32, a->heads, a->batch);
+            hipLaunchKernelGGL((flash_attn_kernel<D, true>), grid, dim3(256), bytes_d, stream, *a);
+            DS_CHECK_LAUNCH();
+            return DS_OK;
+        }
+    }
     DS_ENSURE_DYN_LDS((&flash_attn_kernel<D>), bytes);
     dim3 grid((a->sq + 127) / 128, a->heads, a->batch);
     hipLaunchKernelGGL(flash_attn_kernel<D>, grid, dim3(256), bytes, stream, *a);

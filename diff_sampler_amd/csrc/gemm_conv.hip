@@ -383,6 +383,64 @@ static void set_tune(KParams& p, const ds_conv_args* a) {
     p.t_nb = a->tune.f16dma_nb; p.t_nw = a->tune.f16dma_nw; p.t_ablate = a->tune.ablate;
 }
 
+// ---- 1x1 / Linear on AT MOST FOUR rows (round 6): the embedding path.  The noise / label embedding MLP and the per-block affine projections
+// batched into one wide Linear see ONE row per sampler call when every image shares sigma (512 -> 8 448 on the CIFAR-10 net, 1 280 -> 20 160 on
+// SD-1.5): on the matrix kernel that is one useful row of a 128-row tile and a K loop of 16 - 40 serial tiles -- 24 - 94 us for 17 - 103 MB of
+// weights (tools/time_plan_ops.py, sessions r10a / r10j).  Here a wave owns an output column: 64 lanes x 16 bytes of its weight row per step,
+// the <= 4 input rows from cache, a cross-lane sum at the end -- the weights are read once at streaming rate.  fp32 products and sums (another
+// order than the matrix kernel's: fp32 rounding apart).  Kernel id 2573; ds_conv_tune.mode != 0 keeps the matrix kernels.
+namespace igemm {
+namespace {
+__global__ void __launch_bounds__(256) gemv_rows_kernel(const KParams p) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= p.N) return;
+    const float* w = p.b + (size_t)n * p.ldb;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = lane * 4; k < p.K; k += 256) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if (m < p.M) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(p.a0 + (size_t)m * p.lda0 + k);
+                acc[m] = __builtin_fmaf(xv[0], wv[0], __builtin_fmaf(xv[1], wv[1], __builtin_fmaf(xv[2], wv[2], __builtin_fmaf(xv[3], wv[3], acc[m]))));
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc[m] += __shfl_xor(acc[m], off);
+    }
+    if (lane == 0) {
+        const float bias = p.colbias ? p.colbias[n] : 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if (m < p.M) {
+                float v = (acc[m] + bias) * p.scale;
+                if (p.act == DS_ACT_SILU) v = ds_silu(v);
+                p.out[(size_t)m * p.ldo + n] = v;
+            }
+        }
+    }
+}
+}  // namespace
+
+bool gemv_rows_applicable(const KParams& p) {
+    if (p.taps != 1 || p.stride != 1 || p.M < 1 || p.M > 4 || p.c1 || p.ec0 || p.ec1 || p.norm) return false;
+    if (p.res || p.cbias || p.rowbias || p.stats || p.out_planar || p.out_f16 || p.splits > 1) return false;
+    if (p.act != DS_ACT_NONE && p.act != DS_ACT_SILU) return false;
+    if ((p.K & 3) || (p.lda0 & 3) || (p.ldb & 3) || !ds_aligned16(p.a0) || !ds_aligned16(p.b) || p.nrows_b < p.N) return false;
+    return p.N >= 64;                                          // (narrow outputs are latency either way)
+}
+
+int launch_gemv_rows(const KParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(gemv_rows_kernel, dim3((unsigned)((p.N + 3) / 4)), dim3(256), 0, stream, p);
+    DS_CHECK_LAUNCH();
+    return DS_OK;
+}
+}  // namespace igemm
+
 extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     (void)hipGetLastError();   // drop stale errors of unrelated runtime calls
     if (!a || !a->x0 || !a->wgt || !a->out) return DS_E_ARG;
@@ -503,6 +561,7 @@ extern "C" int ds_conv2d_nhwc(const ds_conv_args* a, void* stream) {
     if (!generic && stride == 1 && conv3x3_halo_supported(p)) return launch_conv3x3_halo(p, (hipStream_t)stream);
     if (p.norm) return DS_E_SHAPE;           // fused input normalisation exists only in the halo kernel
     if (!generic && p.t_mode != 6 && gemm_dma8_applicable(p)) return launch_gemm_dma8(p, (hipStream_t)stream);     // mode 6: no 8-wave DMA kernel
+    if (p.t_mode == 0 && p.t_variant == 0 && gemv_rows_applicable(p)) return launch_gemv_rows(p, (hipStream_t)stream);
     return launch<0>(p, 1, (hipStream_t)stream);
 }
 
@@ -529,7 +588,12 @@ extern "C" int ds_conv_kernel_id(const ds_conv_args* a) {
         KParams q = p; q.HW = p.HW; q.res = nullptr; q.cbias = nullptr; q.stats = nullptr; q.splits = 1; q.norm_act = a->norm_act;
         if (conv3x3_thin_applicable(q)) return 2570;
     }
-    if (a->taps != 9 || a->stride > 1) return (p.t_mode != 6 && gemm_dma8_applicable(p)) ? 2561 : 0;
+    if (a->taps != 9 || a->stride > 1) {
+        if (p.t_mode != 6 && gemm_dma8_applicable(p)) return 2561;
+        KParams q = p; q.a0 = a->x0; q.lda0 = a->ld0; q.b = a->wgt; q.ldb = p.K; q.scale = a->out_scale; q.out_f16 = 0; q.splits = 1;
+        q.rowbias = nullptr; q.stats = a->stats_out;
+        return (p.t_mode == 0 && p.t_variant == 0 && gemv_rows_applicable(q)) ? 2573 : 0;
+    }
     return conv3x3_halo_choice(p);
 }
 

@@ -215,9 +215,12 @@ def fill(dst, value, count=None):
     _lib.check(_lib.load().ds_fill(_p(dst), float(value), dst.numel() if count is None else count, _lib.stream_ptr()), 'ds_fill')
 
 
-def attention(q, k, v, out, *, batch, heads, sq, skv, d, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, scale, f16=False):
-    """f16=True: fp16 operands (ds_attention_f16, the reference's fp16 / autocast attention); fails where the head size is not covered."""
+def attention(q, k, v, out, *, batch, heads, sq, skv, d, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, scale, f16=False, variant=None):
+    """f16=True: fp16 operands (ds_attention_f16, the reference's fp16 / autocast attention); fails where the head size is not covered.
+    variant: ds_attn_args.variant (None = the library's choice)."""
     a = _lib.AttnArgs(_p(q), _p(k), _p(v), _p(out), ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, batch, heads, sq, skv, d, scale)
+    if variant is not None:
+        a.variant = int(variant)
     lib = _lib.load()
     if f16:
         _lib.check(lib.ds_attention_f16(C.byref(a), _lib.stream_ptr()), 'ds_attention_f16')

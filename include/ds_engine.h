@@ -198,8 +198,9 @@ DS_API int ds_conv2d_nhwc(const ds_conv_args* a, void* stream);
  * 256-pixel x 256-channel tiles (64 x 128 per wave; channel counts that are multiples of 256 on 16-, 32- and 64-column images), 1284 =
  * LDS-halo kernel with 128-pixel tiles on eight waves of 64 x 32 (layers with at most one tile per CU), 2570 = the thin-output 3x3 kernel
  * of the network heads (conv3x3_thin_kernel: cout <= 4, one fp32 source, no residual / per-image bias / statistics), 2571 = the stride-2
- * 3x3 convolution on fp16 rows (gemm_f16dma_kernel<.., GATHER>).  Used by bench.py to
- * attribute time per kernel. */
+ * 3x3 convolution on fp16 rows (gemm_f16dma_kernel<.., GATHER>), 2573 (round 6) = the 1x1 / Linear on at most four rows (gemv_rows_kernel: the
+ * embedding path's one-row projections; one fp32 source, bias / scale / SiLU only, cout >= 64; tune.mode != 0 keeps the matrix kernels).  Used by
+ * bench.py to attribute time per kernel. */
 DS_API int ds_conv_kernel_id(const ds_conv_args* a);
 
 /* 1 if a 3x3 convolution on h x w images runs on the LDS-halo kernel (needed for norm_coefs), else 0. */
@@ -344,10 +345,13 @@ typedef struct ds_attn_args {
     int in_f16;      /* ds_attention_f16 only: bit 0: q is an fp16 tensor (ldq / q_bs in halfs, multiples of 8), bit 1: k and v are (ldk, k_bs
                         multiples of 8; ldv, v_bs of 4) -- the fp16 tensors the reference's qkv projection emits in its fp16 mode
                         (networks_edm.py:171-173; attention.py:168-176 under autocast); `scale` then multiplies the fp32 scores */
-    int variant;     /* ABI 4.  ds_attention_f16 only (ds_attention ignores it): 0 = the library's choice (the kernel with one 32-query block per wave,
+    int variant;     /* ABI 4.  ds_attention_f16: 0 = the library's choice (the kernel with one 32-query block per wave,
                         rounds 2 - 6); 1 = the same, explicitly; 2 = two query blocks per wave, skewed by half a phase (round 6 experiment, measured
                         5 - 8 % slower and therefore never chosen; head sizes <= 64, else DS_E_SHAPE) -- for benchmarks and tests: results do not
-                        depend on it */
+                        depend on it.  ds_attention (fp32), head sizes that are multiples of 128: 0 = the library's choice -- the channel-split block
+                        (32 queries, four waves x d / 4 channels) while the query-split grid has fewer than 1 024 waves, i.e. small batches of the
+                        single 256-wide head; 1 = query split, 2 = channel split.  The two agree to fp32 rounding (the scores are summed in a
+                        different order), not bit for bit; other head sizes ignore the field */
 } ds_attn_args;
 
 DS_API int ds_attention(const ds_attn_args* a, void* stream);

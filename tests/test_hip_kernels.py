@@ -236,6 +236,70 @@ def test_fused_attention_matches_softmax_qk_v(d, heads, sq, skv):
     assert _rel(out.cpu(), ref) < TOL
 
 
+@pytest.mark.parametrize('d,bz,heads,sq,skv', [(256, 8, 1, 256, 256), (256, 3, 1, 64, 64), (128, 2, 2, 200, 130), (256, 2, 1, 100, 77), (128, 1, 3, 32, 1000)])
+def test_fused_attention_channel_split_block_agrees_with_the_query_split_kernel(d, bz, heads, sq, skv):
+    """Round 6 (csrc/attention.hip, DSPLIT): for head sizes that are multiples of 128 a small launch takes 32-query blocks whose four waves split the
+    CHANNELS (partial S^T blocks summed through LDS) instead of 128-query blocks whose waves split the queries.  Both against fp64, and against each
+    other: the scores are summed in another order, so fp32 rounding apart (observed 1 - 2e-6 of the output scale; bound 5e-6), not bit for bit; the library's own choice at
+    these sizes is the channel split (equal bits with variant 2), and three repeats of it are identical (the LDS exchange is ordered by barriers)."""
+    from diff_sampler_amd import ops
+    g = torch.Generator().manual_seed(d + bz * 7 + sq)
+    C_ = heads * d
+    q = torch.randn(bz, sq, C_, generator=g)
+    kv = torch.randn(bz, skv, 2 * C_, generator=g) * 1.5
+    scale = d ** -0.5
+    qd, kvd = q.cuda().contiguous(), kv.cuda().contiguous()
+    outs = {}
+    for variant in (1, 2, None, 2, 2):
+        out = torch.full((bz, sq, C_), float('nan'), device='cuda')
+        ops.attention(qd, kvd, kvd[:, :, C_:], out, batch=bz, heads=heads, sq=sq, skv=skv, d=d, ldq=C_, ldk=2 * C_, ldv=2 * C_, ldo=C_,
+                      q_bs=sq * C_, k_bs=skv * 2 * C_, v_bs=skv * 2 * C_, o_bs=sq * C_, scale=scale, variant=variant)
+        torch.cuda.synchronize()
+        outs.setdefault(variant, []).append(out.cpu())
+    qh = q.reshape(bz, sq, heads, d).double()
+    kh = kv[:, :, :C_].reshape(bz, skv, heads, d).double()
+    vh = kv[:, :, C_:].reshape(bz, skv, heads, d).double()
+    w = (torch.einsum('bqhd,bkhd->bhqk', qh, kh) * scale).softmax(-1)
+    ref = torch.einsum('bhqk,bkhd->bqhd', w, vh).reshape(bz, sq, C_).float()
+    assert _rel(outs[1][0], ref) < TOL and _rel(outs[2][0], ref) < TOL
+    assert _rel(outs[2][0], outs[1][0]) < 5e-6
+    assert torch.equal(outs[None][0], outs[2][0]) and torch.equal(outs[2][1], outs[2][0]) and torch.equal(outs[2][2], outs[2][0])
+
+
+@pytest.mark.parametrize('rows,k,cout,act', [(1, 512, 8448, 0), (1, 128, 512, 1), (2, 1280, 20160, 0), (4, 320, 1280, 1), (3, 768, 200, 0), (1, 64, 64, 1)])
+def test_linear_on_at_most_four_rows_streams_the_weights(rows, k, cout, act):
+    """Round 6 (csrc/gemm_conv.hip: gemv_rows_kernel, kernel id 2573): the embedding path's Linear layers see one row per sampler call (up to four:
+    a handful of sigma rows); a wave per output column reads its weight row once instead of a 128-row matrix tile walking K.  Against fp64 and
+    against the matrix kernel the same call takes with ds_conv_tune.mode = 1 (fp32 rounding apart); five rows take the matrix kernel."""
+    import ctypes as C
+    from diff_sampler_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(rows * 31 + k + cout)
+    x = torch.randn(rows, k, generator=g)
+    wt = torch.randn(cout, k, generator=g) / k ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = (x.double() @ wt.double().t() + bias.double()) * 0.75
+    if act:
+        ref = F.silu(ref)
+    xd, wp, bd = x.cuda(), ops.pack_linear_weight(wt.cuda()), bias.cuda()
+    outs = []
+    for mode in (0, 1):
+        out = torch.full((rows, cout), float('nan'), device='cuda')
+        a = _lib.ConvArgs(xd.data_ptr(), None, k, 0, k, 0, rows, 1, 1, 1, wp.data_ptr(), cout, bd.data_ptr(), None, 0, 1, None, 0, 0.75, act,
+                          out.data_ptr(), cout)
+        a.tune.mode = mode
+        assert (lib.ds_conv_kernel_id(C.byref(a)) == 2573) == (mode == 0)
+        assert lib.ds_conv2d_nhwc(C.byref(a), _lib.stream_ptr()) == 0
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+        assert _rel(outs[-1], ref.float()) < TOL, mode
+    assert _rel(outs[0], outs[1]) < 5e-6
+    x5 = torch.randn(5, k, generator=g).cuda()
+    out5 = torch.empty(5, cout, device='cuda')
+    a = _lib.ConvArgs(x5.data_ptr(), None, k, 0, k, 0, 5, 1, 1, 1, wp.data_ptr(), cout, bd.data_ptr(), None, 0, 1, None, 0, 0.75, act, out5.data_ptr(), cout)
+    assert lib.ds_conv_kernel_id(C.byref(a)) != 2573
+
+
 def test_layernorm_geglu_cfg_and_timestep_embedding():
     from diff_sampler_amd import ops
     g = torch.Generator().manual_seed(9)
