@@ -5,4 +5,4 @@ Sub-modules keep the reference's module names so that they drop in:
 ``solvers``, ``solver_utils``, ``solvers_amed``, ``sample`` -- plus ``arch``/``engine`` (denoiser plan) and
 ``_lib`` (ctypes binding of the C-ABI library ``csrc/libdsamd.so``).
 """
-__version__ = "0.5.0"
+__version__ = "0.6.0"
