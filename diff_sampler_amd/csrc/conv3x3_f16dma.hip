@@ -26,7 +26,7 @@
 //     outputs, norms and the residual stream stay fp32.
 // Scope: taps == 9, stride 1, ONE fp16 source [M][c0] (c0 % 64 == 0; the decoder's concatenation is materialised by the norm pass),
 // optional fused 1x1 skip projection on ONE fp16 source [M][ec0], square power-of-two images W in {8, 16, 32, 64} with 256-pixel
-// tiles (one image per tile, or four 8x8 images), cout % 64 == 0.
+// tiles (one image per tile, or four 8x8 images -- fewer in the last tile of a batch that is not a multiple of four), cout % 64 == 0.
 // Split-K (round 4, second part): layers whose widest tiling leaves half of the chip idle (the 8x8 stages: 56 - 64 tiles of 108 - 220 serial
 // taps at the bench batches) contract S contiguous ranges of 64-channel slabs in S workgroups per tile (blockIdx.y), each writing its raw
 // fp32 partial tile to the caller's workspace; splitk_reduce_f16_kernel (gemm_conv.hip) sums them in split order and applies the epilogue
@@ -103,6 +103,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
 
     const int img0 = m0 / p.HW;
     const int r0 = NIMG == 1 ? (m0 - img0 * p.HW) / W : 0;
+    // 8x8 images: four image slots per tile; the last tile of a batch that is not a multiple of four has empty slots (round 6) -- their halo
+    // pixels are zero pages, their output rows lie beyond M and are masked by the epilogue
+    const int nimgs = p.M / p.HW;
 
     // ---- halo DMA: thread tid owns 16-B unit j * 512 + tid of round j: pixel (unit >> 3), LDS chunk slot tid & 7 -----------------
     int hpix[NDMA];                                            // source pixel (-1: zero page)
@@ -116,7 +119,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
         const int sl = hp / (HP * WP), rem = hp - sl * (HP * WP);
         const int hr = rem / WP, hc = rem - hr * WP;
         const int y = r0 + hr - 1, x = hc - 1;
-        const bool ok = hp < NP && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)W;
+        const bool ok = hp < NP && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)W && (NIMG == 1 || img0 + sl < nimgs);
         hpix[j] = ok ? ((img0 + sl) * p.H + y) * W + x : -1;
         if (NORM && hp >= NP) hpix[j] = -2;                    // no such halo pixel: nothing is fetched (the buffer's tail holds the coefficient rows)
     }
@@ -164,7 +167,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
             if (wave * 64 < (int)G::COEF_UNITS) {
                 if (tid < (int)G::COEF_UNITS) {
                     const int sl = tid / 48, rem = tid - sl * 48;
-                    const float* g = p.norm + ((size_t)(img0 + sl) * 3 + (rem >> 4)) * (size_t)(p.c0 + p.c1) + (size_t)chunk * 64 + (rem & 15) * 4;
+                    const int im = NIMG == 1 ? img0 : min(img0 + sl, nimgs - 1);          // (an empty slot's rows are never used: any valid address)
+                    const float* g = p.norm + ((size_t)im * 3 + (rem >> 4)) * (size_t)(p.c0 + p.c1) + (size_t)chunk * 64 + (rem & 15) * 4;
                     DS_RACE_SKEW(wave);
                     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + D * WB + hbuf * HB + G::COEF_OFF + wave * 64 * 16), 16, 0, 0);
                 }
@@ -463,7 +467,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_f16dma_kernel(const KParams p)
 
 template <int W, int NB>
 int launch_w_nb(KParams p, int n_begin, int ntiles, hipStream_t stream) {
-    p.mtiles = p.M / 256;
+    p.mtiles = (p.M + 255) / 256;
     p.ntiles = ntiles;
     p.n_begin = n_begin;
     if (p.splits < 1) p.splits = 1;                            // > 1: set by launch_conv3x3_f16dma (the reduce follows the last column range)
@@ -510,7 +514,8 @@ static int max_nb(const KParams& p) { return (!p.norm && (p.W == 16 || p.W == 32
 bool conv3x3_f16dma_applicable(const KParams& p) {
     if (p.taps != 9 || p.stride > 1) return false;
     if (!(p.W == 8 || p.W == 16 || p.W == 32 || p.W == 64) || p.H != p.W) return false;
-    if (p.HW != p.H * p.W || p.M % 256) return false;
+    if (p.HW != p.H * p.W || p.M % p.HW) return false;
+    if (p.M % 256 && !(p.W == 8 && p.M % 64 == 0)) return false;      // whole 256-pixel tiles; 8x8 images: a last tile with one to three images (round 6)
     if (p.c0 <= 0 || p.c0 % 64 || p.ec0 % 64) return false;
     if (p.norm) {           // fused input normalisation (NORM instantiations): second sources allowed, whole 64-channel slabs each
         if ((p.norm_act != DS_ACT_NONE && p.norm_act != DS_ACT_SILU) || p.c1 % 64 || p.ec1 % 64 || (p.ec1 && !p.ec0)) return false;
@@ -525,7 +530,7 @@ bool conv3x3_f16dma_applicable(const KParams& p) {
 // a layer with few pixel tiles takes narrower column tiles to cover the 256 CUs.
 // `half`: the four-wave half-slab variant (conv3x3_f16dmah.hip): 128-pixel tiles, two workgroups per CU = 512 tile slots per round.
 static int tiling(const KParams& p, int nb0, int (*out)[3], int* cost, bool half = false) {
-    const int mtiles = p.M / (half ? 128 : 256), slots = half ? 512 : 256;
+    const int mtiles = (p.M + (half ? 127 : 255)) / (half ? 128 : 256), slots = half ? 512 : 256;
     int n = 0, col = 0, c = 0;
     for (int w = nb0; w >= 1 && col < p.N; --w) {
         const int t = (p.N - col) / (64 * w);
@@ -566,7 +571,7 @@ static int conv3x3_f16dma_splits(const KParams& p, int (*plan)[3], int* n) {
     int wide[4][3], cost;
     const int nw = tiling(p, max_nb(p), wide, &cost);
     long long tiles = 0;
-    for (int i = 0; i < nw; ++i) tiles += (long long)(p.M / 256) * wide[i][1];
+    for (int i = 0; i < nw; ++i) tiles += (long long)((p.M + 255) / 256) * wide[i][1];
     long long s = p.t_splits > 1 ? p.t_splits : (tiles <= 128 ? 256 / tiles : 1);
     const long long kt_all = (long long)((p.c0 + p.c1) / 64) * 9 + (p.ec0 + p.ec1) / 64, mn = (long long)p.M * p.N;
     if (s > 16) s = 16;

@@ -1010,6 +1010,11 @@ F16DMA_CASES = [
     (8, 8, 64, 64, 64, 0, False),
     (1, 16, 576, 576, 0, 0, True),           # nine slabs; few pixel tiles -> the cost model narrows the column tiles
     (2, 16, 64, 256, 0, 4, False),
+    # 8x8 images of a batch that is not a multiple of four (round 6): the last 256-pixel tile has empty image slots
+    (2, 8, 128, 192, 0, 0, True),            # half a tile (the SD-1.5 8x8 stage at one latent: two U-Net images)
+    (3, 8, 64, 64, 64, 1, True),
+    (5, 8, 64, 128, 0, 2, True),             # one full tile + one image
+    (1, 8, 192, 256, 0, 0, False),
 ]
 
 
@@ -1077,6 +1082,8 @@ F16DMA_SPLIT_CASES = [
     (2, 16, 512, 256, 0, 4, 2, False, 2),            # 256-column tiles through the staged epilogue
     (4, 8, 512, 192, 0, 0, 3, True, 3),              # fp16 residual stream and fp16 rows out of the reduce kernel
     (4, 8, 128, 64, 0, 0, 4, False, 1),              # 18 taps: too short to split -- forced count clamped to 1
+    (2, 8, 1280, 1280, 0, 0, 0, True, None),         # round 6: SD-1.5's 8x8 stage at one latent (half a tile of rows), the library's own split
+    (6, 8, 256, 192, 0, 0, 2, False, 2),             # one full tile + two images
 ]
 
 
@@ -1155,7 +1162,8 @@ def test_conv_f16_activations_rejects_what_it_does_not_cover():
     lib = _lib.load()
     assert lib.ds_conv_f16dma_supported(1, 16, 16, 96, 0, 64) == 0          # channels not a multiple of 64
     assert lib.ds_conv_f16dma_supported(1, 16, 16, 64, 0, 96) == 0
-    assert lib.ds_conv_f16dma_supported(3, 8, 8, 64, 0, 64) == 0            # 8x8 needs whole tiles of four images
+    assert lib.ds_conv_f16dma_supported(3, 8, 8, 64, 0, 64) == 1            # (round 6: 8x8 images need no whole tile of four any more)
+    assert lib.ds_conv_f16dma_supported(3, 16, 8, 64, 0, 64) == 0           # non-square
     assert lib.ds_conv_f16dma_supported(1, 4, 4, 64, 0, 64) == 0
     x = torch.zeros(256, 64, dtype=torch.float16, device='cuda')
     w = torch.zeros(128, 9 * 64 // 2, device='cuda')
