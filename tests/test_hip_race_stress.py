@@ -33,7 +33,7 @@ pytestmark = pytest.mark.gpu
 # the default selection: every test of the kernels that order their own LDS traffic with raw s_barrier + counted waits (conv3x3_f16dma incl. its
 # fused normalisation and split-K, gemm_f16dma incl. the gather form, conv3x3_halo2 split mode, gemm_f16) and of the fp16 attention staging
 HAND_SCHEDULED = ('f16_activations or f16_operands or split_fp16 or gather_kernel or fused_input_normalisation or without_the_lds_transpose '
-                  'or fp16_residual or geglu_fused or fused_attention_f16 or fused_attention_reads or two_query_blocks')
+                  'or fp16_residual or geglu_fused or fused_attention_f16 or fused_attention_reads or two_query_blocks or channel_split')
 
 
 def _run_suite(lib, args, timeout):
