@@ -1850,6 +1850,8 @@ FUSED_NORM_CASES = [
     (8, 8, 256, 128, 256, 'same', 2, True, 0),       # four images per tile: per-image coefficient rows, 8-column swizzle
     (4, 8, 768, 0, 768, 'none', 0, True, 4),         # split-K: every split normalises its own slabs
     (4, 8, 512, 256, 256, 'same', 1, True, 3),       # split-K across the two sources and the appended slabs
+    (2, 8, 256, 128, 256, 'same', 2, True, 0),       # round 6: half a tile of 8x8 images (empty image slots: zero pages, clamped coefficient rows)
+    (7, 8, 192, 0, 192, 'none', 0, True, 2),         # one full tile + three images, split-K
 ]
 
 
